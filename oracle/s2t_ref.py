@@ -1,0 +1,472 @@
+"""ORACLE (test infrastructure only): fp32 CPU restatement of the S2T hot path.
+
+Functional style: every function takes a flat ``W`` dict whose keys are the
+reference's state-dict names and plain tensors.  Only plain
+torch CPU ops are used -- the same third-party arithmetic the reference itself
+bottoms out in -- plus oracle/int_ref.py for the integer parts.
+Each function cites the reference lines it restates.  Pinned against golden
+vectors captured from the real reference (tests/golden/, test_oracle_golden.py).
+"""
+import math
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import int_ref
+
+EncOut = namedtuple("EncOut", "encoder_out encoder_padding_mask src_lengths ctc_out ctc_padding_mask "
+                              "ctc_pred new_lengths encoder_states")
+
+
+def default_cfg(**kw):
+    cfg = dict(D=256, heads=4, ffn=768, enc_layers=6, dec_layers=6, ctc_layer=0, act="relu",
+               enc_pre_ln=True, dec_pre_ln=True, pad=1, strategy="avg", conv_ch=64, feat=80,
+               no_scale_embedding=False, ln_eps=1e-5, bn_eps=1e-5, bn_momentum=0.1)
+    cfg.update(kw)
+    return cfg
+
+
+def act_fn(name):
+    # fairseq/utils.py:390-408 ; fairseq/modules/gelu.py:24-25 (gelu in fp32)
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return lambda x: F.gelu(x.float()).type_as(x)
+    raise ValueError(name)
+
+
+# ------------------------------------------------------------------ positions
+def sinusoid_table(n, dim, padding_idx):
+    """fairseq/modules/sinusoidal_positional_embedding.py:36-58: [sin | cos], row pad = 0."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(n, dtype=torch.float).unsqueeze(1) * freq.unsqueeze(0)
+    emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1).view(n, -1)
+    if dim % 2 == 1:
+        emb = torch.cat([emb, torch.zeros(n, 1)], dim=1)
+    if padding_idx is not None:
+        emb[padding_idx, :] = 0
+    return emb
+
+
+def audio_positions(lengths, T):
+    """positional_embedding_audio.py:21-27 + utils.make_positions (utils.py:192-202):
+    position t+1 for t < len_b, 0 (the padding row) otherwise.  (B,T) int64."""
+    t = torch.arange(T).unsqueeze(0)
+    valid = t < lengths.unsqueeze(1)
+    return (t + 1) * valid
+
+
+def token_positions(tokens, pad):
+    """utils.make_positions: cumsum of non-pad * non-pad + pad."""
+    mask = tokens.ne(pad).int()
+    return (torch.cumsum(mask, dim=1).type_as(mask) * mask).long() + pad
+
+
+def length_mask(lengths, T=None):
+    """create_mask, conv_transformer.py:293-300: True at padding; None if no padding."""
+    T = int(lengths.max()) if T is None else T
+    m = torch.arange(T).unsqueeze(0) >= lengths.unsqueeze(1)
+    return m if bool(m.any()) else None
+
+
+# ------------------------------------------------------------------ subsampler (a2-a4)
+def batch_norm2d(x, w, b, rm, rv, training, momentum, eps):
+    """nn.BatchNorm2d (conv_transformer.py:364-368,212).  Training: biased batch variance
+    normalises, running_var gets the unbiased one; statistics include padded frames."""
+    if training:
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        new_rm = (1 - momentum) * rm + momentum * mean.detach()
+        new_rv = (1 - momentum) * rv + momentum * var.detach() * (n / max(n - 1, 1))
+    else:
+        mean, var, new_rm, new_rv = rm, rv, rm, rv
+    y = (x - mean[None, :, None, None]) * torch.rsqrt(var[None, :, None, None] + eps)
+    y = y * w[None, :, None, None] + b[None, :, None, None]
+    return y, new_rm, new_rv
+
+
+def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
+    """conv_transformer.py:202-232 (no attn_2d): 2x[conv3x3 s2 p1 -> act -> BN] -> flatten
+    (channel-major) -> fc3 -> act -> + positions.  Dropout is identity (parity mode).
+    Returns x (T4,B,D), lengths (B,), dict of updated BN running stats."""
+    act = act_fn(cfg["act"])
+    x = src_tokens.unsqueeze(1)
+    lengths = src_lengths
+    stats = {}
+    for i in range(2):
+        p = "encoder.convolutions.%d." % i
+        x = F.conv2d(x, W[p + "weight"], W[p + "bias"], stride=2, padding=1)
+        x = act(x)
+        q = "encoder.bn.%d." % i
+        x, rm, rv = batch_norm2d(x, W[q + "weight"], W[q + "bias"], W[q + "running_mean"],
+                                 W[q + "running_var"], training, cfg["bn_momentum"], cfg["bn_eps"])
+        stats[q + "running_mean"], stats[q + "running_var"] = rm, rv
+        lengths = torch.ceil(lengths.float() / 2).long()          # :213
+        if trace is not None:
+            trace["conv%d" % i] = x
+    B, C, T4, F4 = x.shape
+    x = x.transpose(1, 2).contiguous().view(B, T4, C * F4).transpose(0, 1)   # :225-226
+    x = act(F.linear(x, W["encoder.fc3.weight"], W["encoder.fc3.bias"]))    # :227
+    if trace is not None:
+        trace["fc3"] = x
+    table = sinusoid_table(T4 + 1, cfg["D"], 0)
+    pos = audio_positions(lengths, T4)
+    x = x + table[pos].transpose(0, 1)                                         # :229
+    if trace is not None:
+        trace["embed"] = x
+    return x, lengths, stats
+
+
+# ------------------------------------------------------------------ attention (a7, a13)
+def mha(W, pfx, heads, query, key, key_padding_mask=None, causal=False):
+    """fairseq/modules/multihead_attention.py:108-366 / F.multi_head_attention_forward
+    (Appendix B1): q,k,v projections with bias, q * d^-1/2, -inf on padded keys and
+    above the diagonal (causal), softmax in fp32, P.V, out-projection.
+    query (Tq,B,D), key (Tk,B,D) -> (Tq,B,D)."""
+    Tq, B, D = query.shape
+    Tk = key.shape[0]
+    d = D // heads
+    q = F.linear(query, W[pfx + "q_proj.weight"], W[pfx + "q_proj.bias"]) * (d ** -0.5)
+    k = F.linear(key, W[pfx + "k_proj.weight"], W[pfx + "k_proj.bias"])
+    v = F.linear(key, W[pfx + "v_proj.weight"], W[pfx + "v_proj.bias"])
+    q = q.contiguous().view(Tq, B * heads, d).transpose(0, 1)
+    k = k.contiguous().view(Tk, B * heads, d).transpose(0, 1)
+    v = v.contiguous().view(Tk, B * heads, d).transpose(0, 1)
+    s = torch.bmm(q, k.transpose(1, 2))
+    if causal:
+        s = s + torch.triu(torch.full((Tq, Tk), float("-inf")), 1).unsqueeze(0)
+    if key_padding_mask is not None:
+        s = s.view(B, heads, Tq, Tk).masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
+        s = s.view(B * heads, Tq, Tk)
+    p = F.softmax(s.float(), dim=-1)
+    o = torch.bmm(p, v).transpose(0, 1).contiguous().view(Tq, B, D)
+    return F.linear(o, W[pfx + "out_proj.weight"], W[pfx + "out_proj.bias"])
+
+
+def layer_norm(W, pfx, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), W[pfx + "weight"], W[pfx + "bias"], eps)
+
+
+def ffn(W, pfx, x, act):
+    return F.linear(act(F.linear(x, W[pfx + "fc1.weight"], W[pfx + "fc1.bias"])),
+                    W[pfx + "fc2.weight"], W[pfx + "fc2.bias"])
+
+
+def encoder_layer(W, cfg, pfx, x, pad_mask):
+    """fairseq/modules/transformer_layer.py:87-139 (dropout = identity)."""
+    act = act_fn(cfg["act"])
+    pre = cfg["enc_pre_ln"]
+    r = x
+    if pre:
+        x = layer_norm(W, pfx + "self_attn_layer_norm.", x)
+    x = r + mha(W, pfx + "self_attn.", cfg["heads"], x, x, pad_mask)
+    if not pre:
+        x = layer_norm(W, pfx + "self_attn_layer_norm.", x)
+    r = x
+    if pre:
+        x = layer_norm(W, pfx + "final_layer_norm.", x)
+    x = r + ffn(W, pfx, x, act)
+    if not pre:
+        x = layer_norm(W, pfx + "final_layer_norm.", x)
+    return x
+
+
+# ------------------------------------------------------------------ CTC compression (a10)
+def ctc_compress(W, cfg, x, lengths):
+    """average_same_ctc_features, conv_transformer.py:278-291.
+    x (T,B,D) -> x_ctc (T,B,V), compressed (T''max,B,D), new_lengths, pred ids (B,T)."""
+    x_ctc = F.linear(x, W["encoder.ctc_fc.weight"], W["encoder.ctc_fc.bias"])
+    with torch.no_grad():
+        prob = F.softmax(x_ctc, dim=-1).transpose(0, 1)                  # (B,T,V)  :282
+        pred = int_ref.argmax_first_np(prob.numpy())                      # (B,T)    :284
+        runs = int_ref.ctc_rle_np(pred, lengths.numpy())                  # :285
+        new_lengths = torch.tensor([len(r) for r in runs], dtype=torch.long)
+        Wm = torch.from_numpy(int_ref.compress_weights_np(prob.numpy(), runs, cfg["strategy"]))
+    out = x.permute(1, 2, 0).bmm(Wm).permute(2, 0, 1)                      # :290-291
+    return x_ctc, out, new_lengths, torch.from_numpy(pred.astype(np.int64))
+
+
+# ------------------------------------------------------------------ encoder (a11)
+def encoder_forward(W, cfg, src_tokens, src_lengths, training=False, trace=None):
+    """ConvolutionalTransformerEncoder.forward, conv_transformer.py:195-276."""
+    x, lengths, stats = subsample(W, cfg, src_tokens, src_lengths, training, trace)
+    mask = length_mask(lengths, x.shape[0])
+    x_ctc = ctc_mask = pred = new_lengths = None
+    states = []
+    for l in range(cfg["enc_layers"]):
+        x = encoder_layer(W, cfg, "encoder.layers.%d." % l, x, mask)
+        if cfg["ctc_layer"] and cfg["ctc_layer"] == l + 1:
+            ctc_mask = mask
+            x_ctc, x, lengths, pred = ctc_compress(W, cfg, x, lengths)
+            new_lengths = lengths
+            mask = length_mask(lengths, x.shape[0])
+        states.append(x)
+    if cfg["enc_pre_ln"]:
+        x = layer_norm(W, "encoder.layer_norm.", x)
+        states[-1] = x
+    return EncOut(x, mask, lengths, x_ctc, ctc_mask, pred, new_lengths, states), stats
+
+
+# ------------------------------------------------------------------ decoder (a12, a13)
+def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="decoder."):
+    """TransformerDecoder.forward, fairseq/models/transformer.py:636-790 (training path)."""
+    act = act_fn(cfg["act"])
+    D = cfg["D"]
+    pad = cfg["pad"]
+    B, L = prev_output_tokens.shape
+    scale = 1.0 if cfg["no_scale_embedding"] else math.sqrt(D)
+    table = sinusoid_table(pad + 1 + L, D, pad)
+    x = scale * W[pfx + "embed_tokens.weight"][prev_output_tokens]           # :720
+    x = x + table[token_positions(prev_output_tokens, pad)]                   # :728-729
+    x = x.transpose(0, 1)
+    self_pad = prev_output_tokens.eq(pad)
+    self_pad = self_pad if bool(self_pad.any()) else None                     # :739-741
+    pre = cfg["dec_pre_ln"]
+    for l in range(cfg["dec_layers"]):
+        p = pfx + "layers.%d." % l
+        r = x
+        if pre:
+            x = layer_norm(W, p + "self_attn_layer_norm.", x)
+        x = r + mha(W, p + "self_attn.", cfg["heads"], x, x, self_pad, causal=True)
+        if not pre:
+            x = layer_norm(W, p + "self_attn_layer_norm.", x)
+        r = x
+        if pre:
+            x = layer_norm(W, p + "encoder_attn_layer_norm.", x)
+        x = r + mha(W, p + "encoder_attn.", cfg["heads"], x, enc_out, enc_pad_mask)
+        if not pre:
+            x = layer_norm(W, p + "encoder_attn_layer_norm.", x)
+        r = x
+        if pre:
+            x = layer_norm(W, p + "final_layer_norm.", x)
+        x = r + ffn(W, p, x, act)
+        if not pre:
+            x = layer_norm(W, p + "final_layer_norm.", x)
+    if pre:
+        x = layer_norm(W, pfx + "layer_norm.", x)
+    x = x.transpose(0, 1)
+    return F.linear(x, W[pfx + "output_projection.weight"])                  # :784-788
+
+
+# ------------------------------------------------------------------ losses (a14-a16)
+def label_smoothed_nll(logits, target, eps, pad):
+    """label_smoothed_cross_entropy.py:12-29 with log_softmax in fp32 (fairseq_decoder.py:58-79)."""
+    lp = F.log_softmax(logits.float(), dim=-1).view(-1, logits.shape[-1])
+    t = target.reshape(-1, 1)
+    nll = -lp.gather(1, t)
+    smooth = -lp.sum(dim=-1, keepdim=True)
+    m = t.eq(pad)
+    nll = nll.masked_fill(m, 0.0).sum()
+    smooth = smooth.masked_fill(m, 0.0).sum()
+    return (1.0 - eps) * nll + (eps / lp.shape[-1]) * smooth, nll
+
+
+class _CTCLoss(torch.autograd.Function):
+    """Summed CTC negative log-likelihood with zero_infinity (CTC_loss.py:143-151), by the
+    Graves alpha/beta recursion in log space; gradient w.r.t. the logits is
+    softmax - occupancy (what F.log_softmax + F.ctc_loss back-propagate)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, input_lengths, target_lengths, blank):
+        T, B, V = logits.shape
+        lp = F.log_softmax(logits.double(), dim=-1).numpy()
+        grad = np.zeros((T, B, V))
+        total = 0.0
+        NEG = -np.inf
+        for b in range(B):
+            Tb, Lb = int(input_lengths[b]), int(target_lengths[b])
+            y = [int(v) for v in targets[b, :Lb]]
+            ext = [blank]
+            for c in y:
+                ext += [c, blank]
+            S = len(ext)
+            la = np.full((Tb, S), NEG)
+            la[0, 0] = lp[0, b, ext[0]]
+            if S > 1:
+                la[0, 1] = lp[0, b, ext[1]]
+            for t in range(1, Tb):
+                for s in range(S):
+                    a = la[t - 1, s]
+                    if s >= 1:
+                        a = np.logaddexp(a, la[t - 1, s - 1])
+                    if s >= 2 and ext[s] != blank and ext[s] != ext[s - 2]:
+                        a = np.logaddexp(a, la[t - 1, s - 2])
+                    la[t, s] = a + lp[t, b, ext[s]]
+            ll = la[Tb - 1, S - 1]
+            if S > 1:
+                ll = np.logaddexp(ll, la[Tb - 1, S - 2])
+            if not np.isfinite(ll):
+                continue                                            # zero_infinity
+            lb = np.full((Tb, S), NEG)
+            lb[Tb - 1, S - 1] = lp[Tb - 1, b, ext[S - 1]]
+            if S > 1:
+                lb[Tb - 1, S - 2] = lp[Tb - 1, b, ext[S - 2]]
+            for t in range(Tb - 2, -1, -1):
+                for s in range(S):
+                    a = lb[t + 1, s]
+                    if s + 1 < S:
+                        a = np.logaddexp(a, lb[t + 1, s + 1])
+                    if s + 2 < S and ext[s + 2] != blank and ext[s + 2] != ext[s]:
+                        a = np.logaddexp(a, lb[t + 1, s + 2])
+                    lb[t, s] = a + lp[t, b, ext[s]]
+            total += -ll
+            occ = np.full((Tb, V), NEG)
+            for s in range(S):
+                occ[:, ext[s]] = np.logaddexp(occ[:, ext[s]], la[:, s] + lb[:, s])
+            grad[:Tb, b, :] = np.exp(lp[:Tb, b, :]) - np.exp(occ - lp[:Tb, b, :] - ll)
+        ctx.save_for_backward(torch.from_numpy(grad).to(logits.dtype))
+        return torch.tensor(total, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
+
+
+def ctc_loss_sum(logits, targets, input_lengths, target_lengths, blank):
+    return _CTCLoss.apply(logits, targets, input_lengths, target_lengths, blank)
+
+
+def ctc_branch(cfg, ctc_out, ctc_pad_mask, transcript, transcript_lengths, blank, pad):
+    """CTCCriterion.forward, CTC_loss.py:101-175 on (T4,B,V) logits.
+    Returns loss, errors, total, input_lengths."""
+    T, B, _ = ctc_out.shape
+    if ctc_pad_mask is None:
+        in_len = torch.full((B,), T, dtype=torch.long)
+    else:
+        in_len = T - ctc_pad_mask.sum(dim=1)                         # mask is (B,T) here
+    loss = ctc_loss_sum(ctc_out, transcript, in_len, transcript_lengths, blank)
+    lp = F.log_softmax(ctc_out.float(), dim=-1).transpose(0, 1)      # (B,T,V)
+    pred = int_ref.argmax_first_np(lp.detach().numpy())
+    err, tot = int_ref.ctc_uer_np(pred, in_len.numpy(), transcript.numpy(), transcript_lengths.numpy(), blank)
+    return loss, err, tot, in_len
+
+
+def ctc_multi_loss(W, cfg, sample, eps, ctc_weight, blank, training=False):
+    """CTCMultiLoss.forward, ctc_multi_loss.py:140-168, with the encoder-owned ctc_fc
+    (--ctc-compress-out) or the criterion-owned fc_out on encoder_states[k-1].
+    Returns loss, sample_size (= the CTC branch's, :168), logging dict, EncOut."""
+    ni = sample["net_input"]
+    enc, stats = encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training)
+    logits = decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+    if enc.ctc_out is not None:
+        ctc_feat, ctc_mask = enc.ctc_out, enc.ctc_padding_mask
+    else:
+        k = sample["ctc_encoder_layer"]
+        ctc_feat = F.linear(enc.encoder_states[k - 1], W["criterion.ctc_aware_model.fc_out.weight"],
+                            W["criterion.ctc_aware_model.fc_out.bias"])
+        ctc_mask = enc.encoder_padding_mask
+    ctc, err, tot, _ = ctc_branch(cfg, ctc_feat, ctc_mask, sample["transcript_target"],
+                                  sample["transcript_target_lengths"], blank, cfg["pad"])
+    real, nll = label_smoothed_nll(logits, sample["target"], eps, cfg["pad"])
+    loss = ctc_weight * ctc + real
+    ctc_ntokens = int(sample["transcript_target_lengths"].sum())
+    log = dict(loss=float(loss.detach()), ctc_loss=float(ctc.detach()), nll_loss=float(nll.detach()), ntokens=sample["ntokens"],
+               nsentences=sample["target"].shape[0], sample_size=sample["ntokens"],
+               ctc_errors=err, ctc_total=tot, nframes=int(ni["src_lengths"].sum()))
+    return loss, ctc_ntokens, log, enc, logits, stats
+
+
+# ------------------------------------------------------------------ optimizer (a19)
+def clip_grad_norm(grads, max_norm):
+    """fairseq/utils.py:253-277."""
+    total = torch.norm(torch.stack([torch.norm(g) for g in grads]))
+    if max_norm > 0:
+        coef = (max_norm / (total + 1e-6)).clamp(max=1)
+        grads = [g * coef for g in grads]
+    return total, grads
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.98, eps=1e-8, wd=0.0):
+    """fairseq/optim/adam.py:147-202 (Appendix B2). Returns new p, m, v."""
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    denom = v.sqrt() + eps
+    step_size = lr * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    if wd != 0:
+        p = p - wd * lr * p
+    p = p - step_size * m / denom
+    return p, m, v
+
+
+def inverse_sqrt_lr(num_updates, lr, warmup_updates, warmup_init_lr):
+    """fairseq/optim/lr_scheduler/inverse_square_root_schedule.py:36-47,66-73."""
+    if warmup_updates > 0 and num_updates < warmup_updates:
+        return warmup_init_lr + num_updates * (lr - warmup_init_lr) / warmup_updates
+    decay = lr * (max(warmup_updates, 1) ** 0.5)
+    return decay * (max(num_updates, 1) ** -0.5)
+
+
+# ------------------------------------------------------------------ deterministic weights
+def param_shapes(cfg, V_src, V_tgt, criterion_fc=False):
+    """State-dict names and shapes of conv_transformer (SURVEY.md 8-b [probe])."""
+    D, Ff, C = cfg["D"], cfg["ffn"], cfg["conv_ch"]
+    f4 = math.ceil(math.ceil(cfg["feat"] / 2) / 2)
+    s = {}
+    s["encoder.convolutions.0.weight"] = (C, 1, 3, 3); s["encoder.convolutions.0.bias"] = (C,)
+    s["encoder.convolutions.1.weight"] = (C, C, 3, 3); s["encoder.convolutions.1.bias"] = (C,)
+    for i in range(2):
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            s["encoder.bn.%d.%s" % (i, n)] = (C,)
+    s["encoder.fc3.weight"] = (D, C * f4); s["encoder.fc3.bias"] = (D,)
+
+    def attn(p):
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[p + n + ".weight"] = (D, D); s[p + n + ".bias"] = (D,)
+
+    def ln(p):
+        s[p + "weight"] = (D,); s[p + "bias"] = (D,)
+
+    def ff(p):
+        s[p + "fc1.weight"] = (Ff, D); s[p + "fc1.bias"] = (Ff,)
+        s[p + "fc2.weight"] = (D, Ff); s[p + "fc2.bias"] = (D,)
+
+    for l in range(cfg["enc_layers"]):
+        p = "encoder.layers.%d." % l
+        attn(p + "self_attn."); ln(p + "self_attn_layer_norm."); ff(p); ln(p + "final_layer_norm.")
+    if cfg["enc_pre_ln"]:
+        ln("encoder.layer_norm.")
+    if cfg["ctc_layer"]:
+        s["encoder.ctc_fc.weight"] = (V_src, D); s["encoder.ctc_fc.bias"] = (V_src,)
+    s["decoder.embed_tokens.weight"] = (V_tgt, D)
+    for l in range(cfg["dec_layers"]):
+        p = "decoder.layers.%d." % l
+        attn(p + "self_attn."); ln(p + "self_attn_layer_norm.")
+        attn(p + "encoder_attn."); ln(p + "encoder_attn_layer_norm.")
+        ff(p); ln(p + "final_layer_norm.")
+    if cfg["dec_pre_ln"]:
+        ln("decoder.layer_norm.")
+    s["decoder.output_projection.weight"] = (V_tgt, D)
+    if criterion_fc:
+        s["criterion.ctc_aware_model.fc_out.weight"] = (V_src, D)
+        s["criterion.ctc_aware_model.fc_out.bias"] = (V_src,)
+    return s
+
+
+def make_weights(shapes, seed):
+    """Deterministic synthetic weights shared by the golden generator and the tests
+    (numpy legacy RandomState is stable across versions).  Scales are chosen so that
+    activations stay O(1) through the stack."""
+    rs = np.random.RandomState(seed)
+    W = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        if k.endswith("running_var"):
+            a = 0.5 + rs.rand(*shp)
+        elif k.endswith("running_mean"):
+            a = 0.1 * rs.randn(*shp)
+        elif "layer_norm" in k or ".bn." in k:
+            a = (1.0 + 0.1 * rs.randn(*shp)) if k.endswith("weight") else 0.1 * rs.randn(*shp)
+        elif k.endswith("bias"):
+            a = 0.05 * rs.randn(*shp)
+        elif "embed_tokens" in k:
+            a = rs.randn(*shp) * (shp[1] ** -0.5)
+        else:
+            fan_in = int(np.prod(shp[1:]))
+            a = rs.randn(*shp) * (1.0 / math.sqrt(fan_in))
+        W[k] = torch.from_numpy(a.astype(np.float32))
+    return W

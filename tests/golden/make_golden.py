@@ -1,0 +1,376 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the REAL reference.
+
+Runs only in the build container (needs /root/reference; never at test time):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Everything here is our own glue: it builds the reference's `conv_transformer`
+through its public registry/CLI surface, loads deterministic synthetic weights
+(oracle.s2t_ref.make_weights -- the tests regenerate the same weights from the
+seed, so the fixtures hold only inputs and expected outputs), runs it on the CPU
+in fp32 and dumps .npz files.  Shims applied from outside the read-only tree are
+the ones listed in SURVEY.md 8-c (numpy aliases, EncoderOut._field_types, drop of
+`transcript_prev_output_tokens` for single-decoder models).  All dropout rates are
+0 on the command line and F.dropout is patched to the identity (the subsampler's
+rate is max(p, 0.1), conv_transformer.py:214; torch's fused SDPA applies its own
+dropout in C++, hence the zero rates) so train-mode BatchNorm statistics can be pinned.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+for _n, _t in (("float", float), ("int", int), ("bool", bool), ("object", object)):
+    if not hasattr(np, _n):
+        setattr(np, _n, _t)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+import fairseq.models.fairseq_encoder as _fe  # noqa: E402
+
+if not hasattr(_fe.EncoderOut, "_field_types"):
+    _fe.EncoderOut._field_types = dict(_fe.EncoderOut.__annotations__)
+
+from fairseq import options, utils  # noqa: E402
+from fairseq.data import Dictionary  # noqa: E402
+
+utils.import_user_module(argparse.Namespace(user_dir=REF + "/examples/speech_recognition"))
+from examples.speech_recognition.tasks.speech_translation_ctc import SpeechTranslationCTCTask  # noqa: E402
+from examples.speech_recognition.data.collaters import Seq2SeqCollater  # noqa: E402
+from examples.speech_recognition.data.transcription_dataset import TranscriptionWrapperDataset  # noqa: E402
+from examples.speech_recognition.models.conv_transformer import CTCCompressStrategy  # noqa: E402
+from fairseq.optim.adam import Adam  # noqa: E402
+
+from oracle import s2t_ref  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(4)
+
+# identity dropout (our patch, outside the tree): pins train-mode BN without RNG
+_real_dropout = F.dropout
+F.dropout = lambda x, p=0.5, training=True, inplace=False: x
+
+
+def mk_dict(n):
+    d = Dictionary()
+    for i in range(n):
+        d.add_symbol("w%d" % i)
+    return d
+
+
+def build(cfgname, D, H, Ff, EL, DL, ctc_layer, compress=True, strategy="avg"):
+    a = ["/nonexistent", "--user-dir", REF + "/examples/speech_recognition",
+         "--task", "speech_translation_with_transcription", "-s", "en", "-t", "de",
+         "--arch", "conv_transformer", "--no-attn-2d", "--input-feat-per-channel", "80",
+         "--encoder-embed-dim", str(D), "--decoder-embed-dim", str(D),
+         "--decoder-output-dim", str(D),
+         "--encoder-ffn-embed-dim", str(Ff), "--decoder-ffn-embed-dim", str(Ff),
+         "--encoder-attention-heads", str(H), "--decoder-attention-heads", str(H),
+         "--encoder-layers", str(EL), "--decoder-layers", str(DL),
+         "--ctc-encoder-layer", str(ctc_layer), "--ctc-compress-strategy", strategy,
+         "--criterion", "ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy",
+         "--label-smoothing", "0.1", "--max-sentences", "4", "--cpu",
+         "--dropout", "0.0", "--attention-dropout", "0.0", "--relu-dropout", "0.0",
+         "--max-source-positions", "2000", "--max-target-positions", "1000"]
+    if compress:
+        a.append("--ctc-compress-out")
+    args = options.parse_args_and_arch(options.get_training_parser(), input_args=a)
+    tgt, src = mk_dict(96), mk_dict(59)
+    src.add_symbol("<ctc_blank>")           # speech_translation_ctc.py:42-46
+    task = SpeechTranslationCTCTask(args, tgt)
+    task.src_dict = src
+    torch.manual_seed(1)
+    model = task.build_model(args)
+    crit = task.build_criterion(args)
+    return args, task, model, crit, len(src), len(tgt)
+
+
+def load_weights(model, crit, W):
+    sd = model.state_dict()
+    for k in sd:
+        if k in W:
+            sd[k] = W[k].clone()
+    model.load_state_dict(sd, strict=True)
+    if "criterion.ctc_aware_model.fc_out.weight" in W:
+        crit.ctc_aware_model.fc_out.weight.data.copy_(W["criterion.ctc_aware_model.fc_out.weight"])
+        crit.ctc_aware_model.fc_out.bias.data.copy_(W["criterion.ctc_aware_model.fc_out.bias"])
+
+
+def make_sample(seed, lens, tgt_lens, tr_lens, V_src, V_tgt, blank):
+    rs = np.random.RandomState(seed)
+    B, T = len(lens), max(lens)
+    x = np.zeros((B, T, 80), np.float32)
+    for b, l in enumerate(lens):
+        x[b, :l] = rs.randn(l, 80).astype(np.float32)
+
+    def toks(ls, V, hi_excl):
+        L = max(ls)
+        tgt = np.full((B, L), 1, np.int64)
+        prev = np.full((B, L), 1, np.int64)
+        for b, l in enumerate(ls):
+            t = rs.randint(4, hi_excl, size=l - 1)
+            tgt[b, : l - 1] = t
+            tgt[b, l - 1] = 2
+            prev[b, 0] = 2
+            prev[b, 1:l] = t
+        return tgt, prev
+
+    tgt, prev = toks(tgt_lens, V_tgt, V_tgt)
+    tr, _ = toks(tr_lens, V_src, blank)       # transcripts never contain the blank
+    return dict(
+        id=np.arange(B, dtype=np.int64), ntokens=int(sum(tgt_lens)), nsentences=B,
+        src_tokens=x, src_lengths=np.array(lens, np.int64), prev_output_tokens=prev,
+        target=tgt, target_lengths=np.array(tgt_lens, np.int64),
+        transcript_target=tr, transcript_target_lengths=np.array(tr_lens, np.int64))
+
+
+def to_ref_sample(s):
+    t = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in s.items()}
+    return dict(id=t["id"], ntokens=t["ntokens"], nsentences=t["nsentences"],
+                net_input=dict(src_tokens=t["src_tokens"], src_lengths=t["src_lengths"],
+                               prev_output_tokens=t["prev_output_tokens"]),     # F6: no transcript_prev_*
+                target=t["target"], target_lengths=t["target_lengths"],
+                transcript_target=t["transcript_target"],
+                transcript_target_lengths=t["transcript_target_lengths"])
+
+
+GRAD_KEYS = ["encoder.convolutions.0.weight", "encoder.convolutions.0.bias", "encoder.convolutions.1.bias",
+             "encoder.bn.0.weight", "encoder.bn.0.bias", "encoder.bn.1.weight", "encoder.bn.1.bias",
+             "encoder.fc3.bias", "encoder.layers.0.self_attn.q_proj.bias", "encoder.layers.0.self_attn.k_proj.weight",
+             "encoder.layers.0.self_attn_layer_norm.weight", "encoder.layers.0.fc1.bias",
+             "encoder.layers.1.fc2.weight", "encoder.layer_norm.weight", "encoder.ctc_fc.bias",
+             "decoder.embed_tokens.weight", "decoder.layers.0.encoder_attn.k_proj.weight",
+             "decoder.layers.0.encoder_attn.q_proj.bias", "decoder.layers.0.self_attn.v_proj.weight",
+             "decoder.layer_norm.bias", "decoder.output_projection.weight"]
+
+
+def run_model_case(name, D, H, Ff, EL, DL, ctc_layer, compress, lens, tgt_lens, tr_lens, seed, opt_steps=0):
+    args, task, model, crit, V_src, V_tgt = build(name, D, H, Ff, EL, DL, ctc_layer, compress)
+    blank = task.source_dictionary.index("<ctc_blank>")
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL,
+                              ctc_layer=ctc_layer if compress else 0)
+    shapes = s2t_ref.param_shapes(dict(cfg, ctc_layer=ctc_layer if compress else 0), V_src, V_tgt,
+                                  criterion_fc=True)
+    W = s2t_ref.make_weights(shapes, seed)
+    load_weights(model, crit, W)
+    s = make_sample(seed + 1, lens, tgt_lens, tr_lens, V_src, V_tgt, blank)
+    sample = to_ref_sample(s)
+    out = {("in_" + k): v for k, v in s.items() if isinstance(v, np.ndarray)}
+    out["in_ntokens"] = np.int64(s["ntokens"])
+    out["meta"] = np.array([D, H, Ff, EL, DL, ctc_layer, int(compress), V_src, V_tgt, blank, seed], np.int64)
+
+    # ---- train mode (BN batch statistics), dropout = identity
+    model.train(); crit.train()
+    trace = {}
+    hooks = []
+    enc = model.encoder
+    def _rec(key):
+        def h(m, i, o):
+            trace[key] = o.detach()
+        return h
+    hooks.append(enc.bn[0].register_forward_hook(_rec("conv0")))
+    hooks.append(enc.bn[1].register_forward_hook(_rec("conv1")))
+    hooks.append(enc.fc3.register_forward_hook(_rec("fc3_pre_act")))
+    for li, layer in enumerate(enc.layers):
+        def _hook(m, i, o, li=li):
+            trace["enc_in%d" % li] = i[0].detach()
+            trace["enc_layer%d" % li] = o.detach()
+        hooks.append(layer.register_forward_hook(_hook))
+    model.zero_grad(); crit.zero_grad()
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    out["train_loss"] = np.float64(loss.item())
+    out["train_sample_size"] = np.int64(sample_size)
+    for k, v in log.items():
+        out["train_log_" + k] = np.float64(float(v))
+    for k, v in trace.items():
+        out["train_" + k] = v.numpy()
+    gn = {}
+    for k, p in list(model.named_parameters()) + [("criterion." + k, p) for k, p in crit.named_parameters()]:
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        gn[k] = float(g.norm())
+        if k in GRAD_KEYS:
+            out["grad_" + k] = g.numpy().copy()
+    out["gradnorm_keys"] = np.array(sorted(gn))
+    out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], np.float64)
+
+    # ---- fresh model for the encoder/decoder tensors in train mode (single BN update)
+    args2, task2, model2, crit2, _, _ = build(name, D, H, Ff, EL, DL, ctc_layer, compress)
+    load_weights(model2, crit2, W)
+    model2.train()
+    with torch.no_grad():
+        eo = model2.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"],
+                            return_all_hiddens=True)
+        logits, _ = model2.decoder(sample["net_input"]["prev_output_tokens"], encoder_out=eo)
+    out["train_encoder_out"] = eo.encoder_out.numpy()
+    out["train_src_lengths_out"] = eo.src_lengths.numpy()
+    out["train_pad_mask"] = (eo.encoder_padding_mask.numpy() if eo.encoder_padding_mask is not None
+                             else np.zeros((0,), bool))
+    if compress:
+        out["train_ctc_out"] = eo.ctc_out.numpy()
+        out["train_ctc_pad_mask"] = (eo.ctc_padding_mask.numpy() if eo.ctc_padding_mask is not None
+                                     else np.zeros((0,), bool))
+    out["train_logits"] = logits.numpy()
+    for i in range(2):
+        out["train_bn%d_running_mean" % i] = model2.encoder.bn[i].running_mean.numpy().copy()
+        out["train_bn%d_running_var" % i] = model2.encoder.bn[i].running_var.numpy().copy()
+
+    # ---- eval mode (running statistics as loaded)
+    args3, task3, model3, crit3, _, _ = build(name, D, H, Ff, EL, DL, ctc_layer, compress)
+    load_weights(model3, crit3, W)
+    model3.eval(); crit3.eval()
+    with torch.no_grad():
+        eo = model3.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+        logits, _ = model3.decoder(sample["net_input"]["prev_output_tokens"], encoder_out=eo)
+        l3, ss3, log3 = crit3(model3, sample)
+    out["eval_encoder_out"] = eo.encoder_out.numpy()
+    out["eval_src_lengths_out"] = eo.src_lengths.numpy()
+    out["eval_logits"] = logits.numpy()
+    out["eval_loss"] = np.float64(l3.item())
+    for k, v in log3.items():
+        out["eval_log_" + k] = np.float64(float(v))
+
+    # ---- optimizer steps (trainer.py:416-443 order: grads * (1/sample_size), clip, Adam)
+    if opt_steps:
+        args4, task4, model4, crit4, _, _ = build(name, D, H, Ff, EL, DL, ctc_layer, compress)
+        load_weights(model4, crit4, W)
+        model4.train(); crit4.train()
+        params = [p for p in list(model4.parameters()) + list(crit4.parameters()) if p.requires_grad]
+        opt = Adam(params, lr=5e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-4)
+        gnorms, losses = [], []
+        for it in range(opt_steps):
+            opt.zero_grad()
+            l4, ss4, _ = crit4(model4, sample)
+            l4.backward()
+            for p in params:
+                if p.grad is not None:
+                    p.grad.data.mul_(1.0 / float(ss4))
+            gnorm = utils.clip_grad_norm_(params, 0.5)
+            opt.step()
+            gnorms.append(float(gnorm)); losses.append(float(l4))
+        out["opt_gnorms"] = np.array(gnorms); out["opt_losses"] = np.array(losses)
+        sd = model4.state_dict()
+        for k in GRAD_KEYS:
+            if k in sd:
+                out["opt_param_" + k] = sd[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "loss", loss.item(), "sample_size", sample_size, {k: float(v) for k, v in log.items()})
+
+
+def run_ctc_cases():
+    """G3: crafted CTC-compression cases through the reference's own
+    average_same_ctc_features with ctc_fc = identity (so x IS the logit tensor)."""
+    D = 64
+    args, task, model, crit, V_src, V_tgt = build("ctc", D, 2, 128, 2, 1, 1, True)
+    enc = model.encoder
+    assert V_src == D
+    with torch.no_grad():
+        enc.ctc_fc.weight.copy_(torch.eye(D)); enc.ctc_fc.bias.zero_()
+    rs = np.random.RandomState(7)
+    T, B = 12, 5
+    x = (0.1 * rs.randn(T, B, D)).astype(np.float32)
+    lens = np.array([12, 12, 9, 7, 1], np.int64)
+
+    def peak(b, t, tok, val=5.0):
+        x[t, b, tok] = val
+    for t in range(T):                      # b0: all frames predict token 3
+        peak(0, t, 3)
+    for t in range(T):                      # b1: alternating 4,5,4,5...
+        peak(1, t, 4 + (t % 2))
+    for t in range(T):                      # b2: runs 3+3+3 valid; the run would continue past len=9
+        peak(2, t, 10 + min(t // 3, 2))
+    for t in range(T):                      # b3: exact ties between tokens 8 and 20 -> first index (8)
+        peak(3, t, 8); peak(3, t, 20)
+    x[2, 3, 8] = 4.0                        #     one frame where 20 wins, splitting the run
+    peak(4, 0, 63)                          # b4: single valid frame, predicts the blank (last symbol)
+    out = dict(x=x, lens=lens)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    for strat in ("avg", "weighted", "softmax"):
+        enc.ctc_compress_method = getattr(CTCCompressStrategy, strat)
+        x_ctc, comp, new_len = enc.average_same_ctc_features(xt, torch.from_numpy(lens))
+        out[strat + "_out"] = comp.detach().numpy()
+        out[strat + "_new_len"] = new_len.numpy()
+        g, = torch.autograd.grad(comp.pow(2).sum(), xt)
+        out[strat + "_grad_x"] = g.numpy()
+    prob = F.softmax(torch.from_numpy(x), dim=-1).transpose(0, 1)
+    out["pred"] = np.stack([prob[b].argmax(-1).numpy() for b in range(B)]).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "ctc_compress.npz"), **out)
+    print("ctc cases new_len", out["avg_new_len"])
+
+
+def run_collate():
+    """G10: the reference's known-answer collater test inputs (tests/speech_recognition/
+    test_collaters.py:24-49) plus ragged ones with equal lengths, and the transcript wrapper."""
+    rs = np.random.RandomState(3)
+    col = Seq2SeqCollater(0, 1, pad_index=1, eos_index=2, move_eos_to_beginning=True)
+    lens = [5, 9, 9, 3, 7, 9]
+    samples, tr = [], []
+    for i, l in enumerate(lens):
+        tl = 2 + (i * 3) % 5
+        tgt = np.concatenate([rs.randint(4, 50, size=tl), [2]]).astype(np.int64)
+        samples.append({"id": i, "data": [rs.randn(l, 4).astype(np.float32), tgt]})
+        tr.append(torch.from_numpy(np.concatenate([rs.randint(4, 30, size=1 + i % 3), [2]]).astype(np.int64)))
+    batch = col.collate(samples)
+    out = {}
+    for i, s in enumerate(samples):
+        out["s%d_src" % i] = s["data"][0]; out["s%d_tgt" % i] = s["data"][1]; out["s%d_tr" % i] = tr[i].numpy()
+    out["n"] = np.int64(len(samples))
+    out["id"] = batch["id"].numpy(); out["ntokens"] = np.int64(batch["ntokens"])
+    out["src_tokens"] = batch["net_input"]["src_tokens"].numpy()
+    out["src_lengths"] = batch["net_input"]["src_lengths"].numpy()
+    out["prev_output_tokens"] = batch["net_input"]["prev_output_tokens"].numpy()
+    out["target"] = batch["target"].numpy(); out["target_lengths"] = batch["target_lengths"].numpy()
+
+    class _Tgt:
+        def collater(self, ss):
+            return col.collate(ss)
+    d = mk_dict(40)
+    wrap = TranscriptionWrapperDataset(_Tgt(), None, d)
+    ws = []
+    for i, s in enumerate(samples):
+        s2 = dict(s); s2["transcript_target"] = tr[i]; ws.append(s2)
+    wb = wrap.collater(ws)
+    out["transcript_target"] = wb["transcript_target"].numpy()
+    out["transcript_target_lengths"] = wb["transcript_target_lengths"].numpy()
+    out["transcript_prev_output_tokens"] = wb["net_input"]["transcript_prev_output_tokens"].numpy()
+    np.savez_compressed(os.path.join(OUT, "collate.npz"), **out)
+    print("collate order", out["id"])
+
+
+def run_uer():
+    """compute_ctc_uer known answers (CTC_loss.py:31-74) on crafted predictions."""
+    from examples.speech_recognition.criterions.CTC_loss import compute_ctc_uer
+    rs = np.random.RandomState(11)
+    B, T, V, L = 6, 20, 12, 9
+    blank = V - 1
+    lp = torch.from_numpy(rs.randn(B, T, V).astype(np.float32)).log_softmax(-1)
+    in_len = torch.tensor([20, 17, 11, 5, 20, 1])
+    tgt_len = torch.tensor([9, 4, 6, 2, 1, 3])
+    tgt = torch.from_numpy(rs.randint(0, V - 1, size=(B, L)).astype(np.int64))
+    e, n = compute_ctc_uer(lp, tgt, in_len, tgt_len, blank)
+    np.savez_compressed(os.path.join(OUT, "ctc_uer.npz"), lp=lp.numpy(), in_len=in_len.numpy(),
+                        tgt=tgt.numpy(), tgt_len=tgt_len.numpy(), blank=np.int64(blank),
+                        errors=np.float64(e), total=np.float64(n))
+    print("uer", e, n)
+
+
+if __name__ == "__main__":
+    run_ctc_cases()
+    run_collate()
+    run_uer()
+    # A: ragged lengths (padding mask present), CTC compression after layer 2, d_head 32
+    run_model_case("model_a", 64, 2, 128, 3, 2, 2, True, [61, 50, 37], [7, 5, 6], [6, 4, 5], seed=100, opt_steps=3)
+    # B: no padding anywhere (mask None branches), d_head 64, compression after layer 1
+    run_model_case("model_b", 128, 2, 256, 2, 1, 1, True, [45, 45], [6, 6], [5, 5], seed=200)
+    # C: no compression: criterion-owned fc_out on encoder_states[k-1]
+    run_model_case("model_c", 64, 2, 128, 2, 1, 2, False, [40, 29, 33], [4, 6, 3], [3, 5, 4], seed=300)

@@ -1,0 +1,32 @@
+"""Shared helpers for the test-suite: golden loading and sample reconstruction."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import s2t_ref
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def model_case(name):
+    """Rebuild cfg, deterministic weights and the sample dict of a model_* fixture."""
+    g = load_golden(name)
+    D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed = [int(v) for v in g["meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL,
+                              ctc_layer=ctc_layer if compress else 0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    t = lambda k: torch.from_numpy(g["in_" + k])
+    sample = dict(
+        id=t("id"), ntokens=int(g["in_ntokens"]), nsentences=int(g["in_src_lengths"].shape[0]),
+        net_input=dict(src_tokens=t("src_tokens"), src_lengths=t("src_lengths"),
+                       prev_output_tokens=t("prev_output_tokens")),
+        target=t("target"), target_lengths=t("target_lengths"),
+        transcript_target=t("transcript_target"), transcript_target_lengths=t("transcript_target_lengths"),
+        ctc_encoder_layer=ctc_layer)
+    return g, cfg, W, sample, dict(V_src=V_src, V_tgt=V_tgt, blank=blank, seed=seed,
+                                   ctc_layer=ctc_layer, compress=bool(compress))

@@ -1,0 +1,154 @@
+"""Pin the CPU oracle (oracle/) against golden vectors captured from the real reference
+(tests/golden/make_golden.py).  fp32 tolerance 1e-4 (north_star); integer paths bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import int_ref, s2t_ref
+from helpers import load_golden, model_case
+
+TOL = 1e-4
+
+
+def close(a, b, tol=TOL, what=""):
+    if torch.is_tensor(a):
+        a = a.detach().numpy()
+    if torch.is_tensor(b):
+        b = b.detach().numpy()
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    scale = max(1.0, np.abs(b).max() if b.size else 1.0)
+    assert err <= tol * scale, "%s: max err %.3e (scale %.3e)" % (what, err, scale)
+
+
+@pytest.mark.parametrize("name", ["model_a", "model_b", "model_c"])
+def test_encoder_decoder_train_mode(name):
+    g, cfg, W, sample, meta = model_case(name)
+    ni = sample["net_input"]
+    trace = {}
+    with torch.no_grad():
+        enc, stats = s2t_ref.encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training=True, trace=trace)
+        logits = s2t_ref.decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+    close(trace["conv0"], g["train_conv0"], what="conv0")
+    close(trace["conv1"], g["train_conv1"], what="conv1")
+    close(enc.encoder_out, g["train_encoder_out"], what="encoder_out")
+    assert np.array_equal(enc.src_lengths.numpy(), g["train_src_lengths_out"])
+    gm = g["train_pad_mask"]
+    if gm.size == 0:
+        assert enc.encoder_padding_mask is None
+    else:
+        assert np.array_equal(enc.encoder_padding_mask.numpy(), gm)
+    if meta["compress"]:
+        close(enc.ctc_out, g["train_ctc_out"], what="ctc_out")
+    close(logits, g["train_logits"], what="logits")
+    for i in range(2):
+        close(stats["encoder.bn.%d.running_mean" % i], g["train_bn%d_running_mean" % i], what="rm")
+        close(stats["encoder.bn.%d.running_var" % i], g["train_bn%d_running_var" % i], what="rv")
+
+
+@pytest.mark.parametrize("name", ["model_a", "model_b", "model_c"])
+def test_eval_mode(name):
+    g, cfg, W, sample, meta = model_case(name)
+    ni = sample["net_input"]
+    with torch.no_grad():
+        enc, _ = s2t_ref.encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training=False)
+        logits = s2t_ref.decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+    close(enc.encoder_out, g["eval_encoder_out"], what="encoder_out")
+    assert np.array_equal(enc.src_lengths.numpy(), g["eval_src_lengths_out"])
+    close(logits, g["eval_logits"], what="logits")
+
+
+@pytest.mark.parametrize("name", ["model_a", "model_b", "model_c"])
+def test_ctc_multi_loss_and_grads(name):
+    g, cfg, W, sample, meta = model_case(name)
+    Wg = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in W.items()}
+    loss, ss, log, enc, logits, _ = s2t_ref.ctc_multi_loss(Wg, cfg, sample, 0.1, 1.0, meta["blank"], training=True)
+    loss.backward()
+    close(float(loss), float(g["train_loss"]), what="loss")
+    assert ss == int(g["train_sample_size"])
+    for k in ("ctc_loss", "nll_loss", "ntokens", "nsentences", "sample_size", "ctc_errors", "ctc_total", "nframes"):
+        close(log[k], float(g["train_log_" + k]), what=k)
+    keys = [str(k) for k in g["gradnorm_keys"]]
+    for k, ref in zip(keys, g["gradnorm_vals"]):
+        gk = Wg[k].grad if k in Wg else None
+        mine = float(gk.norm()) if gk is not None else 0.0
+        assert abs(mine - ref) <= 2e-4 * max(1.0, ref), (k, mine, ref)
+    for k in g:
+        if k.startswith("grad_"):
+            close(Wg[k[5:]].grad, g[k], tol=2e-4, what=k)
+
+
+def test_optimizer_steps():
+    g, cfg, W, sample, meta = model_case("model_a")
+    P = {k: v.clone() for k, v in W.items()}
+    names = [k for k in P if "running" not in k]
+    m = {k: torch.zeros_like(P[k]) for k in names}
+    v = {k: torch.zeros_like(P[k]) for k in names}
+    for it in range(len(g["opt_gnorms"])):
+        Wg = {k: (P[k].clone().requires_grad_(True) if k in names else P[k].clone()) for k in P}
+        loss, ss, log, enc, logits, stats = s2t_ref.ctc_multi_loss(Wg, cfg, sample, 0.1, 1.0, meta["blank"], training=True)
+        loss.backward()
+        close(float(loss), g["opt_losses"][it], tol=2e-4, what="loss%d" % it)
+        grads = [(Wg[k].grad if Wg[k].grad is not None else torch.zeros_like(P[k])) / float(ss) for k in names]
+        gn, grads = s2t_ref.clip_grad_norm(grads, 0.5)
+        close(float(gn), g["opt_gnorms"][it], tol=2e-4, what="gnorm%d" % it)
+        for k, gk in zip(names, grads):
+            P[k], m[k], v[k] = s2t_ref.adam_step(P[k], gk, m[k], v[k], it + 1, 5e-4, wd=1e-4)
+        P.update(stats)
+    for k in g:
+        if k.startswith("opt_param_"):
+            close(P[k[10:]], g[k], tol=2e-4, what=k)
+
+
+def test_ctc_compression_cases_bit_exact():
+    g = load_golden("ctc_compress")
+    x = torch.from_numpy(g["x"]); lens = torch.from_numpy(g["lens"])
+    D = x.shape[-1]
+    W = {"encoder.ctc_fc.weight": torch.eye(D), "encoder.ctc_fc.bias": torch.zeros(D)}
+    for strat in ("avg", "weighted", "softmax"):
+        cfg = s2t_ref.default_cfg(D=D, strategy=strat)
+        xt = x.clone().requires_grad_(True)
+        x_ctc, out, new_len, pred = s2t_ref.ctc_compress(W, cfg, xt, lens)
+        assert np.array_equal(new_len.numpy(), g[strat + "_new_len"])            # bit-exact ints
+        for b in range(x.shape[1]):
+            L = int(lens[b])
+            assert np.array_equal(pred[b, :L].numpy(), g["pred"][b, :L])
+        close(out, g[strat + "_out"], what=strat)
+        gx, = torch.autograd.grad(out.pow(2).sum(), xt)
+        close(gx, g[strat + "_grad_x"], what=strat + " grad")
+    # numpy and C restatements of the RLE agree with each other
+    pred = g["pred"].astype(np.int32)
+    runs = int_ref.ctc_rle_np(pred, g["lens"])
+    c = int_ref.ctc_rle_c(pred, g["lens"])
+    assert [len(r) for r in runs] == list(c["new_len"])
+    for b, r in enumerate(runs):
+        assert [t for t, _ in r] == list(c["run_tok"][b, :len(r)])
+        assert [n for _, n in r] == list(c["run_len"][b, :len(r)])
+    assert np.array_equal(int_ref.argmax_first_c(g["x"].transpose(1, 0, 2)), int_ref.argmax_first_np(g["x"].transpose(1, 0, 2)))
+
+
+def test_ctc_uer_known_answer():
+    g = load_golden("ctc_uer")
+    pred = int_ref.argmax_first_np(g["lp"])
+    e1, n1 = int_ref.ctc_uer_np(pred, g["in_len"], g["tgt"], g["tgt_len"], int(g["blank"]))
+    e2, n2 = int_ref.ctc_uer_c(pred, g["in_len"], g["tgt"], g["tgt_len"], int(g["blank"]))
+    assert (e1, n1) == (float(g["errors"]), float(g["total"]))
+    assert (e2, n2) == (float(g["errors"]), float(g["total"]))
+
+
+def test_ctc_loss_matches_torch():
+    """The oracle's own alpha/beta recursion against torch's F.ctc_loss (the reference's call site)."""
+    torch.manual_seed(0)
+    T, B, V, L = 15, 4, 9, 6
+    logits = torch.randn(T, B, V, requires_grad=True)
+    tgt = torch.randint(0, V - 1, (B, L)); tl = torch.tensor([6, 3, 1, 5]); il = torch.tensor([15, 12, 7, 4])
+    tgt[3, :5] = torch.tensor([1, 1, 1, 1, 1])          # needs 9 frames > 4 available -> infinite -> zeroed
+    mine = s2t_ref.ctc_loss_sum(logits, tgt, il, tl, V - 1)
+    gm, = torch.autograd.grad(mine, logits)
+    l2 = logits.detach().clone().requires_grad_(True)
+    flat = torch.cat([tgt[b, : tl[b]] for b in range(B)])
+    ref = torch.nn.functional.ctc_loss(torch.log_softmax(l2, -1), flat, il, tl, blank=V - 1, reduction="sum", zero_infinity=True)
+    gr, = torch.autograd.grad(ref, l2)
+    close(float(mine), float(ref), what="ctc")
+    close(gm, gr, what="ctc grad")
