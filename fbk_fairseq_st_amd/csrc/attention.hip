@@ -1,0 +1,530 @@
+// Fused multi-head attention (forward + backward) for the S2T Transformer encoder/decoder.
+// Reference semantics: fairseq/modules/multihead_attention.py:190-366 and
+// torch.nn.functional.multi_head_attention_forward: S = (q*d^-1/2) k^T,
+// -inf on padded keys (suffix padding given as per-batch key lengths) and above the diagonal
+// (causal, decoder self-attention), softmax in fp32, dropout on P, O = P V.
+//
+// Flash-style: scores are never written to HBM.  K/V tiles of 64 keys are staged in LDS, QK^T and
+// PV run on MFMA (16x16 tiles, f32 accumulate), softmax statistics are kept per query row in
+// registers with wavefront (16-lane) shuffles.  Workgroup = 4 waves, each wave owns 16 rows.
+// Tensors are addressed as  X[t][b][h][j] = base + t*st + b*sb + h*DH + j  so the kernels read
+// q/k/v straight out of the fused QKV projection output (time-major) and write the
+// context in the (T,B,D) layout the out-projection GEMM consumes.
+//
+// Backward = 3 kernels: delta (rowsum(dO*O)), dK/dV (one workgroup per 64 keys, loops over query
+// tiles) and dQ (one workgroup per 64 queries, loops over key tiles): no atomics, deterministic.
+#include "common.hpp"
+#include "prof.hpp"
+
+template <typename T, int DH> struct ACfg {
+    static constexpr int E = Elem<T>::PER16;
+    static constexpr int ROWB = DH * (int)sizeof(T);      // bytes per row of a [64][DH] tile
+    static constexpr int NCH = ROWB / 16;
+    static constexpr int KG = NCH / 4;                      // MFMA k-groups across DH
+    static constexpr int PROWB = 64 * (int)sizeof(T);     // bytes per row of a [*][64] tile
+    static constexpr int PCH = PROWB / 16;
+    static constexpr int PKG = PCH / 4;                     // k-groups across 64 keys / queries
+    static constexpr int ND = DH / 16;                      // 16-wide output tiles across DH
+    static constexpr int TILE = 64 * ROWB;                  // bytes of a [64][DH] tile
+    static constexpr int TTILE = DH * PROWB;                // bytes of a [DH][64] tile (same)
+    static constexpr int PTILE = 16 * PROWB;                // per-wave [16][64] round-trip tile
+};
+
+__device__ __forceinline__ int swz(int row, int c, int nch) { return c ^ (row & ((nch < 8 ? nch : 8) - 1)); }
+
+// [64 rows][DH] tile, rows = consecutive time steps of one (b,h)
+template <typename T, int DH>
+__device__ __forceinline__ void stage_rows(char* lds, const T* g, long stride, int row0, int nvalid) {
+    typedef ACfg<T, DH> C;
+    for (int cid = threadIdx.x; cid < 64 * C::NCH; cid += 256) {
+        const int row = cid / C::NCH, c = cid % C::NCH;
+        u32x4 v = {0, 0, 0, 0};
+        if (row0 + row < nvalid) v = *reinterpret_cast<const u32x4*>(g + (long)(row0 + row) * stride + c * C::E);
+        *reinterpret_cast<u32x4*>(lds + row * C::ROWB + (swz(row, c, C::NCH) << 4)) = v;
+    }
+}
+
+// transposed tile [DH rows = feature][64 cols = time step]
+template <typename T, int DH>
+__device__ __forceinline__ void stage_cols(char* lds, const T* g, long stride, int row0, int nvalid) {
+    typedef ACfg<T, DH> C;
+    if constexpr (sizeof(T) == 2) {
+        for (int it = threadIdx.x; it < 32 * C::NCH; it += 256) {
+            const int rp = it & 31, dc = it >> 5;
+            u32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+            const int r0 = row0 + 2 * rp;
+            if (r0 < nvalid) v0 = *reinterpret_cast<const u32x4*>(g + (long)r0 * stride + dc * 8);
+            if (r0 + 1 < nvalid) v1 = *reinterpret_cast<const u32x4*>(g + (long)(r0 + 1) * stride + dc * 8);
+            const uint16_t* a = reinterpret_cast<const uint16_t*>(&v0);
+            const uint16_t* b = reinterpret_cast<const uint16_t*>(&v1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = dc * 8 + e;
+                const uint32_t w = (uint32_t)a[e] | ((uint32_t)b[e] << 16);
+                *reinterpret_cast<uint32_t*>(lds + d * C::PROWB + (swz(d, rp >> 2, C::PCH) << 4) + ((rp & 3) << 2)) = w;
+            }
+        }
+    } else {
+        for (int it = threadIdx.x; it < 64 * C::NCH; it += 256) {
+            const int r = it & 63, dc = it >> 6;
+            u32x4 v = {0, 0, 0, 0};
+            if (row0 + r < nvalid) v = *reinterpret_cast<const u32x4*>(g + (long)(row0 + r) * stride + dc * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = dc * 4 + e;
+                *reinterpret_cast<uint32_t*>(lds + d * C::PROWB + (swz(d, r >> 2, C::PCH) << 4) + ((r & 3) << 2)) = v[e];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ u32x4 frag(const char* lds, int row, int chunk, int rowb, int nch) {
+    return *reinterpret_cast<const u32x4*>(lds + row * rowb + (swz(row, chunk, nch) << 4));
+}
+
+// accumulator-layout [16][64] values (acc[j][r]: row 4q+r, col 16j+r16) -> per-wave LDS tile, as T
+template <typename T>
+__device__ __forceinline__ void put_tile(char* lds, const f32x4 (&acc)[4], int q, int r16) {
+    constexpr int PROWB = 64 * (int)sizeof(T), PCH = PROWB / 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * q + r, byte = (16 * j + r16) * (int)sizeof(T);
+            *reinterpret_cast<T*>(lds + row * PROWB + (swz(row, byte >> 4, PCH) << 4) + (byte & 15)) = from_f32<T>(acc[j][r]);
+        }
+}
+// transposed variant: acc rows become LDS columns ([16 cols... used when the wave owns 16 "rows"
+// of the TRANSPOSED product: acc[j][r] = X^T[own 4q+r][other 16j+r16] is stored as is (same as put_tile).
+
+struct AttnArgs {
+    const void *Q, *K, *V; void* O; float* LSE;          // LSE [B][H][Tq]
+    const void *dO; void *dQ, *dK, *dV; const float* Delta;
+    long q_st, q_sb, k_st, k_sb, v_st, v_sb, o_st, o_sb;  // element strides (time, batch)
+    long dq_st, dq_sb, dk_st, dk_sb, dv_st, dv_sb, do_st, do_sb;
+    const int* klen;                                       // [B] valid keys (null = Tk)
+    int B, H, Tq, Tk, causal;
+    float scale, p_drop; unsigned long long seed;
+};
+
+__device__ __forceinline__ float drop_scale(const AttnArgs& p, int b, int h, int qrow, int key) {
+    if (p.p_drop <= 0.f) return 1.f;
+    const uint64_t idx = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + key;
+    const uint32_t th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
+    return dropout_keep(p.seed, idx, th) ? 1.f / (1.f - p.p_drop) : 0.f;
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    typedef ACfg<T, DH> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsK = smem;
+    char* ldsVt = smem + C::TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    char* ldsP = smem + 2 * C::TILE + wave * C::PTILE;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const T* Qg = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
+    const T* Kg = reinterpret_cast<const T*>(p.K) + (long)b * p.k_sb + (long)h * DH;
+    const T* Vg = reinterpret_cast<const T*>(p.V) + (long)b * p.v_sb + (long)h * DH;
+
+    u32x4 qf[C::KG];
+#pragma unroll
+    for (int g = 0; g < C::KG; ++g) {
+        qf[g] = (u32x4){0, 0, 0, 0};
+        if (q0 + r16 < p.Tq) qf[g] = *reinterpret_cast<const u32x4*>(Qg + (long)(q0 + r16) * p.q_st + (4 * g + q) * C::E);
+    }
+    f32x4 o[C::ND];
+#pragma unroll
+    for (int n = 0; n < C::ND; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, l[4] = {0.f, 0.f, 0.f, 0.f};
+
+    int kv_end = klen;
+    if (p.causal) kv_end = min(kv_end, blockIdx.x * 64 + 64);     // block-uniform bound
+    for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
+        __syncthreads();
+        stage_rows<T, DH>(ldsK, Kg, p.k_st, kv0, klen);
+        stage_cols<T, DH>(ldsVt, Vg, p.v_st, kv0, klen);
+        __syncthreads();
+        f32x4 s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < C::KG; ++g)
+                s[j] = mma16<T>(qf[g], frag(ldsK, 16 * j + r16, 4 * g + q, C::ROWB, C::NCH), s[j]);
+        }
+        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = kv0 + 16 * j + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = q0 + 4 * q + r;
+                const bool ok = key < klen && (!p.causal || key <= qrow);
+                s[j][r] = ok ? s[j][r] * p.scale : -INFINITY;
+                mx[r] = fmaxf(mx[r], s[j][r]);
+            }
+        }
+        float alpha[4], rs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = mx[r];
+            v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2));
+            v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 8));
+            const float mn = fmaxf(m[r], v);
+            const float mu = (mn == -INFINITY) ? 0.f : mn;
+            alpha[r] = __expf(m[r] - mu);          // m = -inf -> 0
+            m[r] = mn;
+            mx[r] = mu;
+            rs[r] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __expf(s[j][r] - mx[r]);
+                rs[r] += pv;
+                s[j][r] = pv * drop_scale(p, b, h, q0 + 4 * q + r, kv0 + 16 * j + r16);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = rs[r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            l[r] = l[r] * alpha[r] + v;
+        }
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[n][r] *= alpha[r];
+        put_tile<T>(ldsP, s, q, r16);                  // per-wave region: only this wave reads it back
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): LDS writes of this wave done
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < C::PKG; ++g) {
+            const u32x4 pa = frag(ldsP, r16, 4 * g + q, C::PROWB, C::PCH);
+#pragma unroll
+            for (int n = 0; n < C::ND; ++n)
+                o[n] = mma16<T>(pa, frag(ldsVt, 16 * n + r16, 4 * g + q, C::PROWB, C::PCH), o[n]);
+        }
+    }
+    T* Og = reinterpret_cast<T*>(p.O) + (long)b * p.o_sb + (long)h * DH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * q + r;
+        if (qrow >= p.Tq) continue;
+        const float inv = l[r] > 0.f ? 1.f / l[r] : 0.f;
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n) Og[(long)qrow * p.o_st + 16 * n + r16] = from_f32<T>(o[n][r] * inv);
+        if (r16 == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Tq + qrow] = m[r] + logf(l[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ delta
+// Delta[b][h][t] = sum_j dO[t,b,h,j] * O[t,b,h,j]   (one 16-lane group per row)
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p) {
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 4, li = threadIdx.x & 15;
+    const long total = (long)p.B * p.H * p.Tq;
+    float s = 0.f;
+    if (g < total) {
+        const int t = g % p.Tq, h = (g / p.Tq) % p.H, b = g / (p.Tq * p.H);
+        const T* o = reinterpret_cast<const T*>(p.O) + (long)t * p.o_st + (long)b * p.o_sb + (long)h * DH;
+        const T* d = reinterpret_cast<const T*>(p.dO) + (long)t * p.do_st + (long)b * p.do_sb + (long)h * DH;
+        for (int j = li; j < DH; j += 16) s += to_f32(o[j]) * to_f32(d[j]);
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+    if (g < total && li == 0) {
+        const int t = g % p.Tq, h = (g / p.Tq) % p.H, b = g / (p.Tq * p.H);
+        const_cast<float*>(p.Delta)[((long)b * p.H + h) * p.Tq + t] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------ dK, dV
+// Workgroup: 64 keys of one (b,h); wave w owns keys [16w,16w+16).  Loop over 64-query tiles.
+//   St = K Q^T (rows = keys)    Pt = exp(St*scale - LSE[q])     dV += (D*Pt) dO
+//   dPt = V dO^T                dSt = Pt * (D*dPt - Delta[q]) * scale       dK += dSt Q
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+    typedef ACfg<T, DH> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsQ = smem;                       // [64 q][DH]
+    char* ldsDO = smem + C::TILE;            // [64 q][DH]
+    char* ldsQt = smem + 2 * C::TILE;        // [DH][64 q]
+    char* ldsDOt = smem + 3 * C::TILE;       // [DH][64 q]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    char* ldsP = smem + 4 * C::TILE + wave * 2 * C::PTILE;
+    char* ldsS = ldsP + C::PTILE;
+    const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64 + wave * 16;
+    const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const T* Qg = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
+    const T* Kg = reinterpret_cast<const T*>(p.K) + (long)b * p.k_sb + (long)h * DH;
+    const T* Vg = reinterpret_cast<const T*>(p.V) + (long)b * p.v_sb + (long)h * DH;
+    const T* dOg = reinterpret_cast<const T*>(p.dO) + (long)b * p.do_sb + (long)h * DH;
+    const float* lse = p.LSE + ((long)b * p.H + h) * p.Tq;
+    const float* dlt = p.Delta + ((long)b * p.H + h) * p.Tq;
+
+    u32x4 kf[C::KG], vf[C::KG];
+#pragma unroll
+    for (int g = 0; g < C::KG; ++g) {
+        kf[g] = vf[g] = (u32x4){0, 0, 0, 0};
+        if (k0 + r16 < klen) {
+            kf[g] = *reinterpret_cast<const u32x4*>(Kg + (long)(k0 + r16) * p.k_st + (4 * g + q) * C::E);
+            vf[g] = *reinterpret_cast<const u32x4*>(Vg + (long)(k0 + r16) * p.v_st + (4 * g + q) * C::E);
+        }
+    }
+    f32x4 dk[C::ND], dv[C::ND];
+#pragma unroll
+    for (int n = 0; n < C::ND; ++n) { dk[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[n] = dk[n]; }
+
+    const int qstart = p.causal ? (blockIdx.x * 64) : 0;      // queries before the first key see nothing
+    for (int qt = qstart; qt < p.Tq; qt += 64) {
+        __syncthreads();
+        stage_rows<T, DH>(ldsQ, Qg, p.q_st, qt, p.Tq);
+        stage_rows<T, DH>(ldsDO, dOg, p.do_st, qt, p.Tq);
+        stage_cols<T, DH>(ldsQt, Qg, p.q_st, qt, p.Tq);
+        stage_cols<T, DH>(ldsDOt, dOg, p.do_st, qt, p.Tq);
+        __syncthreads();
+        f32x4 st[4], dp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = st[j];
+#pragma unroll
+            for (int g = 0; g < C::KG; ++g) {
+                st[j] = mma16<T>(kf[g], frag(ldsQ, 16 * j + r16, 4 * g + q, C::ROWB, C::NCH), st[j]);
+                dp[j] = mma16<T>(vf[g], frag(ldsDO, 16 * j + r16, 4 * g + q, C::ROWB, C::NCH), dp[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qrow = qt + 16 * j + r16;
+            const bool qok = qrow < p.Tq;
+            const float L = qok ? lse[qrow] : 0.f, Dl = qok ? dlt[qrow] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + 4 * q + r;
+                const bool ok = qok && key < klen && (!p.causal || key <= qrow);
+                const float pv = ok ? __expf(st[j][r] * p.scale - L) : 0.f;
+                const float ds = ok ? drop_scale(p, b, h, qrow, key) : 0.f;
+                st[j][r] = pv * ds;                                  // D*P   (for dV)
+                dp[j][r] = pv * (ds * dp[j][r] - Dl) * p.scale;      // dS    (for dK)
+            }
+        }
+        put_tile<T>(ldsP, st, q, r16);
+        put_tile<T>(ldsS, dp, q, r16);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < C::PKG; ++g) {
+            const u32x4 pa = frag(ldsP, r16, 4 * g + q, C::PROWB, C::PCH);
+            const u32x4 sa = frag(ldsS, r16, 4 * g + q, C::PROWB, C::PCH);
+#pragma unroll
+            for (int n = 0; n < C::ND; ++n) {
+                dv[n] = mma16<T>(pa, frag(ldsDOt, 16 * n + r16, 4 * g + q, C::PROWB, C::PCH), dv[n]);
+                dk[n] = mma16<T>(sa, frag(ldsQt, 16 * n + r16, 4 * g + q, C::PROWB, C::PCH), dk[n]);
+            }
+        }
+    }
+    T* dKg = reinterpret_cast<T*>(p.dK) + (long)b * p.dk_sb + (long)h * DH;
+    T* dVg = reinterpret_cast<T*>(p.dV) + (long)b * p.dv_sb + (long)h * DH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 4 * q + r;
+        if (key >= p.Tk) continue;
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n) {
+            dKg[(long)key * p.dk_st + 16 * n + r16] = from_f32<T>(dk[n][r]);
+            dVg[(long)key * p.dv_st + 16 * n + r16] = from_f32<T>(dv[n][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ dQ
+// Workgroup: 64 queries of one (b,h); wave w owns rows [16w,16w+16).  Loop over 64-key tiles.
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    typedef ACfg<T, DH> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ldsK = smem;                       // [64 keys][DH]
+    char* ldsV = smem + C::TILE;             // [64 keys][DH]
+    char* ldsKt = smem + 2 * C::TILE;        // [DH][64 keys]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    char* ldsS = smem + 3 * C::TILE + wave * C::PTILE;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 + wave * 16;
+    const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const T* Qg = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
+    const T* Kg = reinterpret_cast<const T*>(p.K) + (long)b * p.k_sb + (long)h * DH;
+    const T* Vg = reinterpret_cast<const T*>(p.V) + (long)b * p.v_sb + (long)h * DH;
+    const T* dOg = reinterpret_cast<const T*>(p.dO) + (long)b * p.do_sb + (long)h * DH;
+    const float* lse = p.LSE + ((long)b * p.H + h) * p.Tq;
+    const float* dlt = p.Delta + ((long)b * p.H + h) * p.Tq;
+
+    u32x4 qf[C::KG], dof[C::KG];
+#pragma unroll
+    for (int g = 0; g < C::KG; ++g) {
+        qf[g] = dof[g] = (u32x4){0, 0, 0, 0};
+        if (q0 + r16 < p.Tq) {
+            qf[g] = *reinterpret_cast<const u32x4*>(Qg + (long)(q0 + r16) * p.q_st + (4 * g + q) * C::E);
+            dof[g] = *reinterpret_cast<const u32x4*>(dOg + (long)(q0 + r16) * p.do_st + (4 * g + q) * C::E);
+        }
+    }
+    float L[4], Dl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * q + r;
+        L[r] = qrow < p.Tq ? lse[qrow] : 0.f;
+        Dl[r] = qrow < p.Tq ? dlt[qrow] : 0.f;
+    }
+    f32x4 dq[C::ND];
+#pragma unroll
+    for (int n = 0; n < C::ND; ++n) dq[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int kv_end = klen;
+    if (p.causal) kv_end = min(kv_end, blockIdx.x * 64 + 64);
+    for (int kv0 = 0; kv0 < kv_end; kv0 += 64) {
+        __syncthreads();
+        stage_rows<T, DH>(ldsK, Kg, p.k_st, kv0, klen);
+        stage_rows<T, DH>(ldsV, Vg, p.v_st, kv0, klen);
+        stage_cols<T, DH>(ldsKt, Kg, p.k_st, kv0, klen);
+        __syncthreads();
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j] = s[j];
+#pragma unroll
+            for (int g = 0; g < C::KG; ++g) {
+                s[j] = mma16<T>(qf[g], frag(ldsK, 16 * j + r16, 4 * g + q, C::ROWB, C::NCH), s[j]);
+                dp[j] = mma16<T>(dof[g], frag(ldsV, 16 * j + r16, 4 * g + q, C::ROWB, C::NCH), dp[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int key = kv0 + 16 * j + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = q0 + 4 * q + r;
+                const bool ok = qrow < p.Tq && key < klen && (!p.causal || key <= qrow);
+                const float pv = ok ? __expf(s[j][r] * p.scale - L[r]) : 0.f;
+                const float ds = ok ? drop_scale(p, b, h, qrow, key) : 0.f;
+                dp[j][r] = pv * (ds * dp[j][r] - Dl[r]) * p.scale;
+            }
+        }
+        put_tile<T>(ldsS, dp, q, r16);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < C::PKG; ++g) {
+            const u32x4 sa = frag(ldsS, r16, 4 * g + q, C::PROWB, C::PCH);
+#pragma unroll
+            for (int n = 0; n < C::ND; ++n)
+                dq[n] = mma16<T>(sa, frag(ldsKt, 16 * n + r16, 4 * g + q, C::PROWB, C::PCH), dq[n]);
+        }
+    }
+    T* dQg = reinterpret_cast<T*>(p.dQ) + (long)b * p.dq_sb + (long)h * DH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + 4 * q + r;
+        if (qrow >= p.Tq) continue;
+#pragma unroll
+        for (int n = 0; n < C::ND; ++n) dQg[(long)qrow * p.dq_st + 16 * n + r16] = from_f32<T>(dq[n][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ C ABI
+static bool strides_ok(int dtype, const long* s, int n) {
+    const int e = dtype == S2T_BF16 ? 8 : 4;
+    for (int i = 0; i < n; ++i) if (s[i] % e) return false;
+    return true;
+}
+
+template <typename T, int DH> static int fwd_launch(const AttnArgs& a, hipStream_t st) {
+    typedef ACfg<T, DH> C;
+    dim3 grid((a.Tq + 63) / 64, a.H, a.B);
+    const size_t lds = 2 * C::TILE + 4 * C::PTILE;
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), grid, dim3(256), lds, st, a);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream_t st) {
+    typedef ACfg<T, DH> C;
+    const long rows = (long)a.B * a.H * a.Tq;
+    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
+    S2T_LAUNCH_CHECK();
+    {
+        static bool attr = false;
+        const size_t lds = 4 * C::TILE + 8 * C::PTILE;
+        if (!attr && lds > 65536) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<T, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH>), dim3((a.Tk + 63) / 64, a.H, a.B), dim3(256), lds, st, a);
+        S2T_LAUNCH_CHECK();
+    }
+    {
+        static bool attr = false;
+        const size_t lds = 3 * C::TILE + 4 * C::PTILE;
+        if (!attr && lds > 65536) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<T, DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DH>), dim3((a.Tq + 63) / 64, a.H, a.B), dim3(256), lds, st, a);
+        S2T_LAUNCH_CHECK();
+    }
+    return S2T_OK;
+}
+
+static int check_common(int dtype, int head_dim, const AttnArgs& a) {
+    if (dtype != S2T_F32 && dtype != S2T_BF16) return S2T_ENOTSUP;
+    if (head_dim != 64 && head_dim != 32) return S2T_ENOTSUP;
+    if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return S2T_EINVAL;
+    if (a.p_drop < 0.f || a.p_drop >= 1.f) return S2T_EINVAL;
+    return S2T_OK;
+}
+
+extern "C" int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
+                            const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
+                            const void* V, long v_st, long v_sb, void* O, long o_st, long o_sb, float* LSE,
+                            const int* klen, int causal, float scale, float p_drop, unsigned long long seed,
+                            void* stream) {
+    AttnArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE;
+    a.q_st = q_st; a.q_sb = q_sb; a.k_st = k_st; a.k_sb = k_sb; a.v_st = v_st; a.v_sb = v_sb; a.o_st = o_st; a.o_sb = o_sb;
+    a.klen = klen; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    if (B == 0 || Tq == 0) return S2T_OK;
+    int rc = check_common(dtype, head_dim, a);
+    if (rc) return rc;
+    if (!Q || !K || !V || !O) return S2T_EINVAL;
+    const long s[] = {q_st, q_sb, k_st, k_sb, v_st, v_sb};
+    if (!strides_ok(dtype, s, 6)) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("attn_fwd", st, 4.0 * B * H * (double)Tq * Tk * head_dim * (causal ? 0.5 : 1.0), 0.0);
+    if (dtype == S2T_BF16) return head_dim == 64 ? fwd_launch<bf16, 64>(a, st) : fwd_launch<bf16, 32>(a, st);
+    return head_dim == 64 ? fwd_launch<float, 64>(a, st) : fwd_launch<float, 32>(a, st);
+}
+
+extern "C" int s2t_attn_bwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
+                            const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
+                            const void* V, long v_st, long v_sb, const void* O, long o_st, long o_sb,
+                            const void* dO, long do_st, long do_sb, const float* LSE, float* Delta,
+                            void* dQ, long dq_st, long dq_sb, void* dK, long dk_st, long dk_sb,
+                            void* dV, long dv_st, long dv_sb,
+                            const int* klen, int causal, float scale, float p_drop, unsigned long long seed,
+                            void* stream) {
+    AttnArgs a{};
+    a.Q = Q; a.K = K; a.V = V; a.O = const_cast<void*>(O); a.LSE = const_cast<float*>(LSE);
+    a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.Delta = Delta;
+    a.q_st = q_st; a.q_sb = q_sb; a.k_st = k_st; a.k_sb = k_sb; a.v_st = v_st; a.v_sb = v_sb; a.o_st = o_st; a.o_sb = o_sb;
+    a.dq_st = dq_st; a.dq_sb = dq_sb; a.dk_st = dk_st; a.dk_sb = dk_sb; a.dv_st = dv_st; a.dv_sb = dv_sb; a.do_st = do_st; a.do_sb = do_sb;
+    a.klen = klen; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
+    if (B == 0 || Tq == 0) return S2T_OK;
+    int rc = check_common(dtype, head_dim, a);
+    if (rc) return rc;
+    if (!Q || !K || !V || !O || !dO || !LSE || !Delta || !dQ || !dK || !dV) return S2T_EINVAL;
+    const long s[] = {q_st, q_sb, k_st, k_sb, v_st, v_sb, do_st, do_sb};
+    if (!strides_ok(dtype, s, 8)) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("attn_bwd", st, 14.0 * B * H * (double)Tq * Tk * head_dim * (causal ? 0.5 : 1.0), 0.0);
+    if (dtype == S2T_BF16) return head_dim == 64 ? bwd_launch<bf16, 64>(a, st) : bwd_launch<bf16, 32>(a, st);
+    return head_dim == 64 ? bwd_launch<float, 64>(a, st) : bwd_launch<float, 32>(a, st);
+}

@@ -1,0 +1,375 @@
+// CTC-based compression of the encoder sequence and the CTC loss.
+// Reference: examples/speech_recognition/models/conv_transformer.py:278-291,385-426
+//            (average_same_ctc_features / CTCCompressStrategy) and
+//            examples/speech_recognition/criterions/CTC_loss.py:101-175 (F.log_softmax + F.ctc_loss,
+//            reduction="sum", zero_infinity=True).
+// The integer part (arg-max of the softmax output with first-index ties, run-length collapse inside
+// src_lengths[b], new lengths) is bit-exact by construction; nothing here goes through a dense
+// (B, T, T') weight matrix: compression is a segment-weighted sum, its backward a gather.
+#include "common.hpp"
+
+// ------------------------------------------------------------------ softmax arg-max per frame
+// logits [T][B][V] (T dtype) -> pred[b][t] = first index of max softmax(logits)[v]; pmax[b][t] = that
+// probability (f32).  One wavefront per (t,b) row, three passes over the row (L2-resident).
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_argmax_kernel(const T* __restrict__ logits, int* __restrict__ pred,
+                                                         float* __restrict__ pmax, int Tn, int B, int V) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)Tn * B) return;
+    const int t = (int)(row / B), b = (int)(row % B);
+    const T* x = logits + row * V;
+    float m = -INFINITY;
+    for (int j = lane; j < V; j += 64) m = fmaxf(m, to_f32(x[j]));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < V; j += 64) s += expf(to_f32(x[j]) - m);
+    s = wave_sum(s);
+    float best = -1.f; int bi = 0x7fffffff;
+    for (int j = lane; j < V; j += 64) {
+        const float p = expf(to_f32(x[j]) - m) / s;           // the softmax value torch would compare
+        if (p > best) { best = p; bi = j; }                      // strict: keeps the lowest index per lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { pred[(long)b * Tn + t] = bi; pmax[(long)b * Tn + t] = best; }
+}
+
+// ------------------------------------------------------------------ run-length collapse + weights
+// One wavefront per utterance.  seg[b][t] = run index (-1 beyond len), run_start/run_len[b][j],
+// new_len[b]; w[b][t] = weight of frame t inside its run:
+//   strategy 0 avg:      1/run_len            (python double 1.0/n rounded to f32, :394)
+//   strategy 1 weighted: p_t / sum_run p      (:407-409)
+//   strategy 2 softmax:  softmax_run(p)_t / sum (= softmax over the run, :422-424)
+__global__ __launch_bounds__(64) void ctc_rle_kernel(const int* __restrict__ pred, const float* __restrict__ pmax,
+                                                     const long long* __restrict__ len, int* __restrict__ seg,
+                                                     int* __restrict__ run_start, int* __restrict__ run_len,
+                                                     long long* __restrict__ new_len, float* __restrict__ w,
+                                                     int Tn, int strategy) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int L = (int)min((long long)Tn, len[b]);
+    const int* p = pred + (long)b * Tn;
+    int* sg = seg + (long)b * Tn; int* rs = run_start + (long)b * Tn; int* rl = run_len + (long)b * Tn;
+    int base = 0;                                   // runs before this 64-frame chunk
+    for (int t0 = 0; t0 < Tn; t0 += 64) {
+        const int t = t0 + lane;
+        const bool valid = t < L;
+        const bool head = valid && (t == 0 || p[t] != p[t - 1]);
+        const unsigned long long heads = __ballot(head);
+        const int before = __popcll(heads & ((1ull << lane) - 1ull)) + (head ? 1 : 0);
+        const int id = valid ? base + before - 1 : -1;
+        if (t < Tn) { sg[t] = id; rs[t] = 0; rl[t] = 0; }
+        base += __popcll(heads);
+    }
+    __syncthreads();
+    for (int t = lane; t < L; t += 64) {             // run boundaries
+        const int id = sg[t];
+        if (t == 0 || sg[t - 1] != id) rs[id] = t;
+        if (t == L - 1 || sg[t + 1] != id) rl[id] = t + 1;   // temporarily the end index
+    }
+    __syncthreads();
+    for (int j = lane; j < base; j += 64) rl[j] = rl[j] - rs[j];
+    if (lane == 0) new_len[b] = base;
+    __syncthreads();
+    float* wb = w + (long)b * Tn;
+    const float* pm = pmax + (long)b * Tn;
+    for (int t = lane; t < Tn; t += 64) {
+        if (t >= L) { wb[t] = 0.f; continue; }
+        const int id = sg[t], s0 = rs[id], n = rl[id];
+        if (strategy == 0) wb[t] = (float)(1.0 / (double)n);
+        else if (strategy == 1) {
+            float sum = 0.f;
+            for (int k = 0; k < n; ++k) sum += pm[s0 + k];
+            wb[t] = pm[t] / sum;
+        } else {
+            float mx = -INFINITY;
+            for (int k = 0; k < n; ++k) mx = fmaxf(mx, pm[s0 + k]);
+            float sum = 0.f;
+            for (int k = 0; k < n; ++k) sum += expf(pm[s0 + k] - mx);
+            const float sm = expf(pm[t] - mx) / sum;
+            float tot = 0.f;
+            for (int k = 0; k < n; ++k) tot += expf(pm[s0 + k] - mx) / sum;
+            wb[t] = sm / tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ segment-weighted sum (forward)
+// out[j][b][:] = sum_{t in run j} w[b][t] * x[t][b][:]   for j < new_len[b], zeros up to Tout
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_compress_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               const int* __restrict__ run_start, const int* __restrict__ run_len,
+                                                               const long long* __restrict__ new_len, T* __restrict__ out,
+                                                               int Tn, int B, int D, int Tout) {
+    const int j = blockIdx.x, b = blockIdx.y;
+    T* o = out + ((long)j * B + b) * D;
+    if (j >= new_len[b]) { for (int d = threadIdx.x; d < D; d += 256) o[d] = from_f32<T>(0.f); return; }
+    const int s0 = run_start[(long)b * Tn + j], n = run_len[(long)b * Tn + j];
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc += w[(long)b * Tn + s0 + k] * to_f32(x[((long)(s0 + k) * B + b) * D + d]);
+        o[d] = from_f32<T>(acc);
+    }
+}
+
+// backward: dx[t][b][:] (+)= w[b][t] * dout[seg[b][t]][b][:]   (weights carry no gradient, :280)
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_compress_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ w,
+                                                               const int* __restrict__ seg, T* __restrict__ dx,
+                                                               int Tn, int B, int D, int accumulate) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int id = seg[(long)b * Tn + t];
+    const float wt = id >= 0 ? w[(long)b * Tn + t] : 0.f;
+    T* o = dx + ((long)t * B + b) * D;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float v = id >= 0 ? wt * to_f32(dout[((long)id * B + b) * D + d]) : 0.f;
+        if (accumulate) v += to_f32(o[d]);
+        o[d] = from_f32<T>(v);
+    }
+}
+
+// ------------------------------------------------------------------ CTC loss
+// Pass 1: per (t,b) row log-sum-exp of the logits (f32) -> lse[t][b].
+template <typename T>
+__global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ logits, float* __restrict__ lse, long rows, int V) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* x = logits + row * V;
+    float m = -INFINITY;
+    for (int j = lane; j < V; j += 64) m = fmaxf(m, to_f32(x[j]));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < V; j += 64) s += expf(to_f32(x[j]) - m);
+    s = wave_sum(s);
+    if (lane == 0) lse[row] = m + logf(s);
+}
+
+__device__ __forceinline__ float lae(float a, float b) {          // log(exp a + exp b), -inf safe
+    if (a == -INFINITY) return b;
+    if (b == -INFINITY) return a;
+    const float m = fmaxf(a, b);
+    return m + log1pf(expf(-fabsf(a - b)));
+}
+
+// Pass 2: alpha (wave 0) and beta (wave 1) recursions of one utterance in log space.
+// Extended target ext[s], s < S = 2L+1 <= 64*SPL; lane owns SPL consecutive s; the two neighbours
+// needed from the previous lane travel by shuffle.  Emissions lp[t][ext[s]] = logit - lse are
+// gathered CH time steps at a time into LDS by the whole workgroup.
+// Outputs: la/lb [B][T][Smax] (f32 log alpha/beta), nll[b] (0 if infeasible: zero_infinity).
+#define CTC_SPL 4
+#define CTC_CH 16
+template <typename T>
+__global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict__ logits, const float* __restrict__ lse,
+                                                            const long long* __restrict__ targets, const long long* __restrict__ tgt_len,
+                                                            const int* __restrict__ in_len, float* __restrict__ la,
+                                                            float* __restrict__ lb, float* __restrict__ nll, int Tn, int B,
+                                                            int V, int Lmax, int Smax, int blank) {
+    __shared__ float em[2][CTC_CH][64 * CTC_SPL];
+    __shared__ int ext_s[64 * CTC_SPL];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, dir = threadIdx.x >> 6;
+    const int L = (int)tgt_len[b], S = 2 * L + 1, Tb = min(in_len[b], Tn);
+    for (int s = threadIdx.x; s < 64 * CTC_SPL; s += 128)
+        ext_s[s] = (s < S) ? ((s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : blank) : -1;
+    __syncthreads();
+    float a[CTC_SPL];
+    bool skip2[CTC_SPL];          // alpha: may come from s-2 ; beta: may go to s+2
+    int es[CTC_SPL];
+#pragma unroll
+    for (int i = 0; i < CTC_SPL; ++i) {
+        const int s = lane * CTC_SPL + i;
+        es[i] = ext_s[s];
+        a[i] = -INFINITY;
+        if (dir == 0) skip2[i] = (s >= 2 && s < S && es[i] != blank && es[i] != ext_s[s - 2]);
+        else skip2[i] = (s + 2 < S && ext_s[s + 2] != blank && ext_s[s + 2] != es[i]);
+    }
+    float* out = (dir == 0 ? la : lb) + (long)b * Tn * Smax;
+    const int nch = (Tb + CTC_CH - 1) / CTC_CH;
+    for (int ch = 0; ch < nch; ++ch) {
+        // chunk of time steps handled in this iteration: alpha walks forward, beta backward
+        const int ta0 = ch * CTC_CH, tb0 = Tb - 1 - ch * CTC_CH;
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 2 * CTC_CH * S; idx += 128) {
+            const int d = idx / (CTC_CH * S), r = idx % (CTC_CH * S), k = r / S, s = r % S;
+            const int t = d == 0 ? ta0 + k : tb0 - k;
+            float v = -INFINITY;
+            if (t >= 0 && t < Tb) v = to_f32(logits[((long)t * B + b) * V + ext_s[s]]) - lse[(long)t * B + b];
+            em[d][k][s] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < CTC_CH; ++k) {
+            const int t = dir == 0 ? ta0 + k : tb0 - k;
+            if (t < 0 || t >= Tb) break;
+            float n[CTC_SPL];
+            if (dir == 0) {
+                const float p1 = __shfl_up(a[CTC_SPL - 1], 1), p2 = __shfl_up(a[CTC_SPL - 2], 1);
+#pragma unroll
+                for (int i = 0; i < CTC_SPL; ++i) {
+                    const int s = lane * CTC_SPL + i;
+                    float v;
+                    if (t == 0) v = (s <= 1 && s < S) ? 0.f : -INFINITY;
+                    else {
+                        const float m1 = (i >= 1) ? a[i - 1] : (lane > 0 ? p1 : -INFINITY);
+                        const float m2 = (i >= 2) ? a[i - 2] : (lane > 0 ? (i == 1 ? p1 : p2) : -INFINITY);
+                        v = lae(a[i], m1);
+                        if (skip2[i]) v = lae(v, m2);
+                    }
+                    n[i] = (s < S) ? v + em[0][k][s] : -INFINITY;
+                }
+            } else {
+                const float p1 = __shfl_down(a[0], 1), p2 = __shfl_down(a[1], 1);
+#pragma unroll
+                for (int i = 0; i < CTC_SPL; ++i) {
+                    const int s = lane * CTC_SPL + i;
+                    float v;
+                    if (t == Tb - 1) v = (s < S && s >= S - 2) ? 0.f : -INFINITY;
+                    else {
+                        const float m1 = (i + 1 < CTC_SPL) ? a[i + 1] : (lane < 63 ? p1 : -INFINITY);
+                        const float m2 = (i + 2 < CTC_SPL) ? a[i + 2] : (lane < 63 ? (i + 2 == CTC_SPL ? p1 : p2) : -INFINITY);
+                        v = lae(a[i], m1);
+                        if (skip2[i]) v = lae(v, m2);
+                    }
+                    n[i] = (s < S) ? v + em[1][k][s] : -INFINITY;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CTC_SPL; ++i) {
+                a[i] = n[i];
+                const int s = lane * CTC_SPL + i;
+                if (s < S) out[(long)t * Smax + s] = a[i];
+            }
+        }
+    }
+    if (dir == 0) {
+        // log-likelihood = logaddexp(alpha[Tb-1][S-1], alpha[Tb-1][S-2])
+        float v = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < CTC_SPL; ++i) {
+            const int s = lane * CTC_SPL + i;
+            if (s < S && s >= S - 2) v = lae(v, a[i]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = lae(v, __shfl_xor(v, o));
+        if (lane == 0) nll[b] = (Tb > 0 && v > -INFINITY) ? -v : INFINITY;
+    }
+}
+
+// Pass 3: gradient w.r.t. the logits, one workgroup per (t,b) row:
+//   g[c] = softmax[c] - sum_{s: ext[s]=c} exp(la+lb - lp[c] + nll)   for t < in_len[b] and finite nll, else 0
+// and the summed loss (atomic add of the finite nll's, done by the t = 0 rows).
+template <typename T>
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ logits, const float* __restrict__ lse,
+                                                       const long long* __restrict__ targets, const long long* __restrict__ tgt_len,
+                                                       const int* __restrict__ in_len, const float* __restrict__ la,
+                                                       const float* __restrict__ lb, const float* __restrict__ nll,
+                                                       T* __restrict__ grad, float* __restrict__ loss_sum, int Tn, int B,
+                                                       int V, int Lmax, int Smax, int blank, float gscale) {
+    extern __shared__ float occ[];                      // [V]
+    const int t = blockIdx.x, b = blockIdx.y;
+    const long row = (long)t * B + b;
+    T* g = grad + row * V;
+    const float nl = nll[b];
+    const bool live = t < min(in_len[b], Tn) && nl < INFINITY;
+    if (t == 0 && threadIdx.x == 0 && nl < INFINITY) atomicAdd(loss_sum, nl);
+    if (!live) { for (int c = threadIdx.x; c < V; c += 256) g[c] = from_f32<T>(0.f); return; }
+    const float ls = lse[row];
+    const T* x = logits + row * V;
+    for (int c = threadIdx.x; c < V; c += 256) occ[c] = 0.f;
+    __syncthreads();
+    const int S = 2 * (int)tgt_len[b] + 1;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const int c = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : blank;
+        const float lab = la[((long)b * Tn + t) * Smax + s] + lb[((long)b * Tn + t) * Smax + s];
+        if (lab > -INFINITY) {
+            const float lp = to_f32(x[c]) - ls;
+            atomicAdd(&occ[c], expf(lab - lp + nl));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < V; c += 256) g[c] = from_f32<T>((expf(to_f32(x[c]) - ls) - occ[c]) * gscale);
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, void* stream) {
+    const long rows = (long)T * B;
+    if (rows <= 0) return S2T_OK;
+    if (!logits || !pred || !pmax || V <= 0) return S2T_EINVAL;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, T, B, V);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, pred, pmax, T, B, V);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_ctc_rle(const int* pred, const float* pmax, const long long* len, int* seg, int* run_start,
+                           int* run_len, long long* new_len, float* w, int T, int B, int strategy, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!pred || !pmax || !len || !seg || !run_start || !run_len || !new_len || !w || strategy < 0 || strategy > 2) return S2T_EINVAL;
+    hipLaunchKernelGGL(ctc_rle_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, pmax, len, seg, run_start, run_len, new_len, w, T, strategy);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_ctc_compress_fwd(int dtype, const void* x, const float* w, const int* run_start, const int* run_len,
+                                    const long long* new_len, void* out, int T, int B, int D, int Tout, void* stream) {
+    if (B <= 0 || Tout <= 0) return S2T_OK;
+    if (!x || !w || !run_start || !run_len || !new_len || !out || Tout > T) return S2T_EINVAL;
+    dim3 grid(Tout, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_compress_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, w, run_start, run_len, new_len, (bf16*)out, T, B, D, Tout);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_compress_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, run_start, run_len, new_len, (float*)out, T, B, D, Tout);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int* seg, void* dx, int T, int B,
+                                    int D, int accumulate, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!dout || !w || !seg || !dx) return S2T_EINVAL;
+    dim3 grid(T, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_compress_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dout, w, seg, (bf16*)dx, T, B, D, accumulate);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_compress_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, w, seg, (float*)dx, T, B, D, accumulate);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+// Fused log-softmax + CTC loss (sum, zero_infinity) + gradient w.r.t. the logits.
+//   logits [T][B][V]; targets [B][Lmax] int64 (first tgt_len[b] entries); in_len [B] int32
+//   workspaces: lse [T*B] f32, la/lb [B*T*Smax] f32 with Smax = 2*Lmax+1, nll [B] f32
+//   outputs: grad [T][B][V] (dtype), loss_sum[0] += sum of finite nll  (caller zeroes it)
+extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len,
+                            const int* in_len, float* lse, float* la, float* lb, float* nll, void* grad,
+                            float* loss_sum, int T, int B, int V, int Lmax, int blank, float grad_scale, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!logits || !targets || !tgt_len || !in_len || !lse || !la || !lb || !nll || !grad || !loss_sum) return S2T_EINVAL;
+    const int Smax = 2 * Lmax + 1;
+    if (Smax > 64 * CTC_SPL) return S2T_ENOTSUP;          // transcripts longer than 127 tokens
+    if ((size_t)V * 4 > 160 * 1024 - 1024) return S2T_ENOTSUP;
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)T * B;
+    dim3 g1((unsigned)((rows + 3) / 4)), g3(T, B);
+    const size_t lds = (size_t)V * 4;
+    if (dtype == S2T_BF16) {
+        hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V);
+        hipLaunchKernelGGL(ctc_alphabeta_kernel<bf16>, dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, Lmax, Smax, blank);
+        static bool attr = false;
+        if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
+        hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, loss_sum, T, B, V, Lmax, Smax, blank, grad_scale);
+    } else if (dtype == S2T_F32) {
+        hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V);
+        hipLaunchKernelGGL(ctc_alphabeta_kernel<float>, dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, Lmax, Smax, blank);
+        static bool attr = false;
+        if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
+        hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, loss_sum, T, B, V, Lmax, Smax, blank, grad_scale);
+    } else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

@@ -1,0 +1,345 @@
+// MFMA GEMM with fused epilogues for the Transformer projections / FFN of the S2T path
+// (reference call sites: F.linear in fairseq/modules/multihead_attention.py:190-208,
+//  fairseq/modules/transformer_layer.py:132-134, examples/speech_recognition/models/conv_transformer.py:227,279,
+//  fairseq/models/transformer.py:784-788, and their autograd backward).
+//
+// C[M,N] = epi( op(A)[M,K] . op(B)[K,N] )
+//   TA=0: A stored [M][K] (k contiguous)     TA=1: A stored [K][M]  (dW = dY^T X)
+//   TB=0: B stored [N][K] (weight layout)    TB=1: B stored [K][N]  (dX = dY W, dW)
+// Tile BMxBN, 256 threads = 4 waves (2x2), each wave (BM/2)x(BN/2) as 16x16 MFMA tiles.
+// LDS image of either operand is always [row][128 bytes of k] with the 16-byte chunk index
+// XOR-swizzled by (row & 7): conflict-free ds_read_b128 fragment reads (cdna_hip_programming.md T2)
+// and conflict-free ds_write_b128/b64 staging in both the direct and the transposing path.
+// The kernel is byte-generic: 128 B of k per row = 64 bf16 or 32 f32; one "k-group" = 16 B per lane.
+// Double-buffered LDS, global loads of tile t+1 issued before the MFMAs of tile t and written to
+// LDS after them (register-staged prefetch, one barrier per k-tile).
+#include "common.hpp"
+#include "prof.hpp"
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;
+    const float* bias; const void* residual; const void* aux; void* aux_out;
+    int M, N, K, lda, ldb, ldc, ldr, ldaux;
+    int act, accumulate, splitk;
+    float alpha;
+    // optional row gather / scatter (implicit-GEMM convolution, subsample.hip):
+    //  mapA (A direct):  A(row r, k) = Asrc[ mapA[(k/periodA)*M + r] ][ k % periodA ]   (-1 -> zeros)
+    //  mapB (B stored [K][N]): B(k, :) = Bsrc[ mapB[k] ][:]                                 (-1 -> zeros)
+    //  mapC: output row r is written to C row mapC[r]
+    const int* mapA; int periodA; const int* mapB; const int* mapC;
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_GELU_BWD = 4 };
+
+template <typename T> __device__ __forceinline__ u32x4 load16_guard(const T* p, int valid) {
+    // element-wise guarded load of up to 16 bytes (valid = number of in-bounds elements)
+    constexpr int E = Elem<T>::PER16;
+    T tmp[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) tmp[i] = (i < valid) ? p[i] : from_f32<T>(0.f);
+    return *reinterpret_cast<u32x4*>(tmp);
+}
+
+// ---- stage a tile whose k is contiguous in global memory: rows x 128 B
+template <typename T, int ROWS>
+struct StageDirect {
+    static constexpr int E = Elem<T>::PER16;
+    static constexpr int N = ROWS * 8 / 256;     // 16-B chunks per thread
+    u32x4 r[N];
+    __device__ __forceinline__ void load(const T* g, int ld, int row0, int nrows, int k0, int K, bool vec,
+                                         const int* map = nullptr, int period = 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            const int gr = row0 + row, gk = k0 + c * E;
+            u32x4 v = {0, 0, 0, 0};
+            if (gr < nrows && gk < K) {
+                long src = gr; int kk = gk;
+                if (map) { const int tap = gk / period; kk = gk - tap * period; src = map[(size_t)tap * nrows + gr]; }
+                if (src >= 0) {
+                    const T* p = g + (size_t)src * ld + kk;
+                    if (vec && gk + E <= K) v = *reinterpret_cast<const u32x4*>(p);
+                    else v = load16_guard<T>(p, K - gk);
+                }
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            *reinterpret_cast<u32x4*>(lds + row * 128 + ((c ^ (row & 7)) << 4)) = r[i];
+        }
+    }
+};
+
+// ---- stage a tile whose k is the strided dimension in global memory ([K][cols], cols contiguous):
+//      each work item = 4 consecutive k x E consecutive cols, transposed in registers.
+template <typename T, int COLS>
+struct StageTrans {
+    static constexpr int E = Elem<T>::PER16;
+    static constexpr int BK = 128 / (int)sizeof(T);
+    static constexpr int NKQ = BK / 4;                  // k-quads per tile (16 bf16 / 8 f32)
+    static constexpr int ITEMS = (COLS / E) * NKQ;      // 256 at COLS=128, 128 at COLS=64
+    static constexpr int N = (ITEMS + 255) / 256;
+    u32x4 r[N][4];
+    __device__ __forceinline__ void load(const T* g, int ld, int col0, int ncols, int k0, int K, bool vec,
+                                         const int* map = nullptr, int period = 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int it = threadIdx.x + 256 * i;
+            const int kq = it % NKQ, cg = it / NKQ;
+            const int gc = col0 + cg * E;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int gk = k0 + 4 * kq + rr;
+                u32x4 v = {0, 0, 0, 0};
+                if (it < ITEMS && gk < K && gc < ncols) {
+                    const long src = map ? (long)map[gk] : (long)gk;
+                    if (src >= 0) {
+                        const T* p = g + (size_t)src * ld + gc;
+                        if (vec && gc + E <= ncols) v = *reinterpret_cast<const u32x4*>(p);
+                        else v = load16_guard<T>(p, ncols - gc);
+                    }
+                }
+                r[i][rr] = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int it = threadIdx.x + 256 * i;
+            if (it >= ITEMS) continue;
+            const int kq = it % NKQ, cg = it / NKQ;
+            if constexpr (sizeof(T) == 2) {
+                // 4(k) x 8(col) bf16 -> for each col 4 k-contiguous bf16 = 8 bytes
+                const uint16_t* e0 = reinterpret_cast<const uint16_t*>(&r[i][0]);
+                const uint16_t* e1 = reinterpret_cast<const uint16_t*>(&r[i][1]);
+                const uint16_t* e2 = reinterpret_cast<const uint16_t*>(&r[i][2]);
+                const uint16_t* e3 = reinterpret_cast<const uint16_t*>(&r[i][3]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = cg * 8 + j;
+                    u32x2 v;
+                    v[0] = (uint32_t)e0[j] | ((uint32_t)e1[j] << 16);
+                    v[1] = (uint32_t)e2[j] | ((uint32_t)e3[j] << 16);
+                    *reinterpret_cast<u32x2*>(lds + col * 128 + (((kq >> 1) ^ (col & 7)) << 4) + ((kq & 1) << 3)) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = cg * 4 + j;
+                    u32x4 v = {r[i][0][j], r[i][1][j], r[i][2][j], r[i][3][j]};
+                    *reinterpret_cast<u32x4*>(lds + col * 128 + ((kq ^ (col & 7)) << 4)) = v;
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int ROWS, bool TRANS> struct StageSel { typedef StageDirect<T, ROWS> type; };
+template <typename T, int ROWS> struct StageSel<T, ROWS, true> { typedef StageTrans<T, ROWS> type; };
+
+template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    constexpr int BK = 128 / (int)sizeof(TI);
+    constexpr int MT = BM / 32, NT = BN / 32;            // 16x16 tiles per wave in m / n
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (BM + BN) * 128;                // bytes of one (A,B) buffer pair
+
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int per = (nk_total + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, kt1 = min(nk_total, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    const TI* A = reinterpret_cast<const TI*>(p.A);
+    const TI* B = reinterpret_cast<const TI*>(p.B);
+    constexpr int E = Elem<TI>::PER16;
+    const bool vecA = (p.lda % E == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+    const bool vecB = (p.ldb % E == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+
+    typename StageSel<TI, BM, TA>::type sa;
+    typename StageSel<TI, BN, TB>::type sb;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    sa.load(A, p.lda, row0, p.M, kt0 * BK, p.K, vecA, p.mapA, p.periodA);
+    sb.load(B, p.ldb, col0, p.N, kt0 * BK, p.K, vecB, p.mapB, 0);
+    sa.store(smem);
+    sb.store(smem + BM * 128);
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = (kt + 1 < kt1);
+        if (more) {
+            sa.load(A, p.lda, row0, p.M, (kt + 1) * BK, p.K, vecA, p.mapA, p.periodA);
+            sb.load(B, p.ldb, col0, p.N, (kt + 1) * BK, p.K, vecB, p.mapB, 0);
+        }
+        const char* la = smem + cur * STAGE + (wr * (BM / 2)) * 128;
+        const char* lb = smem + cur * STAGE + BM * 128 + (wc * (BN / 2)) * 128;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 fa[MT], fb[NT];
+            const int ch = 4 * s + q;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = 16 * i + r16;           // (wr*(BM/2)) is a multiple of 8 -> same swizzle
+                fa[i] = *reinterpret_cast<const u32x4*>(la + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int row = 16 * j + r16;
+                fb[j] = *reinterpret_cast<const u32x4*>(lb + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mma16<TI>(fa[i], fb[j], acc[i][j]);
+        }
+        if (more) {
+            sa.store(smem + (cur ^ 1) * STAGE);
+            sb.store(smem + (cur ^ 1) * STAGE + BM * 128);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue
+    TO* C = reinterpret_cast<TO*>(p.C);
+    const TO* R = reinterpret_cast<const TO*>(p.residual);
+    const TO* AUX = reinterpret_cast<const TO*>(p.aux);
+    TO* AUXO = reinterpret_cast<TO*>(p.aux_out);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = col0 + wc * (BN / 2) + 16 * j + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wr * (BM / 2) + 16 * i + 4 * q + r;
+                if (row >= p.M || col >= p.N) continue;
+                float v = acc[i][j][r] * p.alpha;
+                const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
+                if constexpr (sizeof(TO) == 4) {
+                    if (p.splitk > 1) {
+                        atomicAdd(reinterpret_cast<float*>(C) + orow * p.ldc + col, v);
+                        continue;
+                    }
+                }
+                if (p.bias) v += p.bias[col];
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == ACT_GELU) {
+                    if (AUXO) AUXO[(size_t)row * p.ldaux + col] = from_f32<TO>(v);
+                    v = gelu_f(v);
+                } else if (p.act == ACT_RELU_BWD) {
+                    v = (to_f32(AUX[(size_t)row * p.ldaux + col]) > 0.f) ? v : 0.f;
+                } else if (p.act == ACT_GELU_BWD) {
+                    v *= gelu_grad_f(to_f32(AUX[(size_t)row * p.ldaux + col]));
+                }
+                if (R) v += to_f32(R[(size_t)row * p.ldr + col]);
+                TO* dst = C + orow * p.ldc + col;
+                if (p.accumulate) v += to_f32(*dst);
+                *dst = from_f32<TO>(v);
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
+static int launch(const GemmArgs& a, hipStream_t st) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, a.splitk);
+    const size_t lds = 2 * (BM + BN) * 128;
+    hipLaunchKernelGGL((gemm_kernel<TI, TO, TA, TB, BM, BN>), grid, dim3(256), lds, st, a);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+template <typename TI, typename TO, int BM, int BN>
+static int launch_t(const GemmArgs& a, int ta, int tb, hipStream_t st) {
+    if (!ta && !tb) return launch<TI, TO, false, false, BM, BN>(a, st);
+    if (!ta && tb) return launch<TI, TO, false, true, BM, BN>(a, st);
+    if (ta && tb) return launch<TI, TO, true, true, BM, BN>(a, st);
+    return S2T_ENOTSUP;   // A^T . B^T never occurs on this path
+}
+
+extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
+                               const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                               const float* bias, const void* residual, int ldr, const void* aux, void* aux_out,
+                               int ldaux, int act, int accumulate, int splitk, float alpha,
+                               const int* mapA, int periodA, const int* mapB, const int* mapC, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return (M < 0 || N < 0 || K < 0) ? S2T_EINVAL : S2T_OK;
+    if (!A || !B || !C) return S2T_EINVAL;
+    if (splitk < 1) splitk = 1;
+    if (splitk > 1 && (out_dtype != S2T_F32 || bias || residual || act != ACT_NONE)) return S2T_EINVAL;
+    if ((act == ACT_RELU_BWD || act == ACT_GELU_BWD) && !aux) return S2T_EINVAL;
+    if (mapA && (trans_a || periodA <= 0 || periodA % 8)) return S2T_EINVAL;
+    if (mapB && !trans_b) return S2T_EINVAL;
+    GemmArgs a{A, B, C, bias, residual, aux, aux_out, M, N, K, lda, ldb, ldc, ldr, ldaux, act, accumulate, splitk, alpha,
+               mapA, periodA, mapB, mapC};
+    hipStream_t st = (hipStream_t)stream;
+    const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
+    ProfScope prof(mapA || mapB ? "gemm_gather" : "gemm", st, 2.0 * M * (double)N * K,
+                   esz * ((double)M * K + (double)N * K) + osz * (double)M * N);
+    // small problems: 64x64 tiles so that more workgroups exist than CUs
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
+    const bool small = t128 < 192;
+    if (in_dtype == S2T_BF16 && out_dtype == S2T_BF16)
+        return small ? launch_t<bf16, bf16, 64, 64>(a, trans_a, trans_b, st) : launch_t<bf16, bf16, 128, 128>(a, trans_a, trans_b, st);
+    if (in_dtype == S2T_BF16 && out_dtype == S2T_F32)
+        return small ? launch_t<bf16, float, 64, 64>(a, trans_a, trans_b, st) : launch_t<bf16, float, 128, 128>(a, trans_a, trans_b, st);
+    if (in_dtype == S2T_F32 && out_dtype == S2T_F32)
+        return small ? launch_t<float, float, 64, 64>(a, trans_a, trans_b, st) : launch_t<float, float, 128, 128>(a, trans_a, trans_b, st);
+    return S2T_ENOTSUP;
+}
+
+extern "C" int s2t_gemm(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
+                        const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        const float* bias, const void* residual, int ldr, const void* aux, void* aux_out,
+                        int ldaux, int act, int accumulate, int splitk, float alpha, void* stream) {
+    return s2t_gemm_gather(in_dtype, out_dtype, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr,
+                           aux, aux_out, ldaux, act, accumulate, splitk, alpha, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// Column sums of a [M][N] activation-gradient matrix into an f32 vector (bias gradients):
+// out[n] (+)= sum_m X[m][n].  One block per (64-column strip, row chunk); f32 atomics across chunks.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int ld, int M, int N, float* out, int rows_per_block) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (int m = m0 + w; m < m1; m += 4) s += to_f32(X[(size_t)m * ld + c]);
+    sh[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < N) atomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+extern "C" int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float* out, void* stream) {
+    if (M <= 0 || N <= 0) return S2T_OK;
+    if (!X || !out) return S2T_EINVAL;
+    const int rpb = 512;
+    dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)X, ld, M, N, out, rpb);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ld, M, N, out, rpb);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

@@ -1,0 +1,142 @@
+// Label-smoothed cross entropy fused with its gradient, and the decoder token embedding.
+// Reference: fairseq/criterions/label_smoothed_cross_entropy.py:12-29 with lprobs = log_softmax(logits.float())
+// (fairseq/models/fairseq_decoder.py:58-79); fairseq/models/transformer.py:720-737 (embed*sqrt(D) + sinusoidal
+// positions from utils.make_positions, fairseq/utils.py:192-202).
+#include "common.hpp"
+
+// One workgroup per target row (B*L rows, V columns).  Never materialises lprobs:
+//   lse = logsumexp(row);  nll = lse - x[y];  smooth = V*lse - sum(x)
+//   loss += (1-eps)*nll + eps/V*smooth ; nll_sum += nll     (pad rows contribute nothing)
+//   dlogits[v] = gscale * (softmax[v] - (1-eps)*[v==y] - eps/V)   (0 on pad rows)
+template <typename T>
+__global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits, const long long* __restrict__ target,
+                                                   T* __restrict__ dlogits, float* __restrict__ sums, int V, float eps,
+                                                   int pad, float gscale) {
+    __shared__ float sh[16];
+    const long row = blockIdx.x;
+    const T* x = logits + row * V;
+    T* g = dlogits ? dlogits + row * V : nullptr;
+    const long long y = target[row];
+    if (y == pad) {
+        if (g) for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
+        return;
+    }
+    float m = -INFINITY, sx = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) { const float f = to_f32(x[v]); m = fmaxf(m, f); sx += f; }
+    m = block_max(m, sh);
+    sx = block_sum(sx, sh);
+    float se = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) se += expf(to_f32(x[v]) - m);
+    se = block_sum(se, sh);
+    const float lse = m + logf(se);
+    if (threadIdx.x == 0) {
+        const float nll = lse - to_f32(x[y]);
+        const float smooth = (float)V * lse - sx;
+        atomicAdd(sums + 0, (1.f - eps) * nll + (eps / (float)V) * smooth);
+        atomicAdd(sums + 1, nll);
+    }
+    if (g) {
+        const float ev = eps / (float)V;
+        for (int v = threadIdx.x; v < V; v += 256) {
+            float d = expf(to_f32(x[v]) - lse) - ev;
+            if (v == y) d -= (1.f - eps);
+            g[v] = from_f32<T>(d * gscale);
+        }
+    }
+}
+
+extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2,
+                        long rows, int V, float eps, int pad, float grad_scale, void* stream) {
+    if (rows <= 0) return S2T_OK;
+    if (!logits || !target || !sums2 || V <= 0) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(lsce_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, target, (bf16*)dlogits, sums2, V, eps, pad, grad_scale);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(lsce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, (float*)dlogits, sums2, V, eps, pad, grad_scale);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+// ------------------------------------------------------------------ decoder embedding
+// tokens [B][L] int64 -> out [L][B][D] (time-major): scale*W[tok] + table[pos], pos = pad + #non-pad up to l
+// (pad tokens: position pad -> zero row).  One workgroup per batch row; also emits klen[b] = #non-pad? no:
+// the decoder self-attention padding mask is derived from the tokens on the host side of the ABI.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ tokens, const T* __restrict__ W,
+                                                        const float* __restrict__ table, T* __restrict__ out, int B, int L,
+                                                        int D, float scale, int pad) {
+    __shared__ int pos[1024];
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int l = 0; l < L; ++l) { const bool np = tokens[(long)b * L + l] != pad; c += np; pos[l] = np ? c + pad : pad; }
+    }
+    __syncthreads();
+    for (long i = threadIdx.x; i < (long)L * D; i += 256) {
+        const int l = (int)(i / D), d = (int)(i % D);
+        const long long tok = tokens[(long)b * L + l];
+        out[((long)l * B + b) * D + d] = from_f32<T>(scale * to_f32(W[tok * D + d]) + table[(long)pos[l] * D + d]);
+    }
+}
+// dW[tok][:] += scale * dout[l][b][:]   (f32 atomics; the padding row receives no gradient: nn.Embedding padding_idx)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tokens, const T* __restrict__ dout,
+                                                        float* __restrict__ dW, int B, int L, int D, float scale, int pad) {
+    const int l = blockIdx.x, b = blockIdx.y;
+    const long long tok = tokens[(long)b * L + l];
+    if (tok == pad) return;
+    for (int d = threadIdx.x; d < D; d += 256) atomicAdd(dW + tok * D + d, scale * to_f32(dout[((long)l * B + b) * D + d]));
+}
+
+extern "C" int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float* table, void* out, int B,
+                             int L, int D, float scale, int pad, void* stream) {
+    if (B <= 0 || L <= 0) return S2T_OK;
+    if (!tokens || !W || !table || !out || L > 1024) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16>, dim3(B), dim3(256), 0, st, tokens, (const bf16*)W, table, (bf16*)out, B, L, D, scale, pad);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(B), dim3(256), 0, st, tokens, (const float*)W, table, (float*)out, B, L, D, scale, pad);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+extern "C" int s2t_embed_bwd(int dtype, const long long* tokens, const void* dout, float* dW, int B, int L, int D,
+                             float scale, int pad, void* stream) {
+    if (B <= 0 || L <= 0) return S2T_OK;
+    if (!tokens || !dout || !dW) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(embed_bwd_kernel<bf16>, dim3(L, B), dim3(256), 0, st, tokens, (const bf16*)dout, dW, B, L, D, scale, pad);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(L, B), dim3(256), 0, st, tokens, (const float*)dout, dW, B, L, D, scale, pad);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+// ------------------------------------------------------------------ dropout (Philox, mask regenerated in backward)
+// y = x * keep/(1-p) with keep from (seed, element index); backward = the same call on the gradient.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, float p, unsigned long long seed) {
+    const uint32_t th = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
+    const float inv = 1.f / (1.f - p);
+    const size_t n4 = (n + 3) / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const uint4 r = philox4x32(seed, i);
+        const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t e = i * 4 + k;
+            if (e < n) y[e] = from_f32<T>(rv[k] >= th ? to_f32(x[e]) * inv : 0.f);
+        }
+    }
+}
+extern "C" int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p, unsigned long long seed, void* stream) {
+    if (n == 0) return S2T_OK;
+    if (!x || !y || p < 0.f || p >= 1.f) return S2T_EINVAL;
+    int blocks = (int)(((n + 3) / 4 + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, p, seed);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, n, p, seed);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

@@ -1,0 +1,248 @@
+// HBM-bound row kernels: LayerNorm fwd/bwd (wavefront reductions), flat multi-tensor Adam with fused
+// gradient scaling / clipping, global gradient norm, dtype casts.
+// Reference semantics: fairseq/modules/layer_norm.py:29-32 (nn.LayerNorm, eps 1e-5);
+// fairseq/optim/adam.py:147-202; fairseq/utils.py:253-277 (clip_grad_norm_);
+// fairseq/trainer.py:416-443 (multiply_grads -> clip -> step).
+#include "common.hpp"
+
+// ------------------------------------------------------------------ LayerNorm forward
+// One wavefront per row; the row lives in registers (D <= 1024).  y = (x-mean)*rstd*gamma+beta.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + (size_t)row * D;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = (j < D) ? to_f32(xr[j]) : 0.f;
+        s += v[i];
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = lane + 64 * i;
+        const float d = (j < D) ? v[i] - mu : 0.f;
+        ss += d * d;
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)D + eps);
+    T* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = lane + 64 * i;
+        if (j < D) yr[j] = from_f32<T>((v[i] - mu) * rs * gamma[j] + beta[j]);
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres],  g = dy*gamma;
+// dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (per-lane partials over a grid-stride row loop,
+// combined across the 4 waves in LDS, then one f32 atomic per column per workgroup).
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int D) {
+    __shared__ float sh[2][4][1024];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float ag[16], ab[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const T* xr = x + (size_t)row * D;
+        const T* dr = dy + (size_t)row * D;
+        float xh[16], g[16];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = lane + 64 * i;
+            if (j < D) {
+                const float d = to_f32(dr[j]);
+                xh[i] = (to_f32(xr[j]) - mu) * rs;
+                g[i] = d * gamma[j];
+                ag[i] += d * xh[i];
+                ab[i] += d;
+            } else { xh[i] = 0.f; g[i] = 0.f; }
+            s1 += g[i];
+            s2 += g[i] * xh[i];
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        T* ox = dx + (size_t)row * D;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = lane + 64 * i;
+            if (j < D) {
+                float r = rs * (g[i] - c1 - xh[i] * c2);
+                if (dres) r += to_f32(dres[(size_t)row * D + j]);
+                ox[j] = from_f32<T>(r);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = lane + 64 * i;
+        sh[0][w][j] = ag[i];
+        sh[1][w][j] = ab[i];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < D; j += 256) {
+        atomicAdd(dgamma + j, sh[0][0][j] + sh[0][1][j] + sh[0][2][j] + sh[0][3][j]);
+        atomicAdd(dbeta + j, sh[1][0][j] + sh[1][1][j] + sh[1][2][j] + sh[1][3][j]);
+    }
+}
+
+extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                                 float* mean, float* rstd, int M, int D, float eps, void* stream) {
+    if (M <= 0) return M < 0 ? S2T_EINVAL : S2T_OK;
+    if (D <= 0 || D > 1024) return S2T_ENOTSUP;
+    if (!x || !gamma || !beta || !y || !mean || !rstd) return S2T_EINVAL;
+    dim3 grid((M + 3) / 4);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, eps);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                                 const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                 int M, int D, void* stream) {
+    if (M <= 0) return M < 0 ? S2T_EINVAL : S2T_OK;
+    if (D <= 0 || D > 1024) return S2T_ENOTSUP;
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return S2T_EINVAL;
+    int blocks = (M + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+// ------------------------------------------------------------------ gradient norm, clip, Adam
+// sumsq: acc[0] += sum g^2 (double).  One launch over the flat gradient arena.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* acc) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    const size_t n4 = n / 4;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; s += (double)v * v; }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, shd[0] + shd[1] + shd[2] + shd[3]);
+}
+
+// out[0] = gnorm = scale*sqrt(acc) ; out[1] = multiplier = scale * min(1, max_norm/(gnorm+1e-6))
+// (fairseq/utils.py:268-276 on gradients already multiplied by `scale`, trainer.py:426-436)
+__global__ void clip_coef_kernel(const double* acc, float scale, float max_norm, float* out) {
+    const float gn = scale * (float)sqrt(acc[0]);
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (gn + 1e-6f), 1.f);
+    out[0] = gn;
+    out[1] = scale * coef;
+}
+
+// Adam over the flat arena (fairseq/optim/adam.py:147-202): g' = g*mult; m,v update; decoupled wd;
+// p -= step_size * m / (sqrt(v)+eps); optionally refresh the bf16 shadow used by the MFMA GEMMs.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16* __restrict__ shadow, size_t n, const float* mult_ptr,
+                                                   float lr, float beta1, float beta2, float eps, float wd,
+                                                   float step_size) {
+    const float mult = mult_ptr ? mult_ptr[1] : 1.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * mult;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        float pi = p[i];
+        if (wd != 0.f) pi -= wd * lr * pi;
+        pi -= step_size * mi / (sqrtf(vi) + eps);
+        m[i] = mi; v[i] = vi; p[i] = pi;
+        if (shadow) shadow[i] = (bf16)pi;
+    }
+}
+
+extern "C" int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, float scale, float max_norm,
+                                  float* out2, void* stream) {
+    if (!g || !acc_ws || !out2) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(acc_ws, 0, sizeof(double), st);
+    if (e != hipSuccess) return S2T_EHIP(e);
+    if (n) {
+        int blocks = (int)((n / 4 + 255) / 256);
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, acc_ws);
+        S2T_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, acc_ws, scale, max_norm, out2);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n,
+                             const float* mult2, float lr, float beta1, float beta2, float eps, float wd,
+                             int step, void* stream) {
+    if (n == 0) return S2T_OK;
+    if (!p || !g || !m || !v || step < 1) return S2T_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n,
+                       mult2, lr, beta1, beta2, eps, wd, step_size);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+// ------------------------------------------------------------------ casts / scaling
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = from_f32<TD>(to_f32(s[i]));
+}
+extern "C" int s2t_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, void* stream) {
+    if (n == 0) return S2T_OK;
+    if (!src || !dst) return S2T_EINVAL;
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == S2T_F32 && dst_dtype == S2T_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(blocks), dim3(256), 0, st, (const float*)src, (bf16*)dst, n);
+    else if (src_dtype == S2T_BF16 && dst_dtype == S2T_F32) hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, (float*)dst, n);
+    else if (src_dtype == S2T_F32 && dst_dtype == S2T_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else if (src_dtype == S2T_BF16 && dst_dtype == S2T_BF16) hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, st, (const bf16*)src, (bf16*)dst, n);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+// x *= *scalar (device scalar): upstream loss-gradient scaling without a host sync
+template <typename T>
+__global__ __launch_bounds__(256) void scale_dev_kernel(T* x, size_t n, const float* s) {
+    const float f = *s;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = from_f32<T>(to_f32(x[i]) * f);
+}
+extern "C" int s2t_scale_by_device_scalar(int dtype, void* x, size_t n, const float* scalar, void* stream) {
+    if (n == 0) return S2T_OK;
+    if (!x || !scalar) return S2T_EINVAL;
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(scale_dev_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16*)x, n, scalar);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(scale_dev_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)x, n, scalar);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

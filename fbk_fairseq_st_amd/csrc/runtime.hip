@@ -1,0 +1,118 @@
+// Library info, event-based per-family timing and the host-side CTC unit-error-rate helper.
+#include "common.hpp"
+#include "prof.hpp"
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstring>
+
+int g_s2t_prof_on = 0;
+namespace {
+struct Rec { hipEvent_t a, b; double flops, bytes; };
+struct Fam { std::vector<Rec> recs; double ms = 0, flops = 0, bytes = 0; long long launches = 0; };
+std::map<std::string, Fam> g_fams;
+std::vector<hipEvent_t> g_pool;
+std::mutex g_mu;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void drain(Fam& f) {
+    for (auto& r : f.recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { f.ms += ms; f.flops += r.flops; f.bytes += r.bytes; f.launches += 1; }
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    f.recs.clear();
+}
+}  // namespace
+
+void s2t_prof_push(const char* family, hipStream_t st, double flops, double bytes, bool begin) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Fam& f = g_fams[family];
+    if (begin) {
+        Rec r{get_event(), get_event(), flops, bytes};
+        (void)hipEventRecord(r.a, st);
+        f.recs.push_back(r);
+    } else if (!f.recs.empty()) {
+        (void)hipEventRecord(f.recs.back().b, st);
+    }
+}
+
+extern "C" int s2t_abi_version(void) { return 1; }
+extern "C" const char* s2t_build_info(void) { return "libs2t_hip gfx950 (CDNA4, wave64, MFMA) built " __DATE__ " " __TIME__; }
+extern "C" int s2t_prof_enable(int on) { g_s2t_prof_on = on ? 1 : 0; return S2T_OK; }
+extern "C" int s2t_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_fams) { drain(kv.second); kv.second = Fam(); }
+    return S2T_OK;
+}
+extern "C" int s2t_prof_read(const char* family, double* ms, long long* launches, double* flops, double* bytes) {
+    if (!family) return S2T_EINVAL;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_fams.find(family);
+    if (it == g_fams.end()) { if (ms) *ms = 0; if (launches) *launches = 0; if (flops) *flops = 0; if (bytes) *bytes = 0; return S2T_OK; }
+    drain(it->second);
+    if (ms) *ms = it->second.ms;
+    if (launches) *launches = it->second.launches;
+    if (flops) *flops = it->second.flops;
+    if (bytes) *bytes = it->second.bytes;
+    return S2T_OK;
+}
+
+// ---------------------------------------------------------------- host: CTC unit error rate
+// Greedy path (collapse repeats, drop blanks) then the alignment of wer_utils.EditDistance(False):
+// substitution 4, insertion/deletion 3, diagonal preferred on ties, then insertion, then deletion;
+// errors = number of non-match steps on the back-trace.  Directions are kept in a byte matrix.
+static int align_errors(const std::vector<int>& hyp /*decoded prediction = "refs"*/, const long long* tgt, int nt) {
+    const int nr = (int)hyp.size();
+    if (nr == 0 && nt == 0) return 0;
+    const int cols = nt + 1;
+    std::vector<double> prev(cols), cur(cols);
+    std::vector<unsigned char> dir((size_t)(nr + 1) * cols, 0);   // 0 diag, 1 left (insertion), 2 up (deletion)
+    for (int j = 0; j < cols; ++j) { prev[j] = 3.0 * j; dir[j] = 1; }
+    for (int i = 1; i <= nr; ++i) {
+        cur[0] = 3.0 * i; dir[(size_t)i * cols] = 2;
+        for (int j = 1; j < cols; ++j) {
+            double best = prev[j - 1] + (hyp[i - 1] == (int)tgt[j - 1] ? 0.0 : 4.0);
+            unsigned char d = 0;
+            const double ins = cur[j - 1] + 3.0;
+            if (ins < best) { best = ins; d = 1; }
+            const double del = prev[j] + 3.0;
+            if (del < best) { best = del; d = 2; }
+            cur[j] = best; dir[(size_t)i * cols + j] = d;
+        }
+        std::swap(prev, cur);
+    }
+    int errors = 0, i = nr, j = nt;
+    while (i > 0 || j > 0) {
+        const unsigned char d = dir[(size_t)i * cols + j];
+        if (d == 0) { if (hyp[i - 1] != (int)tgt[j - 1]) ++errors; --i; --j; }
+        else if (d == 1) { ++errors; --j; }
+        else { ++errors; --i; }
+    }
+    return errors;
+}
+
+extern "C" int s2t_host_ctc_uer(const int* pred, const long long* input_len, int B, int T, const long long* targets,
+                                const long long* target_len, int L, int blank, double* errors, double* total) {
+    if (!pred || !input_len || !targets || !target_len || !errors || !total) return S2T_EINVAL;
+    double e = 0, n = 0;
+    std::vector<int> dec;
+    for (int b = 0; b < B; ++b) {
+        dec.clear();
+        const int* p = pred + (size_t)b * T;
+        const int len = (int)(input_len[b] < T ? input_len[b] : T);
+        for (int t = 0; t < len; ++t) {
+            if (t > 0 && p[t] == p[t - 1]) continue;
+            if (p[t] != blank) dec.push_back(p[t]);
+        }
+        const int tl = (int)target_len[b];
+        e += align_errors(dec, targets + (size_t)b * L, tl);
+        n += tl;
+    }
+    *errors = e; *total = n;
+    return S2T_OK;
+}

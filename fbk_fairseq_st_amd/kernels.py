@@ -1,0 +1,314 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point of include/s2t_hip.h).
+
+No arithmetic happens here: each wrapper validates shapes, allocates outputs with torch (device
+memory is torch's job) and passes raw pointers to libs2t_hip.so on torch's current stream.
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+from .lib import ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD  # noqa: F401
+
+
+def _lib():
+    return L.load()
+
+
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_NONE, aux=None, aux_out=None,
+         out=None, out_dtype=None, accumulate=False, splitk=1, alpha=1.0, M=None, N=None, K=None,
+         map_a=None, period_a=0, map_b=None, map_c=None, out_rows=None):
+    """C = epi(op(a) @ op(b)); a is [M,K] (or [K,M] if trans_a), b is [N,K] (or [K,N] if trans_b)."""
+    L.require_cuda(a, b)
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    if M is None:
+        M = a.shape[1] if trans_a else a.shape[0]
+    if K is None:
+        K = a.shape[0] if trans_a else a.shape[1]
+    if N is None:
+        N = b.shape[1] if trans_b else b.shape[0]
+    odt = out_dtype or (out.dtype if out is not None else a.dtype)
+    if out is None:
+        rows = out_rows if out_rows is not None else M
+        out = (torch.zeros if (accumulate or splitk > 1 or map_c is not None) else torch.empty)(
+            (rows, N), dtype=odt, device=a.device)
+    assert out.stride(1) == 1
+    for t in (residual, aux, aux_out):
+        assert t is None or (t.dtype == out.dtype and t.stride(-1) == 1)
+    ldaux = aux.stride(0) if aux is not None else (aux_out.stride(0) if aux_out is not None else 0)
+    rc = _lib().s2t_gemm_gather(
+        L.dt(a), L.dt(out), int(trans_a), int(trans_b), M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0),
+        L.ptr(out), out.stride(0), L.ptr(bias), L.ptr(residual), residual.stride(0) if residual is not None else 0,
+        L.ptr(aux), L.ptr(aux_out), ldaux, act, int(accumulate), splitk, float(alpha),
+        L.ptr(map_a), period_a, L.ptr(map_b), L.ptr(map_c), L.stream())
+    L.check(rc, "s2t_gemm")
+    return out
+
+
+def colsum(x, out):
+    """out[n] += sum_m x[m, n] (f32)."""
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
+    L.check(_lib().s2t_colsum(L.dt(x), L.ptr(x), x.stride(0), x.shape[0], x.shape[1], L.ptr(out), L.stream()), "s2t_colsum")
+    return out
+
+
+def _tb(x):
+    """(time stride, batch stride) in elements of a [T,B,...] view whose last dim is contiguous."""
+    return x.stride(0), x.stride(1)
+
+
+def attn_fwd(q, k, v, heads, klen=None, causal=False, scale=None, p_drop=0.0, seed=0, out=None):
+    """q [Tq,B,D'], k/v [Tk,B,D'] views (last dim contiguous, may be slices of a fused QKV buffer)."""
+    Tq, B, D = q.shape
+    Tk = k.shape[0]
+    d = D // heads
+    if scale is None:
+        scale = d ** -0.5
+    if out is None:
+        out = torch.empty((Tq, B, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, heads, Tq), dtype=torch.float32, device=q.device)
+    rc = _lib().s2t_attn_fwd(L.dt(q), d, B, heads, Tq, Tk, L.ptr(q), *_tb(q), L.ptr(k), *_tb(k), L.ptr(v), *_tb(v),
+                             L.ptr(out), *_tb(out), L.ptr(lse), L.ptr(klen), int(causal), float(scale), float(p_drop),
+                             int(seed), L.stream())
+    L.check(rc, "s2t_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, heads, dq, dk, dv, klen=None, causal=False, scale=None, p_drop=0.0, seed=0):
+    Tq, B, D = q.shape
+    Tk = k.shape[0]
+    d = D // heads
+    if scale is None:
+        scale = d ** -0.5
+    delta = torch.empty((B, heads, Tq), dtype=torch.float32, device=q.device)
+    rc = _lib().s2t_attn_bwd(L.dt(q), d, B, heads, Tq, Tk, L.ptr(q), *_tb(q), L.ptr(k), *_tb(k), L.ptr(v), *_tb(v),
+                             L.ptr(o), *_tb(o), L.ptr(do), *_tb(do), L.ptr(lse), L.ptr(delta),
+                             L.ptr(dq), *_tb(dq), L.ptr(dk), *_tb(dk), L.ptr(dv), *_tb(dv),
+                             L.ptr(klen), int(causal), float(scale), float(p_drop), int(seed), L.stream())
+    L.check(rc, "s2t_attn_bwd")
+    return dq, dk, dv
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    D = x.shape[-1]
+    M = x.numel() // D
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
+    L.check(_lib().s2t_layernorm_fwd(L.dt(x), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+                                     M, D, float(eps), L.stream()), "s2t_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None):
+    D = x.shape[-1]
+    M = x.numel() // D
+    assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
+    dx = torch.empty_like(x)
+    L.check(_lib().s2t_layernorm_bwd(L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres),
+                                     L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), M, D, L.stream()), "s2t_layernorm_bwd")
+    return dx
+
+
+def conv1_fwd(x, w, bias, C, dtype):
+    B, T, F = x.shape
+    T2, F2 = (T + 1) // 2, (F + 1) // 2
+    y = torch.empty((B, T2, F2, C), dtype=dtype, device=x.device)
+    sums = torch.zeros((2 * C,), dtype=torch.float64, device=x.device)
+    L.check(_lib().s2t_conv1_fwd(L.dt(y), L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(sums), B, T, F, C, L.stream()),
+            "s2t_conv1_fwd")
+    return y, sums
+
+
+def conv1_bwd(x, dpre, dw, db):
+    B, T, F = x.shape
+    C = dpre.shape[-1]
+    L.check(_lib().s2t_conv1_bwd(L.dt(dpre), L.ptr(x), L.ptr(dpre), L.ptr(dw), L.ptr(db), B, T, F, C, L.stream()),
+            "s2t_conv1_bwd")
+
+
+def chan_sums(y, C, dyn=None, mean=None, rstd=None):
+    P = y.numel() // C
+    sums = torch.zeros((2 * C,), dtype=torch.float64, device=y.device)
+    L.check(_lib().s2t_chan_sums(L.dt(y), L.ptr(y), L.ptr(dyn), L.ptr(mean), L.ptr(rstd), L.ptr(sums), P, C,
+                                 0 if dyn is None else 1, L.stream()), "s2t_chan_sums")
+    return sums
+
+
+def bn_finalize(sums, gamma, beta, run_mean, run_var, num_batches, count, training, momentum=0.1, eps=1e-5):
+    C = gamma.numel()
+    o = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    L.check(_lib().s2t_bn_finalize(L.ptr(sums), L.ptr(gamma), L.ptr(beta), L.ptr(run_mean), L.ptr(run_var),
+                                   L.ptr(num_batches), L.ptr(o[0]), L.ptr(o[1]), L.ptr(o[2]), L.ptr(o[3]),
+                                   float(count), C, int(training), float(momentum), float(eps), L.stream()), "s2t_bn_finalize")
+    return o[0], o[1], o[2], o[3]            # mean, rstd, scale, shift
+
+
+def bn_apply(y, scale, shift):
+    yn = torch.empty_like(y)
+    L.check(_lib().s2t_bn_apply(L.dt(y), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(yn), y.numel(), scale.numel(), L.stream()),
+            "s2t_bn_apply")
+    return yn
+
+
+def bn_bwd_apply(dyn, y, mean, rstd, gamma, sums, dgamma, dbeta, count, training=True):
+    dpre = torch.empty_like(y)
+    L.check(_lib().s2t_bn_bwd_apply(L.dt(y), L.ptr(dyn), L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(sums),
+                                    L.ptr(dpre), L.ptr(dgamma), L.ptr(dbeta), y.numel(), gamma.numel(), float(count),
+                                    int(training), L.stream()), "s2t_bn_bwd_apply")
+    return dpre
+
+
+def permute_cf(src, dst, N, C, F, mode):
+    L.check(_lib().s2t_permute_cf(L.dt(dst), L.ptr(src), L.ptr(dst), N, C, F, mode, L.stream()), "s2t_permute_cf")
+    return dst
+
+
+def permute_conv_w(src, dst, Co, Ci, mode):
+    L.check(_lib().s2t_permute_conv_w(L.dt(dst), L.ptr(src), L.ptr(dst), Co, Ci, mode, L.stream()), "s2t_permute_conv_w")
+    return dst
+
+
+def add_pos(x, table, len32):
+    T, B, D = x.shape
+    assert x.is_contiguous() and table.shape[0] >= T + 1 and table.shape[1] == D
+    L.check(_lib().s2t_add_pos(L.dt(x), L.ptr(x), L.ptr(table), L.ptr(len32), T, B, D, L.stream()), "s2t_add_pos")
+    return x
+
+
+def ctc_argmax(logits):
+    T, B, V = logits.shape
+    assert logits.is_contiguous()
+    pred = torch.empty((B, T), dtype=torch.int32, device=logits.device)
+    pmax = torch.empty((B, T), dtype=torch.float32, device=logits.device)
+    L.check(_lib().s2t_ctc_argmax(L.dt(logits), L.ptr(logits), L.ptr(pred), L.ptr(pmax), T, B, V, L.stream()), "s2t_ctc_argmax")
+    return pred, pmax
+
+
+def ctc_rle(pred, pmax, len64, strategy=0):
+    B, T = pred.shape
+    dev = pred.device
+    seg = torch.empty((B, T), dtype=torch.int32, device=dev)
+    rs = torch.empty((B, T), dtype=torch.int32, device=dev)
+    rl = torch.empty((B, T), dtype=torch.int32, device=dev)
+    new_len = torch.empty((B,), dtype=torch.int64, device=dev)
+    w = torch.empty((B, T), dtype=torch.float32, device=dev)
+    L.check(_lib().s2t_ctc_rle(L.ptr(pred), L.ptr(pmax), L.ptr(len64), L.ptr(seg), L.ptr(rs), L.ptr(rl), L.ptr(new_len),
+                               L.ptr(w), T, B, strategy, L.stream()), "s2t_ctc_rle")
+    return seg, rs, rl, new_len, w
+
+
+def ctc_compress_fwd(x, w, rs, rl, new_len, Tout):
+    T, B, D = x.shape
+    out = torch.empty((Tout, B, D), dtype=x.dtype, device=x.device)
+    L.check(_lib().s2t_ctc_compress_fwd(L.dt(x), L.ptr(x), L.ptr(w), L.ptr(rs), L.ptr(rl), L.ptr(new_len), L.ptr(out),
+                                        T, B, D, Tout, L.stream()), "s2t_ctc_compress_fwd")
+    return out
+
+
+def ctc_compress_bwd(dout, w, seg, dx, accumulate=False):
+    T, B, D = dx.shape
+    L.check(_lib().s2t_ctc_compress_bwd(L.dt(dx), L.ptr(dout), L.ptr(w), L.ptr(seg), L.ptr(dx), T, B, D, int(accumulate),
+                                        L.stream()), "s2t_ctc_compress_bwd")
+    return dx
+
+
+def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0):
+    """Returns (loss_sum f32[1], grad like logits)."""
+    T, B, V = logits.shape
+    Lmax = targets.shape[1]
+    dev = logits.device
+    S = 2 * Lmax + 1
+    lse = torch.empty((T * B,), dtype=torch.float32, device=dev)
+    la = torch.empty((B * T * S,), dtype=torch.float32, device=dev)
+    lb = torch.empty((B * T * S,), dtype=torch.float32, device=dev)
+    nll = torch.empty((B,), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(logits)
+    loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+    L.check(_lib().s2t_ctc_loss(L.dt(logits), L.ptr(logits), L.ptr(targets), L.ptr(tgt_len), L.ptr(in_len32), L.ptr(lse),
+                                L.ptr(la), L.ptr(lb), L.ptr(nll), L.ptr(grad), L.ptr(loss), T, B, V, Lmax, blank,
+                                float(grad_scale), L.stream()), "s2t_ctc_loss")
+    return loss, grad, nll
+
+
+def lsce(logits, target, eps, pad, want_grad=True, grad_scale=1.0):
+    """logits [rows,V]; returns (sums f32[2] = loss, nll ; dlogits or None)."""
+    rows, V = logits.shape
+    assert logits.is_contiguous() and target.numel() == rows
+    sums = torch.zeros((2,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    L.check(_lib().s2t_lsce(L.dt(logits), L.ptr(logits), L.ptr(target), L.ptr(dl), L.ptr(sums), rows, V, float(eps), pad,
+                            float(grad_scale), L.stream()), "s2t_lsce")
+    return sums, dl
+
+
+def embed_fwd(tokens, W, table, scale, pad):
+    B, Ln = tokens.shape
+    D = W.shape[1]
+    out = torch.empty((Ln, B, D), dtype=W.dtype, device=W.device)
+    L.check(_lib().s2t_embed_fwd(L.dt(W), L.ptr(tokens), L.ptr(W), L.ptr(table), L.ptr(out), B, Ln, D, float(scale), pad,
+                                 L.stream()), "s2t_embed_fwd")
+    return out
+
+
+def embed_bwd(tokens, dout, dW, scale, pad):
+    B, Ln = tokens.shape
+    D = dW.shape[1]
+    L.check(_lib().s2t_embed_bwd(L.dt(dout), L.ptr(tokens), L.ptr(dout), L.ptr(dW), B, Ln, D, float(scale), pad, L.stream()),
+            "s2t_embed_bwd")
+
+
+def dropout(x, p, seed, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(_lib().s2t_dropout(L.dt(x), L.ptr(x), L.ptr(out), x.numel(), float(p), int(seed), L.stream()), "s2t_dropout")
+    return out
+
+
+def grad_norm_clip(g, scale, max_norm, ws, out2):
+    L.check(_lib().s2t_grad_norm_clip(L.ptr(g), g.numel(), L.ptr(ws), float(scale), float(max_norm), L.ptr(out2), L.stream()),
+            "s2t_grad_norm_clip")
+    return out2
+
+
+def adam_step(p, g, m, v, shadow, mult2, lr, beta1, beta2, eps, wd, step):
+    L.check(_lib().s2t_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(shadow), p.numel(), L.ptr(mult2), float(lr),
+                                 float(beta1), float(beta2), float(eps), float(wd), int(step), L.stream()), "s2t_adam_step")
+
+
+def cast(src, dst):
+    assert src.numel() == dst.numel()
+    L.check(_lib().s2t_cast(L.dt(src), L.dt(dst), L.ptr(src), L.ptr(dst), src.numel(), L.stream()), "s2t_cast")
+    return dst
+
+
+def scale_by_device_scalar(x, scalar):
+    L.check(_lib().s2t_scale_by_device_scalar(L.dt(x), L.ptr(x), x.numel(), L.ptr(scalar), L.stream()), "s2t_scale")
+    return x
+
+
+def host_ctc_uer(pred_cpu, in_len_cpu, targets_cpu, tgt_len_cpu, blank):
+    """HOST tensors (int32 pred [B,T], int64 others) -> (errors, total)."""
+    B, T = pred_cpu.shape
+    e, n = ctypes.c_double(0), ctypes.c_double(0)
+    pred_cpu = pred_cpu.contiguous(); targets_cpu = targets_cpu.contiguous()
+    L.check(_lib().s2t_host_ctc_uer(pred_cpu.data_ptr(), in_len_cpu.contiguous().data_ptr(), B, T, targets_cpu.data_ptr(),
+                                    tgt_len_cpu.contiguous().data_ptr(), targets_cpu.shape[1], blank,
+                                    ctypes.addressof(e), ctypes.addressof(n)), "s2t_host_ctc_uer")
+    return e.value, n.value
+
+
+def prof_enable(on):
+    _lib().s2t_prof_enable(int(on))
+
+
+def prof_reset():
+    _lib().s2t_prof_reset()
+
+
+def prof_read(family):
+    ms, fl, by = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+    n = ctypes.c_longlong(0)
+    _lib().s2t_prof_read(family.encode(), ctypes.addressof(ms), ctypes.addressof(n), ctypes.addressof(fl), ctypes.addressof(by))
+    return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)

@@ -1,0 +1,129 @@
+"""ctypes binding of libs2t_hip.so (include/s2t_hip.h).
+
+The product path has NO fallback: if the library is missing, cannot be loaded or lacks a symbol,
+importing an op raises.  Tensors cross the boundary as raw device pointers (``tensor.data_ptr()``)
+plus sizes; the HIP stream is torch's current stream.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libs2t_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD = 0, 1, 2, 3, 4
+
+c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
+                                                        ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t)
+c_ull = ctypes.c_ulonglong
+P = c_void_p
+
+# name -> argtypes (restype is int unless noted).  Mirrors include/s2t_hip.h one to one.
+SIGNATURES = {
+    "s2t_abi_version": [],
+    "s2t_gemm": [c_int] * 7 + [P, c_int, P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P],
+    "s2t_gemm_gather": [c_int] * 7 + [P, c_int, P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int,
+                                       c_float, P, c_int, P, P, P],
+    "s2t_colsum": [c_int, P, c_int, c_int, c_int, P, P],
+    "s2t_attn_fwd": [c_int] * 6 + [P, c_long, c_long] * 4 + [P, P, c_int, c_float, c_float, c_ull, P],
+    "s2t_attn_bwd": [c_int] * 6 + [P, c_long, c_long] * 5 + [P, P] + [P, c_long, c_long] * 3 +
+                    [P, c_int, c_float, c_float, c_ull, P],
+    "s2t_layernorm_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_float, P],
+    "s2t_layernorm_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P],
+    "s2t_conv1_fwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_conv1_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_chan_sums": [c_int, P, P, P, P, P, c_long, c_int, c_int, P],
+    "s2t_bn_finalize": [P] * 10 + [c_double, c_int, c_int, c_float, c_float, P],
+    "s2t_bn_apply": [c_int, P, P, P, P, c_long, c_int, P],
+    "s2t_bn_bwd_apply": [c_int, P, P, P, P, P, P, P, P, P, c_long, c_int, c_double, c_int, P],
+    "s2t_permute_cf": [c_int, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_permute_conv_w": [c_int, P, P, c_int, c_int, c_int, P],
+    "s2t_add_pos": [c_int, P, P, P, c_int, c_int, c_int, P],
+    "s2t_ctc_argmax": [c_int, P, P, P, c_int, c_int, c_int, P],
+    "s2t_ctc_rle": [P] * 8 + [c_int, c_int, c_int, P],
+    "s2t_ctc_compress_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_ctc_compress_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_ctc_loss": [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P],
+    "s2t_lsce": [c_int, P, P, P, P, c_long, c_int, c_float, c_int, c_float, P],
+    "s2t_embed_fwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
+    "s2t_embed_bwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
+    "s2t_dropout": [c_int, P, P, c_size_t, c_float, c_ull, P],
+    "s2t_grad_norm_clip": [P, c_size_t, P, c_float, c_float, P, P],
+    "s2t_adam_step": [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, c_int, P],
+    "s2t_cast": [c_int, c_int, P, P, c_size_t, P],
+    "s2t_scale_by_device_scalar": [c_int, P, c_size_t, P, P],
+    "s2t_prof_enable": [c_int],
+    "s2t_prof_reset": [],
+    "s2t_prof_read": [ctypes.c_char_p, P, P, P, P],
+    "s2t_host_ctc_uer": [P, P, c_int, c_int, P, P, c_int, c_int, P, P],
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libs2t_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 4))]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libs2t_hip.so failed:\n" + res.stdout[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def load():
+    """Load the library and bind every symbol of the header; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libs2t_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU or PyTorch fallback for the S2T hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)         # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.s2t_build_info.restype = ctypes.c_char_p
+    lib.s2t_build_info.argtypes = []
+    _lib = lib
+    return lib
+
+
+class S2THipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc <= -1000:
+            raise S2THipError("%s: HIP error %d" % (what, -rc - 1000))
+        raise S2THipError("%s: error %d (%s)" % (what, rc, {-22: "invalid argument", -95: "not supported"}.get(rc, "?")))
+
+
+def dt(t):
+    """dtype code of a tensor (float32 / bfloat16 only)."""
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("S2T kernels take float32 or bfloat16 tensors, got %s" % t.dtype)
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise S2THipError("S2T kernels need device tensors: the hot path has no CPU fallback")

@@ -1,0 +1,184 @@
+/*
+ * s2t_hip.h -- C ABI of libs2t_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * speech-translation forward/backward hot path of FBK-fairseq-ST (`conv_transformer`).
+ *
+ * The reference has NO native interface on this path: its boundary is Python (fairseq's
+ * register_model / register_task / register_criterion plug-in surface) and every
+ * FLOP is an ATen call.  Each entry point below therefore names the reference *call site* whose
+ * arithmetic it replaces (file:line under the reference tree).  The Python side of the boundary
+ * (fbk_fairseq_st_amd/*.py) mirrors the reference's module interface and binds these symbols with
+ * ctypes; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless noted; no ownership
+ *     transfer; outputs are caller-allocated; calls are stream-ordered on `stream` (a hipStream_t,
+ *     NULL = default stream) and re-entrant per stream; no call synchronises the device.
+ *   - dtype: S2T_F32 = 0 (parity path, exact-f32 MFMA), S2T_BF16 = 1 (bf16 storage, f32 accumulate).
+ *   - return 0 on success; -22 (EINVAL) bad argument; -95 (ENOTSUP) unsupported shape/dtype;
+ *     -(1000 + hipError_t) when the HIP runtime reported an error at launch.
+ *   - time-major activations: X[t][b][:] row index t*B + b (the reference's T x B x C).
+ */
+#ifndef S2T_HIP_H
+#define S2T_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2T_F32 0
+#define S2T_BF16 1
+
+/* epilogue selector of s2t_gemm */
+#define S2T_ACT_NONE 0
+#define S2T_ACT_RELU 1      /* fairseq/utils.py:390-408 ("relu") */
+#define S2T_ACT_GELU 2      /* fairseq/modules/gelu.py:24-25 (erf form, computed in f32); pre-activation -> aux_out */
+#define S2T_ACT_RELU_BWD 3  /* out = acc * (aux > 0)            (aux = forward post-activation) */
+#define S2T_ACT_GELU_BWD 4  /* out = acc * gelu'(aux)           (aux = forward pre-activation)  */
+
+/* ---- library info ------------------------------------------------------------------------- */
+int s2t_abi_version(void);                       /* bumps when a signature changes */
+const char* s2t_build_info(void);                /* "gfx950 <date> ..." */
+
+/* ---- GEMM with fused epilogue (MFMA) --------------------------------------------------------
+ * C[M,N] = act( alpha * op(A)[M,K] . op(B)[K,N] + bias[N] ) + residual[M,N]      (accumulate: C += ...)
+ *   trans_a = 0: A is [M][K];  1: A is [K][M]        trans_b = 0: B is [N][K] (nn.Linear weight);  1: B is [K][N]
+ *   in_dtype: A, B.   out_dtype: C, residual, aux, aux_out.   bias is always f32.
+ *   splitk > 1: K is split over gridDim.z and partial products are added with f32 atomics into C
+ *               (C must be f32 and pre-initialised; no bias/act/residual).
+ * Replaces: F.linear at fairseq/modules/multihead_attention.py:190-208,356 (q/k/v/out projections),
+ *   fairseq/modules/transformer_layer.py:132-134,358-360 (fc1 + activation, fc2 + residual),
+ *   examples/speech_recognition/models/conv_transformer.py:227 (fc3 + activation), :279 (ctc_fc),
+ *   fairseq/models/transformer.py:784-788 (output projection), and their autograd backward
+ *   (dX = dY W: trans_b = 1;  dW = dY^T X: trans_a = trans_b = 1). */
+int s2t_gemm(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
+             const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+             const float* bias, const void* residual, int ldr, const void* aux, void* aux_out, int ldaux,
+             int act, int accumulate, int splitk, float alpha, void* stream);
+
+/* Same kernel with row gather / scatter, used to run Conv2d(64->64, 3x3, stride 2, pad 1)
+ * (conv_transformer.py:203-206, 2nd iteration) and its backward as implicit GEMMs over channels-last
+ * activations:  mapA[(k/periodA)*M + r] = source row of A for output row r and k-block (tap) k/periodA
+ * (-1 = zero padding);  mapB[k] = source row of a [K][N] B operand;  mapC[r] = destination row. */
+int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
+                    const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                    const float* bias, const void* residual, int ldr, const void* aux, void* aux_out, int ldaux,
+                    int act, int accumulate, int splitk, float alpha,
+                    const int* mapA, int periodA, const int* mapB, const int* mapC, void* stream);
+
+/* out[n] += sum_m X[m][n]  (bias gradients of every nn.Linear above; f32 atomics) */
+int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float* out, void* stream);
+
+/* ---- fused multi-head attention ---------------------------------------------------------------
+ * Replaces fairseq/modules/multihead_attention.py:155-177 (F.multi_head_attention_forward) and
+ * :316-355 (own bmm/softmax/bmm path): scores, key-padding (-inf), causal mask
+ * (fairseq/models/transformer.py:798-810), fp32 softmax, dropout on P, P.V.  Scores never reach HBM.
+ * X[t][b][h][j] = X + t*x_st + b*x_sb + h*head_dim + j (element strides);  head_dim in {32, 64}.
+ * klen[b] = number of valid (non-padded) keys of batch b, NULL = all Tk (padding is a suffix on this
+ * path: conv_transformer.py:293-300, transformer.py:739-741).  LSE [B][H][Tq] f32 (saved for backward). */
+int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
+                 const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
+                 const void* V, long v_st, long v_sb, void* O, long o_st, long o_sb, float* LSE,
+                 const int* klen, int causal, float scale, float p_drop, unsigned long long seed, void* stream);
+/* Backward of the above (flash-style recomputation; Delta [B][H][Tq] f32 is workspace). */
+int s2t_attn_bwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
+                 const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
+                 const void* V, long v_st, long v_sb, const void* O, long o_st, long o_sb,
+                 const void* dO, long do_st, long do_sb, const float* LSE, float* Delta,
+                 void* dQ, long dq_st, long dq_sb, void* dK, long dk_st, long dk_sb, void* dV, long dv_st, long dv_sb,
+                 const int* klen, int causal, float scale, float p_drop, unsigned long long seed, void* stream);
+
+/* ---- LayerNorm (fairseq/modules/layer_norm.py:29-32; eps 1e-5; rows of D <= 1024) ------------------ */
+int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                      float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* dx = LN'(dy) + dres (dres optional: the residual branch of a pre-LN block); dgamma/dbeta += (f32) */
+int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                      const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                      int M, int D, void* stream);
+
+/* ---- convolutional subsampler (conv_transformer.py:202-232) ----------------------------------------
+ * conv1: x [B][T][F] f32 -> y [B][T2][F2][C] (channels-last) = relu(conv3x3 s2 p1 + bias); also the
+ * BatchNorm sums: sums[c] += y, sums[C+c] += y^2 (double, caller zeroes).  C in {32, 64, 128}. */
+int s2t_conv1_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, double* sums,
+                  int B, int T, int F, int C, void* stream);
+/* dw[c][3][3] += , db[c] += from dpre [B][T2][F2][C] (gradient after the ReLU mask) */
+int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float* dw, float* db, int B, int T, int F, int C, void* stream);
+/* per-channel double sums over a channels-last [P][C] tensor: mode 0 (y, y^2); mode 1 (dyn, dyn*xhat) */
+int s2t_chan_sums(int dtype, const void* y, const void* dyn, const float* mean, const float* rstd,
+                  double* sums, long P, int C, int mode, void* stream);
+/* nn.BatchNorm2d statistics (conv_transformer.py:212,364-368): training -> batch stats from sums, running
+ * stats momentum update (unbiased var), num_batches += 1; eval -> running stats.  scale/shift for s2t_bn_apply. */
+int s2t_bn_finalize(const double* sums, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                    long long* num_batches, float* mean, float* rstd, float* scale, float* shift,
+                    double count, int C, int training, float momentum, float eps, void* stream);
+int s2t_bn_apply(int dtype, const void* y, const float* scale, const float* shift, void* yn, long n, int C, void* stream);
+/* BatchNorm backward fused with the ReLU mask; sums from s2t_chan_sums(mode 1); dgamma/dbeta += */
+int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const float* mean, const float* rstd,
+                     const float* gamma, const double* sums, void* dpre, float* dgamma, float* dbeta,
+                     long n, int C, double count, int training, void* stream);
+/* fc3 weight [N][C*F] (k = c*F+f, conv_transformer.py:225-226) <-> channels-last k' = f*C+c */
+int s2t_permute_cf(int dst_dtype, const float* src, void* dst, int N, int C, int F, int mode, void* stream);
+/* conv2 weight [Co][Ci][3][3] <-> implicit-GEMM operand layouts (see subsample.hip) */
+int s2t_permute_conv_w(int dst_dtype, const float* src, void* dst, int Co, int Ci, int mode, void* stream);
+/* x[t][b][:] += sinusoid[(t < len[b]) ? t+1 : 0][:]  (positional_embedding_audio.py:21-27) */
+int s2t_add_pos(int dtype, void* x, const float* table, const int* len, int T, int B, int D, void* stream);
+
+/* ---- CTC compression (conv_transformer.py:278-291, 385-426) -----------------------------------------
+ * pred[b][t] = first arg-max of softmax(logits[t][b][:]) (bit-exact integer path), pmax = its probability */
+int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, void* stream);
+/* run-length collapse inside len[b]; seg/run_start/run_len [B][T] int32, new_len [B] int64, w [B][T] f32
+ * strategy 0 avg, 1 weighted, 2 softmax */
+int s2t_ctc_rle(const int* pred, const float* pmax, const long long* len, int* seg, int* run_start, int* run_len,
+                long long* new_len, float* w, int T, int B, int strategy, void* stream);
+/* out[j][b][:] = sum_{t in run j} w[b][t] x[t][b][:]  (zeros for new_len[b] <= j < Tout) */
+int s2t_ctc_compress_fwd(int dtype, const void* x, const float* w, const int* run_start, const int* run_len,
+                         const long long* new_len, void* out, int T, int B, int D, int Tout, void* stream);
+int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int* seg, void* dx, int T, int B, int D,
+                         int accumulate, void* stream);
+
+/* ---- losses ------------------------------------------------------------------------------------
+ * F.log_softmax + F.ctc_loss(reduction="sum", zero_infinity=True) (CTC_loss.py:143-151) and its gradient
+ * w.r.t. the logits [T][B][V].  Workspaces: lse [T*B], la/lb [B*T*(2*Lmax+1)], nll [B] (all f32).
+ * loss_sum[0] += sum_b nll_b (caller zeroes). grad is multiplied by grad_scale. */
+int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len, const int* in_len,
+                 float* lse, float* la, float* lb, float* nll, void* grad, float* loss_sum,
+                 int T, int B, int V, int Lmax, int blank, float grad_scale, void* stream);
+/* label_smoothed_nll_loss over log_softmax(logits.float()) (label_smoothed_cross_entropy.py:12-29), fused
+ * with its gradient: sums2[0] += loss, sums2[1] += nll (caller zeroes); dlogits may be NULL. */
+int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2,
+             long rows, int V, float eps, int pad, float grad_scale, void* stream);
+
+/* ---- decoder embedding (fairseq/models/transformer.py:720-737) -------------------------------------- */
+int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float* table, void* out,
+                  int B, int L, int D, float scale, int pad, void* stream);
+int s2t_embed_bwd(int dtype, const long long* tokens, const void* dout, float* dW, int B, int L, int D,
+                  float scale, int pad, void* stream);
+/* y = x * keep/(1-p), mask from Philox(seed, index); the backward pass calls it again on the gradient */
+int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p, unsigned long long seed, void* stream);
+
+/* ---- optimizer (fairseq/trainer.py:416-443, fairseq/utils.py:253-277, fairseq/optim/adam.py:147-202) ----
+ * out2[0] = gnorm = scale*||g||_2 ; out2[1] = scale * min(1, max_norm/(gnorm+1e-6)) (all on device) */
+int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, float scale, float max_norm, float* out2, void* stream);
+/* Adam over a flat arena; gradients are multiplied by mult2[1] (NULL = 1); optional bf16 shadow refresh */
+int s2t_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, const float* mult2,
+                  float lr, float beta1, float beta2, float eps, float wd, int step, void* stream);
+int s2t_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, void* stream);
+int s2t_scale_by_device_scalar(int dtype, void* x, size_t n, const float* scalar, void* stream);
+
+/* ---- in-library timing of kernel families with HIP events (bench.py roofline) ------------------------
+ * While enabled, every launch of the named family on `stream` is bracketed by hipEvents; s2t_prof_read
+ * synchronises those events and returns accumulated milliseconds, launches and algorithmic flops/bytes. */
+int s2t_prof_enable(int on);
+int s2t_prof_read(const char* family, double* ms, long long* launches, double* flops, double* bytes);
+int s2t_prof_reset(void);
+
+/* ---- host-side helpers (HOST pointers) -------------------------------------------------------------
+ * greedy CTC decode + edit-distance alignment error count (compute_ctc_uer, CTC_loss.py:31-74;
+ * examples/speech_recognition/utils/wer_utils.py:71-203) -- the reference runs this in pure Python
+ * on the critical path of every step. */
+int s2t_host_ctc_uer(const int* pred, const long long* input_len, int B, int T, const long long* targets,
+                     const long long* target_len, int L, int blank, double* errors, double* total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

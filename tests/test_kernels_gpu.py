@@ -1,0 +1,416 @@
+"""GPU parity of every HIP kernel (through the C ABI) against the CPU oracle / plain torch fp32 CPU math.
+fp32 path: 1e-4 (north_star); bf16 path: tolerance stated per test (bf16 has 8 bits of mantissa).
+Integer outputs (CTC compression) are compared bit-exactly."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_golden
+from oracle import int_ref, s2t_ref
+
+pytestmark = pytest.mark.gpu
+
+K = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _k():
+    global K
+    from fbk_fairseq_st_amd import kernels
+    K = kernels
+    K._lib()
+    yield
+
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    a = a.detach().float().cpu().double(); b = b.detach().float().cpu().double()
+    return float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 2e-2
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K_", [(128, 128, 64), (300, 200, 136), (77, 100, 72), (1000, 512, 256), (64, 64, 1280), (5, 3, 8)])
+def test_gemm_nt_epilogues(dtype, M, N, K_):
+    a = rnd(M, K_, dtype=dtype, seed=1); w = rnd(N, K_, dtype=dtype, seed=2, scale=K_ ** -0.5)
+    bias = rnd(N, seed=3); res = rnd(M, N, dtype=dtype, seed=4)
+    ref = a.float() @ w.float().t() + bias
+    out = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV))
+    assert rel_err(out, ref) < tol(dtype)
+    out = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=K.ACT_RELU, residual=res.to(DEV))
+    assert rel_err(out, F.relu(ref) + res.float()) < tol(dtype)
+    pre = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=K.ACT_GELU, aux_out=pre)
+    assert rel_err(out, F.gelu(ref)) < tol(dtype)
+    assert rel_err(pre, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_unaligned_k(dtype):
+    # K = 100 (V_tgt of the fixtures): rows are not 16-byte aligned -> guarded element loads
+    a = rnd(50, 100, dtype=dtype, seed=1); w = rnd(64, 100, dtype=dtype, seed=2, scale=0.1)
+    assert rel_err(K.gemm(a.to(DEV), w.to(DEV)), a.float() @ w.float().t()) < tol(dtype)
+    wt = rnd(100, 64, dtype=dtype, seed=3, scale=0.1)            # NN: dX = dY[50,100] @ W[100,64]
+    assert rel_err(K.gemm(a.to(DEV), wt.to(DEV), trans_b=True), a.float() @ wt.float()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K_", [(256, 128, 192), (130, 70, 100), (2000, 256, 768)])
+def test_gemm_nn_and_bwd_act(dtype, M, N, K_):
+    dy = rnd(M, K_, dtype=dtype, seed=1); w = rnd(K_, N, dtype=dtype, seed=2, scale=K_ ** -0.5)
+    ref = dy.float() @ w.float()
+    assert rel_err(K.gemm(dy.to(DEV), w.to(DEV), trans_b=True), ref) < tol(dtype)
+    aux = rnd(M, N, dtype=dtype, seed=5)
+    out = K.gemm(dy.to(DEV), w.to(DEV), trans_b=True, act=K.ACT_RELU_BWD, aux=aux.to(DEV))
+    assert rel_err(out, ref * (aux.float() > 0)) < tol(dtype)
+    out = K.gemm(dy.to(DEV), w.to(DEV), trans_b=True, act=K.ACT_GELU_BWD, aux=aux.to(DEV))
+    x = aux.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    assert rel_err(out, ref * x.grad) < tol(dtype)
+    acc = rnd(M, N, dtype=dtype, seed=6)
+    out = K.gemm(dy.to(DEV), w.to(DEV), trans_b=True, out=acc.clone().to(DEV), accumulate=True)
+    assert rel_err(out, ref + acc.float()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K_,split", [(128, 128, 512, 1), (256, 64, 3000, 4), (100, 72, 999, 3), (512, 2048, 700, 2)])
+def test_gemm_tn_weight_grad(dtype, M, N, K_, split):
+    # dW[M=N_out, N=K_in] = dY^T[K_, M] X[K_, N], f32 output, split-K with atomics, accumulate into grads
+    dy = rnd(K_, M, dtype=dtype, seed=1); x = rnd(K_, N, dtype=dtype, seed=2)
+    ref = dy.float().t() @ x.float()
+    g0 = rnd(M, N, seed=3)
+    out = K.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, out=g0.clone().to(DEV), accumulate=True,
+                 splitk=split, out_dtype=torch.float32)
+    err = float((out.cpu().double() - (ref + g0).double()).abs().max() / max(1.0, float(ref.abs().max())))
+    assert err < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+def test_gemm_gather_scatter():
+    dtype = torch.float32
+    src = rnd(40, 16, dtype=dtype, seed=1)
+    M, taps = 24, 3
+    g = torch.Generator().manual_seed(5)
+    mp = torch.randint(-1, 40, (taps, M), generator=g, dtype=torch.int32)
+    w = rnd(8, taps * 16, dtype=dtype, seed=2)
+    A = torch.zeros(M, taps * 16)
+    for t in range(taps):
+        for r in range(M):
+            if mp[t, r] >= 0:
+                A[r, t * 16:(t + 1) * 16] = src[mp[t, r]]
+    ref = A @ w.t()
+    out = K.gemm(src.to(DEV), w.to(DEV), M=M, K=taps * 16, map_a=mp.to(DEV), period_a=16)
+    assert rel_err(out, ref) < 1e-4
+    perm = torch.randperm(M, generator=g).to(torch.int32)
+    out = K.gemm(src.to(DEV), w.to(DEV), M=M, K=taps * 16, map_a=mp.to(DEV), period_a=16, map_c=perm.to(DEV))
+    ref2 = torch.zeros_like(ref); ref2[perm.long()] = ref
+    assert rel_err(out, ref2) < 1e-4
+    # gathered B rows for a weight-gradient style product: C[M2,N2] = Adir^T[Kp,M2] . Bsrc[mapB[k]]
+    Kp = 50
+    a2 = rnd(Kp, 12, seed=7); mb = torch.randint(-1, 40, (Kp,), generator=g, dtype=torch.int32)
+    Bg = torch.zeros(Kp, 16)
+    for k in range(Kp):
+        if mb[k] >= 0:
+            Bg[k] = src[mb[k]]
+    out = K.gemm(a2.to(DEV), src.to(DEV), trans_a=True, trans_b=True, K=Kp, map_b=mb.to(DEV))
+    assert rel_err(out, a2.t() @ Bg) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum(dtype):
+    x = rnd(1234, 200, dtype=dtype, seed=1)
+    out = torch.ones(200, device=DEV)
+    K.colsum(x.to(DEV), out)
+    assert rel_err(out, x.float().sum(0) + 1) < (1e-4 if dtype == torch.float32 else 1e-3)
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(q, k, v, heads, klen, causal):
+    Tq, B, D = q.shape; Tk = k.shape[0]; d = D // heads
+    qh = q.view(Tq, B * heads, d).transpose(0, 1) * d ** -0.5
+    kh = k.reshape(Tk, B * heads, d).transpose(0, 1); vh = v.reshape(Tk, B * heads, d).transpose(0, 1)
+    s = torch.bmm(qh, kh.transpose(1, 2))
+    if causal:
+        s = s + torch.triu(torch.full((Tq, Tk), float("-inf")), 1)
+    if klen is not None:
+        m = torch.arange(Tk)[None, :] >= klen[:, None]
+        s = s.view(B, heads, Tq, Tk).masked_fill(m[:, None, None, :], float("-inf")).view(B * heads, Tq, Tk)
+    p = torch.softmax(s, -1)
+    return torch.bmm(p, vh).transpose(0, 1).reshape(Tq, B, D)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("heads,d", [(2, 64), (4, 32)])
+@pytest.mark.parametrize("Tq,Tk,causal,ragged", [(70, 70, False, True), (16, 16, True, True), (130, 130, True, False),
+                                                  (9, 200, False, True), (375, 375, False, False)])
+def test_attention_fwd_bwd(dtype, heads, d, Tq, Tk, causal, ragged):
+    B, D = 3, heads * d
+    qkv = rnd(max(Tq, Tk), B, 3 * D, dtype=dtype, seed=1)
+    q, k, v = qkv[:Tq, :, :D], qkv[:Tk, :, D:2 * D], qkv[:Tk, :, 2 * D:]
+    klen = torch.tensor([Tk, max(1, Tk - 5), max(1, Tk // 2)], dtype=torch.int32) if ragged else None
+    qf, kf, vf = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    ref = attn_ref(qf, kf, vf, heads, klen, causal)
+    do = rnd(Tq, B, D, dtype=dtype, seed=2)
+    ref.backward(do.float())
+    qkv_d = qkv.to(DEV)
+    qd, kd, vd = qkv_d[:Tq, :, :D], qkv_d[:Tk, :, D:2 * D], qkv_d[:Tk, :, 2 * D:]
+    kl = klen.to(DEV) if klen is not None else None
+    out, lse = K.attn_fwd(qd, kd, vd, heads, klen=kl, causal=causal)
+    assert rel_err(out, ref) < tol(dtype)
+    dqkv = torch.zeros_like(qkv_d)
+    K.attn_bwd(qd, kd, vd, out, do.to(DEV), lse, heads, dqkv[:Tq, :, :D], dqkv[:Tk, :, D:2 * D], dqkv[:Tk, :, 2 * D:],
+               klen=kl, causal=causal)
+    t = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel_err(dqkv[:Tq, :, :D], qf.grad) < t
+    assert rel_err(dqkv[:Tk, :, D:2 * D], kf.grad) < t
+    assert rel_err(dqkv[:Tk, :, 2 * D:], vf.grad) < t
+
+
+def test_attention_dropout_consistency():
+    """With dropout the forward/backward masks must agree: finite-difference-free check via linearity in V
+    (O is linear in V for a fixed mask: O(V1+V2) = O(V1)+O(V2)) and dV = (D*P)^T dO."""
+    heads, d, T, B = 2, 64, 50, 2
+    D = heads * d
+    q, k = rnd(T, B, D, seed=1).to(DEV), rnd(T, B, D, seed=2).to(DEV)
+    v1, v2 = rnd(T, B, D, seed=3).to(DEV), rnd(T, B, D, seed=4).to(DEV)
+    o1, _ = K.attn_fwd(q, k, v1, heads, p_drop=0.3, seed=77)
+    o2, _ = K.attn_fwd(q, k, v2, heads, p_drop=0.3, seed=77)
+    o12, lse = K.attn_fwd(q, k, v1 + v2, heads, p_drop=0.3, seed=77)
+    assert rel_err(o12, o1 + o2) < 1e-4
+    o0, _ = K.attn_fwd(q, k, v1, heads)
+    assert rel_err(o0, o1) > 1e-2          # the mask does something
+    do = rnd(T, B, D, seed=5).to(DEV)
+    dq, dk, dv = [torch.empty_like(q) for _ in range(3)]
+    K.attn_bwd(q, k, v1, o1, do, lse, heads, dq, dk, dv, p_drop=0.3, seed=77)
+    # <dO, O(V2)> == <dV, V2> for the same mask
+    lhs = float((do.double() * o2.double()).sum()); rhs = float((dv.double() * v2.double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,D", [(7, 64), (1000, 256), (333, 512), (50, 1024), (20, 100)])
+def test_layernorm(dtype, M, D):
+    x = rnd(M, D, dtype=dtype, seed=1, scale=2.0) + 0.5
+    g, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    xf = x.float().requires_grad_(True); gf = g.clone().requires_grad_(True); bf = b.clone().requires_grad_(True)
+    ref = F.layer_norm(xf, (D,), gf, bf, 1e-5)
+    dy = rnd(M, D, dtype=dtype, seed=4); dres = rnd(M, D, dtype=dtype, seed=5)
+    ref.backward(dy.float())
+    y, mean, rstd = K.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV))
+    assert rel_err(y, ref) < tol(dtype)
+    dg = torch.zeros(D, device=DEV); db = torch.zeros(D, device=DEV)
+    dx = K.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, g.to(DEV), dg, db, dres=dres.to(DEV))
+    assert rel_err(dx, xf.grad + dres.float()) < tol(dtype)
+    assert rel_err(dg, gf.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(db, bf.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+
+
+# ------------------------------------------------------------------ conv1 + BatchNorm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T", [(2, 37), (3, 200)])
+def test_conv1_bn(dtype, B, T):
+    C, Fq = 64, 80
+    x = rnd(B, T, Fq, seed=1); w = rnd(C, 1, 3, 3, seed=2, scale=0.5); bias = 0.1 * rnd(C, seed=3)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    rm, rv = 0.1 * rnd(C, seed=6), 0.5 + torch.rand(C)
+    wf = w.clone().requires_grad_(True); bf = bias.clone().requires_grad_(True)
+    gf = gamma.clone().requires_grad_(True); btf = beta.clone().requires_grad_(True)
+    y = F.relu(F.conv2d(x.unsqueeze(1), wf, bf, stride=2, padding=1))
+    yn, nrm, nrv = s2t_ref.batch_norm2d(y, gf, btf, rm, rv, True, 0.1, 1e-5)
+    dyn = rnd(*yn.shape, seed=7)
+    yn.backward(dyn)
+    yd, sums = K.conv1_fwd(x.to(DEV), w.to(DEV), bias.to(DEV), C, dtype)
+    assert rel_err(yd.permute(0, 3, 1, 2), y) < tol(dtype)
+    rmd, rvd = rm.clone().to(DEV), rv.clone().to(DEV)
+    nb = torch.zeros(1, dtype=torch.int64, device=DEV)
+    cnt = yd.numel() // C
+    mean, rstd, scale, shift = K.bn_finalize(sums, gamma.to(DEV), beta.to(DEV), rmd, rvd, nb, cnt, True)
+    assert rel_err(rmd, nrm) < 1e-3 and rel_err(rvd, nrv) < 1e-3 and int(nb) == 1
+    ynd = K.bn_apply(yd, scale, shift)
+    assert rel_err(ynd.permute(0, 3, 1, 2), yn) < (2e-4 if dtype == torch.float32 else 3e-2)
+    dynd = dyn.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+    s2 = K.chan_sums(yd, C, dyn=dynd, mean=mean, rstd=rstd)
+    dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
+    dpre = K.bn_bwd_apply(dynd, yd, mean, rstd, gamma.to(DEV), s2, dg, db, cnt)
+    t = 5e-4 if dtype == torch.float32 else 5e-2
+    assert rel_err(dg, gf.grad) < t and rel_err(db, btf.grad) < t
+    dw = torch.zeros(C, 9, device=DEV); dbias = torch.zeros(C, device=DEV)
+    K.conv1_bwd(x.to(DEV), dpre, dw, dbias)
+    assert rel_err(dw.view(C, 1, 3, 3), wf.grad) < t
+    assert rel_err(dbias, bf.grad) < t
+
+
+# ------------------------------------------------------------------ CTC compression (integers bit-exact)
+def test_ctc_compress_golden_bit_exact():
+    g = load_golden("ctc_compress")
+    x = torch.from_numpy(g["x"]).to(DEV)          # logits (ctc_fc = identity in the fixture)
+    lens = torch.from_numpy(g["lens"]).to(DEV)
+    T, B, D = x.shape
+    pred, pmax = K.ctc_argmax(x)
+    for b in range(B):
+        Lb = int(g["lens"][b])
+        assert np.array_equal(pred[b, :Lb].cpu().numpy().astype(np.int64), g["pred"][b, :Lb])
+    for si, strat in enumerate(("avg", "weighted", "softmax")):
+        seg, rs, rl, new_len, w = K.ctc_rle(pred, pmax, lens, si)
+        assert np.array_equal(new_len.cpu().numpy(), g[strat + "_new_len"])            # bit-exact
+        c = int_ref.ctc_rle_c(pred.cpu().numpy(), g["lens"])
+        assert np.array_equal(seg.cpu().numpy(), c["seg_id"])
+        nl = c["new_len"]
+        for b in range(B):
+            assert np.array_equal(rs[b, :nl[b]].cpu().numpy(), c["run_start"][b, :nl[b]])
+            assert np.array_equal(rl[b, :nl[b]].cpu().numpy(), c["run_len"][b, :nl[b]])
+        Tout = int(new_len.max())
+        out = K.ctc_compress_fwd(x, w, rs, rl, new_len, Tout)
+        assert rel_err(out, torch.from_numpy(g[strat + "_out"])) < 1e-4
+        dout = (2 * out).contiguous()                                                   # d/dout of sum(out^2)
+        dx = torch.empty_like(x)
+        K.ctc_compress_bwd(dout, w, seg, dx)
+        assert rel_err(dx, torch.from_numpy(g[strat + "_grad_x"])) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ctc_argmax_random_matches_oracle(dtype):
+    T, B, V = 120, 5, 5001
+    x = rnd(T, B, V, dtype=dtype, seed=3, scale=3.0)
+    pred, pmax = K.ctc_argmax(x.to(DEV))
+    prob = torch.softmax(x.float(), -1).transpose(0, 1)
+    ref = int_ref.argmax_first_np(prob.numpy())
+    assert np.array_equal(pred.cpu().numpy(), ref)
+    lens = torch.tensor([120, 100, 64, 65, 1])
+    seg, rs, rl, new_len, w = K.ctc_rle(pred, pmax, lens.to(DEV), 0)
+    runs = int_ref.ctc_rle_np(ref, lens.numpy())
+    assert [len(r) for r in runs] == new_len.cpu().tolist()
+
+
+def test_ctc_rle_long_runs():
+    # runs crossing the 64-frame chunks of the wave-parallel scan
+    B, T = 4, 300
+    pred = torch.zeros(B, T, dtype=torch.int32)
+    pred[1] = torch.arange(T) // 70
+    pred[2] = torch.arange(T) % 2
+    pred[3, 150:] = 9
+    lens = torch.tensor([300, 300, 299, 151])
+    seg, rs, rl, new_len, w = K.ctc_rle(pred.to(DEV), torch.ones(B, T, device=DEV), lens.to(DEV), 0)
+    c = int_ref.ctc_rle_c(pred.numpy(), lens.numpy())
+    assert np.array_equal(new_len.cpu().numpy(), c["new_len"])
+    assert np.array_equal(seg.cpu().numpy(), c["seg_id"])
+
+
+# ------------------------------------------------------------------ losses
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ctc_loss(dtype):
+    T, B, V, Lm = 60, 5, 40, 12
+    blank = V - 1
+    logits = rnd(T, B, V, dtype=dtype, seed=1, scale=2.0)
+    g = torch.Generator().manual_seed(2)
+    tgt = torch.randint(4, blank, (B, Lm), generator=g)
+    tl = torch.tensor([12, 7, 1, 10, 3]); il = torch.tensor([60, 45, 30, 5, 17])
+    tgt[3, :10] = 5                                   # 10 repeats need 19 frames > 5 -> infeasible -> zero_infinity
+    lf = logits.float().requires_grad_(True)
+    ref = s2t_ref.ctc_loss_sum(lf, tgt, il, tl, blank)
+    ref.backward()
+    loss, grad, nll = K.ctc_loss(logits.to(DEV), tgt.to(DEV), tl.to(DEV), il.to(torch.int32).to(DEV), blank)
+    assert abs(float(loss) - float(ref)) < (1e-4 if dtype == torch.float32 else 2e-3) * abs(float(ref))
+    assert rel_err(grad, lf.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    assert not math.isfinite(float(nll[3]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("V", [100, 8000])
+def test_lsce(dtype, V):
+    rows = 37
+    logits = rnd(rows, V, dtype=dtype, seed=1, scale=2.0)
+    g = torch.Generator().manual_seed(2)
+    tgt = torch.randint(4, V, (rows,), generator=g); tgt[5] = 1; tgt[20] = 1
+    lf = logits.float().requires_grad_(True)
+    loss, nll = s2t_ref.label_smoothed_nll(lf, tgt, 0.1, 1)
+    loss.backward()
+    sums, dl = K.lsce(logits.to(DEV), tgt.to(DEV), 0.1, 1)
+    assert abs(float(sums[0]) - float(loss)) < 1e-4 * abs(float(loss))
+    assert abs(float(sums[1]) - float(nll)) < 1e-4 * abs(float(nll))
+    assert rel_err(dl, lf.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding(dtype):
+    V, D, B, Ln, pad = 50, 64, 3, 9, 1
+    W = rnd(V, D, dtype=dtype, seed=1)
+    g = torch.Generator().manual_seed(2)
+    tok = torch.randint(2, V, (B, Ln), generator=g); tok[1, 6:] = pad; tok[2, 3:] = pad
+    table = s2t_ref.sinusoid_table(pad + 1 + Ln, D, pad)
+    ref = (math.sqrt(D) * W.float()[tok] + table[s2t_ref.token_positions(tok, pad)]).transpose(0, 1)
+    out = K.embed_fwd(tok.to(DEV), W.to(DEV), table.to(DEV), math.sqrt(D), pad)
+    assert rel_err(out, ref) < tol(dtype)
+    dout = rnd(Ln, B, D, dtype=dtype, seed=3)
+    dW = torch.zeros(V, D, device=DEV)
+    K.embed_bwd(tok.to(DEV), dout.to(DEV), dW, math.sqrt(D), pad)
+    refg = torch.zeros(V, D)
+    refg.index_put_((tok.t().reshape(-1),), math.sqrt(D) * dout.float().reshape(-1, D), accumulate=True)
+    refg[pad] = 0
+    assert rel_err(dW, refg) < 1e-4
+
+
+def test_dropout_statistics_and_replay():
+    x = torch.ones(1 << 20, device=DEV)
+    y1 = K.dropout(x, 0.25, seed=5); y2 = K.dropout(x, 0.25, seed=5); y3 = K.dropout(x, 0.25, seed=6)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = float((y1 > 0).float().mean())
+    assert abs(keep - 0.75) < 5e-3 and abs(float(y1.max()) - 1 / 0.75) < 1e-6
+
+
+# ------------------------------------------------------------------ optimizer
+def test_gradnorm_clip_adam():
+    n = 100003
+    p = rnd(n, seed=1); g = rnd(n, seed=2); m = torch.zeros(n); v = torch.zeros(n)
+    pd, gd, md, vd = p.to(DEV), g.to(DEV), m.to(DEV), v.to(DEV)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ws = torch.zeros(1, dtype=torch.float64, device=DEV); out2 = torch.zeros(2, device=DEV)
+    scale = 1.0 / 15
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    for step in (1, 2, 3):
+        K.grad_norm_clip(gd, scale, 0.5, ws, out2)
+        gn, gl = s2t_ref.clip_grad_norm([g * scale], 0.5)
+        assert abs(float(out2[0]) - float(gn)) < 1e-4 * float(gn)
+        K.adam_step(pd, gd, md, vd, shadow, out2, 5e-4, 0.9, 0.98, 1e-8, 1e-4, step)
+        pr, mr, vr = s2t_ref.adam_step(pr, gl[0], mr, vr, step, 5e-4, wd=1e-4)
+    assert rel_err(pd, pr) < 1e-5 and rel_err(md, mr) < 1e-5 and rel_err(vd, vr) < 1e-5
+    assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+def test_add_pos_and_permutes():
+    T, B, D = 11, 3, 64
+    x = rnd(T, B, D, seed=1); lens = torch.tensor([11, 7, 1])
+    table = s2t_ref.sinusoid_table(T + 1, D, 0)
+    ref = x + table[s2t_ref.audio_positions(lens, T)].transpose(0, 1)
+    out = K.add_pos(x.clone().to(DEV), table.to(DEV), lens.to(torch.int32).to(DEV))
+    assert rel_err(out, ref) < 1e-6
+    N, C, Fq = 5, 64, 20
+    w = rnd(N, C * Fq, seed=2)
+    wp = K.permute_cf(w.to(DEV), torch.empty(N, C * Fq, device=DEV), N, C, Fq, 0)
+    assert torch.equal(wp.cpu(), w.view(N, C, Fq).transpose(1, 2).reshape(N, -1))
+    acc = torch.ones(N, C * Fq, device=DEV)
+    K.permute_cf(wp, acc, N, C, Fq, 1)
+    assert rel_err(acc, w + 1) < 1e-6
+    w2 = rnd(8, 16, 3, 3, seed=3)
+    f = K.permute_conv_w(w2.to(DEV), torch.empty(8, 9 * 16, device=DEV), 8, 16, 0)
+    assert torch.equal(f.cpu(), w2.permute(0, 2, 3, 1).reshape(8, -1))
+    back = torch.zeros(8, 16, 3, 3, device=DEV)
+    K.permute_conv_w(f, back, 8, 16, 2)
+    assert torch.equal(back.cpu(), w2)
