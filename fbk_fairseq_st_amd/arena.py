@@ -1,0 +1,80 @@
+"""Flat parameter arena in HBM: one f32 master buffer, one f32 gradient buffer, Adam moments and
+(bf16 mode) a bf16 shadow that the MFMA GEMMs read.
+
+MI355X-first replacement for fairseq's per-tensor parameter handling on this path: a single Adam
+launch over the arena (fairseq/optim/adam.py:147-202 loops over tensors), a single gradient-norm
+launch (fairseq/utils.py:253-277 stacks per-tensor norms) and contiguous slices for the bucketed
+RCCL all-reduce (fairseq/legacy_distributed_data_parallel.py:96-134 copies grads into a flat buffer
+first).  nn.Parameters of the model are views into `master`; their .grad are views into `grad`.
+"""
+from collections import OrderedDict
+
+import torch
+
+ALIGN = 64          # elements: every parameter starts 256-byte aligned in the f32 arena (128 B in the shadow)
+
+
+class ParamArena:
+    def __init__(self, named_shapes, device, compute_dtype=torch.float32):
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        self.slices = OrderedDict()
+        off = 0
+        for name, shape in named_shapes.items():
+            n = 1
+            for s in shape:
+                n *= int(s)
+            self.slices[name] = (off, n, tuple(int(s) for s in shape))
+            off += (n + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.shadow = (torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+                       if compute_dtype == torch.bfloat16 else None)
+        self._views = {}
+
+    def _view(self, buf, name):
+        off, n, shape = self.slices[name]
+        return buf[off:off + n].view(shape)
+
+    def p(self, name):
+        """f32 master view."""
+        return self._view(self.master, name)
+
+    def g(self, name):
+        """f32 gradient view (kernels accumulate into it)."""
+        return self._view(self.grad, name)
+
+    def w(self, name):
+        """compute-dtype view handed to the GEMM kernels (bf16 shadow or the master itself)."""
+        key = ("w", name)
+        v = self._views.get(key)
+        if v is None:
+            v = self._view(self.shadow if self.shadow is not None else self.master, name)
+            self._views[key] = v
+        return v
+
+    def has(self, name):
+        return name in self.slices
+
+    def refresh_shadow(self):
+        """master -> bf16 shadow (after init / load_state_dict; Adam refreshes it itself every step)."""
+        if self.shadow is not None:
+            from . import kernels as K
+            K.cast(self.master, self.shadow)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def ensure_adam_state(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.master)
+            self.exp_avg_sq = torch.zeros_like(self.master)
+
+    def slice_of(self, names):
+        """[start, end) element range of the arena covering `names` (contiguous by construction order)."""
+        offs = [self.slices[n][0] for n in names]
+        ends = [self.slices[n][0] + (self.slices[n][1] + ALIGN - 1) // ALIGN * ALIGN for n in names]
+        return min(offs), max(ends)

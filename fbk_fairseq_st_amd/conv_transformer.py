@@ -1,0 +1,518 @@
+"""`conv_transformer` (FBK S-Transformer) behind the reference's model interface, running on the HIP engine.
+
+Mirrors examples/speech_recognition/models/conv_transformer.py: same registry names
+(`--arch conv_transformer{,_big,_big2,_giant}`), same flags (add_args :47-72), same
+encoder/decoder call signatures and output tuples, same state-dict key names.
+On top of the reference's presets it registers the build-defined `s2t_transformer{,_xs,_s,_m,_l}`
+presets that BASELINE.json names.
+
+Out of scope here: ConvAttention2D (`--no-attn-2d` is implied and required),
+`--distance-penalty`, learned positions, adaptive softmax, LayerDrop.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .arena import ParamArena
+from .engine import HParams, S2TEngine
+from .registry import (CTCAwareEncoderOut, EncoderOut, FairseqEncoder, FairseqEncoderDecoderModel,
+                       FairseqIncrementalDecoder, register_model, register_model_architecture)
+
+STRATEGIES = {"avg": 0, "weighted": 1, "softmax": 2}
+
+
+# ------------------------------------------------------------------ state-dict name mapping
+def reference_to_fused(sd, prefix_filter=None):
+    """reference keys (q_proj/k_proj/v_proj separate) -> arena keys (qkv / kv fused)."""
+    out = {}
+    done = set()
+    for k, v in sd.items():
+        if k in done:
+            continue
+        for kind in ("weight", "bias"):
+            if k.endswith("self_attn.q_proj." + kind):
+                base = k[: -len("q_proj." + kind)]
+                out[base + "qkv." + kind] = torch.cat([sd[base + "q_proj." + kind], sd[base + "k_proj." + kind], sd[base + "v_proj." + kind]], 0)
+                done.update(base + n + "." + kind for n in ("q_proj", "k_proj", "v_proj"))
+                break
+            if k.endswith("encoder_attn.k_proj." + kind):
+                base = k[: -len("k_proj." + kind)]
+                out[base + "kv." + kind] = torch.cat([sd[base + "k_proj." + kind], sd[base + "v_proj." + kind]], 0)
+                done.update(base + n + "." + kind for n in ("k_proj", "v_proj"))
+                break
+        else:
+            if ("self_attn.k_proj" in k or "self_attn.v_proj" in k or "encoder_attn.v_proj" in k):
+                continue
+            out[k] = v
+    return out
+
+
+def fused_to_reference(sd):
+    out = {}
+    for k, v in sd.items():
+        if ".self_attn.qkv." in k:
+            D = v.shape[0] // 3
+            for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                out[k.replace("qkv", n)] = v[i * D:(i + 1) * D].clone()
+        elif ".encoder_attn.kv." in k:
+            D = v.shape[0] // 2
+            for i, n in enumerate(("k_proj", "v_proj")):
+                out[k.replace("kv", n)] = v[i * D:(i + 1) * D].clone()
+        else:
+            out[k] = v
+    return out
+
+
+# ------------------------------------------------------------------ autograd bridges
+class _EncoderFn(torch.autograd.Function):
+    """Connects the engine's encoder to torch autograd: outputs (encoder_out, ctc_out, state_k)."""
+
+    @staticmethod
+    def forward(ctx, anchor, enc, src_tokens, src_lengths, training, seed, want_state):
+        out, ectx = enc.engine.encoder_forward(src_tokens, src_lengths, training, seed, return_all_hiddens=want_state is not None)
+        ctx.enc, ctx.ectx, ctx.want_state = enc, ectx, want_state
+        enc._last = out
+        eo = out["out"]
+        co = out["ctc_out"] if out["ctc_out"] is not None else eo.new_zeros(1)
+        st = out["states"][want_state] if want_state is not None else eo.new_zeros(1)
+        ctx.mark_non_differentiable(*[t for t, keep in ((co, out["ctc_out"] is not None), (st, want_state is not None)) if not keep])
+        return eo, co, st
+
+    @staticmethod
+    def backward(ctx, d_out, d_ctc, d_state):
+        eng = ctx.enc.engine
+        has_ctc = ctx.ectx["ctc"] is not None
+        ds = {ctx.want_state: d_state.contiguous()} if (ctx.want_state is not None and d_state is not None) else None
+        eng.encoder_backward(ctx.ectx, d_out, d_ctc.contiguous() if (has_ctc and d_ctc is not None) else None, ds)
+        ctx.enc._after_backward("encoder")
+        return (None,) * 7
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, dec, prev_tokens, enc_out, enc_klen, training, seed):
+        logits, dctx = dec.engine.decoder_forward(prev_tokens, enc_out.contiguous(), enc_klen, training, seed, pfx=dec.pfx)
+        ctx.dec, ctx.dctx = dec, dctx
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        denc = ctx.dec.engine.decoder_backward(ctx.dctx, dlogits.contiguous())
+        ctx.dec._after_backward(ctx.dec.pfx.rstrip("."))
+        c = ctx.dctx
+        return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None
+
+
+# ------------------------------------------------------------------ modules
+def _init_linear(n, k, gain=1.0):
+    w = torch.empty(n, k)
+    nn.init.xavier_uniform_(w, gain=gain)
+    return w
+
+
+class ConvolutionalTransformerEncoder(FairseqEncoder):
+    """ConvolutionalTransformerEncoder (conv_transformer.py:124-345) on the HIP engine."""
+
+    def __init__(self, args, dictionary, audio_features=40, owner=None):
+        super().__init__(dictionary)
+        self.args = args
+        self.owner = owner
+        self.ctc_compress_out = getattr(args, "ctc_compress_out", False)
+        if self.ctc_compress_out:
+            assert args.criterion == "ctc_multi_loss"          # conv_transformer.py:191
+            self.ctc_layer = args.ctc_encoder_layer
+        self._last = None
+
+    @property
+    def engine(self):
+        return self.owner.engine
+
+    @property
+    def output_batch_first(self):
+        return False                                            # conv_transformer.py:302-304
+
+    def _after_backward(self, part):
+        self.owner._notify_grads_ready(part)
+
+    def forward(self, src_tokens, src_lengths, cls_input=None, return_all_hiddens=False, want_state=None, **unused):
+        m = self.owner
+        m._ensure_engine(src_tokens.device)
+        if return_all_hiddens and want_state is None and not self.ctc_compress_out:
+            want_state = getattr(m, "_ctc_state_layer", None)
+        seed = m._next_seed()
+        eo, co, st = _EncoderFn.apply(m.anchor, self, src_tokens, src_lengths, self.training, seed, want_state)
+        o = self._last
+        B = eo.shape[1]
+        pad_mask = None
+        if o["klen"] is not None:
+            pad_mask = torch.arange(eo.shape[0], device=eo.device)[None, :] >= o["lengths"][:, None]
+        states = None
+        if return_all_hiddens:
+            states = list(o["states"]) if o["states"] is not None else None
+            if states is not None and want_state is not None:
+                states[want_state] = st
+        if self.ctc_compress_out:
+            ctc_mask = None
+            if o["ctc_klen"] is not None:
+                ctc_mask = torch.arange(co.shape[0], device=eo.device)[None, :] >= o["ctc_lengths"][:, None]
+            return CTCAwareEncoderOut(eo, pad_mask, None, states, src_tokens, o["lengths"], co, ctc_mask)
+        return EncoderOut(eo, pad_mask, None, states, src_tokens, o["lengths"])
+
+    def forward_non_torchscript(self, net_input):
+        return self.forward(**{k: v for k, v in net_input.items()
+                               if k not in ("prev_output_tokens", "transcript_prev_output_tokens")})   # :306-313
+
+    def reorder_encoder_out(self, encoder_out, new_order):          # conv_transformer.py:315-345
+        if encoder_out.encoder_out is not None:
+            encoder_out = encoder_out._replace(encoder_out=encoder_out.encoder_out.index_select(1, new_order))
+        if encoder_out.encoder_padding_mask is not None:
+            encoder_out = encoder_out._replace(encoder_padding_mask=encoder_out.encoder_padding_mask.index_select(0, new_order))
+        if encoder_out.src_lengths is not None:
+            encoder_out = encoder_out._replace(src_lengths=encoder_out.src_lengths.index_select(0, new_order))
+        return encoder_out
+
+    def max_positions(self):
+        return getattr(self.args, "max_source_positions", 100000)
+
+
+class TransformerDecoder(FairseqIncrementalDecoder):
+    """TransformerDecoder (fairseq/models/transformer.py:517-866), training / scoring path."""
+
+    def __init__(self, args, dictionary, owner=None, pfx="decoder."):
+        super().__init__(dictionary)
+        self.args = args
+        self.owner = owner
+        self.pfx = pfx
+        self.padding_idx = dictionary.pad()
+        self.max_target_positions = getattr(args, "max_target_positions", 100000)
+
+    @property
+    def engine(self):
+        return self.owner.engine
+
+    def _after_backward(self, part):
+        self.owner._notify_grads_ready(part)
+
+    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, **unused):
+        if incremental_state is not None:
+            raise NotImplementedError("incremental decoding (beam search) is a later row of SURVEY.md 8-a (a22)")
+        m = self.owner
+        m._ensure_engine(prev_output_tokens.device)
+        eo = encoder_out.encoder_out
+        klen = None
+        if encoder_out.encoder_padding_mask is not None:
+            klen = encoder_out.src_lengths.to(torch.int32)
+        logits_tm = _DecoderFn.apply(m.anchor, self, prev_output_tokens, eo, klen, self.training, m._next_seed())
+        B, L = prev_output_tokens.shape
+        logits = logits_tm.view(L, B, -1).transpose(0, 1)         # view, no copy: (B, L, V)
+        return logits, {"attn": [None], "inner_states": None}
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        raise NotImplementedError("use the fused label-smoothed CE kernel (criterions.py); lprobs are never materialised")
+
+    def max_positions(self):
+        return self.max_target_positions
+
+
+@register_model("conv_transformer")
+class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
+    """ConvolutionalTransformerModel (conv_transformer.py:35-121)."""
+
+    def __init__(self, args, encoder, decoder, hp):
+        super().__init__(encoder, decoder)
+        self.args = args
+        self.hp = hp
+        object.__setattr__(encoder, "owner", self)
+        object.__setattr__(decoder, "owner", self)
+        # parameters live on the CPU (reference initialisation) until materialize() re-homes them in the arena
+        self.params = nn.ParameterDict()
+        self._names = {}
+        for name, shape in hp.param_shapes().items():
+            self._register(name, self._init_param(name, shape))
+        C = hp.conv_ch
+        for i in range(2):
+            self.register_buffer("bn%d_running_mean" % i, torch.zeros(C))
+            self.register_buffer("bn%d_running_var" % i, torch.ones(C))
+            self.register_buffer("bn%d_num_batches_tracked" % i, torch.zeros(1, dtype=torch.int64))
+        self.anchor = nn.Parameter(torch.zeros(1), requires_grad=True)      # keeps the autograd bridges alive
+        self.engine = None
+        self.arena = None
+        self.compute_dtype = torch.float32
+        self._seed_base, self._seed_ctr = 1, 0
+        self._grad_hooks = []
+        self.extra_param_specs = {}            # e.g. the criterion-owned CTC head, added before materialize()
+
+    # ---- parameter plumbing
+    def _register(self, name, tensor):
+        key = name.replace(".", "__")
+        self.params[key] = nn.Parameter(tensor)
+        self._names[name] = key
+
+    def _init_param(self, name, shape):
+        """Reference initialisation."""
+        hp = self.hp
+        if name.endswith("layer_norm.weight") or (".bn." in name and name.endswith("weight")):
+            return torch.ones(shape)
+        if name.endswith("bias"):
+            return torch.zeros(shape)
+        if "convolutions" in name:                               # conv_transformer.py:348-354
+            cin = shape[1]
+            std = math.sqrt((4 * (1.0 - hp.dropout)) / (3 * cin))
+            return torch.randn(shape) * std
+        if name.endswith("embed_tokens.weight"):                 # :357-361
+            w = torch.randn(shape) * shape[1] ** -0.5
+            w[hp.pad] = 0
+            return w
+        if name.endswith("output_projection.weight"):            # transformer.py:626-631
+            return torch.randn(shape) * shape[1] ** -0.5
+        if name.endswith("self_attn.qkv.weight"):                # multihead_attention.py:88-106 (gain 1/sqrt2 per matrix)
+            D = shape[1]
+            return torch.cat([_init_linear(D, D, 1 / math.sqrt(2)) for _ in range(3)], 0)
+        if name.endswith("encoder_attn.kv.weight"):
+            D = shape[1]
+            return torch.cat([_init_linear(D, D, 1 / math.sqrt(2)) for _ in range(2)], 0)
+        if name.endswith("encoder_attn.q_proj.weight"):
+            return _init_linear(shape[0], shape[1], 1 / math.sqrt(2))
+        if name == "encoder.ctc_fc.weight":                      # nn.Linear default init (:190)
+            w = torch.empty(shape)
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+            return w
+        return _init_linear(shape[0], shape[1])                  # xavier_uniform (:371-375, transformer_layer.py:395-400)
+
+    def named_arena_params(self):
+        return {n: self.params[k] for n, k in self._names.items()}
+
+    def materialize(self, device, compute_dtype=torch.float32, extra=None):
+        """Move every parameter into one flat arena on `device` (and build the engine)."""
+        named = dict(self.named_arena_params())
+        if extra:
+            named.update(extra)
+        arena = ParamArena({n: tuple(p.shape) for n, p in named.items()}, device, compute_dtype)
+        for n, p in named.items():
+            arena.p(n).copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = arena.p(n)
+            p.grad = arena.g(n)
+        self.anchor.data = self.anchor.data.to(device)
+        for b in self.buffers():
+            b.data = b.data.to(device)
+        arena.refresh_shadow()
+        self.arena, self.compute_dtype = arena, compute_dtype
+        self.engine = S2TEngine(self.hp, arena)
+        self.engine.bn_buffers = {
+            "encoder.bn.%d.%s" % (i, n): getattr(self, "bn%d_%s" % (i, n))
+            for i in range(2) for n in ("running_mean", "running_var", "num_batches_tracked")}
+        return arena
+
+    def _ensure_engine(self, device):
+        if self.engine is None:
+            if torch.device(device).type != "cuda":
+                raise RuntimeError("conv_transformer runs on the HIP engine only: move inputs to cuda:N "
+                                   "(there is no CPU fallback for the S2T hot path)")
+            self.materialize(device, self.compute_dtype)
+
+    def _next_seed(self):
+        self._seed_ctr += 1
+        return self._seed_base * 1000 + self._seed_ctr
+
+    def set_seed(self, seed):
+        """dropout streams are keyed on (seed, call counter): trainer reseeds with seed + num_updates (trainer.py:655-661)"""
+        self._seed_base, self._seed_ctr = int(seed) % 1000003, 0
+
+    def add_grads_ready_hook(self, fn):
+        self._grad_hooks.append(fn)
+
+    def _notify_grads_ready(self, part):
+        for fn in self._grad_hooks:
+            fn(part)
+
+    # ---- reference-compatible state dict (split q/k/v, `encoder.bn.N.*` buffers, positional placeholders)
+    def state_dict(self, destination=None, prefix="", keep_vars=False):
+        sd = {n: p.data.detach().float().cpu().clone() for n, p in self.named_arena_params().items()}
+        sd = fused_to_reference(sd)
+        for i in range(2):
+            for n in ("running_mean", "running_var", "num_batches_tracked"):
+                b = getattr(self, "bn%d_%s" % (i, n)).detach().cpu().clone()
+                sd["encoder.bn.%d.%s" % (i, n)] = b.view(()) if n == "num_batches_tracked" else b
+        sd["encoder.embed_positions.embeddings._float_tensor"] = torch.FloatTensor(1)
+        sd["decoder.embed_positions._float_tensor"] = torch.FloatTensor(1)
+        sd["decoder.version"] = torch.Tensor([3])
+        return {prefix + k: v for k, v in sd.items()}
+
+    def load_state_dict(self, state_dict, strict=True, args=None):
+        sd = reference_to_fused({k: v for k, v in state_dict.items()})
+        mine = self.named_arena_params()
+        missing = [n for n in mine if n not in sd]
+        if strict and missing:
+            raise RuntimeError("Missing key(s) in state_dict: " + ", ".join(missing))
+        with torch.no_grad():
+            for n, p in mine.items():
+                if n in sd:
+                    p.data.copy_(sd[n].to(p.data.dtype))
+            for i in range(2):
+                for n in ("running_mean", "running_var", "num_batches_tracked"):
+                    k = "encoder.bn.%d.%s" % (i, n)
+                    if k in sd:
+                        getattr(self, "bn%d_%s" % (i, n)).copy_(sd[k].reshape(getattr(self, "bn%d_%s" % (i, n)).shape))
+        if self.arena is not None:
+            self.arena.refresh_shadow()
+        if getattr(args, "freeze_pretrained", False):            # conv_transformer.py:114-121
+            for n, p in mine.items():
+                if n in sd:
+                    p.requires_grad = False
+        return self
+
+    def raw_state_dict_upgrade(self, state_dict):                   # conv_transformer.py:105-112
+        if self.encoder.ctc_compress_out and "encoder.ctc_fc.weight" not in state_dict["model"]:
+            crit = state_dict.get("criterion", {})
+            if "ctc_aware_model.fc_out.weight" in crit:
+                state_dict["model"]["encoder.ctc_fc.weight"] = crit["ctc_aware_model.fc_out.weight"]
+                state_dict["model"]["encoder.ctc_fc.bias"] = crit["ctc_aware_model.fc_out.bias"]
+        return state_dict
+
+    # ---- registry surface
+    @staticmethod
+    def add_args(parser):
+        """conv_transformer.py:47-72 + the TransformerModel flags this path reads (transformer.py:95-175)."""
+        a = parser.add_argument
+        a("--input-feat-per-channel", type=int, metavar="N")
+        a("--activation-fn", choices=["relu", "gelu"])
+        a("--dropout", type=float, metavar="D"); a("--attention-dropout", type=float, metavar="D")
+        a("--activation-dropout", "--relu-dropout", type=float, metavar="D")
+        a("--encoder-embed-dim", type=int, metavar="N"); a("--encoder-ffn-embed-dim", type=int, metavar="N")
+        a("--encoder-layers", type=int, metavar="N"); a("--encoder-attention-heads", type=int, metavar="N")
+        a("--decoder-embed-dim", type=int, metavar="N"); a("--decoder-ffn-embed-dim", type=int, metavar="N")
+        a("--decoder-layers", type=int, metavar="N"); a("--decoder-attention-heads", type=int, metavar="N")
+        a("--encoder-normalize-before", action="store_true"); a("--decoder-normalize-before", action="store_true")
+        a("--share-decoder-input-output-embed", action="store_true")
+        a("--no-scale-embedding", action="store_true")
+        a("--encoder-convolutions", type=str, metavar="EXPR")
+        a("--normalization-constant", type=float, default=1.0)
+        a("--no-attn-2d", action="store_true", default=False)
+        a("--distance-penalty", type=str, default=False, choices=["log", "gauss"])
+        a("--ctc-compress-out", action="store_true", default=False)
+        a("--ctc-compress-strategy", type=str, default="avg", choices=["avg", "weighted", "softmax"])
+        a("--freeze-pretrained", action="store_true")
+
+    @classmethod
+    def build_model(cls, args, task):
+        base_architecture(args)
+        if not hasattr(args, "max_source_positions"):
+            args.max_source_positions = 100000
+        if not hasattr(args, "max_target_positions"):
+            args.max_target_positions = 100000
+        if getattr(args, "attn_2d", False):
+            raise NotImplementedError("ConvAttention2D is outside this round's hot path: pass --no-attn-2d (SURVEY.md 8-f N3)")
+        if getattr(args, "distance_penalty", False):
+            raise NotImplementedError("--distance-penalty is outside this round's hot path (SURVEY.md 8-f N4)")
+        if getattr(args, "share_decoder_input_output_embed", False):
+            raise NotImplementedError("--share-decoder-input-output-embed")
+        src_dict, tgt_dict = task.source_dictionary, task.target_dictionary
+        enc_dict = src_dict if src_dict is not None else tgt_dict           # conv_transformer.py:100-101
+        convs = eval(args.encoder_convolutions) if isinstance(args.encoder_convolutions, str) else args.encoder_convolutions
+        assert len(convs) == 2 and all(tuple(c[1:]) in ((3,), (3, 3)) for c in convs) and convs[0][0] == convs[1][0], \
+            "the subsampler kernels implement 2 x (C, 3, 3) stride-2 convolutions"
+        assert args.encoder_embed_dim == args.decoder_embed_dim and args.encoder_attention_heads == args.decoder_attention_heads
+        compress = getattr(args, "ctc_compress_out", False)
+        hp = HParams(D=args.encoder_embed_dim, heads=args.encoder_attention_heads, ffn=args.encoder_ffn_embed_dim,
+                     enc_layers=args.encoder_layers, dec_layers=args.decoder_layers, conv_ch=convs[0][0],
+                     feat=args.input_feat_per_channel, ctc_layer=(args.ctc_encoder_layer if compress else 0),
+                     ctc_strategy=STRATEGIES[getattr(args, "ctc_compress_strategy", "avg")],
+                     act=getattr(args, "activation_fn", "relu"), dropout=args.dropout,
+                     attention_dropout=args.attention_dropout, activation_dropout=args.activation_dropout,
+                     pad=tgt_dict.pad(), no_scale_embedding=getattr(args, "no_scale_embedding", False),
+                     V_src=len(enc_dict), V_tgt=len(tgt_dict))
+        assert args.decoder_ffn_embed_dim == args.encoder_ffn_embed_dim
+        encoder = ConvolutionalTransformerEncoder(args, enc_dict, audio_features=args.input_feat_per_channel)
+        decoder = TransformerDecoder(args, tgt_dict)
+        return cls(args, encoder, decoder, hp)
+
+
+# ------------------------------------------------------------------ architectures
+def _common(args):
+    args.dropout = getattr(args, "dropout", 0.3)
+    args.normalization_constant = getattr(args, "normalization_constant", 0.5)
+    args.attention_dropout = getattr(args, "attention_dropout", 0.1)
+    # transformer_layer.py:43-46: activation_dropout, falling back to relu_dropout
+    ad = getattr(args, "activation_dropout", 0) or getattr(args, "relu_dropout", None)
+    args.activation_dropout = 0.1 if ad is None else ad
+    args.relu_dropout = args.activation_dropout
+    args.attn_2d = not getattr(args, "no_attn_2d", False)
+    args.no_token_positional_embeddings = getattr(args, "no_token_positional_embeddings", False)
+    args.share_decoder_input_output_embed = getattr(args, "share_decoder_input_output_embed", False)
+    args.decoder_embed_path = getattr(args, "decoder_embed_path", None)
+    args.encoder_learned_pos = getattr(args, "encoder_learned_pos", False)
+    args.encoder_normalize_before = True          # conv_transformer.py:450 (store_true flag: cannot be disabled)
+    args.decoder_normalize_before = True
+    args.distance_penalty = getattr(args, "distance_penalty", False)
+    args.decoder_learned_pos = getattr(args, "decoder_learned_pos", False)
+    args.no_scale_embedding = getattr(args, "no_scale_embedding", False)
+    args.layernorm_embedding = getattr(args, "layernorm_embedding", False)
+    args.input_feat_per_channel = getattr(args, "input_feat_per_channel", None) or 80
+    args.activation_fn = getattr(args, "activation_fn", None) or "relu"
+
+
+def _sizes(args, D, Ff, H, EL, DL, conv):
+    args.encoder_embed_dim = getattr(args, "encoder_embed_dim", None) or D
+    args.encoder_convolutions = getattr(args, "encoder_convolutions", None) or conv
+    args.encoder_layers = getattr(args, "encoder_layers", None) or EL
+    args.encoder_ffn_embed_dim = getattr(args, "encoder_ffn_embed_dim", None) or Ff
+    args.encoder_attention_heads = getattr(args, "encoder_attention_heads", None) or H
+    args.decoder_embed_dim = getattr(args, "decoder_embed_dim", None) or D
+    args.decoder_layers = getattr(args, "decoder_layers", None) or DL
+    args.decoder_ffn_embed_dim = getattr(args, "decoder_ffn_embed_dim", None) or Ff
+    args.decoder_attention_heads = getattr(args, "decoder_attention_heads", None) or H
+    args.decoder_output_dim = args.decoder_out_embed_dim = args.decoder_embed_dim
+
+
+@register_model_architecture("conv_transformer", "conv_transformer")
+def base_architecture(args):                                       # conv_transformer.py:429-466
+    _common(args); _sizes(args, 256, 768, 4, 6, 6, "[(64, 3, 3)] * 2")
+
+
+@register_model_architecture("conv_transformer", "conv_transformer_big")
+def conv_transformer_big(args):                                    # :469-506
+    _common(args); _sizes(args, 512, 1024, 8, 6, 6, "[(64, 3, 3)] * 2")
+
+
+@register_model_architecture("conv_transformer", "conv_transformer_big2")
+def conv_transformer_big2(args):                                   # :509-546
+    _common(args); _sizes(args, 512, 2048, 8, 6, 6, "[(64, 3, 3)] * 2")
+
+
+@register_model_architecture("conv_transformer", "conv_transformer_giant")
+def conv_transformer_giant(args):                                  # :549-586
+    _common(args); _sizes(args, 1024, 4096, 16, 6, 6, "[(128, 3, 3)] * 2")
+
+
+def _s2t(args, D, Ff, H, EL, DL, p, conv="[(64, 3, 3)] * 2"):
+    """Build-defined presets named by BASELINE.json: conv_transformer structure, S2T sizes."""
+    args.dropout = getattr(args, "dropout", None) if getattr(args, "dropout", None) is not None else p
+    args.no_attn_2d = True
+    _common(args); _sizes(args, D, Ff, H, EL, DL, conv)
+
+
+@register_model_architecture("conv_transformer", "s2t_transformer")
+def s2t_transformer(args):
+    _s2t(args, 256, 2048, 4, 12, 6, 0.1)
+
+
+@register_model_architecture("conv_transformer", "s2t_transformer_s")
+def s2t_transformer_s(args):
+    _s2t(args, 256, 2048, 4, 12, 6, 0.1)
+
+
+@register_model_architecture("conv_transformer", "s2t_transformer_xs")
+def s2t_transformer_xs(args):
+    _s2t(args, 256, 1024, 4, 6, 3, 0.3)
+
+
+@register_model_architecture("conv_transformer", "s2t_transformer_m")
+def s2t_transformer_m(args):
+    _s2t(args, 512, 2048, 8, 12, 6, 0.15)
+
+
+@register_model_architecture("conv_transformer", "s2t_transformer_l")
+def s2t_transformer_l(args):
+    _s2t(args, 1024, 4096, 16, 12, 6, 0.2, "[(128, 3, 3)] * 2")

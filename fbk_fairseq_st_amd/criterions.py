@@ -1,0 +1,219 @@
+"""Criteria of the S2T path on fused HIP loss kernels, behind the reference's criterion interface.
+
+  label_smoothed_cross_entropy  fairseq/criterions/label_smoothed_cross_entropy.py:32-99
+  ctc_multi_loss                examples/speech_recognition/criterions/ctc_multi_loss.py:107-194
+                                (+ CTC_loss.py:101-175 for the CTC branch and its unit-error-rate logging)
+
+Differences that are deliberate (and invisible in the returned values):
+  * log-probabilities are never materialised (fused log-softmax + loss + gradient kernels);
+  * logging outputs stay device scalars until the trainer reduces them (no .item() per criterion);
+  * the CTC unit-error-rate alignment runs in native code on predictions that were already copied to
+    the host at the CTC-compression sync point (the reference runs a pure-Python DP on the critical path).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from .registry import CRITERION_REGISTRY, FairseqCriterion, register_criterion
+
+
+def _item(v):
+    return v.item() if torch.is_tensor(v) else v
+
+
+class _LSCEFn(torch.autograd.Function):
+    """loss, nll = label_smoothed_nll_loss(log_softmax(logits.float()), target) with fused gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, target, eps, pad):
+        B, L, V = logits.shape
+        lt = logits.transpose(0, 1)                       # the decoder produces time-major rows: this is a view
+        if not lt.is_contiguous():
+            lt = lt.contiguous()
+        tt = target.t().contiguous()
+        sums, dl = K.lsce(lt.view(L * B, V), tt.view(-1), eps, pad, want_grad=True)
+        ctx.dl, ctx.shape = dl, (L, B, V)
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_nll):
+        L, B, V = ctx.shape
+        dl = K.scale_by_device_scalar(ctx.dl, g_loss.contiguous().float())
+        return dl.view(L, B, V).transpose(0, 1), None, None, None
+
+
+class _CTCFn(torch.autograd.Function):
+    """sum over the batch of -log p(target | logits) (zero_infinity) with fused gradient w.r.t. the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, tgt_len, in_len32, blank):
+        loss, grad, _ = K.ctc_loss(logits.contiguous(), targets.contiguous(), tgt_len.contiguous(), in_len32.contiguous(), blank)
+        ctx.grad = grad
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return K.scale_by_device_scalar(ctx.grad, g.contiguous().float()), None, None, None, None
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the HIP GEMM, for heads owned by a criterion (ctc_aware_model.fc_out)."""
+
+    @staticmethod
+    def forward(ctx, x, model, wname, bname):
+        eng = model.engine
+        T, B, D = x.shape
+        x2 = x.contiguous().view(T * B, D)
+        y = K.gemm(x2, eng.W(wname), bias=eng.P(bname))
+        ctx.model, ctx.x2, ctx.names, ctx.shape = model, x2, (wname, bname), (T, B, D)
+        return y.view(T, B, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.model.engine
+        T, B, D = ctx.shape
+        wname, bname = ctx.names
+        dx = eng.linear_bwd(dy.contiguous().view(T * B, -1), ctx.x2, wname[: -len(".weight")])
+        return dx.view(T, B, D), None, None, None
+
+
+@register_criterion("label_smoothed_cross_entropy")
+class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
+    def __init__(self, task, sentence_avg, label_smoothing):
+        super().__init__(task)
+        self.sentence_avg = sentence_avg
+        self.eps = label_smoothing
+
+    @classmethod
+    def build_criterion(cls, args, task):
+        return cls(task, getattr(args, "sentence_avg", False), getattr(args, "label_smoothing", 0.0))
+
+    @staticmethod
+    def add_args(parser):
+        parser.add_argument("--label-smoothing", default=0.0, type=float, metavar="D")
+
+    def forward(self, model, sample, reduce=True):
+        net_output = model(**sample["net_input"])
+        loss, nll_loss = self.compute_loss(model, net_output, sample, reduce=reduce)
+        sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        logging_output = {"loss": loss.detach(), "nll_loss": nll_loss.detach(), "ntokens": sample["ntokens"],
+                          "nsentences": sample["target"].size(0), "sample_size": sample_size}
+        return loss, sample_size, logging_output
+
+    def compute_loss(self, model, net_output, sample, reduce=True):
+        assert reduce, "the fused kernel returns the summed loss"
+        target = model.get_targets(sample, net_output)
+        return _LSCEFn.apply(net_output[0], target, self.eps, self.padding_idx)
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        loss_sum = sum(_item(l.get("loss", 0)) for l in logging_outputs)
+        nll_sum = sum(_item(l.get("nll_loss", 0)) for l in logging_outputs)
+        ntokens = sum(_item(l.get("ntokens", 0)) for l in logging_outputs)
+        sample_size = sum(_item(l.get("sample_size", 0)) for l in logging_outputs)
+        nll = nll_sum / ntokens / math.log(2)
+        return {"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
+                "ntokens": ntokens, "sample_size": sample_size}
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True
+
+
+class CTCEncoderWrapperModel(nn.Module):
+    """ctc_multi_loss.py:14-46: owns fc_out, used when the encoder does not produce ctc_out itself."""
+
+    def __init__(self, args, ctc_dictionary):
+        super().__init__()
+        self.fc_out = nn.Linear(args.encoder_embed_dim, len(ctc_dictionary))
+        self.ctc_encoder_layer = args.ctc_encoder_layer
+
+
+@register_criterion("ctc_multi_loss")
+class CTCMultiLoss(FairseqCriterion):
+    def __init__(self, args, task):
+        super().__init__(task)
+        assert task.source_dictionary is not None
+        self.args = args
+        self.ctc_aware_model = CTCEncoderWrapperModel(args, task.source_dictionary)
+        self.blank_idx = task.source_dictionary.index("<ctc_blank>")          # ctc_multi_loss.py:103
+        self.pad_idx = task.source_dictionary.pad()
+        saved = args.criterion
+        args.criterion = args.underlying_criterion
+        assert saved != args.underlying_criterion
+        self.real_criterion = CRITERION_REGISTRY[args.criterion].build_criterion(args, task)
+        args.criterion = saved
+        self.ctc_weight = args.ctc_weight
+        self.sentence_avg = getattr(args, "sentence_avg", False)
+        self.use_source_side_sample_size = getattr(args, "use_source_side_sample_size", False)
+
+    @staticmethod
+    def add_args(parser):
+        parser.add_argument("--use-source-side-sample-size", action="store_true", default=False)
+        parser.add_argument("--ctc-encoder-layer", default=6, type=int, metavar="LAYER_NUM")
+        parser.add_argument("--ctc-weight", default=1.0, type=float, metavar="W")
+        parser.add_argument("--underlying-criterion", type=str, metavar="VAL", required=True)
+
+    def arena_params(self):
+        """criterion-owned parameters that must live in the model's arena (optimised together)."""
+        return {"criterion.ctc_aware_model.fc_out.weight": self.ctc_aware_model.fc_out.weight,
+                "criterion.ctc_aware_model.fc_out.bias": self.ctc_aware_model.fc_out.bias}
+
+    def forward(self, model, sample, reduce=True, log_probs=True):
+        ni = {k: v for k, v in sample["net_input"].items() if k != "transcript_prev_output_tokens"}
+        enc = model.encoder
+        k = self.ctc_aware_model.ctc_encoder_layer
+        model._ctc_state_layer = k - 1
+        encoder_out = enc(ni["src_tokens"], src_lengths=ni["src_lengths"], return_all_hiddens=True)
+        decoder_out = model.decoder(ni["prev_output_tokens"], encoder_out=encoder_out)
+        last = enc._last
+        if hasattr(encoder_out, "ctc_out"):
+            ctc_feat, in_len, in_len_host, pred = encoder_out.ctc_out, last["ctc_lengths"], last["ctc_lengths_host"], last.get("pred_host")
+        else:
+            ctc_feat = _LinearFn.apply(encoder_out.encoder_states[k - 1], model,
+                                       "criterion.ctc_aware_model.fc_out.weight", "criterion.ctc_aware_model.fc_out.bias")
+            in_len, in_len_host, pred = last["lengths"], last["lengths_host"], None
+        tr, tr_len = sample["transcript_target"], sample["transcript_target_lengths"]
+        ctc_loss = _CTCFn.apply(ctc_feat, tr, tr_len, in_len.to(torch.int32), self.blank_idx)
+        # unit error rate (logging only): greedy path + native edit-distance alignment on the host
+        if pred is None:
+            pred = K.ctc_argmax(ctc_feat.detach().contiguous())[0].cpu()
+        tr_host = sample.get("transcript_target_host")
+        tr_host = tr.cpu() if tr_host is None else tr_host
+        trl_host = sample.get("transcript_target_lengths_host")
+        trl_host = tr_len.cpu() if trl_host is None else trl_host
+        errors, total = K.host_ctc_uer(pred, torch.tensor(in_len_host, dtype=torch.int64), tr_host, trl_host, self.blank_idx)
+        ctc_ntokens = int(trl_host.sum())
+        if self.sentence_avg:
+            ctc_sample_size = sample["target"].size(0)
+        elif self.use_source_side_sample_size:
+            ctc_sample_size = int(sum(in_len_host))
+        else:
+            ctc_sample_size = ctc_ntokens
+        real_loss, nll = self.real_criterion.compute_loss(model, decoder_out, sample, reduce=reduce)
+        real_ss = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        loss = self.ctc_weight * ctc_loss + real_loss
+        nframes = sample.get("nframes")
+        if nframes is None:
+            nframes = int(ni["src_lengths"].sum())
+        logging_output = {"loss": loss.detach(), "ctc_loss": ctc_loss.detach(), "ntokens": sample["ntokens"],
+                          "nsentences": sample["target"].size(0), "sample_size": real_ss, "ctc_errors": errors,
+                          "ctc_total": total, "nframes": nframes, "nll_loss": nll.detach()}
+        return loss, ctc_sample_size, logging_output                       # (:168 returns the CTC sample size)
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        s = lambda k: sum(_item(l.get(k, 0)) for l in logging_outputs)
+        loss_sum, ctc_sum, nll_sum = s("loss"), s("ctc_loss"), s("nll_loss")
+        ntokens, sample_size = s("ntokens"), s("sample_size")
+        errors, total, nframes = s("ctc_errors"), s("ctc_total"), s("nframes")
+        nll = nll_sum / ntokens / math.log(2)
+        return {"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
+                "ctc_loss": ctc_sum / sample_size / math.log(2),
+                "ctc_acc": 100.0 - min(errors * 100.0 / max(total, 1), 100.0), "nframes": nframes}

@@ -27,6 +27,7 @@ struct GemmArgs {
     //  mapB (B stored [K][N]): B(k, :) = Bsrc[ mapB[k] ][:]                                 (-1 -> zeros)
     //  mapC: output row r is written to C row mapC[r]
     const int* mapA; int periodA; const int* mapB; const int* mapC;
+    float p_drop; unsigned long long seed;   // dropout on the activated value, before the residual add
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_GELU_BWD = 4 };
@@ -251,6 +252,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 } else if (p.act == ACT_GELU_BWD) {
                     v *= gelu_grad_f(to_f32(AUX[(size_t)row * p.ldaux + col]));
                 }
+                if (p.p_drop > 0.f) {
+                    const uint32_t th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
+                    v = dropout_keep(p.seed, (uint64_t)row * p.N + col, th) ? v / (1.f - p.p_drop) : 0.f;
+                }
                 if (R) v += to_f32(R[(size_t)row * p.ldr + col]);
                 TO* dst = C + orow * p.ldc + col;
                 if (p.accumulate) v += to_f32(*dst);
@@ -282,7 +287,8 @@ extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int tra
                                const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                                const float* bias, const void* residual, int ldr, const void* aux, void* aux_out,
                                int ldaux, int act, int accumulate, int splitk, float alpha,
-                               const int* mapA, int periodA, const int* mapB, const int* mapC, void* stream) {
+                               const int* mapA, int periodA, const int* mapB, const int* mapC,
+                               float p_drop, unsigned long long seed, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return (M < 0 || N < 0 || K < 0) ? S2T_EINVAL : S2T_OK;
     if (!A || !B || !C) return S2T_EINVAL;
     if (splitk < 1) splitk = 1;
@@ -290,8 +296,9 @@ extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int tra
     if ((act == ACT_RELU_BWD || act == ACT_GELU_BWD) && !aux) return S2T_EINVAL;
     if (mapA && (trans_a || periodA <= 0 || periodA % 8)) return S2T_EINVAL;
     if (mapB && !trans_b) return S2T_EINVAL;
+    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && splitk > 1)) return S2T_EINVAL;
     GemmArgs a{A, B, C, bias, residual, aux, aux_out, M, N, K, lda, ldb, ldc, ldr, ldaux, act, accumulate, splitk, alpha,
-               mapA, periodA, mapB, mapC};
+               mapA, periodA, mapB, mapC, p_drop, seed};
     hipStream_t st = (hipStream_t)stream;
     const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
     ProfScope prof(mapA || mapB ? "gemm_gather" : "gemm", st, 2.0 * M * (double)N * K,
@@ -313,7 +320,7 @@ extern "C" int s2t_gemm(int in_dtype, int out_dtype, int trans_a, int trans_b, i
                         const float* bias, const void* residual, int ldr, const void* aux, void* aux_out,
                         int ldaux, int act, int accumulate, int splitk, float alpha, void* stream) {
     return s2t_gemm_gather(in_dtype, out_dtype, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr,
-                           aux, aux_out, ldaux, act, accumulate, splitk, alpha, nullptr, 0, nullptr, nullptr, stream);
+                           aux, aux_out, ldaux, act, accumulate, splitk, alpha, nullptr, 0, nullptr, nullptr, 0.f, 0ull, stream);
 }
 
 // Column sums of a [M][N] activation-gradient matrix into an f32 vector (bias gradients):

@@ -140,3 +140,43 @@ extern "C" int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p,
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
+
+// ------------------------------------------------------------------ activation backward (elementwise)
+// out = dy * act'(.)   act 1: relu with y = post-activation (mask y > 0); act 2: gelu with y = pre-activation
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = to_f32(dy[i]), v = to_f32(y[i]);
+        out[i] = from_f32<T>(act == 1 ? (v > 0.f ? d : 0.f) : d * gelu_grad_f(v));
+    }
+}
+extern "C" int s2t_act_bwd(int dtype, const void* dy, const void* y, void* out, size_t n, int act, void* stream) {
+    if (n == 0) return S2T_OK;
+    if (!dy || !y || !out || (act != 1 && act != 2)) return S2T_EINVAL;
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)out, n, act);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)out, n, act);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+// ------------------------------------------------------------------ y += x (gradient merge points)
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = from_f32<T>(to_f32(y[i]) + to_f32(x[i]));
+}
+extern "C" int s2t_add_inplace(int dtype, const void* x, void* y, size_t n, void* stream) {
+    if (n == 0) return S2T_OK;
+    if (!x || !y) return S2T_EINVAL;
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(add_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, n);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

@@ -1,0 +1,497 @@
+"""Forward / backward schedule of the S2T hot path as explicit sequences of HIP kernel launches.
+
+Restates, launch by launch, what the reference executes through torch autograd
+(SURVEY.md 3.2 / 8-a): ConvolutionalTransformerEncoder.forward (conv_transformer.py:195-276),
+TransformerEncoderLayer / TransformerDecoderLayer.forward (fairseq/modules/transformer_layer.py:87-139,
+243-377), TransformerDecoder.extract_features/output_layer (fairseq/models/transformer.py:674-790) and the
+corresponding backward passes.  No torch arithmetic is used: every FLOP is a call into libs2t_hip.so;
+torch only allocates buffers and does integer index bookkeeping.  Gradients of parameters are
+accumulated by the kernels directly into the arena's flat f32 gradient buffer.
+"""
+import math
+
+import torch
+
+from . import kernels as K
+
+
+class HParams:
+    """Static model description (what conv_transformer.py reads from `args`)."""
+
+    def __init__(self, **kw):
+        self.D = 256; self.heads = 4; self.ffn = 768; self.enc_layers = 6; self.dec_layers = 6
+        self.conv_ch = 64; self.feat = 80
+        self.ctc_layer = 0                       # 0 = no CTC compression inside the encoder
+        self.ctc_strategy = 0                    # 0 avg, 1 weighted, 2 softmax
+        self.act = "relu"
+        self.dropout = 0.0; self.attention_dropout = 0.0; self.activation_dropout = 0.0
+        self.sub_dropout = None                  # None -> max(dropout, 0.1) (conv_transformer.py:214)
+        self.pad = 1; self.no_scale_embedding = False
+        self.V_src = 0; self.V_tgt = 0
+        self.ln_eps = 1e-5; self.bn_eps = 1e-5; self.bn_momentum = 0.1
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+    @property
+    def F4(self):
+        return ((self.feat + 1) // 2 + 1) // 2
+
+    def param_shapes(self):
+        """Arena layout in forward order (so that backward finishes contiguous slices last-to-first)."""
+        D, Ff, C = self.D, self.ffn, self.conv_ch
+        s = {}
+        s["encoder.convolutions.0.weight"] = (C, 1, 3, 3); s["encoder.convolutions.0.bias"] = (C,)
+        s["encoder.bn.0.weight"] = (C,); s["encoder.bn.0.bias"] = (C,)
+        s["encoder.convolutions.1.weight"] = (C, C, 3, 3); s["encoder.convolutions.1.bias"] = (C,)
+        s["encoder.bn.1.weight"] = (C,); s["encoder.bn.1.bias"] = (C,)
+        s["encoder.fc3.weight"] = (D, C * self.F4); s["encoder.fc3.bias"] = (D,)
+
+        def ln(p):
+            s[p + ".weight"] = (D,); s[p + ".bias"] = (D,)
+
+        def lin(p, n, k, bias=True):
+            s[p + ".weight"] = (n, k)
+            if bias:
+                s[p + ".bias"] = (n,)
+
+        for l in range(self.enc_layers):
+            p = "encoder.layers.%d." % l
+            ln(p + "self_attn_layer_norm"); lin(p + "self_attn.qkv", 3 * D, D); lin(p + "self_attn.out_proj", D, D)
+            ln(p + "final_layer_norm"); lin(p + "fc1", Ff, D); lin(p + "fc2", D, Ff)
+            if self.ctc_layer == l + 1:
+                lin("encoder.ctc_fc", self.V_src, D)
+        ln("encoder.layer_norm")
+        s["decoder.embed_tokens.weight"] = (self.V_tgt, D)
+        for l in range(self.dec_layers):
+            p = "decoder.layers.%d." % l
+            ln(p + "self_attn_layer_norm"); lin(p + "self_attn.qkv", 3 * D, D); lin(p + "self_attn.out_proj", D, D)
+            ln(p + "encoder_attn_layer_norm"); lin(p + "encoder_attn.q_proj", D, D); lin(p + "encoder_attn.kv", 2 * D, D)
+            lin(p + "encoder_attn.out_proj", D, D)
+            ln(p + "final_layer_norm"); lin(p + "fc1", Ff, D); lin(p + "fc2", D, Ff)
+        ln("decoder.layer_norm")
+        lin("decoder.output_projection", self.V_tgt, D, bias=False)
+        return s
+
+
+def sinusoid_table(n, dim, padding_idx, device):
+    """Host-computed table, same expression as fairseq/modules/sinusoidal_positional_embedding.py:36-58
+    (f32 arange * exp(...), [sin | cos], padding row zero); uploaded once and cached by the caller."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float) * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(n, dtype=torch.float).unsqueeze(1) * freq.unsqueeze(0)
+    emb = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1).view(n, -1)
+    if dim % 2 == 1:
+        emb = torch.cat([emb, torch.zeros(n, 1)], dim=1)
+    if padding_idx is not None:
+        emb[padding_idx, :] = 0
+    return emb.to(device)
+
+
+_TAPS_BY_CLASS = [(0, 0, [(1, 1)]), (0, 1, [(1, 0), (1, 2)]), (1, 0, [(0, 1), (2, 1)]),
+                  (1, 1, [(0, 0), (0, 2), (2, 0), (2, 2)])]            # slot order = kTapSlot in subsample.hip
+_CLASS_SLOT0 = [0, 1, 3, 5]
+
+
+def conv2_maps(B, T2, F2, device):
+    """Row maps of the implicit-GEMM formulation of Conv2d(3x3, stride 2, pad 1) over channels-last
+    pixels (index bookkeeping only; built once per batch shape and cached)."""
+    T4, F4 = (T2 + 1) // 2, (F2 + 1) // 2
+    t4 = torch.arange(T4).view(T4, 1, 1); b = torch.arange(B).view(1, B, 1); f4 = torch.arange(F4).view(1, 1, F4)
+    fwd = []
+    for kh in range(3):
+        for kw in range(3):
+            t2 = 2 * t4 + kh - 1; f2 = 2 * f4 + kw - 1
+            ok = (t2 >= 0) & (t2 < T2) & (f2 >= 0) & (f2 < F2)
+            pix = (b * T2 + t2) * F2 + f2
+            fwd.append(torch.where(ok, pix, torch.full_like(pix, -1)).reshape(-1))
+    fwd = torch.stack(fwd).to(torch.int32).contiguous().to(device)          # [9][P2]
+    bwd = []
+    for (pt, pf, taps) in _TAPS_BY_CLASS:
+        t2 = torch.arange(pt, T2, 2).view(1, -1, 1); f2 = torch.arange(pf, F2, 2).view(1, 1, -1)
+        bb = torch.arange(B).view(B, 1, 1)
+        rows = ((bb * T2 + t2) * F2 + f2).reshape(-1)
+        if rows.numel() == 0:
+            bwd.append(None)
+            continue
+        maps = []
+        for (kh, kw) in taps:
+            t4s = (t2 + 1 - kh) // 2; f4s = (f2 + 1 - kw) // 2
+            ok = (t4s >= 0) & (t4s < T4) & (f4s >= 0) & (f4s < F4)
+            pos = (t4s * B + bb) * F4 + f4s
+            maps.append(torch.where(ok, pos, torch.full_like(pos, -1)).reshape(-1))
+        bwd.append((rows.to(torch.int32).contiguous().to(device),
+                    torch.stack(maps).to(torch.int32).contiguous().to(device)))
+    return dict(fwd=fwd, bwd=bwd, T4=T4, F4=F4)
+
+
+def _splitk(n_out, k_in, m_tokens):
+    tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
+    if tiles >= 256:
+        return 1
+    return int(max(1, min(512 // tiles, m_tokens // 256, 32)))
+
+
+class S2TEngine:
+    def __init__(self, hp, arena):
+        self.hp = hp
+        self.A = arena
+        self.dtype = arena.compute_dtype
+        self.dev = arena.device
+        self._tables = {}
+        self._maps = {}
+        self.bn_buffers = None          # set by the model: dict name -> tensor (running_mean/var, num_batches)
+        if hp.act not in ("relu", "gelu"):
+            raise NotImplementedError("activation_fn %s" % hp.act)
+        self.act_fwd = K.ACT_RELU if hp.act == "relu" else K.ACT_GELU
+        self.act_bwd = K.ACT_RELU_BWD if hp.act == "relu" else K.ACT_GELU_BWD
+
+    # ------------------------------------------------------------------ small helpers
+    def table(self, n, pad):
+        key = (pad,)
+        t = self._tables.get(key)
+        if t is None or t.shape[0] < n:
+            t = sinusoid_table(max(n, 1024), self.hp.D, pad, self.dev)
+            self._tables[key] = t
+        return t
+
+    def maps(self, B, T2, F2):
+        key = (B, T2, F2)
+        m = self._maps.get(key)
+        if m is None:
+            m = conv2_maps(B, T2, F2, self.dev)
+            self._maps[key] = m
+        return m
+
+    def W(self, n):
+        return self.A.w(n)
+
+    def P(self, n):
+        return self.A.p(n)
+
+    def G(self, n):
+        return self.A.g(n)
+
+    def linear(self, x2d, name, act=K.ACT_NONE, residual=None, aux_out=None, p_drop=0.0, seed=0, bias=True):
+        return K.gemm(x2d, self.W(name + ".weight"), bias=self.P(name + ".bias") if bias else None, act=act,
+                      residual=residual, aux_out=aux_out, p_drop=p_drop, seed=seed)
+
+    def linear_bwd(self, dy2d, x2d, name, need_dx=True, act=K.ACT_NONE, aux=None, alpha=1.0, dx_out=None,
+                   dx_accumulate=False, bias=True):
+        """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
+        w = self.W(name + ".weight")
+        gw = self.G(name + ".weight")
+        K.gemm(dy2d, x2d, trans_a=True, trans_b=True, out=gw, accumulate=True,
+               splitk=_splitk(gw.shape[0], gw.shape[1], dy2d.shape[0]))
+        if bias:
+            K.colsum(dy2d, self.G(name + ".bias"))
+        if not need_dx:
+            return None
+        return K.gemm(dy2d, w, trans_b=True, act=act, aux=aux, alpha=alpha, out=dx_out, accumulate=dx_accumulate)
+
+    # ------------------------------------------------------------------ subsampler
+    def subsample_fwd(self, src_tokens, len_dev64, training, seed):
+        hp, C = self.hp, self.hp.conv_ch
+        if hp.act != "relu":
+            raise NotImplementedError("the convolutional subsampler kernels implement ReLU (reference default) only")
+        B, T, F = src_tokens.shape
+        x = src_tokens if src_tokens.dtype == torch.float32 else src_tokens.float()
+        x = x.contiguous()
+        T2, F2 = (T + 1) // 2, (F + 1) // 2
+        mp = self.maps(B, T2, F2)
+        T4, F4 = mp["T4"], mp["F4"]
+        bufs = self.bn_buffers
+        p_sub = (max(hp.dropout, 0.1) if hp.sub_dropout is None else hp.sub_dropout) if training else 0.0
+        c = dict(x=x, B=B, T=T, F=F, T2=T2, F2=F2, T4=T4, F4=F4, training=training, p_sub=p_sub, seed=seed)
+        # conv1 + BN1
+        y1, sums1 = K.conv1_fwd(x, self.P("encoder.convolutions.0.weight"), self.P("encoder.convolutions.0.bias"), C, self.dtype)
+        cnt1 = B * T2 * F2
+        mean1, rstd1, sc1, sh1 = K.bn_finalize(sums1, self.P("encoder.bn.0.weight"), self.P("encoder.bn.0.bias"),
+                                               bufs["encoder.bn.0.running_mean"], bufs["encoder.bn.0.running_var"],
+                                               bufs["encoder.bn.0.num_batches_tracked"], cnt1, training, hp.bn_momentum, hp.bn_eps)
+        y1n = K.bn_apply(y1, sc1, sh1)
+        if p_sub > 0:
+            K.dropout(y1n, p_sub, seed + 1, out=y1n)
+        # conv2 as implicit GEMM + BN2
+        w2p = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 0)
+        P2 = T4 * B * F4
+        z2 = K.gemm(y1n.view(-1, C), w2p, M=P2, K=9 * C, map_a=mp["fwd"], period_a=C,
+                    bias=self.P("encoder.convolutions.1.bias"), act=K.ACT_RELU)
+        sums2 = K.chan_sums(z2, C)
+        mean2, rstd2, sc2, sh2 = K.bn_finalize(sums2, self.P("encoder.bn.1.weight"), self.P("encoder.bn.1.bias"),
+                                               bufs["encoder.bn.1.running_mean"], bufs["encoder.bn.1.running_var"],
+                                               bufs["encoder.bn.1.num_batches_tracked"], P2, training, hp.bn_momentum, hp.bn_eps)
+        z2n = K.bn_apply(z2, sc2, sh2)
+        if p_sub > 0:
+            K.dropout(z2n, p_sub, seed + 2, out=z2n)
+        # fc3 on channels-last rows: weight columns re-ordered k = c*F4+f -> k' = f*C+c
+        w3p = K.permute_cf(self.P("encoder.fc3.weight"), torch.empty((hp.D, F4 * C), dtype=self.dtype, device=self.dev), hp.D, C, F4, 0)
+        h3 = K.gemm(z2n.view(T4 * B, F4 * C), w3p, bias=self.P("encoder.fc3.bias"), act=K.ACT_RELU)
+        # lengths: ceil(len/2) twice (conv_transformer.py:213) -- integer bookkeeping on device
+        len4 = (((len_dev64 + 1) // 2) + 1) // 2
+        len4_32 = len4.to(torch.int32)
+        xe = h3.clone().view(T4, B, hp.D)
+        K.add_pos(xe, self.table(T4 + 1, 0), len4_32)
+        p = hp.dropout if training else 0.0
+        if p > 0:
+            K.dropout(xe, p, seed + 3, out=xe)
+        c.update(y1=y1, y1n=y1n, z2=z2, z2n=z2n, h3=h3, w2p=w2p, w3p=w3p, mean1=mean1, rstd1=rstd1, mean2=mean2,
+                 rstd2=rstd2, cnt1=cnt1, P2=P2, p=p)
+        return xe, len4, len4_32, c
+
+    def subsample_bwd(self, c, dx):
+        """dx: gradient w.r.t. the subsampler output [T4*B, D]."""
+        hp, C = self.hp, self.hp.conv_ch
+        B, T4, F4 = c["B"], c["T4"], c["F4"]
+        mp = self.maps(B, c["T2"], c["F2"])
+        if c["p"] > 0:
+            dx = K.dropout(dx, c["p"], c["seed"] + 3)
+        dh3 = K.act_bwd(dx, c["h3"], 1)
+        # fc3: weight gradient in the re-ordered layout, then scattered back (+=) to the master layout
+        z2n2d = c["z2n"].view(T4 * B, F4 * C)
+        gw3p = K.gemm(dh3, z2n2d, trans_a=True, trans_b=True, out_dtype=torch.float32, accumulate=True,
+                      splitk=_splitk(hp.D, F4 * C, dh3.shape[0]))
+        K.permute_cf(gw3p, self.G("encoder.fc3.weight"), hp.D, C, F4, 1)
+        K.colsum(dh3, self.G("encoder.fc3.bias"))
+        dz2n = K.gemm(dh3, c["w3p"], trans_b=True).view(-1, C)
+        if c["p_sub"] > 0:
+            K.dropout(dz2n, c["p_sub"], c["seed"] + 2, out=dz2n)
+        # BN2 backward (+ ReLU mask) -> gradient w.r.t. conv2 + bias
+        s2 = K.chan_sums(c["z2"], C, dyn=dz2n, mean=c["mean2"], rstd=c["rstd2"])
+        dpre2 = K.bn_bwd_apply(dz2n, c["z2"], c["mean2"], c["rstd2"], self.P("encoder.bn.1.weight"), s2,
+                               self.G("encoder.bn.1.weight"), self.G("encoder.bn.1.bias"), c["P2"], c["training"])
+        K.colsum(dpre2, self.G("encoder.convolutions.1.bias"))
+        # conv2 weight gradient: 9 gathered TN GEMMs (one per tap) into [Co][tap*Ci+ci], then back to [Co][Ci][3][3]
+        y1n2d = c["y1n"].view(-1, C)
+        gw2p = torch.zeros((C, 9 * C), dtype=torch.float32, device=self.dev)
+        sk = int(max(1, min(64, c["P2"] // 2048)))
+        for tap in range(9):
+            K.gemm(dpre2, y1n2d, trans_a=True, trans_b=True, K=c["P2"], out=gw2p[:, tap * C:(tap + 1) * C],
+                   accumulate=True, splitk=sk, map_b=mp["fwd"][tap])
+        K.permute_conv_w(gw2p, self.G("encoder.convolutions.1.weight"), C, C, 2)
+        # conv2 data gradient: one gathered GEMM per input-pixel parity class, scattered to the class's pixels
+        w2q = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 1)
+        dy1n = torch.zeros_like(c["y1n"]).view(-1, C)
+        for ci, (pt, pf, taps) in enumerate(_TAPS_BY_CLASS):
+            if mp["bwd"][ci] is None:
+                continue
+            rows, maps = mp["bwd"][ci]
+            s0, nt = _CLASS_SLOT0[ci], len(taps)
+            K.gemm(dpre2, w2q[:, s0 * C:(s0 + nt) * C], M=rows.numel(), K=nt * C, map_a=maps, period_a=C, map_c=rows, out=dy1n)
+        if c["p_sub"] > 0:
+            K.dropout(dy1n, c["p_sub"], c["seed"] + 1, out=dy1n)
+        s1 = K.chan_sums(c["y1"], C, dyn=dy1n, mean=c["mean1"], rstd=c["rstd1"])
+        dpre1 = K.bn_bwd_apply(dy1n, c["y1"].view(-1, C), c["mean1"], c["rstd1"], self.P("encoder.bn.0.weight"), s1,
+                               self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"])
+        K.conv1_bwd(c["x"], dpre1.view(B, c["T2"], c["F2"], C), self.G("encoder.convolutions.0.weight").view(C, 9),
+                    self.G("encoder.convolutions.0.bias"))
+
+    # ------------------------------------------------------------------ transformer blocks
+    def self_attn_block_fwd(self, pfx, x, klen32, causal, training, seed):
+        """x [T,B,D] -> x + dropout(out_proj(attn(LN(x))))   (pre-LN; transformer_layer.py:103-124)"""
+        hp = self.hp
+        T, B, D = x.shape
+        x2 = x.view(T * B, D)
+        h, mean, rstd = K.layernorm_fwd(x2, self.P(pfx + "self_attn_layer_norm.weight"), self.P(pfx + "self_attn_layer_norm.bias"), hp.ln_eps)
+        qkv = self.linear(h, pfx + "self_attn.qkv").view(T, B, 3 * D)
+        pa = hp.attention_dropout if training else 0.0
+        ctx, lse = K.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], hp.heads, klen=klen32, causal=causal,
+                              p_drop=pa, seed=seed + 1)
+        p = hp.dropout if training else 0.0
+        y = self.linear(ctx.view(T * B, D), pfx + "self_attn.out_proj", residual=x2, p_drop=p, seed=seed + 2)
+        c = dict(x=x2, h=h, mean=mean, rstd=rstd, qkv=qkv, ctx=ctx, lse=lse, klen=klen32, causal=causal, pa=pa, p=p, seed=seed, T=T, B=B)
+        return y.view(T, B, D), c
+
+    def self_attn_block_bwd(self, pfx, c, dy):
+        """dy [T*B, D] gradient w.r.t. the block output; returns gradient w.r.t. the block input."""
+        hp = self.hp
+        T, B, D = c["T"], c["B"], self.hp.D
+        d = K.dropout(dy, c["p"], c["seed"] + 2) if c["p"] > 0 else dy
+        dctx = self.linear_bwd(d, c["ctx"].view(T * B, D), pfx + "self_attn.out_proj")
+        dqkv = torch.empty_like(c["qkv"])
+        qkv = c["qkv"]
+        K.attn_bwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], c["ctx"], dctx.view(T, B, D), c["lse"], hp.heads,
+                   dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], klen=c["klen"], causal=c["causal"],
+                   p_drop=c["pa"], seed=c["seed"] + 1)
+        dh = self.linear_bwd(dqkv.view(T * B, 3 * D), c["h"], pfx + "self_attn.qkv")
+        return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "self_attn_layer_norm.weight"),
+                               self.G(pfx + "self_attn_layer_norm.weight"), self.G(pfx + "self_attn_layer_norm.bias"), dres=dy)
+
+    def cross_attn_block_fwd(self, pfx, x, enc2d, Ts, enc_klen32, training, seed):
+        """decoder encoder-attention (transformer_layer.py:324-352): q from x, k/v from the encoder output."""
+        hp = self.hp
+        T, B, D = x.shape
+        x2 = x.view(T * B, D)
+        h, mean, rstd = K.layernorm_fwd(x2, self.P(pfx + "encoder_attn_layer_norm.weight"), self.P(pfx + "encoder_attn_layer_norm.bias"), hp.ln_eps)
+        q = self.linear(h, pfx + "encoder_attn.q_proj").view(T, B, D)
+        kv = self.linear(enc2d, pfx + "encoder_attn.kv").view(Ts, B, 2 * D)
+        pa = hp.attention_dropout if training else 0.0
+        ctx, lse = K.attn_fwd(q, kv[:, :, :D], kv[:, :, D:], hp.heads, klen=enc_klen32, causal=False, p_drop=pa, seed=seed + 1)
+        p = hp.dropout if training else 0.0
+        y = self.linear(ctx.view(T * B, D), pfx + "encoder_attn.out_proj", residual=x2, p_drop=p, seed=seed + 2)
+        c = dict(x=x2, h=h, mean=mean, rstd=rstd, q=q, kv=kv, ctx=ctx, lse=lse, klen=enc_klen32, pa=pa, p=p, seed=seed, T=T, B=B, Ts=Ts, enc2d=enc2d)
+        return y.view(T, B, D), c
+
+    def cross_attn_block_bwd(self, pfx, c, dy, denc):
+        """accumulates the encoder-output gradient into denc [Ts*B, D]; returns dx."""
+        hp = self.hp
+        T, B, D, Ts = c["T"], c["B"], self.hp.D, c["Ts"]
+        d = K.dropout(dy, c["p"], c["seed"] + 2) if c["p"] > 0 else dy
+        dctx = self.linear_bwd(d, c["ctx"].view(T * B, D), pfx + "encoder_attn.out_proj")
+        dq = torch.empty_like(c["q"]); dkv = torch.empty_like(c["kv"])
+        kv = c["kv"]
+        K.attn_bwd(c["q"], kv[:, :, :D], kv[:, :, D:], c["ctx"], dctx.view(T, B, D), c["lse"], hp.heads,
+                   dq, dkv[:, :, :D], dkv[:, :, D:], klen=c["klen"], causal=False, p_drop=c["pa"], seed=c["seed"] + 1)
+        self.linear_bwd(dkv.view(Ts * B, 2 * D), c["enc2d"], pfx + "encoder_attn.kv", dx_out=denc, dx_accumulate=True)
+        dh = self.linear_bwd(dq.view(T * B, D), c["h"], pfx + "encoder_attn.q_proj")
+        return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "encoder_attn_layer_norm.weight"),
+                               self.G(pfx + "encoder_attn_layer_norm.weight"), self.G(pfx + "encoder_attn_layer_norm.bias"), dres=dy)
+
+    def ffn_block_fwd(self, pfx, x, training, seed):
+        """x + dropout(fc2(dropout_act(act(fc1(LN(x))))))   (transformer_layer.py:128-136)"""
+        hp = self.hp
+        T, B, D = x.shape
+        x2 = x.view(T * B, D)
+        h, mean, rstd = K.layernorm_fwd(x2, self.P(pfx + "final_layer_norm.weight"), self.P(pfx + "final_layer_norm.bias"), hp.ln_eps)
+        pact = hp.activation_dropout if training else 0.0
+        pre = torch.empty((T * B, hp.ffn), dtype=self.dtype, device=self.dev) if hp.act == "gelu" else None
+        a = self.linear(h, pfx + "fc1", act=self.act_fwd, aux_out=pre, p_drop=pact, seed=seed + 3)
+        p = hp.dropout if training else 0.0
+        y = self.linear(a, pfx + "fc2", residual=x2, p_drop=p, seed=seed + 4)
+        c = dict(x=x2, h=h, mean=mean, rstd=rstd, a=a, pre=pre, pact=pact, p=p, seed=seed)
+        return y.view(T, B, D), c
+
+    def ffn_block_bwd(self, pfx, c, dy):
+        d = K.dropout(dy, c["p"], c["seed"] + 4) if c["p"] > 0 else dy
+        if self.hp.act == "relu":
+            # a = relu(z) * keep/(1-p): a > 0 <=> active and kept; the 1/(1-p) factor goes in alpha
+            da = self.linear_bwd(d, c["a"], pfx + "fc2", act=K.ACT_RELU_BWD, aux=c["a"], alpha=1.0 / (1.0 - c["pact"]))
+        else:
+            da = self.linear_bwd(d, c["a"], pfx + "fc2", act=K.ACT_GELU_BWD, aux=c["pre"])
+            if c["pact"] > 0:
+                K.dropout(da, c["pact"], c["seed"] + 3, out=da)
+        dh = self.linear_bwd(da, c["h"], pfx + "fc1")
+        return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "final_layer_norm.weight"),
+                               self.G(pfx + "final_layer_norm.weight"), self.G(pfx + "final_layer_norm.bias"), dres=dy)
+
+    # ------------------------------------------------------------------ encoder
+    def encoder_forward(self, src_tokens, src_lengths, training, seed=0, return_all_hiddens=False):
+        """Returns dict(out [T'',B,D], lengths int64 [B] (device), lengths_host list, ctc_out, ctc_lengths, ...), ctx."""
+        hp = self.hp
+        len_host = [int(v) for v in (src_lengths.tolist() if torch.is_tensor(src_lengths) else src_lengths)]
+        len_dev = torch.tensor(len_host, dtype=torch.int64).to(self.dev, non_blocking=True) if not (
+            torch.is_tensor(src_lengths) and src_lengths.is_cuda) else src_lengths.to(torch.int64)
+        x, len4, len4_32, sub = self.subsample_fwd(src_tokens, len_dev, training, seed * 1000)
+        T4, B, D = x.shape
+        lens_host = [((l + 1) // 2 + 1) // 2 for l in len_host]
+        klen = len4_32 if min(lens_host) < T4 else None             # create_mask -> None when nothing is padded
+        ctx = dict(sub=sub, layers=[], ctc=None, T4=T4, B=B)
+        out = dict(ctc_out=None, ctc_lengths=None, ctc_lengths_host=None, pred=None, states=[] if return_all_hiddens else None)
+        cur_len, cur_len_host, cur_klen = len4, lens_host, klen
+        for l in range(hp.enc_layers):
+            pfx = "encoder.layers.%d." % l
+            x, ca = self.self_attn_block_fwd(pfx, x, cur_klen, False, training, seed * 1000 + 10 * (l + 1))
+            x, cf = self.ffn_block_fwd(pfx, x, training, seed * 1000 + 10 * (l + 1))
+            ctx["layers"].append((ca, cf))
+            if hp.ctc_layer == l + 1:
+                Tn = x.shape[0]
+                x2 = x.view(Tn * B, D)
+                x_ctc = self.linear(x2, "encoder.ctc_fc").view(Tn, B, hp.V_src)
+                pred, pmax = K.ctc_argmax(x_ctc)
+                seg, rs, rl, new_len, w = K.ctc_rle(pred, pmax, cur_len, hp.ctc_strategy)
+                new_len_host = new_len.tolist()                     # the one host sync of the forward pass
+                out["pred_host"] = pred.cpu()                       # greedy path for the host-side UER (logging)
+                Tout = max(new_len_host)
+                xc = K.ctc_compress_fwd(x, w, rs, rl, new_len, Tout)
+                ctx["ctc"] = dict(layer=l, x=x2, seg=seg, w=w, Tn=Tn, Tout=Tout)
+                out.update(ctc_out=x_ctc, ctc_lengths=cur_len, ctc_lengths_host=cur_len_host, ctc_klen=cur_klen, pred=pred)
+                x = xc
+                cur_len, cur_len_host = new_len, new_len_host
+                cur_klen = new_len.to(torch.int32) if min(new_len_host) < Tout else None
+            if return_all_hiddens:
+                out["states"].append(x)
+        Tn = x.shape[0]
+        xn, mean, rstd = K.layernorm_fwd(x.view(Tn * B, D), self.P("encoder.layer_norm.weight"), self.P("encoder.layer_norm.bias"), hp.ln_eps)
+        ctx["final"] = dict(x=x.view(Tn * B, D), mean=mean, rstd=rstd)
+        if return_all_hiddens:
+            out["states"][-1] = xn.view(Tn, B, D)
+        out.update(out=xn.view(Tn, B, D), lengths=cur_len, lengths_host=cur_len_host, klen=cur_klen)
+        return out, ctx
+
+    def encoder_backward(self, ctx, d_out, d_ctc_out=None, d_states=None):
+        """d_out [T'',B,D] gradient w.r.t. the (layer-normed) encoder output; d_ctc_out [T4,B,V_src] or None;
+        d_states: optional {layer index: gradient} for encoder_states consumers (criterion-owned CTC head)."""
+        hp = self.hp
+        B, D = ctx["B"], hp.D
+        f = ctx["final"]
+        if d_out is None:
+            d_out = torch.zeros_like(f["x"])
+        d_out = d_out.reshape(-1, D).contiguous()
+        if d_states and (hp.enc_layers - 1) in d_states:
+            d_out = K.add_inplace(d_states[hp.enc_layers - 1].reshape(-1, D).contiguous(), d_out.clone())
+        dx = K.layernorm_bwd(d_out.reshape(-1, D).contiguous(), f["x"], f["mean"], f["rstd"], self.P("encoder.layer_norm.weight"),
+                             self.G("encoder.layer_norm.weight"), self.G("encoder.layer_norm.bias"))
+        for l in reversed(range(hp.enc_layers)):
+            pfx = "encoder.layers.%d." % l
+            if d_states and l in d_states and l != hp.enc_layers - 1:
+                K.add_inplace(d_states[l].reshape(-1, D).contiguous(), dx)
+            if ctx["ctc"] is not None and ctx["ctc"]["layer"] == l:
+                cc = ctx["ctc"]
+                dxk = torch.empty((cc["Tn"], B, D), dtype=self.dtype, device=self.dev)
+                K.ctc_compress_bwd(dx.view(cc["Tout"], B, D), cc["w"], cc["seg"], dxk)
+                dxk = dxk.view(cc["Tn"] * B, D)
+                if d_ctc_out is not None:
+                    self.linear_bwd(d_ctc_out.reshape(-1, hp.V_src), cc["x"], "encoder.ctc_fc", dx_out=dxk, dx_accumulate=True)
+                dx = dxk
+            ca, cf = ctx["layers"][l]
+            dx = self.ffn_block_bwd(pfx, cf, dx)
+            dx = self.self_attn_block_bwd(pfx, ca, dx)
+        self.subsample_bwd(ctx["sub"], dx)
+
+    # ------------------------------------------------------------------ decoder
+    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder."):
+        hp = self.hp
+        B, L = prev_tokens.shape
+        D = hp.D
+        scale = 1.0 if hp.no_scale_embedding else math.sqrt(D)
+        tok = prev_tokens.contiguous()
+        x = K.embed_fwd(tok, self.W(pfx + "embed_tokens.weight"), self.table(hp.pad + 1 + L, hp.pad), scale, hp.pad)
+        p = hp.dropout if training else 0.0
+        if p > 0:
+            K.dropout(x, p, seed * 1000 + 501, out=x)
+        tlen = tok.ne(hp.pad).sum(dim=1).to(torch.int32)            # integer bookkeeping (suffix padding)
+        Ts = enc_out.shape[0]
+        enc2d = enc_out.reshape(Ts * B, D)
+        ctx = dict(tok=tok, layers=[], B=B, L=L, Ts=Ts, scale=scale, p=p, seed=seed, pfx=pfx)
+        for l in range(hp.dec_layers):
+            lp = pfx + "layers.%d." % l
+            s = seed * 1000 + 510 + 10 * l
+            x, c1 = self.self_attn_block_fwd(lp, x, tlen, True, training, s)
+            x, c2 = self.cross_attn_block_fwd(lp, x, enc2d, Ts, enc_klen32, training, s + 3)
+            x, c3 = self.ffn_block_fwd(lp, x, training, s + 4)
+            ctx["layers"].append((c1, c2, c3))
+        xn, mean, rstd = K.layernorm_fwd(x.view(L * B, D), self.P(pfx + "layer_norm.weight"), self.P(pfx + "layer_norm.bias"), hp.ln_eps)
+        ctx["final"] = dict(x=x.view(L * B, D), xn=xn, mean=mean, rstd=rstd)
+        logits = K.gemm(xn, self.W(pfx + "output_projection.weight"))          # [L*B, V] time-major rows
+        return logits, ctx
+
+    def decoder_backward(self, ctx, dlogits):
+        """dlogits [L*B, V] (time-major).  Returns the gradient w.r.t. the encoder output [Ts*B, D]."""
+        hp = self.hp
+        pfx, B, L, D = ctx["pfx"], ctx["B"], ctx["L"], hp.D
+        f = ctx["final"]
+        dxn = self.linear_bwd(dlogits, f["xn"], pfx + "output_projection", bias=False)
+        dx = K.layernorm_bwd(dxn, f["x"], f["mean"], f["rstd"], self.P(pfx + "layer_norm.weight"),
+                             self.G(pfx + "layer_norm.weight"), self.G(pfx + "layer_norm.bias"))
+        denc = torch.zeros((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
+        for l in reversed(range(hp.dec_layers)):
+            lp = pfx + "layers.%d." % l
+            c1, c2, c3 = ctx["layers"][l]
+            dx = self.ffn_block_bwd(lp, c3, dx)
+            dx = self.cross_attn_block_bwd(lp, c2, dx, denc)
+            dx = self.self_attn_block_bwd(lp, c1, dx)
+        if ctx["p"] > 0:
+            K.dropout(dx, ctx["p"], ctx["seed"] * 1000 + 501, out=dx)
+        K.embed_bwd(ctx["tok"], dx.view(L, B, D), self.G(pfx + "embed_tokens.weight"), ctx["scale"], hp.pad)
+        return denc

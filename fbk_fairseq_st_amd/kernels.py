@@ -17,7 +17,7 @@ def _lib():
 
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_NONE, aux=None, aux_out=None,
          out=None, out_dtype=None, accumulate=False, splitk=1, alpha=1.0, M=None, N=None, K=None,
-         map_a=None, period_a=0, map_b=None, map_c=None, out_rows=None):
+         map_a=None, period_a=0, map_b=None, map_c=None, out_rows=None, p_drop=0.0, seed=0):
     """C = epi(op(a) @ op(b)); a is [M,K] (or [K,M] if trans_a), b is [N,K] (or [K,N] if trans_b)."""
     L.require_cuda(a, b)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -40,7 +40,7 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_N
         L.dt(a), L.dt(out), int(trans_a), int(trans_b), M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0),
         L.ptr(out), out.stride(0), L.ptr(bias), L.ptr(residual), residual.stride(0) if residual is not None else 0,
         L.ptr(aux), L.ptr(aux_out), ldaux, act, int(accumulate), splitk, float(alpha),
-        L.ptr(map_a), period_a, L.ptr(map_b), L.ptr(map_c), L.stream())
+        L.ptr(map_a), period_a, L.ptr(map_b), L.ptr(map_c), float(p_drop), int(seed), L.stream())
     L.check(rc, "s2t_gemm")
     return out
 
@@ -257,6 +257,19 @@ def embed_bwd(tokens, dout, dW, scale, pad):
     D = dW.shape[1]
     L.check(_lib().s2t_embed_bwd(L.dt(dout), L.ptr(tokens), L.ptr(dout), L.ptr(dW), B, Ln, D, float(scale), pad, L.stream()),
             "s2t_embed_bwd")
+
+
+def act_bwd(dy, y, act):
+    out = torch.empty_like(dy)
+    L.check(_lib().s2t_act_bwd(L.dt(dy), L.ptr(dy), L.ptr(y), L.ptr(out), dy.numel(), act, L.stream()), "s2t_act_bwd")
+    return out
+
+
+def add_inplace(x, y):
+    """y += x"""
+    assert x.numel() == y.numel() and x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()
+    L.check(_lib().s2t_add_inplace(L.dt(y), L.ptr(x), L.ptr(y), y.numel(), L.stream()), "s2t_add_inplace")
+    return y
 
 
 def dropout(x, p, seed, out=None):

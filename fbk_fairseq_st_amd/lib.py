@@ -27,7 +27,7 @@ SIGNATURES = {
     "s2t_abi_version": [],
     "s2t_gemm": [c_int] * 7 + [P, c_int, P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "s2t_gemm_gather": [c_int] * 7 + [P, c_int, P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int,
-                                       c_float, P, c_int, P, P, P],
+                                       c_float, P, c_int, P, P, c_float, c_ull, P],
     "s2t_colsum": [c_int, P, c_int, c_int, c_int, P, P],
     "s2t_attn_fwd": [c_int] * 6 + [P, c_long, c_long] * 4 + [P, P, c_int, c_float, c_float, c_ull, P],
     "s2t_attn_bwd": [c_int] * 6 + [P, c_long, c_long] * 5 + [P, P] + [P, c_long, c_long] * 3 +
@@ -51,6 +51,8 @@ SIGNATURES = {
     "s2t_lsce": [c_int, P, P, P, P, c_long, c_int, c_float, c_int, c_float, P],
     "s2t_embed_fwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
     "s2t_embed_bwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
+    "s2t_act_bwd": [c_int, P, P, P, c_size_t, c_int, P],
+    "s2t_add_inplace": [c_int, P, P, c_size_t, P],
     "s2t_dropout": [c_int, P, P, c_size_t, c_float, c_ull, P],
     "s2t_grad_norm_clip": [P, c_size_t, P, c_float, c_float, P, P],
     "s2t_adam_step": [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, c_int, P],

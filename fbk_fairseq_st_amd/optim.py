@@ -1,0 +1,83 @@
+"""Optimizer side of the training step on the flat arena.
+
+  FairseqOptimizer surface   fairseq/optim/fairseq_optimizer.py:79-101 (backward / multiply_grads /
+                             clip_grad_norm / step / zero_grad / get_lr / set_lr)
+  Adam                       fairseq/optim/adam.py:147-202 (one fused launch over all parameters)
+  clip_grad_norm_            fairseq/utils.py:253-277 (norm, coefficient and scaling stay on the device)
+  inverse_sqrt schedule      fairseq/optim/lr_scheduler/inverse_square_root_schedule.py:36-73
+"""
+import torch
+
+from . import kernels as K
+
+
+class ArenaAdam:
+    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.arena = arena
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
+        self.step_count = 0
+        self._scale = 1.0                         # pending multiply_grads factor, folded into the clip / Adam kernels
+        self._ws = torch.zeros(1, dtype=torch.float64, device=arena.device)
+        self._out2 = torch.ones(2, dtype=torch.float32, device=arena.device)
+        self._have_mult = False
+        arena.ensure_adam_state()
+
+    def backward(self, loss):
+        loss.backward()
+
+    def multiply_grads(self, c):
+        """fairseq_optimizer.py:83-87; applied lazily inside the norm / Adam kernels (no extra pass over HBM)."""
+        self._scale *= float(c)
+
+    def clip_grad_norm(self, max_norm):
+        """Returns the (device) gradient norm after multiply_grads; the clip coefficient stays on the device."""
+        K.grad_norm_clip(self.arena.grad, self._scale, float(max_norm), self._ws, self._out2)
+        self._have_mult = True
+        return self._out2[0]
+
+    def step(self):
+        self.step_count += 1
+        if not self._have_mult:
+            self._out2[1] = self._scale
+        a = self.arena
+        K.adam_step(a.master, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, self._out2, self.lr, self.betas[0], self.betas[1],
+                    self.eps, self.weight_decay, self.step_count)
+        self._scale, self._have_mult = 1.0, False
+
+    def zero_grad(self):
+        self.arena.zero_grad()
+        self._scale, self._have_mult = 1.0, False
+
+    def get_lr(self):
+        return self.lr
+
+    def set_lr(self, lr):
+        self.lr = float(lr)
+
+    def state_dict(self):
+        a = self.arena
+        return {"step": self.step_count, "lr": self.lr, "exp_avg": a.exp_avg.cpu(), "exp_avg_sq": a.exp_avg_sq.cpu()}
+
+    def load_state_dict(self, sd):
+        a = self.arena
+        self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+        a.exp_avg.copy_(sd["exp_avg"]); a.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class InverseSquareRootSchedule:
+    def __init__(self, optimizer, lr, warmup_updates=4000, warmup_init_lr=-1):
+        self.optimizer = optimizer
+        self.lr_peak = lr
+        self.warmup_updates = warmup_updates
+        self.warmup_init_lr = (0 if warmup_updates > 0 else lr) if warmup_init_lr < 0 else warmup_init_lr
+        self.lr_step = (lr - self.warmup_init_lr) / max(warmup_updates, 1)
+        self.decay_factor = lr * max(warmup_updates, 1) ** 0.5
+        self.step_update(0)
+
+    def step_update(self, num_updates):
+        if num_updates < self.warmup_updates:
+            lr = self.warmup_init_lr + num_updates * self.lr_step
+        else:
+            lr = self.decay_factor * max(num_updates, 1) ** -0.5
+        self.optimizer.set_lr(lr)
+        return lr

@@ -1,0 +1,294 @@
+"""The plug-in surface of the reference, mirrored: decorator registries and base classes.
+
+Same names, argument meaning and error behaviour as fairseq's
+  register_model / register_model_architecture   (fairseq/models/__init__.py:51-119)
+  register_task                                   (fairseq/tasks/__init__.py:20-53)
+  register_criterion                              (fairseq/registry.py:12-62, fairseq/criterions/__init__.py:13-17)
+so that model / task / criterion code written against the reference's interface
+reads the same here.  This file holds no arithmetic.
+"""
+import argparse
+from typing import List, NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+MODEL_REGISTRY = {}
+ARCH_MODEL_REGISTRY = {}
+ARCH_MODEL_INV_REGISTRY = {}
+ARCH_CONFIG_REGISTRY = {}
+TASK_REGISTRY = {}
+CRITERION_REGISTRY = {}
+
+
+# ------------------------------------------------------------------ encoder output tuples
+class EncoderOut(NamedTuple):                      # fairseq/models/fairseq_encoder.py:11-21
+    encoder_out: Tensor                            # T x B x C
+    encoder_padding_mask: Optional[Tensor]         # B x T (True at padding) or None
+    encoder_embedding: Optional[Tensor]
+    encoder_states: Optional[List[Tensor]]
+    src_tokens: Optional[Tensor]
+    src_lengths: Optional[Tensor]
+
+
+class CTCAwareEncoderOut(NamedTuple):              # conv_transformer.py:28-32
+    encoder_out: Tensor
+    encoder_padding_mask: Optional[Tensor]
+    encoder_embedding: Optional[Tensor]
+    encoder_states: Optional[List[Tensor]]
+    src_tokens: Optional[Tensor]
+    src_lengths: Optional[Tensor]
+    ctc_out: Tensor                                # T4 x B x V_src logits
+    ctc_padding_mask: Optional[Tensor]             # B x T4
+
+
+# ------------------------------------------------------------------ registries
+def register_model(name):
+    def deco(cls):
+        if name in MODEL_REGISTRY:
+            raise ValueError("Cannot register duplicate model ({})".format(name))
+        if not issubclass(cls, BaseFairseqModel):
+            raise ValueError("Model ({}: {}) must extend BaseFairseqModel".format(name, cls.__name__))
+        MODEL_REGISTRY[name] = cls
+        return cls
+    return deco
+
+
+def register_model_architecture(model_name, arch_name):
+    def deco(fn):
+        if model_name not in MODEL_REGISTRY:
+            raise ValueError("Cannot register model architecture for unknown model type ({})".format(model_name))
+        if arch_name in ARCH_MODEL_REGISTRY:
+            raise ValueError("Cannot register duplicate model architecture ({})".format(arch_name))
+        if not callable(fn):
+            raise ValueError("Model architecture must be callable ({})".format(arch_name))
+        ARCH_MODEL_REGISTRY[arch_name] = MODEL_REGISTRY[model_name]
+        ARCH_MODEL_INV_REGISTRY.setdefault(model_name, []).append(arch_name)
+        ARCH_CONFIG_REGISTRY[arch_name] = fn
+        return fn
+    return deco
+
+
+def register_task(name):
+    def deco(cls):
+        if name in TASK_REGISTRY:
+            raise ValueError("Cannot register duplicate task ({})".format(name))
+        if not issubclass(cls, FairseqTask):
+            raise ValueError("Task ({}: {}) must extend FairseqTask".format(name, cls.__name__))
+        TASK_REGISTRY[name] = cls
+        return cls
+    return deco
+
+
+def register_criterion(name):
+    def deco(cls):
+        if name in CRITERION_REGISTRY:
+            raise ValueError("Cannot register duplicate criterion ({})".format(name))
+        if not issubclass(cls, FairseqCriterion):
+            raise ValueError("criterion ({}: {}) must extend FairseqCriterion".format(name, cls.__name__))
+        CRITERION_REGISTRY[name] = cls
+        return cls
+    return deco
+
+
+# ------------------------------------------------------------------ model base classes
+class FairseqEncoder(nn.Module):                   # fairseq/models/fairseq_encoder.py:24-91
+    def __init__(self, dictionary):
+        super().__init__()
+        self.dictionary = dictionary
+
+    def forward(self, src_tokens, src_lengths=None, **kwargs):
+        raise NotImplementedError
+
+    def forward_torchscript(self, net_input):
+        return self.forward_non_torchscript(net_input)
+
+    def forward_non_torchscript(self, net_input):
+        return self.forward(**{k: v for k, v in net_input.items() if k != "prev_output_tokens"})
+
+    def reorder_encoder_out(self, encoder_out, new_order):
+        raise NotImplementedError
+
+    def max_positions(self):
+        return 1e6
+
+    def upgrade_state_dict(self, state_dict):
+        return state_dict
+
+
+class FairseqDecoder(nn.Module):                   # fairseq/models/fairseq_decoder.py
+    def __init__(self, dictionary):
+        super().__init__()
+        self.dictionary = dictionary
+        self.onnx_trace = False
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        raise NotImplementedError
+
+    def max_positions(self):
+        return 1e6
+
+
+class FairseqIncrementalDecoder(FairseqDecoder):   # fairseq/models/fairseq_incremental_decoder.py:13-96
+    def reorder_incremental_state(self, incremental_state, new_order):
+        pass
+
+
+class BaseFairseqModel(nn.Module):                 # fairseq/models/fairseq_model.py:22-220
+    @staticmethod
+    def add_args(parser):
+        pass
+
+    @classmethod
+    def build_model(cls, args, task):
+        raise NotImplementedError("Model must implement the build_model method")
+
+    def get_targets(self, sample, net_output):
+        return sample["target"]
+
+    def max_positions(self):
+        return None
+
+    def set_num_updates(self, num_updates):
+        pass
+
+    def make_generation_fast_(self, **kwargs):
+        self.eval()
+
+    def raw_state_dict_upgrade(self, state_dict):
+        return state_dict
+
+
+class FairseqEncoderDecoderModel(BaseFairseqModel):    # fairseq/models/fairseq_model.py:233-307
+    def __init__(self, encoder, decoder):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        assert isinstance(self.encoder, FairseqEncoder)
+        assert isinstance(self.decoder, FairseqDecoder)
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens, **kwargs):
+        encoder_out = self.encoder(src_tokens, src_lengths=src_lengths, **kwargs)
+        return self.decoder(prev_output_tokens, encoder_out=encoder_out, **kwargs)
+
+    def get_normalized_probs(self, net_output, log_probs, sample=None):
+        return self.decoder.get_normalized_probs(net_output, log_probs, sample)
+
+    def max_positions(self):
+        return (self.encoder.max_positions(), self.decoder.max_positions())
+
+    def max_decoder_positions(self):
+        return self.decoder.max_positions()
+
+
+# ------------------------------------------------------------------ criterion / task base classes
+class FairseqCriterion(nn.Module):                 # fairseq/criterions/fairseq_criterion.py
+    def __init__(self, task):
+        super().__init__()
+        self.task = task
+        tgt = getattr(task, "target_dictionary", None)
+        self.padding_idx = tgt.pad() if tgt is not None else -100
+
+    @staticmethod
+    def add_args(parser):
+        pass
+
+    @classmethod
+    def build_criterion(cls, args, task):
+        return cls(args, task)
+
+    def forward(self, model, sample, reduce=True):
+        raise NotImplementedError
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        raise NotImplementedError
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return False
+
+
+class FairseqTask(object):                         # fairseq/tasks/fairseq_task.py:14-420
+    @staticmethod
+    def add_args(parser):
+        pass
+
+    def __init__(self, args):
+        self.args = args
+        self.datasets = {}
+
+    @classmethod
+    def setup_task(cls, args, **kwargs):
+        return cls(args, **kwargs)
+
+    @property
+    def source_dictionary(self):
+        raise NotImplementedError
+
+    @property
+    def target_dictionary(self):
+        raise NotImplementedError
+
+    def load_dataset(self, split, combine=False, **kwargs):
+        raise NotImplementedError
+
+    def dataset(self, split):
+        if split not in self.datasets:
+            raise KeyError("Dataset not loaded: " + split)
+        return self.datasets[split]
+
+    def build_model(self, args):
+        return build_model(args, self)
+
+    def build_criterion(self, args):
+        return build_criterion(args, self)
+
+    def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
+        """fairseq_task.py:352-381: forward, (zero the loss for dummy batches), backward."""
+        model.train()
+        model.set_num_updates(update_num)
+        loss, sample_size, logging_output = criterion(model, sample)
+        if ignore_grad:
+            loss *= 0
+        optimizer.backward(loss)
+        return loss, sample_size, logging_output
+
+    def valid_step(self, sample, model, criterion):
+        model.eval()
+        with torch.no_grad():
+            loss, sample_size, logging_output = criterion(model, sample)
+        return loss, sample_size, logging_output
+
+    def max_positions(self):
+        return None
+
+    def logging_outputs_can_be_summed(self, criterion):
+        return criterion.logging_outputs_can_be_summed()
+
+    def reduce_metrics(self, logging_outputs, criterion):
+        return criterion.__class__.reduce_metrics(logging_outputs)
+
+
+def build_model(args, task):
+    return ARCH_MODEL_REGISTRY[args.arch].build_model(args, task)      # fairseq/models/__init__.py:47-48
+
+
+def build_criterion(args, task):
+    return CRITERION_REGISTRY[args.criterion].build_criterion(args, task)
+
+
+def setup_task(args, **kwargs):
+    return TASK_REGISTRY[args.task].setup_task(args, **kwargs)
+
+
+def apply_arch(args):
+    """options.parse_args_and_arch tail (fairseq/options.py:191-192): fill the arch defaults in place."""
+    if getattr(args, "arch", None) in ARCH_CONFIG_REGISTRY:
+        ARCH_CONFIG_REGISTRY[args.arch](args)
+    return args
+
+
+def namespace(**kw):
+    return argparse.Namespace(**kw)

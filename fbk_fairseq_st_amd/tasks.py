@@ -1,0 +1,78 @@
+"""Tasks of the S2T path behind the reference's task interface.
+
+  speech_translation_with_transcription   examples/speech_recognition/tasks/speech_translation_ctc.py:18-79
+                                           (target dictionary + source dictionary with <ctc_blank> appended)
+  dummy_s2t                                synthetic-filterbank benchmark task, after the pattern of
+                                           fairseq/benchmark/dummy_lm.py:50-119 (one pre-built batch forever)
+"""
+import os
+
+from .data import Dictionary, synthetic_batch
+from .registry import FairseqTask, register_task
+
+
+@register_task("speech_translation_with_transcription")
+class SpeechTranslationCTCTask(FairseqTask):
+    @staticmethod
+    def add_args(parser):
+        a = parser.add_argument
+        a("data", help="path to data directory")
+        a("-s", "--source-lang", default=None, metavar="SRC")
+        a("-t", "--target-lang", default=None, metavar="TARGET")
+        a("--max-source-positions", default=1024, type=int, metavar="N")
+        a("--max-target-positions", default=1024, type=int, metavar="N")
+        a("--skip-normalization", action="store_true")
+        a("--specaugment", action="store_true")
+
+    def __init__(self, args, tgt_dict, src_dict=None):
+        super().__init__(args)
+        self.tgt_dict = tgt_dict
+        self.src_dict = src_dict
+        self.is_source_speech = True                     # read by generate.py:61-67
+
+    @classmethod
+    def setup_task(cls, args, **kwargs):
+        """speech_translation_ctc.py:35-47: dict.<tgt>.txt, dict.<src>.txt (+ <ctc_blank> as last symbol)."""
+        tgt = Dictionary.load(os.path.join(args.data, "dict.%s.txt" % args.target_lang))
+        src = Dictionary.load(os.path.join(args.data, "dict.%s.txt" % args.source_lang))
+        src.add_symbol("<ctc_blank>")
+        return cls(args, tgt, src)
+
+    @property
+    def source_dictionary(self):
+        return self.src_dict
+
+    @property
+    def target_dictionary(self):
+        return self.tgt_dict
+
+    def max_positions(self):
+        return (getattr(self.args, "max_source_positions", 1024), getattr(self.args, "max_target_positions", 1024))
+
+
+@register_task("dummy_s2t")
+class DummyS2TTask(SpeechTranslationCTCTask):
+    """Synthetic 80-mel filterbank batches of a fixed shape; dictionaries of the requested sizes."""
+
+    @staticmethod
+    def add_args(parser):
+        a = parser.add_argument
+        a("--dict-size", default=8000 - 4, type=int)
+        a("--src-dict-size", default=5000 - 4, type=int)
+        a("--batch-size", default=8, type=int)
+        a("--frames", default=1500, type=int)
+        a("--tgt-len", default=40, type=int)
+        a("--transcript-len", default=40, type=int)
+
+    @classmethod
+    def setup_task(cls, args, **kwargs):
+        tgt = Dictionary.synthetic(getattr(args, "dict_size", 7996))
+        src = Dictionary.synthetic(getattr(args, "src_dict_size", 4996))
+        src.add_symbol("<ctc_blank>")
+        return cls(args, tgt, src)
+
+    def dummy_batch(self, seed=0, lengths=None):
+        a = self.args
+        return synthetic_batch(a.batch_size, a.frames, a.tgt_len, a.transcript_len, len(self.tgt_dict),
+                               self.src_dict.index("<ctc_blank>"), feat=getattr(a, "input_feat_per_channel", 80),
+                               seed=seed, lengths=lengths)

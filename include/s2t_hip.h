@@ -58,12 +58,15 @@ int s2t_gemm(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N
 /* Same kernel with row gather / scatter, used to run Conv2d(64->64, 3x3, stride 2, pad 1)
  * (conv_transformer.py:203-206, 2nd iteration) and its backward as implicit GEMMs over channels-last
  * activations:  mapA[(k/periodA)*M + r] = source row of A for output row r and k-block (tap) k/periodA
- * (-1 = zero padding);  mapB[k] = source row of a [K][N] B operand;  mapC[r] = destination row. */
+ * (-1 = zero padding);  mapB[k] = source row of a [K][N] B operand;  mapC[r] = destination row.
+ * p_drop > 0: dropout (Philox(seed, row*N+col)) on the activated value before the residual add
+ * (transformer_layer.py:123-124,133-136: x = residual + dropout(linear(...))). */
 int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
                     const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                     const float* bias, const void* residual, int ldr, const void* aux, void* aux_out, int ldaux,
                     int act, int accumulate, int splitk, float alpha,
-                    const int* mapA, int periodA, const int* mapB, const int* mapC, void* stream);
+                    const int* mapA, int periodA, const int* mapB, const int* mapC,
+                    float p_drop, unsigned long long seed, void* stream);
 
 /* out[n] += sum_m X[m][n]  (bias gradients of every nn.Linear above; f32 atomics) */
 int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float* out, void* stream);
@@ -152,6 +155,10 @@ int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float
                   int B, int L, int D, float scale, int pad, void* stream);
 int s2t_embed_bwd(int dtype, const long long* tokens, const void* dout, float* dW, int B, int L, int D,
                   float scale, int pad, void* stream);
+/* out = dy * act'(y): act 1 = relu (y = post-activation), act 2 = gelu (y = pre-activation) */
+int s2t_act_bwd(int dtype, const void* dy, const void* y, void* out, size_t n, int act, void* stream);
+/* y += x (merging the gradients of two consumers of one activation) */
+int s2t_add_inplace(int dtype, const void* x, void* y, size_t n, void* stream);
 /* y = x * keep/(1-p), mask from Philox(seed, index); the backward pass calls it again on the gradient */
 int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p, unsigned long long seed, void* stream);
 
