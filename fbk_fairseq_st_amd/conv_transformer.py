@@ -379,7 +379,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         a("--input-feat-per-channel", type=int, metavar="N")
         a("--activation-fn", choices=["relu", "gelu"])
         a("--dropout", type=float, metavar="D"); a("--attention-dropout", type=float, metavar="D")
-        a("--activation-dropout", "--relu-dropout", type=float, metavar="D")
+        a("--activation-dropout", type=float, metavar="D"); a("--relu-dropout", type=float, metavar="D")
         a("--encoder-embed-dim", type=int, metavar="N"); a("--encoder-ffn-embed-dim", type=int, metavar="N")
         a("--encoder-layers", type=int, metavar="N"); a("--encoder-attention-heads", type=int, metavar="N")
         a("--decoder-embed-dim", type=int, metavar="N"); a("--decoder-ffn-embed-dim", type=int, metavar="N")
@@ -434,10 +434,12 @@ def _common(args):
     args.dropout = getattr(args, "dropout", 0.3)
     args.normalization_constant = getattr(args, "normalization_constant", 0.5)
     args.attention_dropout = getattr(args, "attention_dropout", 0.1)
-    # transformer_layer.py:43-46: activation_dropout, falling back to relu_dropout
-    ad = getattr(args, "activation_dropout", 0) or getattr(args, "relu_dropout", None)
-    args.activation_dropout = 0.1 if ad is None else ad
-    args.relu_dropout = args.activation_dropout
+    # conv_transformer.py:434 (relu_dropout defaults to 0.1) + transformer_layer.py:43-46 (activation_dropout,
+    # and when that is 0 the layer falls back to relu_dropout -- also when 0 was asked for explicitly)
+    rd = getattr(args, "relu_dropout", None)
+    args.relu_dropout = 0.1 if rd is None else rd
+    ad = getattr(args, "activation_dropout", None) or 0
+    args.activation_dropout = ad if ad != 0 else args.relu_dropout
     args.attn_2d = not getattr(args, "no_attn_2d", False)
     args.no_token_positional_embeddings = getattr(args, "no_token_positional_embeddings", False)
     args.share_decoder_input_output_embed = getattr(args, "share_decoder_input_output_embed", False)

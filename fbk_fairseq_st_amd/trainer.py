@@ -1,0 +1,126 @@
+"""Training step driver, after fairseq/trainer.py:334-495.
+
+Order of one update, as in the reference: reseed (seed + num_updates) -> zero grads -> for each
+micro-batch: move to the GPU, task.train_step (forward, loss, backward) -> sum logging outputs and
+sample sizes over ranks -> gradients x 1/sum(sample_size) -> global-norm clip -> Adam -> LR schedule.
+What differs is where the work runs: the gradient all-reduce is launched bucket by bucket from inside
+backward (distributed.BucketedGradReducer), scaling + clipping are folded into the norm / Adam kernels,
+and nothing but the CTC-compression lengths synchronises the host with the GPU before the final stats.
+"""
+import time
+
+import torch
+
+from . import distributed as D
+from .optim import ArenaAdam, InverseSquareRootSchedule
+
+
+def move_to_device(sample, device):
+    if torch.is_tensor(sample):
+        return sample.to(device, non_blocking=True)
+    if isinstance(sample, dict):
+        return {k: move_to_device(v, device) for k, v in sample.items()}
+    if isinstance(sample, (list, tuple)):
+        return type(sample)(move_to_device(v, device) for v in sample)
+    return sample
+
+
+class Trainer:
+    def __init__(self, args, task, model, criterion, device=None, compute_dtype=None):
+        self.args, self.task, self.model, self.criterion = args, task, model, criterion
+        self.device = torch.device(device if device is not None else "cuda:%d" % getattr(args, "device_id", 0))
+        if compute_dtype is None:
+            compute_dtype = torch.bfloat16 if getattr(args, "bf16", False) else torch.float32
+        extra = criterion.arena_params() if hasattr(criterion, "arena_params") else None
+        self.arena = model.materialize(self.device, compute_dtype, extra=extra)
+        betas = eval(args.adam_betas) if isinstance(getattr(args, "adam_betas", None), str) else getattr(args, "adam_betas", (0.9, 0.999))
+        lr = args.lr[0] if isinstance(args.lr, (list, tuple)) else args.lr
+        self.optimizer = ArenaAdam(self.arena, lr=lr, betas=betas, eps=getattr(args, "adam_eps", 1e-8),
+                                   weight_decay=getattr(args, "weight_decay", 0.0))
+        self.lr_scheduler = InverseSquareRootSchedule(self.optimizer, lr, getattr(args, "warmup_updates", 4000),
+                                                      getattr(args, "warmup_init_lr", -1))
+        self.num_updates = 0
+        self.world = D.get_world_size()
+        self.reducer = D.BucketedGradReducer(self.arena.grad, getattr(args, "bucket_cap_mb", 64) << 20)
+        model.add_grads_ready_hook(self._grads_ready)
+        self._part_ranges = self._build_part_ranges()
+        self.last_stats = {}
+
+    # ---- overlap of the gradient all-reduce with backward
+    def _build_part_ranges(self):
+        names = list(self.arena.slices)
+        r = {}
+        for part in ("encoder", "decoder"):
+            mine = [n for n in names if n.startswith(part + ".")]
+            if mine:
+                r[part] = self.arena.slice_of(mine)
+        return r
+
+    def _grads_ready(self, part):
+        if part in self._part_ranges and self.world > 1:
+            self.reducer.notify(*self._part_ranges[part])
+
+    def _prepare_sample(self, sample):
+        """trainer.py:631-653 + host-side statistics taken BEFORE the copy (no device round trip later)."""
+        if sample is None or len(sample) == 0:
+            return None
+        s = dict(sample)
+        if "transcript_target" in s and torch.is_tensor(s["transcript_target"]) and not s["transcript_target"].is_cuda:
+            s["transcript_target_host"] = s["transcript_target"]
+            s["transcript_target_lengths_host"] = s["transcript_target_lengths"]
+        ni = s["net_input"]
+        if torch.is_tensor(ni["src_lengths"]) and not ni["src_lengths"].is_cuda:
+            s.setdefault("nframes", int(ni["src_lengths"].sum()))
+            lens_host = ni["src_lengths"]
+        else:
+            lens_host = None
+        host_keys = {k: s[k] for k in ("transcript_target_host", "transcript_target_lengths_host") if k in s}
+        s = move_to_device({k: v for k, v in s.items() if k not in host_keys}, self.device)
+        s.update(host_keys)
+        if lens_host is not None:
+            s["net_input"]["src_lengths"] = lens_host          # the encoder takes host lengths (no sync)
+        return s
+
+    def train_step(self, samples):
+        """One optimizer update over a list of micro-batches (`--update-freq`).  Returns the reduced stats."""
+        self.model.set_seed(getattr(self.args, "seed", 1) + self.num_updates)        # trainer.py:655-661
+        self.model.train(); self.criterion.train()
+        self.optimizer.zero_grad()
+        self.reducer.reset()
+        logs, sample_size = [], 0
+        for i, sample in enumerate(samples):
+            s = self._prepare_sample(sample)
+            if s is None:
+                continue
+            loss, ss, log = self.task.train_step(s, self.model, self.criterion, self.optimizer, self.num_updates)
+            logs.append(log)
+            sample_size += ss
+        self.reducer.finish()                                                       # R2
+        stats = {"sample_size": float(sample_size)}
+        if self.world > 1:
+            stats = D.all_reduce_stats(stats, self.device)                          # R3 (must land before scaling)
+        total_ss = max(stats["sample_size"], 1.0)
+        self.optimizer.multiply_grads(1.0 / total_ss)                               # trainer.py:426-430
+        gnorm = self.optimizer.clip_grad_norm(getattr(self.args, "clip_norm", 25.0))
+        self.optimizer.step()
+        self.num_updates += 1
+        self.lr_scheduler.step_update(self.num_updates)
+        self._pending = (logs, gnorm, total_ss)
+        return self._pending
+
+    def reduce_stats(self):
+        """Materialise (one sync) and sum the logging outputs of the last update."""
+        logs, gnorm, total_ss = self._pending
+        agg = {}
+        for l in logs:
+            for k, v in l.items():
+                agg[k] = agg.get(k, 0.0) + (float(v) if not torch.is_tensor(v) else float(v.item()))
+        agg["gnorm"] = float(gnorm.item())
+        if self.world > 1:
+            g = agg.pop("gnorm")
+            agg = D.all_reduce_stats(agg, self.device)
+            agg["gnorm"] = g
+            if getattr(self.args, "check_grad_norms", False):
+                D.check_grad_norms(g, self.device)                                   # R4
+        self.last_stats = agg
+        return agg

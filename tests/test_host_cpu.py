@@ -1,0 +1,125 @@
+"""Host-side logic that needs no GPU: registries, arch presets, state-dict naming, collate, arena, reducer."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fbk_fairseq_st_amd import conv_transformer, criterions, data, tasks  # noqa: F401
+from fbk_fairseq_st_amd import registry as R
+from fbk_fairseq_st_amd.arena import ParamArena
+from fbk_fairseq_st_amd.distributed import BucketedGradReducer
+from helpers import load_golden, model_case
+from oracle import s2t_ref
+
+
+def tiny_args(**kw):
+    a = dict(arch="conv_transformer", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+             label_smoothing=0.1, ctc_compress_out=True, ctc_encoder_layer=2, ctc_weight=1.0, encoder_embed_dim=64,
+             encoder_ffn_embed_dim=128, encoder_attention_heads=2, encoder_layers=3, decoder_layers=2,
+             decoder_embed_dim=64, decoder_ffn_embed_dim=128, decoder_attention_heads=2, no_attn_2d=True,
+             input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0)
+    a.update(kw)
+    return R.namespace(**a)
+
+
+def tiny_task(args):
+    tgt, src = data.Dictionary.synthetic(96), data.Dictionary.synthetic(59)
+    src.add_symbol("<ctc_blank>")
+    return tasks.SpeechTranslationCTCTask(args, tgt, src)
+
+
+def test_registries_mirror_reference_names():
+    for arch in ("conv_transformer", "conv_transformer_big", "conv_transformer_big2", "conv_transformer_giant",
+                 "s2t_transformer", "s2t_transformer_xs", "s2t_transformer_s", "s2t_transformer_m", "s2t_transformer_l"):
+        assert arch in R.ARCH_MODEL_REGISTRY
+    assert "ctc_multi_loss" in R.CRITERION_REGISTRY and "label_smoothed_cross_entropy" in R.CRITERION_REGISTRY
+    assert "speech_translation_with_transcription" in R.TASK_REGISTRY and "dummy_s2t" in R.TASK_REGISTRY
+    with pytest.raises(ValueError):
+        R.register_model("conv_transformer")(conv_transformer.ConvolutionalTransformerModel)     # duplicate
+    with pytest.raises(ValueError):
+        R.register_model_architecture("nope", "x")(lambda a: None)
+    a = R.namespace(arch="s2t_transformer_m")
+    R.apply_arch(a)
+    assert (a.encoder_embed_dim, a.encoder_ffn_embed_dim, a.encoder_attention_heads, a.encoder_layers, a.decoder_layers, a.dropout) == (512, 2048, 8, 12, 6, 0.15)
+    b = R.namespace(arch="conv_transformer_big2")
+    R.apply_arch(b)
+    assert (b.encoder_embed_dim, b.encoder_ffn_embed_dim, b.encoder_layers, b.dropout, b.attention_dropout) == (512, 2048, 6, 0.3, 0.1)
+
+
+def test_state_dict_uses_reference_key_names_and_round_trips():
+    args = tiny_args()
+    task = tiny_task(args)
+    model = task.build_model(args)
+    sd = model.state_dict()
+    ref_shapes = s2t_ref.param_shapes(s2t_ref.default_cfg(D=64, heads=2, ffn=128, enc_layers=3, dec_layers=2, ctc_layer=2), 64, 100)
+    for k, shp in ref_shapes.items():
+        assert k in sd and tuple(sd[k].shape) == tuple(shp), k
+    for k in ("encoder.bn.0.num_batches_tracked", "encoder.embed_positions.embeddings._float_tensor", "decoder.version"):
+        assert k in sd
+    W = s2t_ref.make_weights(ref_shapes, 5)
+    model.load_state_dict(W)
+    sd2 = model.state_dict()
+    for k in W:
+        assert torch.equal(sd2[k], W[k]), k
+    with pytest.raises(RuntimeError):
+        model.load_state_dict({k: v for k, v in W.items() if "fc3" not in k})
+
+
+def test_model_refuses_cpu_inputs():
+    args = tiny_args()
+    model = tiny_task(args).build_model(args)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.encoder(torch.zeros(1, 8, 80), torch.tensor([8]))
+
+
+def test_unsupported_options_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        a = tiny_args(no_attn_2d=False)
+        tiny_task(a).build_model(a)
+    with pytest.raises(NotImplementedError):
+        a = tiny_args(distance_penalty="log")
+        tiny_task(a).build_model(a)
+    with pytest.raises(AssertionError):          # conv_transformer.py:191
+        a = tiny_args(criterion="label_smoothed_cross_entropy")
+        tiny_task(a).build_model(a)
+
+
+def test_collate_matches_reference_golden():
+    g = load_golden("collate")
+    n = int(g["n"])
+    samples = [{"id": i, "data": [g["s%d_src" % i], g["s%d_tgt" % i]], "transcript_target": torch.from_numpy(g["s%d_tr" % i])}
+               for i in range(n)]
+    b = data.collate_with_transcripts(data.Seq2SeqCollater(0, 1, 1, 2, True), samples, 1, 2)
+    for k in ("id", "target", "target_lengths", "transcript_target", "transcript_target_lengths"):
+        assert np.array_equal(b[k].numpy(), g[k]), k
+    for k in ("src_tokens", "src_lengths", "prev_output_tokens", "transcript_prev_output_tokens"):
+        assert np.array_equal(b["net_input"][k].numpy(), g[k]), k
+    assert b["ntokens"] == int(g["ntokens"])
+    assert data.Seq2SeqCollater().collate([]) == {}
+
+
+def test_arena_layout_and_views():
+    ar = ParamArena({"a.weight": (3, 5), "a.bias": (3,), "b.weight": (130,)}, "cpu")
+    assert ar.slices["a.bias"][0] % 64 == 0 and ar.slices["b.weight"][0] % 64 == 0
+    ar.p("a.weight").fill_(2.0)
+    assert float(ar.master[:15].sum()) == 30.0 and float(ar.master[15:64].abs().sum()) == 0.0
+    ar.g("b.weight").add_(1.0)
+    ar.zero_grad()
+    assert float(ar.grad.abs().sum()) == 0.0
+    s, e = ar.slice_of(["a.bias", "b.weight"])
+    assert s == ar.slices["a.bias"][0] and e == ar.numel
+
+
+def test_bucketed_reducer_covers_every_element_once():
+    flat = torch.zeros(1000)
+    r = BucketedGradReducer(flat, bucket_bytes=4 * 300)
+    r.notify(700, 1000); r.notify(650, 700); r.notify(300, 650); r.notify(100, 300)
+    r.finish()
+    cover = torch.zeros(1000)
+    for s, e in r.launched:
+        cover[s:e] += 1
+    assert torch.all(cover == 1) and len(r.launched) >= 3
+    r.reset(); r.finish()
+    assert r.launched == [(0, 1000)]

@@ -22,7 +22,8 @@ def build(name, dtype=torch.float32):
                      label_smoothing=0.1, ctc_compress_out=meta["compress"], ctc_encoder_layer=meta["ctc_layer"], ctc_weight=1.0,
                      encoder_embed_dim=cfg["D"], encoder_ffn_embed_dim=cfg["ffn"], encoder_attention_heads=cfg["heads"],
                      encoder_layers=cfg["enc_layers"], decoder_layers=cfg["dec_layers"], no_attn_2d=True,
-                     input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, sentence_avg=False)
+                     decoder_embed_dim=cfg["D"], decoder_ffn_embed_dim=cfg["ffn"], decoder_attention_heads=cfg["heads"],
+                     input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False)
     tgt, src = Dictionary.synthetic(96), Dictionary.synthetic(59)
     src.add_symbol("<ctc_blank>")
     task = tasks.SpeechTranslationCTCTask(args, tgt, src)
