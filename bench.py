@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the S2T training hot path on MI355X.
+
+Metric (BASELINE.json): audio-frames/sec (train fwd+bwd) of s2t_transformer_m on 80-mel synthetic filterbanks,
+= sum of src_lengths (10 ms input frames, the reference's own `nframes` counter, CTC_loss.py:173) divided by
+the wall time of full updates (forward + CTC/label-smoothed losses + backward + gradient all-reduce + clip + Adam).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (configs[2] of BASELINE.json): s2t_transformer_m (conv_transformer structure,
+D=512, FFN=2048, 8 heads, 12+6 layers) + ctc_multi_loss with --ctc-compress-out after encoder layer 8,
+T=1500 frames x 80 mel, per-GPU batch 64 utterances (96,000 frames: the effective per-GPU batch of the
+reference's paper script, --max-tokens 12000 x --update-freq 8, README.md:144,152, taken in one pass because
+288 GB of HBM allows it), target/transcript length 40, V_tgt=8000, V_src=5000+<ctc_blank>, bf16 storage with f32
+accumulation and f32 master weights, dropout ON at the preset rates.  Weak scaling: every rank gets its own batch.
+
+Rank 0 prints ONE JSON line.  `roofline` times the dominant kernel family (the MFMA GEMMs) with HIP events
+inside the library (s2t_prof_*) during extra instrumented steps after the timed region; `cpu_baseline` times the
+CPU oracle (port of the reference path, verified against it) on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
+PEAK_F32_TFLOPS = 157.3
+
+
+def build_all(args, device, dtype):
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.registry import apply_arch, namespace, setup_task
+    from fbk_fairseq_st_amd.trainer import Trainer
+    a = namespace(arch=args.arch, task="dummy_s2t", criterion="ctc_multi_loss",
+                  underlying_criterion="label_smoothed_cross_entropy", label_smoothing=0.1, sentence_avg=True,
+                  ctc_compress_out=True, ctc_encoder_layer=args.ctc_layer, ctc_weight=1.0, ctc_compress_strategy="avg",
+                  input_feat_per_channel=80, no_attn_2d=True, dict_size=8000 - 4, src_dict_size=5000 - 4,
+                  batch_size=args.batch, frames=args.frames, tgt_len=args.tgt_len, transcript_len=args.tgt_len,
+                  lr=[5e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=20.0,
+                  warmup_updates=4000, warmup_init_lr=3e-4, seed=1, bf16=(dtype == torch.bfloat16), bucket_cap_mb=64)
+    apply_arch(a)
+    task = setup_task(a)
+    torch.manual_seed(1)
+    model = task.build_model(a)
+    crit = task.build_criterion(a)
+    ref_sd = model.state_dict() if args.cpu_baseline else None
+    trainer = Trainer(a, task, model, crit, device=device, compute_dtype=dtype)
+    return a, task, model, crit, trainer, ref_sd
+
+
+def cpu_baseline(args, a, ref_sd, task):
+    """The CPU oracle (oracle/s2t_ref.py, a verified port of the reference path) on the host cores: forward +
+    losses + backward of the same model on a bounded sample of the same workload (B_cpu utterances x T frames)."""
+    from oracle import s2t_ref
+    import torch.nn.functional as F
+    # torch's intra-op pool does not scale past a few dozen threads on these small GEMMs (256 threads measured
+    # 80x slower than 8 on this path): use min(32, host cores) and report that number as `cores`
+    ncores = min(args.cpu_threads, os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    cfg = s2t_ref.default_cfg(D=a.encoder_embed_dim, heads=a.encoder_attention_heads, ffn=a.encoder_ffn_embed_dim,
+                              enc_layers=a.encoder_layers, dec_layers=a.decoder_layers, ctc_layer=a.ctc_encoder_layer)
+    W = {k: v.clone().requires_grad_(v.dtype.is_floating_point and v.dim() > 0 and "running" not in k and "_float_tensor" not in k
+                                     and "version" not in k)
+         for k, v in ref_sd.items()}
+    Bc = args.cpu_batch
+    from fbk_fairseq_st_amd.data import synthetic_batch
+    s = synthetic_batch(Bc, args.frames, args.tgt_len, args.tgt_len, len(task.tgt_dict), task.src_dict.index("<ctc_blank>"), seed=7)
+    blank = task.src_dict.index("<ctc_blank>")
+    # the reference calls torch's own F.ctc_loss (CTC_loss.py:143): use it for a representative cost
+    s2t_ref.ctc_loss_sum = lambda logits, t, il, tl, b: F.ctc_loss(
+        F.log_softmax(logits.float(), -1), torch.cat([t[i, : tl[i]] for i in range(t.shape[0])]), il, tl,
+        blank=b, reduction="sum", zero_infinity=True)
+    times = []
+    for it in range(args.cpu_iters + 1):
+        for v in W.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        loss, ss, log, enc, logits, _ = s2t_ref.ctc_multi_loss(W, cfg, s, 0.1, 1.0, blank, training=True)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": Bc * args.frames / t, "unit": "audio-frames/s", "cores": ncores, "kind": "port",
+            "sample": "oracle/s2t_ref.py ctc_multi_loss fwd+bwd, fp32, %d x %d frames, best of %d after 1 warm-up" % (Bc, args.frames, args.cpu_iters)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--arch", default="s2t_transformer_m")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per update")
+    ap.add_argument("--frames", type=int, default=1500)
+    ap.add_argument("--tgt-len", type=int, default=40)
+    ap.add_argument("--ctc-layer", type=int, default=8)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
+    ap.add_argument("--no-roofline", dest="roofline", action="store_false")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--prof-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the S2T hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    from fbk_fairseq_st_amd import distributed as D
+    from fbk_fairseq_st_amd import kernels as K
+    D.distributed_init("nccl", device)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    args.cpu_baseline = args.cpu_baseline and rank == 0 and world == 1
+    a, task, model, crit, trainer, ref_sd = build_all(args, device, dtype)
+    sample = task.dummy_batch(seed=100 + rank)                       # per-rank data (weak scaling)
+    frames_per_step = int(sample["nframes"])
+    sample = trainer.prepare(sample)                                 # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step([sample])
+    trainer.reduce_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step([sample])
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = trainer.reduce_stats()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    roof = None
+    if args.roofline and rank == 0:
+        K.prof_reset(); K.prof_enable(True)
+        for _ in range(args.prof_steps):
+            trainer.train_step([sample])
+        torch.cuda.synchronize()
+        K.prof_enable(False)
+        fam = {f: K.prof_read(f) for f in ("gemm", "gemm_gather", "attn_fwd", "attn_bwd")}
+        gm = fam["gemm"]
+        if gm["launches"] > 0 and gm["ms"] > 0:
+            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+            peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+            roof = {"bound": "mfma", "kernel": "gemm_kernel (libs2t_hip.so, all s2t_gemm launches of a step)",
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None, "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 2),
+                    "launches_per_step": gm["launches"] // args.prof_steps,
+                    "ms_per_step": {k: round(v["ms"] / args.prof_steps, 3) for k, v in fam.items()}}
+    if world > 1:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        out = {"metric": "audio-frames/sec (train fwd+bwd) s2t_transformer_m, 80-mel",
+               "value": round(world * frames_per_step * args.steps / dt, 1), "unit": "audio-frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "%s + ctc_multi_loss(ctc-compress-out @ layer %d) full update, %d x %d x 80 fbank per GPU, "
+                                      "tgt/transcript len %d, V_tgt 8000, V_src 5001, dropout on" %
+                                      (args.arch, args.ctc_layer, args.batch, args.frames, args.tgt_len),
+                          "global_batch": args.batch * world, "frames_per_step": frames_per_step * world, "parallelism": "dp%d" % world},
+               "loss": round(stats.get("loss", float("nan")) / max(stats.get("sample_size", 1), 1), 4),
+               "gnorm": round(stats.get("gnorm", float("nan")), 4)}
+        if roof is not None:
+            out["roofline"] = roof
+        if args.cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, a, ref_sd, task)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

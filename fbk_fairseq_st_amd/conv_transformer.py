@@ -85,7 +85,7 @@ class _EncoderFn(torch.autograd.Function):
         eng = ctx.enc.engine
         has_ctc = ctx.ectx["ctc"] is not None
         ds = {ctx.want_state: d_state.contiguous()} if (ctx.want_state is not None and d_state is not None) else None
-        eng.encoder_backward(ctx.ectx, d_out, d_ctc.contiguous() if (has_ctc and d_ctc is not None) else None, ds)
+        eng.encoder_backward(ctx.ectx, d_out, d_ctc if (has_ctc and d_ctc is not None) else None, ds)
         ctx.enc._after_backward("encoder")
         return (None,) * 7
 
@@ -99,7 +99,7 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
-        denc = ctx.dec.engine.decoder_backward(ctx.dctx, dlogits.contiguous())
+        denc = ctx.dec.engine.decoder_backward(ctx.dctx, dlogits if dlogits.stride(-1) == 1 else dlogits.contiguous())
         ctx.dec._after_backward(ctx.dec.pfx.rstrip("."))
         c = ctx.dctx
         return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None

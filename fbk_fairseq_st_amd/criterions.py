@@ -30,10 +30,10 @@ class _LSCEFn(torch.autograd.Function):
     def forward(ctx, logits, target, eps, pad):
         B, L, V = logits.shape
         lt = logits.transpose(0, 1)                       # the decoder produces time-major rows: this is a view
-        if not lt.is_contiguous():
+        if lt.stride(2) != 1 or lt.stride(0) != B * lt.stride(1):
             lt = lt.contiguous()
         tt = target.t().contiguous()
-        sums, dl = K.lsce(lt.view(L * B, V), tt.view(-1), eps, pad, want_grad=True)
+        sums, dl = K.lsce(lt.reshape(L * B, V), tt.view(-1), eps, pad, want_grad=True)
         ctx.dl, ctx.shape = dl, (L, B, V)
         return sums[0], sums[1]
 
@@ -49,7 +49,9 @@ class _CTCFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, targets, tgt_len, in_len32, blank):
-        loss, grad, _ = K.ctc_loss(logits.contiguous(), targets.contiguous(), tgt_len.contiguous(), in_len32.contiguous(), blank)
+        if logits.stride(2) != 1 or logits.stride(0) != logits.shape[1] * logits.stride(1):
+            logits = logits.contiguous()
+        loss, grad, _ = K.ctc_loss(logits, targets.contiguous(), tgt_len.contiguous(), in_len32.contiguous(), blank)
         ctx.grad = grad
         return loss[0]
 
@@ -66,7 +68,8 @@ class _LinearFn(torch.autograd.Function):
         eng = model.engine
         T, B, D = x.shape
         x2 = x.contiguous().view(T * B, D)
-        y = K.gemm(x2, eng.W(wname), bias=eng.P(bname))
+        w = eng.W(wname)
+        y = K.gemm(x2, w, bias=eng.P(bname), out=K.alloc_rows((T * B,), w.shape[0], x2.dtype, x2.device))
         ctx.model, ctx.x2, ctx.names, ctx.shape = model, x2, (wname, bname), (T, B, D)
         return y.view(T, B, -1)
 
@@ -75,7 +78,8 @@ class _LinearFn(torch.autograd.Function):
         eng = ctx.model.engine
         T, B, D = ctx.shape
         wname, bname = ctx.names
-        dx = eng.linear_bwd(dy.contiguous().view(T * B, -1), ctx.x2, wname[: -len(".weight")])
+        dy2 = dy.reshape(T * B, -1)
+        dx = eng.linear_bwd(dy2 if dy2.stride(1) == 1 else dy2.contiguous(), ctx.x2, wname[: -len(".weight")])
         return dx.view(T, B, D), None, None, None
 
 
@@ -179,7 +183,7 @@ class CTCMultiLoss(FairseqCriterion):
         ctc_loss = _CTCFn.apply(ctc_feat, tr, tr_len, in_len.to(torch.int32), self.blank_idx)
         # unit error rate (logging only): greedy path + native edit-distance alignment on the host
         if pred is None:
-            pred = K.ctc_argmax(ctc_feat.detach().contiguous())[0].cpu()
+            pred = K.ctc_argmax(ctc_feat.detach())[0].cpu()
         tr_host = sample.get("transcript_target_host")
         tr_host = tr.cpu() if tr_host is None else tr_host
         trl_host = sample.get("transcript_target_lengths_host")

@@ -13,12 +13,12 @@
 // probability (f32).  One wavefront per (t,b) row, three passes over the row (L2-resident).
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_argmax_kernel(const T* __restrict__ logits, int* __restrict__ pred,
-                                                         float* __restrict__ pmax, int Tn, int B, int V) {
+                                                         float* __restrict__ pmax, int Tn, int B, int V, int ld) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)Tn * B) return;
     const int t = (int)(row / B), b = (int)(row % B);
-    const T* x = logits + row * V;
+    const T* x = logits + row * ld;
     float m = -INFINITY;
     for (int j = lane; j < V; j += 64) m = fmaxf(m, to_f32(x[j]));
     m = wave_max(m);
@@ -134,11 +134,11 @@ __global__ __launch_bounds__(256) void ctc_compress_bwd_kernel(const T* __restri
 // ------------------------------------------------------------------ CTC loss
 // Pass 1: per (t,b) row log-sum-exp of the logits (f32) -> lse[t][b].
 template <typename T>
-__global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ logits, float* __restrict__ lse, long rows, int V) {
+__global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ logits, float* __restrict__ lse, long rows, int V, int ld) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const T* x = logits + row * V;
+    const T* x = logits + row * ld;
     float m = -INFINITY;
     for (int j = lane; j < V; j += 64) m = fmaxf(m, to_f32(x[j]));
     m = wave_max(m);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
                                                             const long long* __restrict__ targets, const long long* __restrict__ tgt_len,
                                                             const int* __restrict__ in_len, float* __restrict__ la,
                                                             float* __restrict__ lb, float* __restrict__ nll, int Tn, int B,
-                                                            int V, int Lmax, int Smax, int blank) {
+                                                            int V, int ld, int Lmax, int Smax, int blank) {
     __shared__ float em[2][CTC_CH][64 * CTC_SPL];
     __shared__ int ext_s[64 * CTC_SPL];
     const int b = blockIdx.x, lane = threadIdx.x & 63, dir = threadIdx.x >> 6;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
             const int d = idx / (CTC_CH * S), r = idx % (CTC_CH * S), k = r / S, s = r % S;
             const int t = d == 0 ? ta0 + k : tb0 - k;
             float v = -INFINITY;
-            if (t >= 0 && t < Tb) v = to_f32(logits[((long)t * B + b) * V + ext_s[s]]) - lse[(long)t * B + b];
+            if (t >= 0 && t < Tb) v = to_f32(logits[((long)t * B + b) * ld + ext_s[s]]) - lse[(long)t * B + b];
             em[d][k][s] = v;
         }
         __syncthreads();
@@ -266,17 +266,17 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const int* __restrict__ in_len, const float* __restrict__ la,
                                                        const float* __restrict__ lb, const float* __restrict__ nll,
                                                        T* __restrict__ grad, float* __restrict__ loss_sum, int Tn, int B,
-                                                       int V, int Lmax, int Smax, int blank, float gscale) {
+                                                       int V, int ld, int Lmax, int Smax, int blank, float gscale) {
     extern __shared__ float occ[];                      // [V]
     const int t = blockIdx.x, b = blockIdx.y;
     const long row = (long)t * B + b;
-    T* g = grad + row * V;
+    T* g = grad + row * ld;
     const float nl = nll[b];
     const bool live = t < min(in_len[b], Tn) && nl < INFINITY;
     if (t == 0 && threadIdx.x == 0 && nl < INFINITY) atomicAdd(loss_sum, nl);
     if (!live) { for (int c = threadIdx.x; c < V; c += 256) g[c] = from_f32<T>(0.f); return; }
     const float ls = lse[row];
-    const T* x = logits + row * V;
+    const T* x = logits + row * ld;
     for (int c = threadIdx.x; c < V; c += 256) occ[c] = 0.f;
     __syncthreads();
     const int S = 2 * (int)tgt_len[b] + 1;
@@ -293,14 +293,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
 }
 
 // ------------------------------------------------------------------ C ABI
-extern "C" int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, void* stream) {
+extern "C" int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, int ld, void* stream) {
     const long rows = (long)T * B;
     if (rows <= 0) return S2T_OK;
-    if (!logits || !pred || !pmax || V <= 0) return S2T_EINVAL;
+    if (!logits || !pred || !pmax || V <= 0 || ld < V) return S2T_EINVAL;
     dim3 grid((unsigned)((rows + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, T, B, V);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, pred, pmax, T, B, V);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, T, B, V, ld);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, pred, pmax, T, B, V, ld);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
@@ -342,14 +342,15 @@ extern "C" int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w,
 }
 
 // Fused log-softmax + CTC loss (sum, zero_infinity) + gradient w.r.t. the logits.
+//   logits / grad rows have stride ld >= V elements (pad ld to a multiple of 8 so GEMMs can vector-load them)
 //   logits [T][B][V]; targets [B][Lmax] int64 (first tgt_len[b] entries); in_len [B] int32
 //   workspaces: lse [T*B] f32, la/lb [B*T*Smax] f32 with Smax = 2*Lmax+1, nll [B] f32
 //   outputs: grad [T][B][V] (dtype), loss_sum[0] += sum of finite nll  (caller zeroes it)
 extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len,
                             const int* in_len, float* lse, float* la, float* lb, float* nll, void* grad,
-                            float* loss_sum, int T, int B, int V, int Lmax, int blank, float grad_scale, void* stream) {
+                            float* loss_sum, int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
-    if (!logits || !targets || !tgt_len || !in_len || !lse || !la || !lb || !nll || !grad || !loss_sum) return S2T_EINVAL;
+    if (!logits || !targets || !tgt_len || !in_len || !lse || !la || !lb || !nll || !grad || !loss_sum || ld < V) return S2T_EINVAL;
     const int Smax = 2 * Lmax + 1;
     if (Smax > 64 * CTC_SPL) return S2T_ENOTSUP;          // transcripts longer than 127 tokens
     if ((size_t)V * 4 > 160 * 1024 - 1024) return S2T_ENOTSUP;
@@ -358,17 +359,17 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
     dim3 g1((unsigned)((rows + 3) / 4)), g3(T, B);
     const size_t lds = (size_t)V * 4;
     if (dtype == S2T_BF16) {
-        hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V);
-        hipLaunchKernelGGL(ctc_alphabeta_kernel<bf16>, dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, Lmax, Smax, blank);
+        hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V, ld);
+        hipLaunchKernelGGL(ctc_alphabeta_kernel<bf16>, dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
-        hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, loss_sum, T, B, V, Lmax, Smax, blank, grad_scale);
+        hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, loss_sum, T, B, V, ld, Lmax, Smax, blank, grad_scale);
     } else if (dtype == S2T_F32) {
-        hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V);
-        hipLaunchKernelGGL(ctc_alphabeta_kernel<float>, dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, Lmax, Smax, blank);
+        hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V, ld);
+        hipLaunchKernelGGL(ctc_alphabeta_kernel<float>, dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
-        hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, loss_sum, T, B, V, Lmax, Smax, blank, grad_scale);
+        hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, loss_sum, T, B, V, ld, Lmax, Smax, blank, grad_scale);
     } else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

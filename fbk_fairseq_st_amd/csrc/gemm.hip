@@ -221,45 +221,99 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 
     // ---------------- epilogue
+    // Park the f32 accumulators in LDS (free after the main loop); then every thread finishes CW consecutive
+    // columns of one row (16 bytes of output): bias / activation / dropout / residual on vectors, one 16-byte
+    // store.  Split-K partial sums leave as f32 atomics with the lanes of a wave on 64 consecutive columns
+    // (256 contiguous bytes per wave-instruction: the full-rate shape, MI355X_MICROARCH.md "Global float atomics").
     TO* C = reinterpret_cast<TO*>(p.C);
     const TO* R = reinterpret_cast<const TO*>(p.residual);
     const TO* AUX = reinterpret_cast<const TO*>(p.aux);
     TO* AUXO = reinterpret_cast<TO*>(p.aux_out);
+    constexpr int RS = BN * 4 + 16;                           // LDS row stride (bytes), +16 breaks the 4-row bank aliasing
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = col0 + wc * (BN / 2) + 16 * j + r16;
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + wr * (BM / 2) + 16 * i + 4 * q + r;
+                const int lr = wr * (BM / 2) + 16 * i + 4 * q + r, lc = wc * (BN / 2) + 16 * j + r16;
+                *reinterpret_cast<float*>(smem + lr * RS + lc * 4) = acc[i][j][r] * p.alpha;
+            }
+    __syncthreads();
+    if constexpr (sizeof(TO) == 4) {
+        if (p.splitk > 1) {
+            for (int idx = threadIdx.x; idx < BM * BN; idx += 256) {
+                const int lr = idx / BN, lc = idx % BN;
+                const int row = row0 + lr, col = col0 + lc;
                 if (row >= p.M || col >= p.N) continue;
-                float v = acc[i][j][r] * p.alpha;
                 const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
-                if constexpr (sizeof(TO) == 4) {
-                    if (p.splitk > 1) {
-                        atomicAdd(reinterpret_cast<float*>(C) + orow * p.ldc + col, v);
-                        continue;
-                    }
-                }
-                if (p.bias) v += p.bias[col];
-                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == ACT_GELU) {
-                    if (AUXO) AUXO[(size_t)row * p.ldaux + col] = from_f32<TO>(v);
-                    v = gelu_f(v);
-                } else if (p.act == ACT_RELU_BWD) {
-                    v = (to_f32(AUX[(size_t)row * p.ldaux + col]) > 0.f) ? v : 0.f;
-                } else if (p.act == ACT_GELU_BWD) {
-                    v *= gelu_grad_f(to_f32(AUX[(size_t)row * p.ldaux + col]));
-                }
-                if (p.p_drop > 0.f) {
-                    const uint32_t th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
-                    v = dropout_keep(p.seed, (uint64_t)row * p.N + col, th) ? v / (1.f - p.p_drop) : 0.f;
-                }
-                if (R) v += to_f32(R[(size_t)row * p.ldr + col]);
-                TO* dst = C + orow * p.ldc + col;
-                if (p.accumulate) v += to_f32(*dst);
-                *dst = from_f32<TO>(v);
+                atomicAdd(reinterpret_cast<float*>(C) + orow * p.ldc + col, *reinterpret_cast<const float*>(smem + lr * RS + lc * 4));
+            }
+            return;
+        }
+    }
+    constexpr int CW = 16 / (int)sizeof(TO);                  // output elements per 16-byte chunk
+    constexpr int CPR = BN / CW;
+    const uint32_t drop_th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
+    const float drop_inv = 1.f / (1.f - p.p_drop);
+    const bool vC = (p.ldc % CW == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    const bool vR = !R || ((p.ldr % CW == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0));
+    const bool vX = !AUX || ((p.ldaux % CW == 0) && ((reinterpret_cast<uintptr_t>(AUX) & 15) == 0));
+    const bool vO = !AUXO || ((p.ldaux % CW == 0) && ((reinterpret_cast<uintptr_t>(AUXO) & 15) == 0));
+    for (int c = threadIdx.x; c < BM * CPR; c += 256) {
+        const int lr = c / CPR, cc = c % CPR;
+        const int row = row0 + lr, col = col0 + cc * CW;
+        if (row >= p.M || col >= p.N) continue;
+        const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
+        float v[CW];
+#pragma unroll
+        for (int k = 0; k < CW / 4; ++k) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + lr * RS + (cc * CW + 4 * k) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * k + e] = a0[e];
+        }
+        const bool fast = (col + CW <= p.N) && vC && vR && vX && vO;
+        TO rres[CW], raux[CW];
+        if (fast) {
+            if (R) *reinterpret_cast<u32x4*>(rres) = *reinterpret_cast<const u32x4*>(R + (size_t)row * p.ldr + col);
+            if (AUX) *reinterpret_cast<u32x4*>(raux) = *reinterpret_cast<const u32x4*>(AUX + (size_t)row * p.ldaux + col);
+        } else {
+#pragma unroll
+            for (int e = 0; e < CW; ++e) {
+                const bool ok = col + e < p.N;
+                rres[e] = (R && ok) ? R[(size_t)row * p.ldr + col + e] : from_f32<TO>(0.f);
+                raux[e] = (AUX && ok) ? AUX[(size_t)row * p.ldaux + col + e] : from_f32<TO>(0.f);
+            }
+        }
+        TO pre[CW], o[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+            float x = v[e];
+            if (p.bias && col + e < p.N) x += p.bias[col + e];
+            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+            else if (p.act == ACT_GELU) { pre[e] = from_f32<TO>(x); x = gelu_f(x); }
+            else if (p.act == ACT_RELU_BWD) x = (to_f32(raux[e]) > 0.f) ? x : 0.f;
+            else if (p.act == ACT_GELU_BWD) x *= gelu_grad_f(to_f32(raux[e]));
+            if (p.p_drop > 0.f) x = dropout_keep(p.seed, (uint64_t)row * p.N + col + e, drop_th) ? x * drop_inv : 0.f;
+            if (R) x += to_f32(rres[e]);
+            o[e] = from_f32<TO>(x);
+        }
+        TO* dst = C + orow * p.ldc + col;
+        if (fast) {
+            if (p.accumulate) {
+                TO old[CW];
+                *reinterpret_cast<u32x4*>(old) = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+                for (int e = 0; e < CW; ++e) o[e] = from_f32<TO>(to_f32(o[e]) + to_f32(old[e]));
+            }
+            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(o);
+            if (p.act == ACT_GELU && AUXO) *reinterpret_cast<u32x4*>(AUXO + (size_t)row * p.ldaux + col) = *reinterpret_cast<const u32x4*>(pre);
+        } else {
+#pragma unroll
+            for (int e = 0; e < CW; ++e) {
+                if (col + e >= p.N) continue;
+                dst[e] = p.accumulate ? from_f32<TO>(to_f32(o[e]) + to_f32(dst[e])) : o[e];
+                if (p.act == ACT_GELU && AUXO) AUXO[(size_t)row * p.ldaux + col + e] = pre[e];
             }
         }
     }
@@ -269,7 +323,12 @@ template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
 static int launch(const GemmArgs& a, hipStream_t st) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     dim3 grid(tiles, 1, a.splitk);
-    const size_t lds = 2 * (BM + BN) * 128;
+    size_t lds = 2 * (BM + BN) * 128;
+    if ((size_t)BM * (BN * 4 + 16) > lds) lds = (size_t)BM * (BN * 4 + 16);   // epilogue staging of the f32 tile
+    if (lds > 65536) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    }
     hipLaunchKernelGGL((gemm_kernel<TI, TO, TA, TB, BM, BN>), grid, dim3(256), lds, st, a);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
@@ -306,12 +365,15 @@ extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int tra
     // small problems: 64x64 tiles so that more workgroups exist than CUs
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
     const bool small = t128 < 192;
-    if (in_dtype == S2T_BF16 && out_dtype == S2T_BF16)
-        return small ? launch_t<bf16, bf16, 64, 64>(a, trans_a, trans_b, st) : launch_t<bf16, bf16, 128, 128>(a, trans_a, trans_b, st);
-    if (in_dtype == S2T_BF16 && out_dtype == S2T_F32)
-        return small ? launch_t<bf16, float, 64, 64>(a, trans_a, trans_b, st) : launch_t<bf16, float, 128, 128>(a, trans_a, trans_b, st);
-    if (in_dtype == S2T_F32 && out_dtype == S2T_F32)
-        return small ? launch_t<float, float, 64, 64>(a, trans_a, trans_b, st) : launch_t<float, float, 128, 128>(a, trans_a, trans_b, st);
+    const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
+#define S2T_PICK(TI_, TO_)                                                                   \
+    return small ? launch_t<TI_, TO_, 64, 64>(a, trans_a, trans_b, st)                       \
+                 : (narrow ? launch_t<TI_, TO_, 128, 64>(a, trans_a, trans_b, st)            \
+                           : launch_t<TI_, TO_, 128, 128>(a, trans_a, trans_b, st))
+    if (in_dtype == S2T_BF16 && out_dtype == S2T_BF16) { S2T_PICK(bf16, bf16); }
+    if (in_dtype == S2T_BF16 && out_dtype == S2T_F32) { S2T_PICK(bf16, float); }
+    if (in_dtype == S2T_F32 && out_dtype == S2T_F32) { S2T_PICK(float, float); }
+#undef S2T_PICK
     return S2T_ENOTSUP;
 }
 
@@ -324,28 +386,52 @@ extern "C" int s2t_gemm(int in_dtype, int out_dtype, int trans_a, int trans_b, i
 }
 
 // Column sums of a [M][N] activation-gradient matrix into an f32 vector (bias gradients):
-// out[n] (+)= sum_m X[m][n].  One block per (64-column strip, row chunk); f32 atomics across chunks.
+// out[n] (+)= sum_m X[m][n].  Each lane owns 16 bytes of columns (8 bf16 / 4 f32), a workgroup = 4 row slots x
+// 64 lanes; rows are grid-strided in chunks, partial sums meet in LDS, one f32 atomic per column per workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int ld, int M, int N, float* out, int rows_per_block) {
-    __shared__ float sh[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int w = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int ld, int M, int N, float* out, int rows_per_block, int vec) {
+    constexpr int E = Elem<T>::PER16;
+    __shared__ float sh[4][64 * 8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * E;
     const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
-    float s = 0.f;
-    if (c < N)
-        for (int m = m0 + w; m < m1; m += 4) s += to_f32(X[(size_t)m * ld + c]);
-    sh[w][threadIdx.x & 63] = s;
+    float s[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] = 0.f;
+    if (c0 < N) {
+        if (vec && c0 + E <= N) {
+            for (int m = m0 + w; m < m1; m += 4) {
+                T tmp[E];
+                *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(X + (size_t)m * ld + c0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[e] += to_f32(tmp[e]);
+            }
+        } else {
+            for (int m = m0 + w; m < m1; m += 4)
+#pragma unroll
+                for (int e = 0; e < E; ++e) if (c0 + e < N) s[e] += to_f32(X[(size_t)m * ld + c0 + e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) sh[w][lane * E + e] = s[e];
     __syncthreads();
-    if (w == 0 && c < N) atomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    for (int i = threadIdx.x; i < 64 * E; i += 256) {
+        const int c = blockIdx.x * 64 * E + i;
+        if (c < N) atomicAdd(out + c, sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i]);
+    }
 }
 
 extern "C" int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float* out, void* stream) {
     if (M <= 0 || N <= 0) return S2T_OK;
     if (!X || !out) return S2T_EINVAL;
-    const int rpb = 512;
-    dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)X, ld, M, N, out, rpb);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ld, M, N, out, rpb);
+    const int E = dtype == S2T_BF16 ? 8 : 4;
+    const int vec = (ld % E == 0) && (((uintptr_t)X & 15) == 0);
+    const int col_blocks = (N + 64 * E - 1) / (64 * E);
+    int rpb = (int)(((long)M * col_blocks + 1023) / 1024);       // aim at ~1024 workgroups
+    rpb = rpb < 64 ? 64 : rpb;
+    dim3 grid(col_blocks, (M + rpb - 1) / rpb);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)X, ld, M, N, out, rpb, vec);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ld, M, N, out, rpb, vec);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

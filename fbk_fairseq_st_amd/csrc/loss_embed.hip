@@ -10,12 +10,12 @@
 //   dlogits[v] = gscale * (softmax[v] - (1-eps)*[v==y] - eps/V)   (0 on pad rows)
 template <typename T>
 __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits, const long long* __restrict__ target,
-                                                   T* __restrict__ dlogits, float* __restrict__ sums, int V, float eps,
-                                                   int pad, float gscale) {
+                                                   T* __restrict__ dlogits, float* __restrict__ sums, int V, int ld,
+                                                   float eps, int pad, float gscale) {
     __shared__ float sh[16];
     const long row = blockIdx.x;
-    const T* x = logits + row * V;
-    T* g = dlogits ? dlogits + row * V : nullptr;
+    const T* x = logits + row * ld;
+    T* g = dlogits ? dlogits + row * ld : nullptr;
     const long long y = target[row];
     if (y == pad) {
         if (g) for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits,
 }
 
 extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2,
-                        long rows, int V, float eps, int pad, float grad_scale, void* stream) {
+                        long rows, int V, int ld, float eps, int pad, float grad_scale, void* stream) {
     if (rows <= 0) return S2T_OK;
-    if (!logits || !target || !sums2 || V <= 0) return S2T_EINVAL;
+    if (!logits || !target || !sums2 || V <= 0 || ld < V) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(lsce_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, target, (bf16*)dlogits, sums2, V, eps, pad, grad_scale);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(lsce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, (float*)dlogits, sums2, V, eps, pad, grad_scale);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(lsce_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, target, (bf16*)dlogits, sums2, V, ld, eps, pad, grad_scale);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(lsce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, (float*)dlogits, sums2, V, ld, eps, pad, grad_scale);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
@@ -117,21 +117,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, float p, unsigned long long seed) {
     const uint32_t th = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
     const float inv = 1.f / (1.f - p);
-    const size_t n4 = (n + 3) / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const uint4 r = philox4x32(seed, i);
-        const uint32_t rv[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const size_t e = i * 4 + k;
-            if (e < n) y[e] = from_f32<T>(rv[k] >= th ? to_f32(x[e]) * inv : 0.f);
-        }
-    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = from_f32<T>(dropout_keep(seed, i, th) ? to_f32(x[i]) * inv : 0.f);
 }
 extern "C" int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p, unsigned long long seed, void* stream) {
     if (n == 0) return S2T_OK;
     if (!x || !y || p < 0.f || p >= 1.f) return S2T_EINVAL;
-    int blocks = (int)(((n + 3) / 4 + 255) / 256);
+    int blocks = (int)((n + 255) / 256);
     blocks = blocks > 4096 ? 4096 : blocks;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2T_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, p, seed);

@@ -5,94 +5,138 @@
 // fairseq/trainer.py:416-443 (multiply_grads -> clip -> step).
 #include "common.hpp"
 
-// ------------------------------------------------------------------ LayerNorm forward
-// One wavefront per row; the row lives in registers (D <= 1024).  y = (x-mean)*rstd*gamma+beta.
-template <typename T>
+// ------------------------------------------------------------------ LayerNorm
+// One wavefront per row.  Lane l owns EPL contiguous elements [l*EPL, l*EPL+EPL) (D = 64*EPL, EPL in {4,8,16}):
+// 8/16/32-byte loads per lane, fully coalesced, the row lives in registers; statistics by wavefront
+// shuffles.  Other widths (D <= 1024) take the strided scalar variant (EPL = 0).
+template <typename T, int EPL> struct RowIO {
+    static __device__ __forceinline__ void load(const T* row, int lane, int D, float (&v)[16]) {
+        if constexpr (EPL == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; v[i] = (j < D) ? to_f32(row[j]) : 0.f; }
+        } else {
+            constexpr int VE = 16 / (int)sizeof(T);                    // elements per 16-byte vector
+            constexpr int NV = (EPL * (int)sizeof(T) + 15) / 16;       // vectors per lane
+            constexpr int PER = EPL < VE ? EPL : VE;                   // elements taken from each vector
+            const T* p = row + lane * EPL;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                T tmp[VE];
+                if constexpr (EPL * sizeof(T) >= 16) *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(p + k * VE);
+                else *reinterpret_cast<u32x2*>(tmp) = *reinterpret_cast<const u32x2*>(p);
+#pragma unroll
+                for (int e = 0; e < PER; ++e) v[k * VE + e] = to_f32(tmp[e]);
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(T* row, int lane, int D, const float (&v)[16]) {
+        if constexpr (EPL == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int j = lane + 64 * i; if (j < D) row[j] = from_f32<T>(v[i]); }
+        } else {
+            constexpr int VE = 16 / (int)sizeof(T);
+            constexpr int NV = (EPL * (int)sizeof(T) + 15) / 16;
+            constexpr int PER = EPL < VE ? EPL : VE;
+            T* p = row + lane * EPL;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                T tmp[VE];
+#pragma unroll
+                for (int e = 0; e < PER; ++e) tmp[e] = from_f32<T>(v[k * VE + e]);
+                if constexpr (EPL * sizeof(T) >= 16) *reinterpret_cast<u32x4*>(p + k * VE) = *reinterpret_cast<const u32x4*>(tmp);
+                else *reinterpret_cast<u32x2*>(p) = *reinterpret_cast<const u32x2*>(tmp);
+            }
+        }
+    }
+    // column index of register slot i of this lane
+    static __device__ __forceinline__ int col(int lane, int i) { return EPL == 0 ? lane + 64 * i : lane * EPL + i; }
+    static constexpr int N = EPL == 0 ? 16 : EPL;
+};
+
+template <typename T, int EPL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      int M, int D, float eps) {
+    typedef RowIO<T, EPL> IO;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const T* xr = x + (size_t)row * D;
     float v[16];
+    IO::load(x + (size_t)row * D, lane, D, v);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = lane + 64 * i;
-        v[i] = (j < D) ? to_f32(xr[j]) : 0.f;
-        s += v[i];
-    }
+    for (int i = 0; i < IO::N; ++i) s += v[i];
     const float mu = wave_sum(s) / (float)D;
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = lane + 64 * i;
-        const float d = (j < D) ? v[i] - mu : 0.f;
-        ss += d * d;
-    }
+    for (int i = 0; i < IO::N; ++i) { const float d = (IO::col(lane, i) < D) ? v[i] - mu : 0.f; ss += d * d; }
     const float rs = rsqrtf(wave_sum(ss) / (float)D + eps);
-    T* yr = y + (size_t)row * D;
+    if constexpr (EPL != 0) {
+        // gamma / beta as 16-byte vectors (a lane's EPL columns are contiguous)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = lane + 64 * i;
-        if (j < D) yr[j] = from_f32<T>((v[i] - mu) * rs * gamma[j] + beta[j]);
+        for (int k = 0; k < EPL / 4; ++k) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + lane * EPL + 4 * k);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + lane * EPL + 4 * k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * k + e] = (v[4 * k + e] - mu) * rs * gv[e] + bv[e];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < IO::N; ++i) { const int j = IO::col(lane, i); if (j < D) v[i] = (v[i] - mu) * rs * gamma[j] + beta[j]; }
     }
+    IO::store(y + (size_t)row * D, lane, D, v);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// ------------------------------------------------------------------ LayerNorm backward
 // dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres],  g = dy*gamma;
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (per-lane partials over a grid-stride row loop,
 // combined across the 4 waves in LDS, then one f32 atomic per column per workgroup).
-template <typename T>
+template <typename T, int EPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D) {
+    typedef RowIO<T, EPL> IO;
     __shared__ float sh[2][4][1024];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float ag[16], ab[16];
+    float ag[16], ab[16], gm[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < IO::N; ++i) { const int j = IO::col(lane, i); if (j < D) gm[i] = gamma[j]; }
     for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        const T* xr = x + (size_t)row * D;
-        const T* dr = dy + (size_t)row * D;
-        float xh[16], g[16];
+        float xv[16], dv[16], rv[16];
+        IO::load(x + (size_t)row * D, lane, D, xv);
+        IO::load(dy + (size_t)row * D, lane, D, dv);
+        if (dres) IO::load(dres + (size_t)row * D, lane, D, rv);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = lane + 64 * i;
-            if (j < D) {
-                const float d = to_f32(dr[j]);
-                xh[i] = (to_f32(xr[j]) - mu) * rs;
-                g[i] = d * gamma[j];
-                ag[i] += d * xh[i];
-                ab[i] += d;
-            } else { xh[i] = 0.f; g[i] = 0.f; }
-            s1 += g[i];
-            s2 += g[i] * xh[i];
+        for (int i = 0; i < IO::N; ++i) {
+            const bool ok = IO::col(lane, i) < D;
+            xv[i] = ok ? (xv[i] - mu) * rs : 0.f;             // xhat
+            const float d = ok ? dv[i] : 0.f;
+            ag[i] += d * xv[i];
+            ab[i] += d;
+            dv[i] = d * gm[i];                                 // g
+            s1 += dv[i];
+            s2 += dv[i] * xv[i];
         }
         const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
-        T* ox = dx + (size_t)row * D;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = lane + 64 * i;
-            if (j < D) {
-                float r = rs * (g[i] - c1 - xh[i] * c2);
-                if (dres) r += to_f32(dres[(size_t)row * D + j]);
-                ox[j] = from_f32<T>(r);
-            }
+        for (int i = 0; i < IO::N; ++i) {
+            float r = rs * (dv[i] - c1 - xv[i] * c2);
+            if (dres) r += rv[i];
+            dv[i] = r;
         }
+        IO::store(dx + (size_t)row * D, lane, D, dv);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = lane + 64 * i;
-        sh[0][w][j] = ag[i];
-        sh[1][w][j] = ab[i];
+    for (int i = 0; i < IO::N; ++i) {
+        const int j = IO::col(lane, i);
+        if (j < 1024) { sh[0][w][j] = ag[i]; sh[1][w][j] = ab[i]; }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < D; j += 256) {
@@ -101,14 +145,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
+static int ln_epl(int D, const void* a, const void* b, const void* c, const void* d, const void* e = nullptr, const void* f = nullptr) {
+    const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f;
+    if ((al & 15) != 0) return 0;
+    if (D == 256) return 4;
+    if (D == 512) return 8;
+    if (D == 1024) return 16;
+    return 0;
+}
+
+#define LN_DISPATCH(KERNEL, T, epl, grid, ...)                                                              \
+    do {                                                                                                    \
+        if (epl == 4) hipLaunchKernelGGL((KERNEL<T, 4>), grid, dim3(256), 0, st, __VA_ARGS__);              \
+        else if (epl == 8) hipLaunchKernelGGL((KERNEL<T, 8>), grid, dim3(256), 0, st, __VA_ARGS__);         \
+        else if (epl == 16) hipLaunchKernelGGL((KERNEL<T, 16>), grid, dim3(256), 0, st, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((KERNEL<T, 0>), grid, dim3(256), 0, st, __VA_ARGS__);                       \
+    } while (0)
+
 extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                                  float* mean, float* rstd, int M, int D, float eps, void* stream) {
     if (M <= 0) return M < 0 ? S2T_EINVAL : S2T_OK;
     if (D <= 0 || D > 1024) return S2T_ENOTSUP;
     if (!x || !gamma || !beta || !y || !mean || !rstd) return S2T_EINVAL;
     dim3 grid((M + 3) / 4);
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, eps);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+    hipStream_t st = (hipStream_t)stream;
+    const int epl = ln_epl(D, x, y, gamma, beta);
+    if (dtype == S2T_BF16) LN_DISPATCH(ln_fwd_kernel, bf16, epl, grid, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, eps);
+    else if (dtype == S2T_F32) LN_DISPATCH(ln_fwd_kernel, float, epl, grid, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
@@ -122,8 +185,11 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return S2T_EINVAL;
     int blocks = (M + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D);
+    dim3 grid(blocks);
+    hipStream_t st = (hipStream_t)stream;
+    const int epl = ln_epl(D, dy, x, dres, dx);
+    if (dtype == S2T_BF16) LN_DISPATCH(ln_bwd_kernel, bf16, epl, grid, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
+    else if (dtype == S2T_F32) LN_DISPATCH(ln_bwd_kernel, float, epl, grid, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

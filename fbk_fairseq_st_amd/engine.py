@@ -173,9 +173,11 @@ class S2TEngine:
     def G(self, n):
         return self.A.g(n)
 
-    def linear(self, x2d, name, act=K.ACT_NONE, residual=None, aux_out=None, p_drop=0.0, seed=0, bias=True):
-        return K.gemm(x2d, self.W(name + ".weight"), bias=self.P(name + ".bias") if bias else None, act=act,
-                      residual=residual, aux_out=aux_out, p_drop=p_drop, seed=seed)
+    def linear(self, x2d, name, act=K.ACT_NONE, residual=None, aux_out=None, p_drop=0.0, seed=0, bias=True, pad_rows=False):
+        w = self.W(name + ".weight")
+        out = K.alloc_rows((x2d.shape[0],), w.shape[0], self.dtype, self.dev) if pad_rows else None
+        return K.gemm(x2d, w, bias=self.P(name + ".bias") if bias else None, act=act,
+                      residual=residual, aux_out=aux_out, p_drop=p_drop, seed=seed, out=out)
 
     def linear_bwd(self, dy2d, x2d, name, need_dx=True, act=K.ACT_NONE, aux=None, alpha=1.0, dx_out=None,
                    dx_accumulate=False, bias=True):
@@ -397,7 +399,7 @@ class S2TEngine:
             if hp.ctc_layer == l + 1:
                 Tn = x.shape[0]
                 x2 = x.view(Tn * B, D)
-                x_ctc = self.linear(x2, "encoder.ctc_fc").view(Tn, B, hp.V_src)
+                x_ctc = self.linear(x2, "encoder.ctc_fc", pad_rows=True).view(Tn, B, hp.V_src)   # row stride padded to 16 B
                 pred, pmax = K.ctc_argmax(x_ctc)
                 seg, rs, rl, new_len, w = K.ctc_rle(pred, pmax, cur_len, hp.ctc_strategy)
                 new_len_host = new_len.tolist()                     # the one host sync of the forward pass
@@ -473,7 +475,7 @@ class S2TEngine:
             ctx["layers"].append((c1, c2, c3))
         xn, mean, rstd = K.layernorm_fwd(x.view(L * B, D), self.P(pfx + "layer_norm.weight"), self.P(pfx + "layer_norm.bias"), hp.ln_eps)
         ctx["final"] = dict(x=x.view(L * B, D), xn=xn, mean=mean, rstd=rstd)
-        logits = K.gemm(xn, self.W(pfx + "output_projection.weight"))          # [L*B, V] time-major rows
+        logits = self.linear(xn, pfx + "output_projection", bias=False, pad_rows=True)   # [L*B, V] time-major rows
         return logits, ctx
 
     def decoder_backward(self, ctx, dlogits):

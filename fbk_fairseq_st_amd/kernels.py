@@ -177,12 +177,33 @@ def add_pos(x, table, len32):
     return x
 
 
+def padded_cols(V, dtype):
+    """row stride (elements) that keeps every row 16-byte aligned"""
+    e = 8 if dtype == torch.bfloat16 else 4
+    return (V + e - 1) // e * e
+
+
+def alloc_rows(rows_shape, V, dtype, device, zero=False):
+    """[..., V] view of a buffer whose row stride is padded (see padded_cols)."""
+    ld = padded_cols(V, dtype)
+    buf = (torch.zeros if zero else torch.empty)(tuple(rows_shape) + (ld,), dtype=dtype, device=device)
+    return buf[..., :V]
+
+
+def _row_ld(x):
+    """row stride of a [T,B,V] / [rows,V] view with dense leading dims"""
+    assert x.stride(-1) == 1
+    ld = x.stride(-2)
+    if x.dim() == 3:
+        assert x.stride(0) == x.shape[1] * ld
+    return ld
+
+
 def ctc_argmax(logits):
     T, B, V = logits.shape
-    assert logits.is_contiguous()
     pred = torch.empty((B, T), dtype=torch.int32, device=logits.device)
     pmax = torch.empty((B, T), dtype=torch.float32, device=logits.device)
-    L.check(_lib().s2t_ctc_argmax(L.dt(logits), L.ptr(logits), L.ptr(pred), L.ptr(pmax), T, B, V, L.stream()), "s2t_ctc_argmax")
+    L.check(_lib().s2t_ctc_argmax(L.dt(logits), L.ptr(logits), L.ptr(pred), L.ptr(pmax), T, B, V, _row_ld(logits), L.stream()), "s2t_ctc_argmax")
     return pred, pmax
 
 
@@ -224,10 +245,11 @@ def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0):
     la = torch.empty((B * T * S,), dtype=torch.float32, device=dev)
     lb = torch.empty((B * T * S,), dtype=torch.float32, device=dev)
     nll = torch.empty((B,), dtype=torch.float32, device=dev)
-    grad = torch.empty_like(logits)
+    ld = _row_ld(logits)
+    grad = torch.empty((T, B, ld), dtype=logits.dtype, device=dev)[..., :V]
     loss = torch.zeros((1,), dtype=torch.float32, device=dev)
     L.check(_lib().s2t_ctc_loss(L.dt(logits), L.ptr(logits), L.ptr(targets), L.ptr(tgt_len), L.ptr(in_len32), L.ptr(lse),
-                                L.ptr(la), L.ptr(lb), L.ptr(nll), L.ptr(grad), L.ptr(loss), T, B, V, Lmax, blank,
+                                L.ptr(la), L.ptr(lb), L.ptr(nll), L.ptr(grad), L.ptr(loss), T, B, V, ld, Lmax, blank,
                                 float(grad_scale), L.stream()), "s2t_ctc_loss")
     return loss, grad, nll
 
@@ -235,10 +257,11 @@ def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0):
 def lsce(logits, target, eps, pad, want_grad=True, grad_scale=1.0):
     """logits [rows,V]; returns (sums f32[2] = loss, nll ; dlogits or None)."""
     rows, V = logits.shape
-    assert logits.is_contiguous() and target.numel() == rows
+    assert target.numel() == rows
+    ld = _row_ld(logits)
     sums = torch.zeros((2,), dtype=torch.float32, device=logits.device)
-    dl = torch.empty_like(logits) if want_grad else None
-    L.check(_lib().s2t_lsce(L.dt(logits), L.ptr(logits), L.ptr(target), L.ptr(dl), L.ptr(sums), rows, V, float(eps), pad,
+    dl = torch.empty((rows, ld), dtype=logits.dtype, device=logits.device)[:, :V] if want_grad else None
+    L.check(_lib().s2t_lsce(L.dt(logits), L.ptr(logits), L.ptr(target), L.ptr(dl), L.ptr(sums), rows, V, ld, float(eps), pad,
                             float(grad_scale), L.stream()), "s2t_lsce")
     return sums, dl
 
@@ -297,7 +320,9 @@ def cast(src, dst):
 
 
 def scale_by_device_scalar(x, scalar):
-    L.check(_lib().s2t_scale_by_device_scalar(L.dt(x), L.ptr(x), x.numel(), L.ptr(scalar), L.stream()), "s2t_scale")
+    d = x if x.is_contiguous() else x._base           # row-padded views: scale the whole backing buffer
+    assert d is not None and d.is_contiguous()
+    L.check(_lib().s2t_scale_by_device_scalar(L.dt(d), L.ptr(d), d.numel(), L.ptr(scalar), L.stream()), "s2t_scale")
     return x
 
 

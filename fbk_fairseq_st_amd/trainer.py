@@ -64,6 +64,8 @@ class Trainer:
         """trainer.py:631-653 + host-side statistics taken BEFORE the copy (no device round trip later)."""
         if sample is None or len(sample) == 0:
             return None
+        if sample.get("_prepared", False):
+            return sample
         s = dict(sample)
         if "transcript_target" in s and torch.is_tensor(s["transcript_target"]) and not s["transcript_target"].is_cuda:
             s["transcript_target_host"] = s["transcript_target"]
@@ -79,7 +81,12 @@ class Trainer:
         s.update(host_keys)
         if lens_host is not None:
             s["net_input"]["src_lengths"] = lens_host          # the encoder takes host lengths (no sync)
+        s["_prepared"] = True
         return s
+
+    def prepare(self, sample):
+        """Stage a batch in HBM ahead of time (what a prefetching data loader does)."""
+        return self._prepare_sample(sample)
 
     def train_step(self, samples):
         """One optimizer update over a list of micro-batches (`--update-freq`).  Returns the reduced stats."""

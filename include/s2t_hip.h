@@ -126,8 +126,10 @@ int s2t_permute_conv_w(int dst_dtype, const float* src, void* dst, int Co, int C
 int s2t_add_pos(int dtype, void* x, const float* table, const int* len, int T, int B, int D, void* stream);
 
 /* ---- CTC compression (conv_transformer.py:278-291, 385-426) -----------------------------------------
- * pred[b][t] = first arg-max of softmax(logits[t][b][:]) (bit-exact integer path), pmax = its probability */
-int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, void* stream);
+ * pred[b][t] = first arg-max of softmax(logits[t][b][:]) (bit-exact integer path), pmax = its probability.
+ * Logit rows have a stride of ld >= V elements (here and in the two loss kernels): the producer GEMM pads the
+ * row stride to a multiple of 8 so that every GEMM touching the logits can use 16-byte loads. */
+int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, int ld, void* stream);
 /* run-length collapse inside len[b]; seg/run_start/run_len [B][T] int32, new_len [B] int64, w [B][T] f32
  * strategy 0 avg, 1 weighted, 2 softmax */
 int s2t_ctc_rle(const int* pred, const float* pmax, const long long* len, int* seg, int* run_start, int* run_len,
@@ -144,11 +146,11 @@ int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int*
  * loss_sum[0] += sum_b nll_b (caller zeroes). grad is multiplied by grad_scale. */
 int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len, const int* in_len,
                  float* lse, float* la, float* lb, float* nll, void* grad, float* loss_sum,
-                 int T, int B, int V, int Lmax, int blank, float grad_scale, void* stream);
+                 int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, void* stream);
 /* label_smoothed_nll_loss over log_softmax(logits.float()) (label_smoothed_cross_entropy.py:12-29), fused
  * with its gradient: sums2[0] += loss, sums2[1] += nll (caller zeroes); dlogits may be NULL. */
 int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2,
-             long rows, int V, float eps, int pad, float grad_scale, void* stream);
+             long rows, int V, int ld, float eps, int pad, float grad_scale, void* stream);
 
 /* ---- decoder embedding (fairseq/models/transformer.py:720-737) -------------------------------------- */
 int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float* table, void* out,

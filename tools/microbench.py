@@ -15,7 +15,7 @@ def timeit(fn, n=20, w=3):
     return s.elapsed_time(e) / n * 1e-3
 
 M = int(os.environ.get("M", 24000))
-for dtype in (torch.bfloat16, torch.float32):
+for dtype in ((torch.bfloat16,) if os.environ.get("BF16_ONLY") else (torch.bfloat16, torch.float32)):
     print("== dtype", dtype)
     for (N, Kd) in [(512, 512), (1536, 512), (2048, 512), (512, 2048), (512, 1280), (5001, 512), (8000, 512)]:
         mm = M if N not in (8000,) else 2560
@@ -46,3 +46,14 @@ for dtype in (torch.bfloat16, torch.float32):
     x = torch.randn(M, 512, device=dev).to(dtype); g = torch.ones(512, device=dev); b = torch.zeros(512, device=dev)
     t = timeit(lambda: K.layernorm_fwd(x, g, b))
     print("layernorm fwd M=%d D=512 %8.1f us  %6.2f TB/s" % (M, t * 1e6, 2 * x.numel() * x.element_size() / t / 1e12))
+    dy = torch.randn(M, 512, device=dev).to(dtype); mean = torch.zeros(M, device=dev); rstd = torch.ones(M, device=dev)
+    dg = torch.zeros(512, device=dev); db = torch.zeros(512, device=dev)
+    t = timeit(lambda: K.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dy))
+    print("layernorm bwd            %8.1f us  %6.2f TB/s" % (t * 1e6, 4 * x.numel() * x.element_size() / t / 1e12))
+    for N in (512, 2048):
+        xx = torch.randn(M, N, device=dev).to(dtype); o = torch.zeros(N, device=dev)
+        t = timeit(lambda: K.colsum(xx, o))
+        print("colsum N=%d              %8.1f us  %6.2f TB/s" % (N, t * 1e6, xx.numel() * xx.element_size() / t / 1e12))
+    w5 = torch.randn(512, 512, device=dev).to(dtype)
+    t = timeit(lambda: K.gemm(x, w5, bias=g, residual=x, p_drop=0.15, seed=3))
+    print("NT 512x512 + residual + dropout epilogue  %8.1f us" % (t * 1e6))
