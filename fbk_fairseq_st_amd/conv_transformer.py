@@ -286,9 +286,10 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
 
     def materialize(self, device, compute_dtype=torch.float32, extra=None):
         """Move every parameter into one flat arena on `device` (and build the engine)."""
-        named = dict(self.named_arena_params())
-        if extra:
-            named.update(extra)
+        # extras (criterion-owned heads) go FIRST: backward finalises the arena tail-first, so whatever is never
+        # reported as ready must not sit behind the decoder (distributed.BucketedGradReducer)
+        named = dict(extra) if extra else {}
+        named.update(self.named_arena_params())
         arena = ParamArena({n: tuple(p.shape) for n, p in named.items()}, device, compute_dtype)
         for n, p in named.items():
             arena.p(n).copy_(p.data.to(device=device, dtype=torch.float32))

@@ -142,6 +142,7 @@ class S2TEngine:
         self._tables = {}
         self._maps = {}
         self.bn_buffers = None          # set by the model: dict name -> tensor (running_mean/var, num_batches)
+        self.on_grads_ready = None      # callback(prefix): every gradient of parameters named prefix* is final
         if hp.act not in ("relu", "gelu"):
             raise NotImplementedError("activation_fn %s" % hp.act)
         self.act_fwd = K.ACT_RELU if hp.act == "relu" else K.ACT_GELU
@@ -163,6 +164,10 @@ class S2TEngine:
             m = conv2_maps(B, T2, F2, self.dev)
             self._maps[key] = m
         return m
+
+    def _ready(self, prefix):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(prefix)
 
     def W(self, n):
         return self.A.w(n)
@@ -449,7 +454,14 @@ class S2TEngine:
             ca, cf = ctx["layers"][l]
             dx = self.ffn_block_bwd(pfx, cf, dx)
             dx = self.self_attn_block_bwd(pfx, ca, dx)
+            if l == hp.enc_layers - 1:
+                self._ready("encoder.layer_norm.")
+            if hp.ctc_layer == l + 1:
+                self._ready("encoder.ctc_fc.")
+            self._ready(pfx)
         self.subsample_bwd(ctx["sub"], dx)
+        for n in ("encoder.fc3.", "encoder.bn.1.", "encoder.convolutions.1.", "encoder.bn.0.", "encoder.convolutions.0."):
+            self._ready(n)
 
     # ------------------------------------------------------------------ decoder
     def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder."):
@@ -493,7 +505,12 @@ class S2TEngine:
             dx = self.ffn_block_bwd(lp, c3, dx)
             dx = self.cross_attn_block_bwd(lp, c2, dx, denc)
             dx = self.self_attn_block_bwd(lp, c1, dx)
+            if l == hp.dec_layers - 1:
+                self._ready(pfx + "output_projection.")
+                self._ready(pfx + "layer_norm.")
+            self._ready(lp)
         if ctx["p"] > 0:
             K.dropout(dx, ctx["p"], ctx["seed"] * 1000 + 501, out=dx)
         K.embed_bwd(ctx["tok"], dx.view(L, B, D), self.G(pfx + "embed_tokens.weight"), ctx["scale"], hp.pad)
+        self._ready(pfx + "embed_tokens.")
         return denc

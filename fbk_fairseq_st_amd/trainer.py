@@ -42,23 +42,23 @@ class Trainer:
         self.num_updates = 0
         self.world = D.get_world_size()
         self.reducer = D.BucketedGradReducer(self.arena.grad, getattr(args, "bucket_cap_mb", 64) << 20)
-        model.add_grads_ready_hook(self._grads_ready)
-        self._part_ranges = self._build_part_ranges()
+        model.engine.on_grads_ready = self._grads_ready
+        self._ranges = {}
         self.last_stats = {}
 
     # ---- overlap of the gradient all-reduce with backward
-    def _build_part_ranges(self):
-        names = list(self.arena.slices)
-        r = {}
-        for part in ("encoder", "decoder"):
-            mine = [n for n in names if n.startswith(part + ".")]
-            if mine:
-                r[part] = self.arena.slice_of(mine)
-        return r
-
-    def _grads_ready(self, part):
-        if part in self._part_ranges and self.world > 1:
-            self.reducer.notify(*self._part_ranges[part])
+    def _grads_ready(self, prefix):
+        """Called by the engine as backward finishes a parameter group (last layer first): hand the finished,
+        contiguous tail of the flat gradient buffer to the reducer, which launches RCCL on it asynchronously."""
+        if self.world <= 1:
+            return
+        r = self._ranges.get(prefix)
+        if r is None:
+            names = [n for n in self.arena.slices if n.startswith(prefix)]
+            r = self.arena.slice_of(names) if names else (0, 0)
+            self._ranges[prefix] = r
+        if r[1] > r[0]:
+            self.reducer.notify(*r)
 
     def _prepare_sample(self, sample):
         """trainer.py:631-653 + host-side statistics taken BEFORE the copy (no device round trip later)."""
