@@ -15,6 +15,7 @@
 // LDS after them (register-staged prefetch, one barrier per k-tile).
 #include "common.hpp"
 #include "prof.hpp"
+#include <cstdlib>
 
 struct GemmArgs {
     const void* A; const void* B; void* C;
@@ -143,6 +144,120 @@ struct StageTrans {
 template <typename T, int ROWS, bool TRANS> struct StageSel { typedef StageDirect<T, ROWS> type; };
 template <typename T, int ROWS> struct StageSel<T, ROWS, true> { typedef StageTrans<T, ROWS> type; };
 
+// Shared epilogue (see the comment inside): acc -> LDS -> 16-byte vector finish / split-K atomics.
+template <typename TO, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[BM / 32][BN / 32], char* smem,
+                                              int row0, int col0, int wr, int wc, int q, int r16) {
+    constexpr int MT = BM / 32, NT = BN / 32;
+    // ---------------- epilogue
+    // Park the f32 accumulators in LDS (free after the main loop); then every thread finishes CW consecutive
+    // columns of one row (16 bytes of output): bias / activation / dropout / residual on vectors, one 16-byte
+    // store.  Split-K partial sums leave as f32 atomics with the lanes of a wave on 64 consecutive columns
+    // (256 contiguous bytes per wave-instruction: the full-rate shape, MI355X_MICROARCH.md "Global float atomics").
+    TO* C = reinterpret_cast<TO*>(p.C);
+    const TO* R = reinterpret_cast<const TO*>(p.residual);
+    const TO* AUX = reinterpret_cast<const TO*>(p.aux);
+    TO* AUXO = reinterpret_cast<TO*>(p.aux_out);
+    constexpr int RS = BN * 4 + 16;                           // LDS row stride (bytes); 528 B = 4 banks mod 32: b128 writes conflict-free
+    // the MFMAs ran as (W-rows x X-rows): acc[i][j][r] = C[m = 16i + r16][n = 16j + 4q + r]  ->  one 16-byte LDS write each
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int lr = wr * (BM / 2) + 16 * i + r16, lc = wc * (BN / 2) + 16 * j + 4 * q;
+            *reinterpret_cast<f32x4*>(smem + lr * RS + lc * 4) = acc[i][j] * p.alpha;
+        }
+    __syncthreads();
+    if constexpr (sizeof(TO) == 4) {
+        if (p.splitk > 1) {
+            for (int idx = threadIdx.x; idx < BM * BN; idx += 256) {
+                const int lr = idx / BN, lc = idx % BN;
+                const int row = row0 + lr, col = col0 + lc;
+                if (row >= p.M || col >= p.N) continue;
+                const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
+                atomicAdd(reinterpret_cast<float*>(C) + orow * p.ldc + col, *reinterpret_cast<const float*>(smem + lr * RS + lc * 4));
+            }
+            return;
+        }
+    }
+    constexpr int CW = 16 / (int)sizeof(TO);                  // output elements per 16-byte chunk
+    constexpr int CPR = BN / CW;
+    const uint32_t drop_th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
+    const float drop_inv = 1.f / (1.f - p.p_drop);
+    const bool vC = (p.ldc % CW == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+    const bool vR = !R || ((p.ldr % CW == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0));
+    const bool vX = !AUX || ((p.ldaux % CW == 0) && ((reinterpret_cast<uintptr_t>(AUX) & 15) == 0));
+    const bool vO = !AUXO || ((p.ldaux % CW == 0) && ((reinterpret_cast<uintptr_t>(AUXO) & 15) == 0));
+    for (int c = threadIdx.x; c < BM * CPR; c += 256) {
+        const int lr = c / CPR, cc = c % CPR;
+        const int row = row0 + lr, col = col0 + cc * CW;
+        if (row >= p.M || col >= p.N) continue;
+        const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
+        float v[CW];
+#pragma unroll
+        for (int k = 0; k < CW / 4; ++k) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + lr * RS + (cc * CW + 4 * k) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * k + e] = a0[e];
+        }
+        const bool fast = (col + CW <= p.N) && vC && vR && vX && vO;
+        TO rres[CW], raux[CW];
+        if (fast) {
+            if (R) *reinterpret_cast<u32x4*>(rres) = *reinterpret_cast<const u32x4*>(R + (size_t)row * p.ldr + col);
+            if (AUX) *reinterpret_cast<u32x4*>(raux) = *reinterpret_cast<const u32x4*>(AUX + (size_t)row * p.ldaux + col);
+        } else {
+#pragma unroll
+            for (int e = 0; e < CW; ++e) {
+                const bool ok = col + e < p.N;
+                rres[e] = (R && ok) ? R[(size_t)row * p.ldr + col + e] : from_f32<TO>(0.f);
+                raux[e] = (AUX && ok) ? AUX[(size_t)row * p.ldaux + col + e] : from_f32<TO>(0.f);
+            }
+        }
+        float bv[CW];
+        if (p.bias && fast && ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0)) {
+#pragma unroll
+            for (int k = 0; k < CW / 4; ++k) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col + 4 * k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[4 * k + e] = b4[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < CW; ++e) bv[e] = (p.bias && col + e < p.N) ? p.bias[col + e] : 0.f;
+        }
+        TO pre[CW], o[CW];
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+            float x = v[e] + bv[e];
+            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
+            else if (p.act == ACT_GELU) { pre[e] = from_f32<TO>(x); x = gelu_f(x); }
+            else if (p.act == ACT_RELU_BWD) x = (to_f32(raux[e]) > 0.f) ? x : 0.f;
+            else if (p.act == ACT_GELU_BWD) x *= gelu_grad_f(to_f32(raux[e]));
+            if (p.p_drop > 0.f) x = dropout_keep(p.seed, (uint64_t)row * p.N + col + e, drop_th) ? x * drop_inv : 0.f;
+            if (R) x += to_f32(rres[e]);
+            o[e] = from_f32<TO>(x);
+        }
+        TO* dst = C + orow * p.ldc + col;
+        if (fast) {
+            if (p.accumulate) {
+                TO old[CW];
+                *reinterpret_cast<u32x4*>(old) = *reinterpret_cast<const u32x4*>(dst);
+#pragma unroll
+                for (int e = 0; e < CW; ++e) o[e] = from_f32<TO>(to_f32(o[e]) + to_f32(old[e]));
+            }
+            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(o);
+            if (p.act == ACT_GELU && AUXO) *reinterpret_cast<u32x4*>(AUXO + (size_t)row * p.ldaux + col) = *reinterpret_cast<const u32x4*>(pre);
+        } else {
+#pragma unroll
+            for (int e = 0; e < CW; ++e) {
+                if (col + e >= p.N) continue;
+                dst[e] = p.accumulate ? from_f32<TO>(to_f32(o[e]) + to_f32(dst[e])) : o[e];
+                if (p.act == ACT_GELU && AUXO) AUXO[(size_t)row * p.ldaux + col + e] = pre[e];
+            }
+        }
+    }
+}
+
 template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int BK = 128 / (int)sizeof(TI);
@@ -211,7 +326,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mma16<TI>(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < NT; ++j) acc[i][j] = mma16<TI>(fb[j], fa[i], acc[i][j]);   // swapped roles: a lane ends up with 4 consecutive n of one m
         }
         if (more) {
             sa.store(smem + (cur ^ 1) * STAGE);
@@ -220,109 +335,206 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---------------- epilogue
-    // Park the f32 accumulators in LDS (free after the main loop); then every thread finishes CW consecutive
-    // columns of one row (16 bytes of output): bias / activation / dropout / residual on vectors, one 16-byte
-    // store.  Split-K partial sums leave as f32 atomics with the lanes of a wave on 64 consecutive columns
-    // (256 contiguous bytes per wave-instruction: the full-rate shape, MI355X_MICROARCH.md "Global float atomics").
-    TO* C = reinterpret_cast<TO*>(p.C);
-    const TO* R = reinterpret_cast<const TO*>(p.residual);
-    const TO* AUX = reinterpret_cast<const TO*>(p.aux);
-    TO* AUXO = reinterpret_cast<TO*>(p.aux_out);
-    constexpr int RS = BN * 4 + 16;                           // LDS row stride (bytes), +16 breaks the 4-row bank aliasing
+    gemm_epilogue<TO, BM, BN>(p, acc, smem, row0, col0, wr, wc, q, r16);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast path (aligned operands, K % BK == 0, no gather): per-thread source pointers and LDS offsets are computed
+// once (rows/cols beyond the edge are clamped to valid memory and discarded by the epilogue: no guards in the loop),
+// and global loads run TWO k-tiles ahead of the MFMAs in two named register sets, so a load has two compute
+// phases to land before it is written to LDS (PMC showed the guarded 1-deep variant 54 % parked in s_waitcnt
+// and issuing 9 VALU per MFMA).
+template <typename T, int ROWS> struct FastDirect {
+    static constexpr int E = Elem<T>::PER16;
+    static constexpr int BK = 128 / (int)sizeof(T);
+    static constexpr int N = ROWS * 8 / 256;
+    struct Regs { u32x4 r[N]; };
+    const char* base;          // wave-uniform (kernel argument): lets the loads use the saddr + 32-bit voffset form
+    uint32_t goff[N];          // byte offsets from base (operands are < 4 GiB)
+    int off[N];
+    __device__ __forceinline__ void init(const T* g, int ld, int row0, int nrows, int k0) {
+        base = reinterpret_cast<const char*>(g);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            const int gr = min(row0 + row, nrows - 1);
+            goff[i] = (uint32_t)(((size_t)gr * ld + k0 + c * E) * sizeof(T));
+            off[i] = row * 128 + ((c ^ (row & 7)) << 4);
+        }
+    }
+    // step = 128 while tiles remain, 0 afterwards (the tail re-reads the last tile: branch-free and in bounds)
+    __device__ __forceinline__ void load(Regs& R, int step) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { R.r[i] = *reinterpret_cast<const u32x4*>(base + goff[i]); goff[i] += step; }
+    }
+    __device__ __forceinline__ void store(char* lds, const Regs& R) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) *reinterpret_cast<u32x4*>(lds + off[i]) = R.r[i];
+    }
+};
+
+template <typename T, int COLS> struct FastTrans {
+    static constexpr int E = Elem<T>::PER16;
+    static constexpr int BK = 128 / (int)sizeof(T);
+    static constexpr int NKQ = BK / 4;
+    static constexpr int ITEMS = (COLS / E) * NKQ;
+    static constexpr int N = (ITEMS + 255) / 256;
+    struct Regs { u32x4 r[N][4]; };
+    const T* ptr[N];
+    size_t ld;
+    __device__ __forceinline__ void init(const T* g, int ld_, int col0, int ncols, int k0) {
+        ld = (size_t)ld_;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int it = min((int)threadIdx.x + 256 * i, ITEMS - 1);
+            const int kq = it % NKQ, cg = it / NKQ;
+            const int gc = min(col0 + cg * E, ncols - E);
+            ptr[i] = g + (size_t)(k0 + 4 * kq) * ld + gc;
+        }
+    }
+    __device__ __forceinline__ void load(Regs& R, int step) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) R.r[i][rr] = *reinterpret_cast<const u32x4*>(ptr[i] + rr * ld);
+            if (step) ptr[i] += (size_t)BK * ld;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, const Regs& R) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int it = threadIdx.x + 256 * i;
+            if (it >= ITEMS) continue;
+            const int kq = it % NKQ, cg = it / NKQ;
+            if constexpr (sizeof(T) == 2) {
+                const uint16_t* e0 = reinterpret_cast<const uint16_t*>(&R.r[i][0]);
+                const uint16_t* e1 = reinterpret_cast<const uint16_t*>(&R.r[i][1]);
+                const uint16_t* e2 = reinterpret_cast<const uint16_t*>(&R.r[i][2]);
+                const uint16_t* e3 = reinterpret_cast<const uint16_t*>(&R.r[i][3]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int col = cg * 8 + j;
+                    u32x2 v;
+                    v[0] = (uint32_t)e0[j] | ((uint32_t)e1[j] << 16);
+                    v[1] = (uint32_t)e2[j] | ((uint32_t)e3[j] << 16);
+                    *reinterpret_cast<u32x2*>(lds + col * 128 + (((kq >> 1) ^ (col & 7)) << 4) + ((kq & 1) << 3)) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = cg * 4 + j;
+                    u32x4 v = {R.r[i][0][j], R.r[i][1][j], R.r[i][2][j], R.r[i][3][j]};
+                    *reinterpret_cast<u32x4*>(lds + col * 128 + ((kq ^ (col & 7)) << 4)) = v;
+                }
+            }
+        }
+    }
+};
+
+template <typename T, int ROWS, bool TRANS> struct FastSel { typedef FastDirect<T, ROWS> type; };
+template <typename T, int ROWS> struct FastSel<T, ROWS, true> { typedef FastTrans<T, ROWS> type; };
+
+template <typename TI, int MT, int NT>
+__device__ __forceinline__ void mma_tile(const char* la, const char* lb, int r16, int q, f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 fa[MT], fb[NT];
+        const int sw = ((4 * s + q) ^ (r16 & 7)) << 4;          // (16*i + r16) & 7 == r16 & 7
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const u32x4*>(la + (16 * i + r16) * 128 + sw);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(lb + (16 * j + r16) * 128 + sw);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mma16<TI>(fb[j], fa[i], acc[i][j]);   // swapped roles: a lane ends up with 4 consecutive n of one m
+    }
+}
+
+template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
+    constexpr int BK = 128 / (int)sizeof(TI);
+    constexpr int MT = BM / 32, NT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (BM + BN) * 128;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nk_total = p.K / BK;
+    const int per = (nk_total + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per, kt1 = min(nk_total, kt0 + per);
+    const int nk = kt1 - kt0;
+    if (nk <= 0) return;
+
+    typedef typename FastSel<TI, BM, TA>::type SA;
+    typedef typename FastSel<TI, BN, TB>::type SB;
+    SA sa; SB sb;
+    sa.init(reinterpret_cast<const TI*>(p.A), p.lda, row0, p.M, kt0 * BK);
+    sb.init(reinterpret_cast<const TI*>(p.B), p.ldb, col0, p.N, kt0 * BK);
+    typename SA::Regs a0, a1;
+    typename SB::Regs b0, b1;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, r16 = lane & 15, q = lane >> 4;
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = wr * (BM / 2) + 16 * i + 4 * q + r, lc = wc * (BN / 2) + 16 * j + r16;
-                *reinterpret_cast<float*>(smem + lr * RS + lc * 4) = acc[i][j][r] * p.alpha;
-            }
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    char* l0 = smem;
+    char* l1 = smem + STAGE;
+    const int aoff = (wr * (BM / 2)) * 128, boff = BM * 128 + (wc * (BN / 2)) * 128;
+
+    int left = nk;                                  // tiles not yet requested from global memory
+    auto step = [&]() { left -= 1; return left > 0 ? 128 : 0; };
+    { const int st = step(); sa.load(a0, st); sb.load(b0, st); }      // tile 0
+    { const int st = step(); sa.load(a1, st); sb.load(b1, st); }      // tile 1 (or tile 0 again)
+    sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
     __syncthreads();
-    if constexpr (sizeof(TO) == 4) {
-        if (p.splitk > 1) {
-            for (int idx = threadIdx.x; idx < BM * BN; idx += 256) {
-                const int lr = idx / BN, lc = idx % BN;
-                const int row = row0 + lr, col = col0 + lc;
-                if (row >= p.M || col >= p.N) continue;
-                const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
-                atomicAdd(reinterpret_cast<float*>(C) + orow * p.ldc + col, *reinterpret_cast<const float*>(smem + lr * RS + lc * 4));
-            }
-            return;
-        }
+    for (int t = 0; t < nk; t += 2) {
+        { const int st = step(); sa.load(a0, st); sb.load(b0, st); }  // tile t+2 -> set 0
+        mma_tile<TI, MT, NT>(l0 + aoff, l0 + boff, r16, q, acc);       // tile t
+        sa.store(l1, a1); sb.store(l1 + BM * 128, b1);                 // tile t+1
+        __syncthreads();
+        { const int st = step(); sa.load(a1, st); sb.load(b1, st); }  // tile t+3 -> set 1
+        if (t + 1 < nk) mma_tile<TI, MT, NT>(l1 + aoff, l1 + boff, r16, q, acc);
+        sa.store(l0, a0); sb.store(l0 + BM * 128, b0);                 // tile t+2
+        __syncthreads();
     }
-    constexpr int CW = 16 / (int)sizeof(TO);                  // output elements per 16-byte chunk
-    constexpr int CPR = BN / CW;
-    const uint32_t drop_th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
-    const float drop_inv = 1.f / (1.f - p.p_drop);
-    const bool vC = (p.ldc % CW == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
-    const bool vR = !R || ((p.ldr % CW == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0));
-    const bool vX = !AUX || ((p.ldaux % CW == 0) && ((reinterpret_cast<uintptr_t>(AUX) & 15) == 0));
-    const bool vO = !AUXO || ((p.ldaux % CW == 0) && ((reinterpret_cast<uintptr_t>(AUXO) & 15) == 0));
-    for (int c = threadIdx.x; c < BM * CPR; c += 256) {
-        const int lr = c / CPR, cc = c % CPR;
-        const int row = row0 + lr, col = col0 + cc * CW;
-        if (row >= p.M || col >= p.N) continue;
-        const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
-        float v[CW];
-#pragma unroll
-        for (int k = 0; k < CW / 4; ++k) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + lr * RS + (cc * CW + 4 * k) * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * k + e] = a0[e];
-        }
-        const bool fast = (col + CW <= p.N) && vC && vR && vX && vO;
-        TO rres[CW], raux[CW];
-        if (fast) {
-            if (R) *reinterpret_cast<u32x4*>(rres) = *reinterpret_cast<const u32x4*>(R + (size_t)row * p.ldr + col);
-            if (AUX) *reinterpret_cast<u32x4*>(raux) = *reinterpret_cast<const u32x4*>(AUX + (size_t)row * p.ldaux + col);
-        } else {
-#pragma unroll
-            for (int e = 0; e < CW; ++e) {
-                const bool ok = col + e < p.N;
-                rres[e] = (R && ok) ? R[(size_t)row * p.ldr + col + e] : from_f32<TO>(0.f);
-                raux[e] = (AUX && ok) ? AUX[(size_t)row * p.ldaux + col + e] : from_f32<TO>(0.f);
-            }
-        }
-        TO pre[CW], o[CW];
-#pragma unroll
-        for (int e = 0; e < CW; ++e) {
-            float x = v[e];
-            if (p.bias && col + e < p.N) x += p.bias[col + e];
-            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-            else if (p.act == ACT_GELU) { pre[e] = from_f32<TO>(x); x = gelu_f(x); }
-            else if (p.act == ACT_RELU_BWD) x = (to_f32(raux[e]) > 0.f) ? x : 0.f;
-            else if (p.act == ACT_GELU_BWD) x *= gelu_grad_f(to_f32(raux[e]));
-            if (p.p_drop > 0.f) x = dropout_keep(p.seed, (uint64_t)row * p.N + col + e, drop_th) ? x * drop_inv : 0.f;
-            if (R) x += to_f32(rres[e]);
-            o[e] = from_f32<TO>(x);
-        }
-        TO* dst = C + orow * p.ldc + col;
-        if (fast) {
-            if (p.accumulate) {
-                TO old[CW];
-                *reinterpret_cast<u32x4*>(old) = *reinterpret_cast<const u32x4*>(dst);
-#pragma unroll
-                for (int e = 0; e < CW; ++e) o[e] = from_f32<TO>(to_f32(o[e]) + to_f32(old[e]));
-            }
-            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(o);
-            if (p.act == ACT_GELU && AUXO) *reinterpret_cast<u32x4*>(AUXO + (size_t)row * p.ldaux + col) = *reinterpret_cast<const u32x4*>(pre);
-        } else {
-#pragma unroll
-            for (int e = 0; e < CW; ++e) {
-                if (col + e >= p.N) continue;
-                dst[e] = p.accumulate ? from_f32<TO>(to_f32(o[e]) + to_f32(dst[e])) : o[e];
-                if (p.act == ACT_GELU && AUXO) AUXO[(size_t)row * p.ldaux + col + e] = pre[e];
-            }
-        }
-    }
+    gemm_epilogue<TO, BM, BN>(p, acc, smem, row0, col0, wr, wc, q, r16);
+}
+
+template <typename TI, bool TA, bool TB>
+static bool fast_ok(const GemmArgs& a) {
+    constexpr int E = Elem<TI>::PER16;
+    constexpr int BK = 128 / (int)sizeof(TI);
+    if (a.mapA || a.mapB || a.K % BK) return false;
+    if ((a.lda % E) || (a.ldb % E) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return false;
+    const size_t rowsA = TA ? (size_t)a.K : (size_t)a.M, rowsB = TB ? (size_t)a.K : (size_t)a.N;
+    if (rowsA * a.lda * sizeof(TI) >= (1ull << 32) || rowsB * a.ldb * sizeof(TI) >= (1ull << 32)) return false;   // 32-bit offsets
+    if (TA && (a.M % E || a.M < E)) return false;          // transposed operands: whole 16-byte column chunks only
+    if (TB && (a.N % E || a.N < E)) return false;
+    return true;
 }
 
 template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
 static int launch(const GemmArgs& a, hipStream_t st) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     dim3 grid(tiles, 1, a.splitk);
+    static const bool no_fast = getenv("S2T_GEMM_NOFAST") != nullptr;     // A/B switch for benchmarking
+    if (!no_fast && fast_ok<TI, TA, TB>(a)) {
+        size_t lds = 2 * (BM + BN) * 128;
+        if ((size_t)BM * (BN * 4 + 16) > lds) lds = (size_t)BM * (BN * 4 + 16);
+        if (lds > 65536) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        }
+        hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), grid, dim3(256), lds, st, a);
+        S2T_LAUNCH_CHECK();
+        return S2T_OK;
+    }
     size_t lds = 2 * (BM + BN) * 128;
     if ((size_t)BM * (BN * 4 + 16) > lds) lds = (size_t)BM * (BN * 4 + 16);   // epilogue staging of the f32 tile
     if (lds > 65536) {

@@ -161,6 +161,7 @@ def test_dropout_training_step_runs_and_is_reproducible():
         loss, _, _ = crit(model, s)
         loss.backward()
         outs.append((float(loss), float(model.arena.grad.norm())))
-    assert outs[0] == outs[1]
+    # same masks in both runs; only the order of f32 atomic partial sums (loss / BN statistics) may differ
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[0][0]) and abs(outs[0][1] - outs[1][1]) <= 1e-4 * outs[0][1]
     assert abs(outs[0][0] - float(g["train_loss"])) > 1e-3          # dropout changes the loss
     assert np.isfinite(outs[0][1])
