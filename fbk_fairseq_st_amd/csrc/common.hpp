@@ -99,31 +99,23 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-// Philox-4x32-10 counter RNG: one call -> 4 uniform u32. Used for dropout masks that are
-// regenerated (not stored) in the backward pass from (seed, offset).
-__device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t ctr) {
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x243F6A88u, c3 = 0x85A308D3u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-// keep-decision for element `idx` of a tensor: a stateless 2-round integer hash of (seed, idx) -- ~14 integer ops
-// per element against ~70 for Philox-4x32-10, and every element is independent, so the GEMM / attention
-// epilogues can evaluate it in whatever register layout they hold (the backward pass re-evaluates it).
+// Dropout masks are a stateless integer hash of (seed, element index): nothing is stored, the backward pass
+// re-evaluates it, and every element is independent so GEMM / attention epilogues can evaluate it in whatever
+// register layout they hold.  One 32-bit hash serves the element pair (2i, 2i+1) as two 16-bit uniforms
+// (the rate is quantised to 1/65536): ~6 integer ops per element.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+__device__ __forceinline__ uint32_t drop_hash2(uint64_t seed, uint64_t pair) {
+    uint32_t h = mix32((uint32_t)pair ^ (uint32_t)seed);
+    h ^= (uint32_t)(seed >> 32) + (uint32_t)(pair >> 32) * 0x9E3779B9u;
+    h *= 0x846ca68bu; h ^= h >> 15;
+    return h;
+}
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh /* p * 2^32 */) {
-    const uint32_t h = mix32((uint32_t)idx + (uint32_t)seed * 0x9E3779B9u);
-    return mix32(h ^ (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32) ^ 0x85ebca6bu) >= thresh;
+    const uint32_t h = drop_hash2(seed, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= (thresh >> 16);
 }
 
 // bijective XCD-aware remap of a linear workgroup id (cdna_hip_programming.md section 5, T1):

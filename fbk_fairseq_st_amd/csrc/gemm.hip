@@ -29,6 +29,7 @@ struct GemmArgs {
     //  mapC: output row r is written to C row mapC[r]
     const int* mapA; int periodA; const int* mapB; const int* mapC;
     float p_drop; unsigned long long seed;   // dropout on the activated value, before the residual add
+    int dbg;                                 // benchmarking ablations (S2T_GEMM_DBG): 1 = skip the epilogue, 2 = skip the k-loop
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_GELU_BWD = 4 };
@@ -144,42 +145,15 @@ struct StageTrans {
 template <typename T, int ROWS, bool TRANS> struct StageSel { typedef StageDirect<T, ROWS> type; };
 template <typename T, int ROWS> struct StageSel<T, ROWS, true> { typedef StageTrans<T, ROWS> type; };
 
-// Shared epilogue (see the comment inside): acc -> LDS -> 16-byte vector finish / split-K atomics.
-template <typename TO, int BM, int BN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[BM / 32][BN / 32], char* smem,
-                                              int row0, int col0, int wr, int wc, int q, int r16) {
-    constexpr int MT = BM / 32, NT = BN / 32;
-    // ---------------- epilogue
-    // Park the f32 accumulators in LDS (free after the main loop); then every thread finishes CW consecutive
-    // columns of one row (16 bytes of output): bias / activation / dropout / residual on vectors, one 16-byte
-    // store.  Split-K partial sums leave as f32 atomics with the lanes of a wave on 64 consecutive columns
-    // (256 contiguous bytes per wave-instruction: the full-rate shape, MI355X_MICROARCH.md "Global float atomics").
+// Finishing loop of the epilogue, specialised on the activation: every thread completes CW consecutive columns
+// of one row per iteration (16 bytes of output) from the f32 tile parked in LDS.
+template <typename TO, int BM, int BN, int ACT>
+__device__ __forceinline__ void gemm_finish(const GemmArgs& p, const char* smem, int row0, int col0) {
     TO* C = reinterpret_cast<TO*>(p.C);
     const TO* R = reinterpret_cast<const TO*>(p.residual);
     const TO* AUX = reinterpret_cast<const TO*>(p.aux);
     TO* AUXO = reinterpret_cast<TO*>(p.aux_out);
-    constexpr int RS = BN * 4 + 16;                           // LDS row stride (bytes); 528 B = 4 banks mod 32: b128 writes conflict-free
-    // the MFMAs ran as (W-rows x X-rows): acc[i][j][r] = C[m = 16i + r16][n = 16j + 4q + r]  ->  one 16-byte LDS write each
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int lr = wr * (BM / 2) + 16 * i + r16, lc = wc * (BN / 2) + 16 * j + 4 * q;
-            *reinterpret_cast<f32x4*>(smem + lr * RS + lc * 4) = acc[i][j] * p.alpha;
-        }
-    __syncthreads();
-    if constexpr (sizeof(TO) == 4) {
-        if (p.splitk > 1) {
-            for (int idx = threadIdx.x; idx < BM * BN; idx += 256) {
-                const int lr = idx / BN, lc = idx % BN;
-                const int row = row0 + lr, col = col0 + lc;
-                if (row >= p.M || col >= p.N) continue;
-                const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
-                atomicAdd(reinterpret_cast<float*>(C) + orow * p.ldc + col, *reinterpret_cast<const float*>(smem + lr * RS + lc * 4));
-            }
-            return;
-        }
-    }
+    constexpr int RS = BN * 4 + 16;
     constexpr int CW = 16 / (int)sizeof(TO);                  // output elements per 16-byte chunk
     constexpr int CPR = BN / CW;
     const uint32_t drop_th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
@@ -225,15 +199,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
             for (int e = 0; e < CW; ++e) bv[e] = (p.bias && col + e < p.N) ? p.bias[col + e] : 0.f;
         }
+        // one hash per element pair when rows start on an even element index
+        const bool pair_ok = (p.N & 1) == 0;
+        uint32_t dh[CW / 2];
+        if (p.p_drop > 0.f && pair_ok) {
+            const uint64_t base = ((uint64_t)row * p.N + col) >> 1;
+#pragma unroll
+            for (int k = 0; k < CW / 2; ++k) dh[k] = drop_hash2(p.seed, base + k);
+        }
         TO pre[CW], o[CW];
 #pragma unroll
         for (int e = 0; e < CW; ++e) {
             float x = v[e] + bv[e];
-            if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
-            else if (p.act == ACT_GELU) { pre[e] = from_f32<TO>(x); x = gelu_f(x); }
-            else if (p.act == ACT_RELU_BWD) x = (to_f32(raux[e]) > 0.f) ? x : 0.f;
-            else if (p.act == ACT_GELU_BWD) x *= gelu_grad_f(to_f32(raux[e]));
-            if (p.p_drop > 0.f) x = dropout_keep(p.seed, (uint64_t)row * p.N + col + e, drop_th) ? x * drop_inv : 0.f;
+            if constexpr (ACT == ACT_RELU) x = fmaxf(x, 0.f);
+            else if constexpr (ACT == ACT_GELU) { pre[e] = from_f32<TO>(x); x = gelu_f(x); }
+            else if constexpr (ACT == ACT_RELU_BWD) x = (to_f32(raux[e]) > 0.f) ? x : 0.f;
+            else if constexpr (ACT == ACT_GELU_BWD) x *= gelu_grad_f(to_f32(raux[e]));
+            if (p.p_drop > 0.f) {
+                bool keep;
+                if (pair_ok) keep = ((e & 1) ? (dh[e >> 1] >> 16) : (dh[e >> 1] & 0xffffu)) >= (drop_th >> 16);
+                else keep = dropout_keep(p.seed, (uint64_t)row * p.N + col + e, drop_th);
+                x = keep ? x * drop_inv : 0.f;
+            }
             if (R) x += to_f32(rres[e]);
             o[e] = from_f32<TO>(x);
         }
@@ -246,15 +233,60 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
                 for (int e = 0; e < CW; ++e) o[e] = from_f32<TO>(to_f32(o[e]) + to_f32(old[e]));
             }
             *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(o);
-            if (p.act == ACT_GELU && AUXO) *reinterpret_cast<u32x4*>(AUXO + (size_t)row * p.ldaux + col) = *reinterpret_cast<const u32x4*>(pre);
+            if (ACT == ACT_GELU && AUXO) *reinterpret_cast<u32x4*>(AUXO + (size_t)row * p.ldaux + col) = *reinterpret_cast<const u32x4*>(pre);
         } else {
 #pragma unroll
             for (int e = 0; e < CW; ++e) {
                 if (col + e >= p.N) continue;
                 dst[e] = p.accumulate ? from_f32<TO>(to_f32(o[e]) + to_f32(dst[e])) : o[e];
-                if (p.act == ACT_GELU && AUXO) AUXO[(size_t)row * p.ldaux + col + e] = pre[e];
+                if (ACT == ACT_GELU && AUXO) AUXO[(size_t)row * p.ldaux + col + e] = pre[e];
             }
         }
+    }
+}
+
+// Shared epilogue (see the comment inside): acc -> LDS -> 16-byte vector finish / split-K atomics.
+template <typename TO, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[BM / 32][BN / 32], char* smem,
+                                              int row0, int col0, int wr, int wc, int q, int r16) {
+    constexpr int MT = BM / 32, NT = BN / 32;
+    // ---------------- epilogue
+    // Park the f32 accumulators in LDS (free after the main loop); then every thread finishes CW consecutive
+    // columns of one row (16 bytes of output): bias / activation / dropout / residual on vectors, one 16-byte
+    // store.  Split-K partial sums leave as f32 atomics with the lanes of a wave on 64 consecutive columns
+    // (256 contiguous bytes per wave-instruction: the full-rate shape, MI355X_MICROARCH.md "Global float atomics").
+    TO* C = reinterpret_cast<TO*>(p.C);
+    const TO* R = reinterpret_cast<const TO*>(p.residual);
+    const TO* AUX = reinterpret_cast<const TO*>(p.aux);
+    TO* AUXO = reinterpret_cast<TO*>(p.aux_out);
+    constexpr int RS = BN * 4 + 16;                           // LDS row stride (bytes); 528 B = 4 banks mod 32: b128 writes conflict-free
+    // the MFMAs ran as (W-rows x X-rows): acc[i][j][r] = C[m = 16i + r16][n = 16j + 4q + r]  ->  one 16-byte LDS write each
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int lr = wr * (BM / 2) + 16 * i + r16, lc = wc * (BN / 2) + 16 * j + 4 * q;
+            *reinterpret_cast<f32x4*>(smem + lr * RS + lc * 4) = acc[i][j] * p.alpha;
+        }
+    __syncthreads();
+    if constexpr (sizeof(TO) == 4) {
+        if (p.splitk > 1) {
+            for (int idx = threadIdx.x; idx < BM * BN; idx += 256) {
+                const int lr = idx / BN, lc = idx % BN;
+                const int row = row0 + lr, col = col0 + lc;
+                if (row >= p.M || col >= p.N) continue;
+                const size_t orow = p.mapC ? (size_t)p.mapC[row] : (size_t)row;
+                atomicAdd(reinterpret_cast<float*>(C) + orow * p.ldc + col, *reinterpret_cast<const float*>(smem + lr * RS + lc * 4));
+            }
+            return;
+        }
+    }
+    switch (p.act) {          // the activation is compile-time inside the finishing loop (27 -> ~6 VALU per element)
+        case ACT_RELU: gemm_finish<TO, BM, BN, ACT_RELU>(p, smem, row0, col0); break;
+        case ACT_GELU: gemm_finish<TO, BM, BN, ACT_GELU>(p, smem, row0, col0); break;
+        case ACT_RELU_BWD: gemm_finish<TO, BM, BN, ACT_RELU_BWD>(p, smem, row0, col0); break;
+        case ACT_GELU_BWD: gemm_finish<TO, BM, BN, ACT_GELU_BWD>(p, smem, row0, col0); break;
+        default: gemm_finish<TO, BM, BN, ACT_NONE>(p, smem, row0, col0); break;
     }
 }
 
@@ -335,6 +367,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
+    if (p.dbg & 1) {                                 // ablation: keep the accumulators live, store nothing
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     gemm_epilogue<TO, BM, BN>(p, acc, smem, row0, col0, wr, wc, q, r16);
 }
 
@@ -493,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
     { const int st = step(); sa.load(a1, st); sb.load(b1, st); }      // tile 1 (or tile 0 again)
     sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
     __syncthreads();
-    for (int t = 0; t < nk; t += 2) {
+    for (int t = 0; t < ((p.dbg & 2) ? 0 : nk); t += 2) {
         { const int st = step(); sa.load(a0, st); sb.load(b0, st); }  // tile t+2 -> set 0
         mma_tile<TI, MT, NT>(l0 + aoff, l0 + boff, r16, q, acc);       // tile t
         sa.store(l1, a1); sb.store(l1 + BM * 128, b1);                 // tile t+1
@@ -502,6 +541,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
         if (t + 1 < nk) mma_tile<TI, MT, NT>(l1 + aoff, l1 + boff, r16, q, acc);
         sa.store(l0, a0); sb.store(l0 + BM * 128, b0);                 // tile t+2
         __syncthreads();
+    }
+    if (p.dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
     }
     gemm_epilogue<TO, BM, BN>(p, acc, smem, row0, col0, wr, wc, q, r16);
 }
@@ -569,7 +615,8 @@ extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int tra
     if (mapB && !trans_b) return S2T_EINVAL;
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && splitk > 1)) return S2T_EINVAL;
     GemmArgs a{A, B, C, bias, residual, aux, aux_out, M, N, K, lda, ldb, ldc, ldr, ldaux, act, accumulate, splitk, alpha,
-               mapA, periodA, mapB, mapC, p_drop, seed};
+               mapA, periodA, mapB, mapC, p_drop, seed, 0};
+    { static const char* e = getenv("S2T_GEMM_DBG"); if (e) a.dbg = atoi(e); }
     hipStream_t st = (hipStream_t)stream;
     const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
     ProfScope prof(mapA || mapB ? "gemm_gather" : "gemm", st, 2.0 * M * (double)N * K,
