@@ -160,9 +160,8 @@ __device__ __forceinline__ float lae(float a, float b) {          // log(exp a +
 // needed from the previous lane travel by shuffle.  Emissions lp[t][ext[s]] = logit - lse are
 // gathered CH time steps at a time into LDS by the whole workgroup.
 // Outputs: la/lb [B][T][Smax] (f32 log alpha/beta), nll[b] (0 if infeasible: zero_infinity).
-#define CTC_SPL 4
 #define CTC_CH 16
-template <typename T>
+template <typename T, int CTC_SPL>
 __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict__ logits, const float* __restrict__ lse,
                                                             const long long* __restrict__ targets, const long long* __restrict__ tgt_len,
                                                             const int* __restrict__ in_len, float* __restrict__ la,
@@ -205,7 +204,10 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
             if (t < 0 || t >= Tb) break;
             float n[CTC_SPL];
             if (dir == 0) {
-                const float p1 = __shfl_up(a[CTC_SPL - 1], 1), p2 = __shfl_up(a[CTC_SPL - 2], 1);
+                // alpha[s-1], alpha[s-2] of the previous lane(s): with one position per lane they sit 1 and 2 lanes back
+                const float p1 = __shfl_up(a[CTC_SPL - 1], 1);
+                const float p2 = CTC_SPL >= 2 ? __shfl_up(a[CTC_SPL >= 2 ? CTC_SPL - 2 : 0], 1) : __shfl_up(a[0], 2);
+                const bool has2 = CTC_SPL >= 2 ? lane > 0 : lane > 1;
 #pragma unroll
                 for (int i = 0; i < CTC_SPL; ++i) {
                     const int s = lane * CTC_SPL + i;
@@ -213,14 +215,16 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
                     if (t == 0) v = (s <= 1 && s < S) ? 0.f : -INFINITY;
                     else {
                         const float m1 = (i >= 1) ? a[i - 1] : (lane > 0 ? p1 : -INFINITY);
-                        const float m2 = (i >= 2) ? a[i - 2] : (lane > 0 ? (i == 1 ? p1 : p2) : -INFINITY);
+                        const float m2 = (i >= 2) ? a[i - 2] : (i == 1 ? (lane > 0 ? p1 : -INFINITY) : (has2 ? p2 : -INFINITY));
                         v = lae(a[i], m1);
                         if (skip2[i]) v = lae(v, m2);
                     }
                     n[i] = (s < S) ? v + em[0][k][s] : -INFINITY;
                 }
             } else {
-                const float p1 = __shfl_down(a[0], 1), p2 = __shfl_down(a[1], 1);
+                const float p1 = __shfl_down(a[0], 1);
+                const float p2 = CTC_SPL >= 2 ? __shfl_down(a[CTC_SPL >= 2 ? 1 : 0], 1) : __shfl_down(a[0], 2);
+                const bool has2 = CTC_SPL >= 2 ? lane < 63 : lane < 62;
 #pragma unroll
                 for (int i = 0; i < CTC_SPL; ++i) {
                     const int s = lane * CTC_SPL + i;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
                     if (t == Tb - 1) v = (s < S && s >= S - 2) ? 0.f : -INFINITY;
                     else {
                         const float m1 = (i + 1 < CTC_SPL) ? a[i + 1] : (lane < 63 ? p1 : -INFINITY);
-                        const float m2 = (i + 2 < CTC_SPL) ? a[i + 2] : (lane < 63 ? (i + 2 == CTC_SPL ? p1 : p2) : -INFINITY);
+                        const float m2 = (i + 2 < CTC_SPL) ? a[i + 2] : (i + 2 == CTC_SPL ? (lane < 63 ? p1 : -INFINITY) : (has2 ? p2 : -INFINITY));
                         v = lae(a[i], m1);
                         if (skip2[i]) v = lae(v, m2);
                     }
@@ -352,7 +356,8 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
     if (B <= 0 || T <= 0) return S2T_OK;
     if (!logits || !targets || !tgt_len || !in_len || !lse || !la || !lb || !nll || !grad || !loss_sum || ld < V) return S2T_EINVAL;
     const int Smax = 2 * Lmax + 1;
-    if (Smax > 64 * CTC_SPL) return S2T_ENOTSUP;          // transcripts longer than 127 tokens
+    if (Smax > 64 * 4) return S2T_ENOTSUP;                // transcripts longer than 127 tokens
+    const int spl = Smax <= 64 ? 1 : (Smax <= 128 ? 2 : 4);   // extended-target positions per lane
     if ((size_t)V * 4 > 160 * 1024 - 1024) return S2T_ENOTSUP;
     hipStream_t st = (hipStream_t)stream;
     const long rows = (long)T * B;
@@ -360,13 +365,17 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
     const size_t lds = (size_t)V * 4;
     if (dtype == S2T_BF16) {
         hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V, ld);
-        hipLaunchKernelGGL(ctc_alphabeta_kernel<bf16>, dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 1>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 2>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 4>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
         hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, loss_sum, T, B, V, ld, Lmax, Smax, blank, grad_scale);
     } else if (dtype == S2T_F32) {
         hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V, ld);
-        hipLaunchKernelGGL(ctc_alphabeta_kernel<float>, dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 1>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 2>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 4>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
         hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, loss_sum, T, B, V, ld, Lmax, Smax, blank, grad_scale);

@@ -184,7 +184,7 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
     if (D <= 0 || D > 1024) return S2T_ENOTSUP;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return S2T_EINVAL;
     int blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 512) blocks = 512;            // 2 workgroups per CU; each ends in 2*D same-address atomics
     dim3 grid(blocks);
     hipStream_t st = (hipStream_t)stream;
     const int epl = ln_epl(D, dy, x, dres, dx);

@@ -255,8 +255,9 @@ extern "C" int s2t_conv1_fwd(int dtype, const float* x, const float* w, const fl
                              int B, int T, int F, int C, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
     if (!x || !w || !bias || !y || !sums || (C != 64 && C != 128 && C != 32) || F <= 0) return S2T_EINVAL;
-    const int T2 = (T + 1) / 2, F2 = (F + 1) / 2, ppb = 256;
+    const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
+    const int ppb = (int)((P + 1023) / 1024 < 64 ? 64 : (P + 1023) / 1024);   // <= ~1024 workgroups: every one ends in 2C same-address atomics
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
@@ -270,8 +271,9 @@ extern "C" int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float*
                              int C, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
     if (!x || !dpre || !dw || !db || (C != 64 && C != 128 && C != 32)) return S2T_EINVAL;
-    const int T2 = (T + 1) / 2, F2 = (F + 1) / 2, ppb = 1024;
+    const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
+    const int ppb = (int)((P + 511) / 512 < 256 ? 256 : (P + 511) / 512);     // <= ~512 workgroups (10C atomics each)
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
@@ -285,7 +287,7 @@ extern "C" int s2t_chan_sums(int dtype, const void* y, const void* dyn, const fl
                              double* sums, long P, int C, int mode, void* stream) {
     if (P <= 0) return S2T_OK;
     if (!y || !sums || (C != 64 && C != 128 && C != 32) || (mode && (!dyn || !mean || !rstd))) return S2T_EINVAL;
-    const int ppb = 1024;
+    const int ppb = (int)((P + 511) / 512 < 256 ? 256 : (P + 511) / 512);
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,

@@ -414,3 +414,21 @@ def test_add_pos_and_permutes():
     back = torch.zeros(8, 16, 3, 3, device=DEV)
     K.permute_conv_w(f, back, 8, 16, 2)
     assert torch.equal(back.cpu(), w2)
+
+
+@pytest.mark.parametrize("M,N,K_", [(2500, 384, 192), (4096, 128, 64), (3000, 640, 1280), (2048, 200, 128), (24000, 512, 512)])
+def test_gemm_v2_direct_to_lds_kernel(M, N, K_, monkeypatch):
+    """bf16 forward-shaped GEMMs large enough for gemm_v2_kernel (256x128 tiles, global_load_lds ring; opt-in via
+    S2T_GEMM_V2, read once per process: run this file with S2T_GEMM_V2=1 to exercise it, otherwise the same shapes go
+    through the default kernels)."""
+    dtype = torch.bfloat16
+    a = rnd(M, K_, dtype=dtype, seed=1); w = rnd(N, K_, dtype=dtype, seed=2, scale=K_ ** -0.5)
+    bias = rnd(N, seed=3); res = rnd(M, N, dtype=dtype, seed=4)
+    ref = a.float() @ w.float().t() + bias
+    assert rel_err(K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV)), ref) < 2e-2
+    out = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=K.ACT_RELU, residual=res.to(DEV))
+    assert rel_err(out, F.relu(ref) + res.float()) < 2e-2
+    # dropout in the epilogue: same mask as the standalone kernel on the same index space
+    y = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), p_drop=0.25, seed=9)
+    y0 = K.dropout(K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV)), 0.25, 9)
+    assert rel_err(y, y0) < 2e-2

@@ -42,6 +42,7 @@ def test_training_reduces_loss(dtype):
 def test_update_freq_accumulates_gradients():
     """two micro-batches in one update == gradient sum (trainer.py:347-411 semantics)"""
     a, task, model, crit, tr = _setup(torch.float32, dropout=0.0)
+    model.hp.sub_dropout = 0.0            # the subsampler's rate is max(dropout, 0.1) (conv_transformer.py:214)
     s1 = tr.prepare(task.dummy_batch(seed=1)); s2 = tr.prepare(task.dummy_batch(seed=2))
     model.train(); crit.train()
     tr.optimizer.zero_grad()
