@@ -105,6 +105,31 @@ class _DecoderFn(torch.autograd.Function):
         return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None
 
 
+class _DualDecoderFn(torch.autograd.Function):
+    """Both decoders of the dual-decoder model over one encoder output; the two encoder-output gradients are
+    accumulated by the kernels into one buffer (no autograd add)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, prev_tokens, aux_prev_tokens, enc_out, enc_klen, training, seed):
+        eng = model.engine
+        eo = enc_out.contiguous()
+        l1, c1 = eng.decoder_forward(prev_tokens, eo, enc_klen, training, seed, pfx="decoder.")
+        l2, c2 = eng.decoder_forward(aux_prev_tokens, eo, enc_klen, training, seed + 1, pfx="auxiliary_decoder.")
+        ctx.model, ctx.c1, ctx.c2 = model, c1, c2
+        return l1, l2
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        eng = ctx.model.engine
+        fix = lambda d: d if d.stride(-1) == 1 else d.contiguous()
+        denc = eng.decoder_backward(ctx.c2, fix(d2))
+        ctx.model._notify_grads_ready("auxiliary_decoder")
+        denc = eng.decoder_backward(ctx.c1, fix(d1), denc=denc)
+        ctx.model._notify_grads_ready("decoder")
+        c = ctx.c1
+        return None, None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None
+
+
 # ------------------------------------------------------------------ modules
 def _init_linear(n, k, gain=1.0):
     w = torch.empty(n, k)
@@ -430,6 +455,58 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         return cls(args, encoder, decoder, hp)
 
 
+@register_model("conv_transformer_dualdecoder")
+class ConvolutionalTransformerDualDecoder(ConvolutionalTransformerModel):
+    """conv_transformer_dualdecoder.py:13-81 (+ multi_task.py:7-21): one encoder, a translation decoder and an
+    auxiliary transcript decoder over the same encoder output."""
+
+    def __init__(self, args, encoder, decoder, hp, auxiliary_decoder):
+        super().__init__(args, encoder, decoder, hp)
+        self.auxiliary_decoder = auxiliary_decoder
+        object.__setattr__(auxiliary_decoder, "owner", self)
+
+    @staticmethod
+    def add_args(parser):
+        ConvolutionalTransformerModel.add_args(parser)
+        parser.add_argument("--auxiliary-decoder-embed-path", type=str, metavar="STR")
+
+    @classmethod
+    def build_model(cls, args, task):
+        assert task.source_dictionary is not None, "the dual-decoder model needs a task with transcripts (:41)"
+        base = ConvolutionalTransformerModel.build_model.__func__(ConvolutionalTransformerModel, args, _TgtOnly(task))
+        hp = base.hp
+        hp.V_aux = len(task.source_dictionary)
+        enc = ConvolutionalTransformerEncoder(args, task.target_dictionary, audio_features=args.input_feat_per_channel)
+        dec = TransformerDecoder(args, task.target_dictionary)
+        aux = TransformerDecoder(args, task.source_dictionary, pfx="auxiliary_decoder.")
+        return cls(args, enc, dec, hp, aux)
+
+    def get_auxiliary_target(self, sample, auxiliary_output):
+        return sample["transcript_target"]
+
+    def get_auxiliary_token_lens(self, sample):
+        return sample["transcript_target_lengths"]
+
+    def forward(self, src_tokens, src_lengths, prev_output_tokens, transcript_prev_output_tokens, **kwargs):
+        self._ensure_engine(src_tokens.device)
+        eo = self.encoder(src_tokens, src_lengths=src_lengths)
+        klen = eo.src_lengths.to(torch.int32) if eo.encoder_padding_mask is not None else None
+        l1, l2 = _DualDecoderFn.apply(self.anchor, self, prev_output_tokens, transcript_prev_output_tokens, eo.encoder_out,
+                                      klen, self.training, self._next_seed())
+        (B, L1), L2 = prev_output_tokens.shape, transcript_prev_output_tokens.shape[1]
+        extra = {"attn": [None], "inner_states": None}
+        return (l1.view(L1, B, -1).transpose(0, 1), extra), (l2.view(L2, B, -1).transpose(0, 1), extra)
+
+
+class _TgtOnly:
+    """task view whose source dictionary is hidden: the dual-decoder encoder is built with the TARGET dictionary
+    (conv_transformer_dualdecoder.py:59-60)"""
+
+    def __init__(self, task):
+        self.target_dictionary = task.target_dictionary
+        self.source_dictionary = None
+
+
 # ------------------------------------------------------------------ architectures
 def _common(args):
     args.dropout = getattr(args, "dropout", 0.3)
@@ -519,3 +596,21 @@ def s2t_transformer_m(args):
 @register_model_architecture("conv_transformer", "s2t_transformer_l")
 def s2t_transformer_l(args):
     _s2t(args, 1024, 4096, 16, 12, 6, 0.2, "[(128, 3, 3)] * 2")
+
+
+@register_model_architecture("conv_transformer_dualdecoder", "conv_transformer_dualdecoder")
+def dualdecoder_base(args):                                        # conv_transformer_dualdecoder.py:91-94
+    base_architecture(args)
+    args.auxiliary_decoder_embed_path = getattr(args, "auxiliary_decoder_embed_path", None)
+
+
+@register_model_architecture("conv_transformer_dualdecoder", "conv_transformer_dualdecoder_big")
+def dualdecoder_big(args):
+    conv_transformer_big(args)
+    args.auxiliary_decoder_embed_path = getattr(args, "auxiliary_decoder_embed_path", None)
+
+
+@register_model_architecture("conv_transformer_dualdecoder", "conv_transformer_dualdecoder_big2")
+def dualdecoder_big2(args):
+    conv_transformer_big2(args)
+    args.auxiliary_decoder_embed_path = getattr(args, "auxiliary_decoder_embed_path", None)

@@ -221,3 +221,112 @@ class CTCMultiLoss(FairseqCriterion):
         return {"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
                 "ctc_loss": ctc_sum / sample_size / math.log(2),
                 "ctc_acc": 100.0 - min(errors * 100.0 / max(total, 1), 100.0), "nframes": nframes}
+
+
+class _KDFn(torch.autograd.Function):
+    """(1-lambda) * NLL + lambda * KD(tau) summed over non-pad rows, fused with its gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, target, tidx, tlog, lam, tau, pad):
+        B, L, V = logits.shape
+        lt = logits.transpose(0, 1)
+        if lt.stride(2) != 1 or lt.stride(0) != B * lt.stride(1):
+            lt = lt.contiguous()
+        Kt = tidx.shape[-1]
+        ti = tidx.transpose(0, 1).contiguous().view(L * B, Kt).long()
+        tl = tlog.transpose(0, 1).contiguous().view(L * B, Kt).float()
+        s, dl = K.kd_loss(lt.reshape(L * B, V), target.t().contiguous().view(-1), ti, tl, lam, tau, pad)
+        ctx.dl, ctx.shape = dl, (L, B, V)
+        return s[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L, B, V = ctx.shape
+        dl = K.scale_by_device_scalar(ctx.dl, g.contiguous().float())
+        return dl.view(L, B, V).transpose(0, 1), None, None, None, None, None, None
+
+
+@register_criterion("knowledge_distillation")
+class CrossEntropyKnowledgeDistillationCriterion(FairseqCriterion):
+    """fairseq/criterions/knowledge_distillation.py:17-119 (teacher top-K logits come with the sample:
+    fairseq/data/knowledge_distillation.py:91-140)."""
+
+    def __init__(self, args, task):
+        super().__init__(task)
+        self._lambda = args.kd_lambda
+        self.temperature = args.kd_temperature
+        self.sentence_avg = getattr(args, "sentence_avg", False)
+
+    @staticmethod
+    def add_args(parser):
+        parser.add_argument("--kd-lambda", default=0.0, type=float, metavar="D")
+        parser.add_argument("--kd-temperature", default=1.0, type=float, metavar="D")
+
+    def forward(self, model, sample, reduce=True):
+        assert reduce
+        net_output = model(**sample["net_input"])
+        target = model.get_targets(sample, net_output)
+        tidx, tlog = sample["teacher_output"][0], sample["teacher_output"][1]
+        loss = _KDFn.apply(net_output[0], target, tidx, tlog, self._lambda, self.temperature, self.padding_idx)
+        sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        return loss, sample_size, {"loss": loss.detach(), "ntokens": sample["ntokens"],
+                                   "nsentences": sample["target"].size(0), "sample_size": sample_size}
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        s = lambda k: sum(_item(l.get(k, 0)) for l in logging_outputs)
+        loss_sum, ntokens, sample_size = s("loss"), s("ntokens"), s("sample_size")
+        out = {"loss": loss_sum / sample_size / math.log(2)}
+        nll = loss_sum / ntokens / math.log(2) if sample_size != ntokens else out["loss"]
+        out.update(nll_loss=nll, ppl=2 ** nll)
+        return out
+
+
+@register_criterion("cross_entropy_dualdecoder")
+class CrossEntropyDualDecoder(FairseqCriterion):
+    """examples/speech_recognition/criterions/cross_entropy_dualdecoder.py:8-83."""
+
+    def __init__(self, args, task):
+        super().__init__(task)
+        self.eps = getattr(args, "label_smoothing", 0.0)
+        self.sentence_avg = getattr(args, "sentence_avg", False)
+        self.auxiliary_loss_weight = getattr(args, "auxiliary_loss_weight", 0.5)
+        self.primary_loss_weight = getattr(args, "primary_loss_weight", 0.5)
+
+    @staticmethod
+    def add_args(parser):
+        parser.add_argument("--primary-loss-weight", default=0.5, type=float, metavar="W")
+        parser.add_argument("--auxiliary-loss-weight", default=0.5, type=float, metavar="W")
+        parser.add_argument("--label-smoothing", default=0.0, type=float, metavar="D")
+
+    def forward(self, model, sample, reduce=True, log_probs=True):
+        assert reduce
+        net_output = model(**sample["net_input"])
+        sample_size = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        p_loss, p_nll = _LSCEFn.apply(net_output[0][0], model.get_targets(sample, net_output[0]), self.eps, self.padding_idx)
+        a_loss, a_nll = _LSCEFn.apply(net_output[1][0], model.get_auxiliary_target(sample, net_output[1]), self.eps, self.padding_idx)
+        loss = self.primary_loss_weight * p_loss + self.auxiliary_loss_weight * a_loss
+        aux_ntok = sample.get("transcript_ntokens")
+        if aux_ntok is None:
+            aux_ntok = int(model.get_auxiliary_token_lens(sample).sum())
+        log = {"loss": loss.detach(), "primary_loss": p_loss.detach(), "primary_nll_loss": p_nll.detach(),
+               "auxiliary_loss": a_loss.detach(), "auxiliary_nll_loss": a_nll.detach(), "ntokens": sample["ntokens"],
+               "auxiliary_ntokens": aux_ntok, "nsentences": sample["target"].size(0), "sample_size": sample_size}
+        return loss, sample_size, log
+
+    @staticmethod
+    def logging_outputs_can_be_summed():
+        return True
+
+    @staticmethod
+    def reduce_metrics(logging_outputs):
+        s = lambda k: sum(_item(l.get(k, 0)) for l in logging_outputs)
+        ss, nt, ant = s("sample_size"), s("ntokens"), s("auxiliary_ntokens")
+        ln2 = math.log(2)
+        return {"loss": s("loss") / ss / ln2, "primary_loss": s("primary_loss") / ss / ln2,
+                "auxiliary_loss": s("auxiliary_loss") / ss / ln2, "primary_nll_loss": s("primary_nll_loss") / nt / ln2,
+                "auxiliary_nll_loss": s("auxiliary_nll_loss") / max(ant, 1) / ln2}

@@ -172,3 +172,80 @@ extern "C" int s2t_add_inplace(int dtype, const void* x, void* y, size_t n, void
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
+
+// ------------------------------------------------------------------ word-level knowledge distillation loss
+// fairseq/criterions/knowledge_distillation.py:44-96, fused with its gradient.  Per non-pad row:
+//   kd    = - sum_k softmax(teacher_logits/tau)_k * log_softmax(logits/tau)[idx_k]          (if lambda > 0)
+//   truth = - log_softmax(logits)[y]                                                           (if lambda < 1)
+//   loss += (1-lambda)*truth + lambda*kd
+//   dlogits = gscale * [ (1-lambda)*(softmax(x) - onehot(y)) + (lambda/tau)*(softmax(x/tau) - scatter_k(w_k)) ]
+// teacher_idx [rows][Kt] int64, teacher_logits [rows][Kt] f32.
+template <typename T>
+__global__ __launch_bounds__(256) void kd_kernel(const T* __restrict__ logits, const long long* __restrict__ target,
+                                                 const long long* __restrict__ tidx, const float* __restrict__ tlog,
+                                                 T* __restrict__ dlogits, float* __restrict__ sums, int V, int ld, int Kt,
+                                                 float lambda, float tau, int pad, float gscale) {
+    __shared__ float sh[16];
+    __shared__ float wk[64];
+    const long row = blockIdx.x;
+    const T* x = logits + row * ld;
+    T* g = dlogits ? dlogits + row * ld : nullptr;
+    const long long y = target[row];
+    if (y == pad) {
+        if (g) for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
+        return;
+    }
+    const float it = 1.f / tau;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, to_f32(x[v]));
+    m = block_max(m, sh);
+    float s1 = 0.f, st = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) { const float d = to_f32(x[v]) - m; s1 += expf(d); st += expf(d * it); }
+    s1 = block_sum(s1, sh);
+    st = block_sum(st, sh);
+    const float lse1 = m + logf(s1), lset = m * it + logf(st);
+    // teacher weights softmax(tlog / tau) over Kt <= 64 entries (one wave)
+    if (threadIdx.x < 64) {
+        const float tv = threadIdx.x < Kt ? tlog[row * Kt + threadIdx.x] * it : -INFINITY;
+        const float tm = wave_max(tv);
+        const float te = threadIdx.x < Kt ? expf(tv - tm) : 0.f;
+        const float ts = wave_sum(te);
+        wk[threadIdx.x] = te / ts;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float kd = 0.f;
+        if (lambda > 0.f) for (int k = 0; k < Kt; ++k) kd -= wk[k] * (to_f32(x[tidx[row * Kt + k]]) * it - lset);
+        const float truth = lambda < 1.f ? lse1 - to_f32(x[y]) : 0.f;
+        atomicAdd(sums, (1.f - lambda) * truth + lambda * kd);
+    }
+    if (g) {
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const float xv = to_f32(x[v]);
+            float d = 0.f;
+            if (lambda < 1.f) d += (1.f - lambda) * (expf(xv - lse1) - (v == y ? 1.f : 0.f));
+            if (lambda > 0.f) d += lambda * it * expf(xv * it - lset);
+            g[v] = from_f32<T>(d * gscale);
+        }
+        __syncthreads();
+        if (lambda > 0.f && threadIdx.x == 0)          // few entries, possibly repeated indices: serial fix-up
+            for (int k = 0; k < Kt; ++k) {
+                const long long c = tidx[row * Kt + k];
+                g[c] = from_f32<T>(to_f32(g[c]) - lambda * it * wk[k] * gscale);
+            }
+    }
+}
+
+extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* target, const long long* teacher_idx,
+                           const float* teacher_logits, void* dlogits, float* sum1, long rows, int V, int ld, int Kt,
+                           float lambda, float tau, int pad, float grad_scale, void* stream) {
+    if (rows <= 0) return S2T_OK;
+    if (!logits || !target || !sum1 || V <= 0 || ld < V || tau <= 0.f || lambda < 0.f || lambda > 1.f) return S2T_EINVAL;
+    if (lambda > 0.f && (!teacher_idx || !teacher_logits || Kt < 1 || Kt > 64)) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(kd_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, target, teacher_idx, teacher_logits, (bf16*)dlogits, sum1, V, ld, Kt, lambda, tau, pad, grad_scale);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(kd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, teacher_idx, teacher_logits, (float*)dlogits, sum1, V, ld, Kt, lambda, tau, pad, grad_scale);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

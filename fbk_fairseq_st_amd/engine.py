@@ -28,6 +28,7 @@ class HParams:
         self.sub_dropout = None                  # None -> max(dropout, 0.1) (conv_transformer.py:214)
         self.pad = 1; self.no_scale_embedding = False
         self.V_src = 0; self.V_tgt = 0
+        self.V_aux = 0                           # > 0: second decoder `auxiliary_decoder.*` over this vocabulary (dual-decoder model)
         self.ln_eps = 1e-5; self.bn_eps = 1e-5; self.bn_momentum = 0.1
         for k, v in kw.items():
             if not hasattr(self, k):
@@ -63,15 +64,18 @@ class HParams:
             if self.ctc_layer == l + 1:
                 lin("encoder.ctc_fc", self.V_src, D)
         ln("encoder.layer_norm")
-        s["decoder.embed_tokens.weight"] = (self.V_tgt, D)
-        for l in range(self.dec_layers):
-            p = "decoder.layers.%d." % l
-            ln(p + "self_attn_layer_norm"); lin(p + "self_attn.qkv", 3 * D, D); lin(p + "self_attn.out_proj", D, D)
-            ln(p + "encoder_attn_layer_norm"); lin(p + "encoder_attn.q_proj", D, D); lin(p + "encoder_attn.kv", 2 * D, D)
-            lin(p + "encoder_attn.out_proj", D, D)
-            ln(p + "final_layer_norm"); lin(p + "fc1", Ff, D); lin(p + "fc2", D, Ff)
-        ln("decoder.layer_norm")
-        lin("decoder.output_projection", self.V_tgt, D, bias=False)
+        for dec, V in (("decoder.", self.V_tgt), ("auxiliary_decoder.", self.V_aux)):
+            if V <= 0:
+                continue
+            s[dec + "embed_tokens.weight"] = (V, D)
+            for l in range(self.dec_layers):
+                p = dec + "layers.%d." % l
+                ln(p + "self_attn_layer_norm"); lin(p + "self_attn.qkv", 3 * D, D); lin(p + "self_attn.out_proj", D, D)
+                ln(p + "encoder_attn_layer_norm"); lin(p + "encoder_attn.q_proj", D, D); lin(p + "encoder_attn.kv", 2 * D, D)
+                lin(p + "encoder_attn.out_proj", D, D)
+                ln(p + "final_layer_norm"); lin(p + "fc1", Ff, D); lin(p + "fc2", D, Ff)
+            ln(dec + "layer_norm")
+            lin(dec + "output_projection", V, D, bias=False)
         return s
 
 
@@ -490,15 +494,17 @@ class S2TEngine:
         logits = self.linear(xn, pfx + "output_projection", bias=False, pad_rows=True)   # [L*B, V] time-major rows
         return logits, ctx
 
-    def decoder_backward(self, ctx, dlogits):
-        """dlogits [L*B, V] (time-major).  Returns the gradient w.r.t. the encoder output [Ts*B, D]."""
+    def decoder_backward(self, ctx, dlogits, denc=None):
+        """dlogits [L*B, V] (time-major).  Returns the gradient w.r.t. the encoder output [Ts*B, D]
+        (accumulated into `denc` when given: second decoder of the dual-decoder model)."""
         hp = self.hp
         pfx, B, L, D = ctx["pfx"], ctx["B"], ctx["L"], hp.D
         f = ctx["final"]
         dxn = self.linear_bwd(dlogits, f["xn"], pfx + "output_projection", bias=False)
         dx = K.layernorm_bwd(dxn, f["x"], f["mean"], f["rstd"], self.P(pfx + "layer_norm.weight"),
                              self.G(pfx + "layer_norm.weight"), self.G(pfx + "layer_norm.bias"))
-        denc = torch.zeros((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
+        if denc is None:
+            denc = torch.zeros((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
         for l in reversed(range(hp.dec_layers)):
             lp = pfx + "layers.%d." % l
             c1, c2, c3 = ctx["layers"][l]

@@ -266,6 +266,18 @@ def lsce(logits, target, eps, pad, want_grad=True, grad_scale=1.0):
     return sums, dl
 
 
+def kd_loss(logits, target, teacher_idx, teacher_logits, lam, tau, pad, want_grad=True, grad_scale=1.0):
+    """logits [rows,V]; teacher_idx/logits [rows,Kt]. Returns (loss f32[1], dlogits or None)."""
+    rows, V = logits.shape
+    ld = _row_ld(logits)
+    s = torch.zeros((1,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty((rows, ld), dtype=logits.dtype, device=logits.device)[:, :V] if want_grad else None
+    Kt = teacher_idx.shape[-1] if teacher_idx is not None else 0
+    L.check(_lib().s2t_kd_loss(L.dt(logits), L.ptr(logits), L.ptr(target), L.ptr(teacher_idx), L.ptr(teacher_logits), L.ptr(dl),
+                               L.ptr(s), rows, V, ld, Kt, float(lam), float(tau), pad, float(grad_scale), L.stream()), "s2t_kd_loss")
+    return s, dl
+
+
 def embed_fwd(tokens, W, table, scale, pad):
     B, Ln = tokens.shape
     D = W.shape[1]

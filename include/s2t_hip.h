@@ -152,6 +152,12 @@ int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const 
 int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2,
              long rows, int V, int ld, float eps, int pad, float grad_scale, void* stream);
 
+/* word-level knowledge distillation from stored teacher top-K logits (fairseq/criterions/knowledge_distillation.py:44-96):
+ * sum1[0] += sum_rows (1-lambda)*NLL + lambda*KD(tau); teacher_idx [rows][Kt] int64, teacher_logits [rows][Kt] f32, Kt <= 64 */
+int s2t_kd_loss(int dtype, const void* logits, const long long* target, const long long* teacher_idx,
+                const float* teacher_logits, void* dlogits, float* sum1, long rows, int V, int ld, int Kt,
+                float lambda, float tau, int pad, float grad_scale, void* stream);
+
 /* ---- decoder embedding (fairseq/models/transformer.py:720-737) -------------------------------------- */
 int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float* table, void* out,
                   int B, int L, int D, float scale, int pad, void* stream);

@@ -371,6 +371,37 @@ def ctc_multi_loss(W, cfg, sample, eps, ctc_weight, blank, training=False):
     return loss, ctc_ntokens, log, enc, logits, stats
 
 
+def kd_loss(logits, target, teacher_idx, teacher_logits, lam, tau, pad):
+    """CrossEntropyKnowledgeDistillationCriterion.forward, fairseq/criterions/knowledge_distillation.py:44-96 (summed)."""
+    V = logits.shape[-1]
+    t = target.reshape(-1)
+    mask = t.ne(pad)
+    loss = logits.new_zeros(())
+    if lam > 0:
+        lp = F.log_softmax((logits / tau).float(), dim=-1).view(-1, V)
+        tp = F.softmax(teacher_logits / tau, dim=-1).view(-1, teacher_logits.shape[-1])
+        sel = lp.gather(1, teacher_idx.reshape(-1, teacher_idx.shape[-1]).long())
+        loss = loss + lam * (-(sel * tp).sum(-1) * mask.float()).sum()
+    if lam < 1:
+        lp = F.log_softmax(logits.float(), dim=-1).view(-1, V)
+        loss = loss + (1 - lam) * F.nll_loss(lp, t, ignore_index=pad, reduction="sum")
+    return loss
+
+
+def dual_decoder_loss(W, cfg, sample, eps, w_primary=0.5, w_aux=0.5, training=False):
+    """ConvolutionalTransformerDualDecoder.forward + CrossEntropyDualDecoder.forward
+    (conv_transformer_dualdecoder.py:74-81, cross_entropy_dualdecoder.py:31-59)."""
+    ni = sample["net_input"]
+    enc, stats = encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training)
+    lg = decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+    la = decoder_forward(W, cfg, ni["transcript_prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask,
+                         pfx="auxiliary_decoder.")
+    pl, pn = label_smoothed_nll(lg, sample["target"], eps, cfg["pad"])
+    al, an = label_smoothed_nll(la, sample["transcript_target"], eps, cfg["pad"])
+    return w_primary * pl + w_aux * al, dict(primary_loss=float(pl.detach()), auxiliary_loss=float(al.detach()),
+                                              primary_nll_loss=float(pn.detach()), auxiliary_nll_loss=float(an.detach())), lg, la
+
+
 # ------------------------------------------------------------------ optimizer (a19)
 def clip_grad_norm(grads, max_norm):
     """fairseq/utils.py:253-277."""
@@ -402,7 +433,7 @@ def inverse_sqrt_lr(num_updates, lr, warmup_updates, warmup_init_lr):
 
 
 # ------------------------------------------------------------------ deterministic weights
-def param_shapes(cfg, V_src, V_tgt, criterion_fc=False):
+def param_shapes(cfg, V_src, V_tgt, criterion_fc=False, V_aux=0):
     """State-dict names and shapes of conv_transformer (SURVEY.md 8-b [probe])."""
     D, Ff, C = cfg["D"], cfg["ffn"], cfg["conv_ch"]
     f4 = math.ceil(math.ceil(cfg["feat"] / 2) / 2)
@@ -432,15 +463,18 @@ def param_shapes(cfg, V_src, V_tgt, criterion_fc=False):
         ln("encoder.layer_norm.")
     if cfg["ctc_layer"]:
         s["encoder.ctc_fc.weight"] = (V_src, D); s["encoder.ctc_fc.bias"] = (V_src,)
-    s["decoder.embed_tokens.weight"] = (V_tgt, D)
-    for l in range(cfg["dec_layers"]):
-        p = "decoder.layers.%d." % l
-        attn(p + "self_attn."); ln(p + "self_attn_layer_norm.")
-        attn(p + "encoder_attn."); ln(p + "encoder_attn_layer_norm.")
-        ff(p); ln(p + "final_layer_norm.")
-    if cfg["dec_pre_ln"]:
-        ln("decoder.layer_norm.")
-    s["decoder.output_projection.weight"] = (V_tgt, D)
+    for dec, V in (("decoder.", V_tgt), ("auxiliary_decoder.", V_aux)):
+        if V <= 0:
+            continue
+        s[dec + "embed_tokens.weight"] = (V, D)
+        for l in range(cfg["dec_layers"]):
+            p = dec + "layers.%d." % l
+            attn(p + "self_attn."); ln(p + "self_attn_layer_norm.")
+            attn(p + "encoder_attn."); ln(p + "encoder_attn_layer_norm.")
+            ff(p); ln(p + "final_layer_norm.")
+        if cfg["dec_pre_ln"]:
+            ln(dec + "layer_norm.")
+        s[dec + "output_projection.weight"] = (V, D)
     if criterion_fc:
         s["criterion.ctc_aware_model.fc_out.weight"] = (V_src, D)
         s["criterion.ctc_aware_model.fc_out.bias"] = (V_src,)

@@ -66,20 +66,23 @@ def mk_dict(n):
     return d
 
 
-def build(cfgname, D, H, Ff, EL, DL, ctc_layer, compress=True, strategy="avg"):
+def build(cfgname, D, H, Ff, EL, DL, ctc_layer, compress=True, strategy="avg", arch="conv_transformer",
+          criterion=("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy"), extra=()):
     a = ["/nonexistent", "--user-dir", REF + "/examples/speech_recognition",
          "--task", "speech_translation_with_transcription", "-s", "en", "-t", "de",
-         "--arch", "conv_transformer", "--no-attn-2d", "--input-feat-per-channel", "80",
+         "--arch", arch, "--no-attn-2d", "--input-feat-per-channel", "80",
          "--encoder-embed-dim", str(D), "--decoder-embed-dim", str(D),
          "--decoder-output-dim", str(D),
          "--encoder-ffn-embed-dim", str(Ff), "--decoder-ffn-embed-dim", str(Ff),
          "--encoder-attention-heads", str(H), "--decoder-attention-heads", str(H),
          "--encoder-layers", str(EL), "--decoder-layers", str(DL),
-         "--ctc-encoder-layer", str(ctc_layer), "--ctc-compress-strategy", strategy,
-         "--criterion", "ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy",
-         "--label-smoothing", "0.1", "--max-sentences", "4", "--cpu",
+         "--ctc-compress-strategy", strategy,
+         "--criterion", criterion[0]] + list(criterion[1:]) + list(extra) + [
+         "--max-sentences", "4", "--cpu",
          "--dropout", "0.0", "--attention-dropout", "0.0", "--relu-dropout", "0.0",
          "--max-source-positions", "2000", "--max-target-positions", "1000"]
+    if criterion[0] == "ctc_multi_loss":
+        a += ["--ctc-encoder-layer", str(ctc_layer), "--label-smoothing", "0.1"]
     if compress:
         a.append("--ctc-compress-out")
     args = options.parse_args_and_arch(options.get_training_parser(), input_args=a)
@@ -364,7 +367,73 @@ def run_uer():
     print("uer", e, n)
 
 
+def run_kd_case():
+    """G7a: word-level knowledge distillation (fairseq/criterions/knowledge_distillation.py) on a single-decoder model."""
+    D, H, Ff, EL, DL, seed = 64, 2, 128, 2, 2, 400
+    args, task, model, crit, V_src, V_tgt = build("kd", D, H, Ff, EL, DL, 0, False,
+                                                  criterion=("knowledge_distillation", "--kd-lambda", "0.6", "--kd-temperature", "2.0"))
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt), seed)
+    load_weights(model, crit, W)
+    s = make_sample(seed + 1, [44, 39, 30], [6, 4, 5], [3, 3, 3], V_src, V_tgt, V_src - 1)
+    rs = np.random.RandomState(9)
+    B, L = s["target"].shape
+    Kt = 8
+    tidx = np.stack([[rs.choice(V_tgt, Kt, replace=False) for _ in range(L)] for _ in range(B)]).astype(np.int64)
+    tlog = rs.randn(B, L, Kt).astype(np.float32) * 2
+    sample = to_ref_sample(s)
+    sample["teacher_output"] = [torch.from_numpy(tidx), torch.from_numpy(tlog)]
+    model.train(); crit.train()
+    model.zero_grad()
+    loss, ss, log = crit(model, sample)
+    loss.backward()
+    out = {("in_" + k): v for k, v in s.items() if isinstance(v, np.ndarray)}
+    out.update(in_ntokens=np.int64(s["ntokens"]), teacher_idx=tidx, teacher_logits=tlog,
+               meta=np.array([D, H, Ff, EL, DL, 0, 0, V_src, V_tgt, V_src - 1, seed], np.int64),
+               loss=np.float64(loss.item()), sample_size=np.int64(ss))
+    gn = {k: float((p.grad if p.grad is not None else torch.zeros_like(p)).norm()) for k, p in model.named_parameters()}
+    out["gradnorm_keys"] = np.array(sorted(gn)); out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], np.float64)
+    np.savez_compressed(os.path.join(OUT, "kd.npz"), **out)
+    print("kd loss", loss.item(), ss)
+
+
+def run_dual_case():
+    """G7b: conv_transformer_dualdecoder + cross_entropy_dualdecoder (a18)."""
+    D, H, Ff, EL, DL, seed = 64, 2, 128, 2, 2, 500
+    args, task, model, crit, V_src, V_tgt = build("dual", D, H, Ff, EL, DL, 0, False, arch="conv_transformer_dualdecoder",
+                                                  criterion=("cross_entropy_dualdecoder", "--label-smoothing", "0.1"))
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, V_aux=V_src), seed)
+    load_weights(model, crit, W)
+    s = make_sample(seed + 1, [52, 41, 33], [7, 5, 6], [6, 4, 5], V_src, V_tgt, V_src - 1)
+    sample = to_ref_sample(s)
+    tr = torch.from_numpy(s["transcript_target"]); trl = s["transcript_target_lengths"]
+    prev = torch.full_like(tr, 1)
+    for b in range(tr.shape[0]):
+        l = int(trl[b]); prev[b, 0] = 2; prev[b, 1:l] = tr[b, : l - 1]
+    sample["net_input"]["transcript_prev_output_tokens"] = prev
+    model.train(); crit.train()
+    model.zero_grad()
+    loss, ss, log = crit(model, sample)
+    loss.backward()
+    out = {("in_" + k): v for k, v in s.items() if isinstance(v, np.ndarray)}
+    out.update(in_ntokens=np.int64(s["ntokens"]), in_transcript_prev_output_tokens=prev.numpy(),
+               meta=np.array([D, H, Ff, EL, DL, 0, 0, V_src, V_tgt, V_src - 1, seed], np.int64),
+               loss=np.float64(loss.item()), sample_size=np.int64(ss))
+    for k, v in log.items():
+        out["log_" + k] = np.float64(float(v))
+    with torch.no_grad():
+        (lg, _), (la, _) = model(**sample["net_input"])
+    out["logits"] = lg.numpy(); out["aux_logits"] = la.numpy()
+    gn = {k: float((p.grad if p.grad is not None else torch.zeros_like(p)).norm()) for k, p in model.named_parameters()}
+    out["gradnorm_keys"] = np.array(sorted(gn)); out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], np.float64)
+    np.savez_compressed(os.path.join(OUT, "dual.npz"), **out)
+    print("dual loss", loss.item(), ss, {k: float(v) for k, v in log.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        run_kd_case(); run_dual_case(); sys.exit(0)
     run_ctc_cases()
     run_collate()
     run_uer()

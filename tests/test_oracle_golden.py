@@ -152,3 +152,46 @@ def test_ctc_loss_matches_torch():
     gr, = torch.autograd.grad(ref, l2)
     close(float(mine), float(ref), what="ctc")
     close(gm, gr, what="ctc grad")
+
+
+def _extra_case(name, V_aux=False):
+    g = load_golden(name)
+    D, H, Ff, EL, DL, _, _, V_src, V_tgt, blank, seed = [int(v) for v in g["meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, V_aux=V_src if V_aux else 0), seed)
+    t = lambda k: torch.from_numpy(g["in_" + k])
+    sample = dict(ntokens=int(g["in_ntokens"]), net_input=dict(src_tokens=t("src_tokens"), src_lengths=t("src_lengths"),
+                  prev_output_tokens=t("prev_output_tokens")), target=t("target"), transcript_target=t("transcript_target"),
+                  transcript_target_lengths=t("transcript_target_lengths"))
+    return g, cfg, W, sample
+
+
+def _check_gradnorms(g, Wg):
+    for k, ref in zip([str(k) for k in g["gradnorm_keys"]], g["gradnorm_vals"]):
+        mine = float(Wg[k].grad.norm()) if (k in Wg and Wg[k].grad is not None) else 0.0
+        assert abs(mine - ref) <= 2e-4 * max(1.0, ref), (k, mine, ref)
+
+
+def test_knowledge_distillation_loss():
+    g, cfg, W, sample = _extra_case("kd")
+    Wg = {k: v.clone().requires_grad_("running" not in k) for k, v in W.items()}
+    ni = sample["net_input"]
+    enc, _ = s2t_ref.encoder_forward(Wg, cfg, ni["src_tokens"], ni["src_lengths"], training=True)
+    logits = s2t_ref.decoder_forward(Wg, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+    loss = s2t_ref.kd_loss(logits, sample["target"], torch.from_numpy(g["teacher_idx"]), torch.from_numpy(g["teacher_logits"]), 0.6, 2.0, 1)
+    loss.backward()
+    close(float(loss), float(g["loss"]), what="kd loss")
+    _check_gradnorms(g, Wg)
+
+
+def test_dual_decoder_loss():
+    g, cfg, W, sample = _extra_case("dual", V_aux=True)
+    sample["net_input"]["transcript_prev_output_tokens"] = torch.from_numpy(g["in_transcript_prev_output_tokens"])
+    Wg = {k: v.clone().requires_grad_("running" not in k) for k, v in W.items()}
+    loss, log, lg, la = s2t_ref.dual_decoder_loss(Wg, cfg, sample, 0.1, training=True)
+    loss.backward()
+    close(float(loss), float(g["loss"]), what="dual loss")
+    for k in ("primary_loss", "auxiliary_loss", "primary_nll_loss", "auxiliary_nll_loss"):
+        close(log[k], float(g["log_" + k]), what=k)
+    close(lg, g["logits"], what="logits"); close(la, g["aux_logits"], what="aux logits")
+    _check_gradnorms(g, Wg)
