@@ -221,10 +221,17 @@ class TransformerDecoder(FairseqIncrementalDecoder):
         self.owner._notify_grads_ready(part)
 
     def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, **unused):
-        if incremental_state is not None:
-            raise NotImplementedError("incremental decoding (beam search) is a later row of SURVEY.md 8-a (a22)")
         m = self.owner
         m._ensure_engine(prev_output_tokens.device)
+        if incremental_state is not None:
+            # transformer.py:690-760 with incremental_state: only the last token is embedded, K/V come from the cache.
+            key = "s2t_hip_state.%s" % self.pfx
+            st = incremental_state.get(key)
+            if st is None:
+                st = incremental_state[key] = self.begin_incremental(encoder_out, min(self.max_positions(), 1024))
+            assert st["steps"] == prev_output_tokens.shape[1] - 1, "incremental decoding must advance one token at a time"
+            logits = self.step_incremental(st, prev_output_tokens[:, -1])
+            return logits.unsqueeze(1), {"attn": [None], "inner_states": None}
         eo = encoder_out.encoder_out
         klen = None
         if encoder_out.encoder_padding_mask is not None:
@@ -235,7 +242,36 @@ class TransformerDecoder(FairseqIncrementalDecoder):
         return logits, {"attn": [None], "inner_states": None}
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
-        raise NotImplementedError("use the fused label-smoothed CE kernel (criterions.py); lprobs are never materialised")
+        if self.training:
+            raise NotImplementedError("use the fused label-smoothed CE kernel (criterions.py); lprobs are never materialised")
+        logits = net_output[0]
+        lp = K.log_softmax(logits.reshape(-1, logits.shape[-1]).contiguous()).view(logits.shape)
+        if not log_probs:
+            raise NotImplementedError("probabilities are only needed in log space on this path")
+        return lp
+
+    # ---- incremental decoding: state = per-hypothesis K/V rows owned by the engine
+    def begin_incremental(self, encoder_out, max_steps):
+        if self.training:
+            raise RuntimeError("incremental decoding requires model.eval()")
+        klen = None
+        if encoder_out.encoder_padding_mask is not None:
+            klen = encoder_out.src_lengths.to(torch.int32)
+        with torch.no_grad():
+            return self.engine.decoder_begin(encoder_out.encoder_out.contiguous(), klen, max_steps, pfx=self.pfx)
+
+    def step_incremental(self, state, last_tokens):
+        """last_tokens int64 [N] -> logits [N, V] (row stride padded)."""
+        with torch.no_grad():
+            return self.engine.decoder_step(state, last_tokens)
+
+    def reorder_incremental(self, state, new_order):
+        self.engine.decoder_reorder(state, new_order)
+
+    def reorder_incremental_state(self, incremental_state, new_order):       # transformer.py:840-852
+        st = incremental_state.get("s2t_hip_state.%s" % self.pfx)
+        if st is not None:
+            self.engine.decoder_reorder(st, new_order)
 
     def max_positions(self):
         return self.max_target_positions

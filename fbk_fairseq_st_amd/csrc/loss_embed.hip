@@ -64,11 +64,11 @@ extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, 
 template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ tokens, const T* __restrict__ W,
                                                         const float* __restrict__ table, T* __restrict__ out, int B, int L,
-                                                        int D, float scale, int pad) {
+                                                        int D, float scale, int pad, int pos_offset) {
     __shared__ int pos[1024];
     const int b = blockIdx.x;
     if (threadIdx.x == 0) {
-        int c = 0;
+        int c = pos_offset;                      // incremental decoding: tokens before this slice (transformer.py:714-717)
         for (int l = 0; l < L; ++l) { const bool np = tokens[(long)b * L + l] != pad; c += np; pos[l] = np ? c + pad : pad; }
     }
     __syncthreads();
@@ -89,12 +89,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restr
 }
 
 extern "C" int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float* table, void* out, int B,
-                             int L, int D, float scale, int pad, void* stream) {
+                             int L, int D, float scale, int pad, int pos_offset, void* stream) {
     if (B <= 0 || L <= 0) return S2T_OK;
     if (!tokens || !W || !table || !out || L > 1024) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16>, dim3(B), dim3(256), 0, st, tokens, (const bf16*)W, table, (bf16*)out, B, L, D, scale, pad);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(B), dim3(256), 0, st, tokens, (const float*)W, table, (float*)out, B, L, D, scale, pad);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(embed_fwd_kernel<bf16>, dim3(B), dim3(256), 0, st, tokens, (const bf16*)W, table, (bf16*)out, B, L, D, scale, pad, pos_offset);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(B), dim3(256), 0, st, tokens, (const float*)W, table, (float*)out, B, L, D, scale, pad, pos_offset);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
@@ -245,6 +245,35 @@ extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* targe
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S2T_BF16) hipLaunchKernelGGL(kd_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, target, teacher_idx, teacher_logits, (bf16*)dlogits, sum1, V, ld, Kt, lambda, tau, pad, grad_scale);
     else if (dtype == S2T_F32) hipLaunchKernelGGL(kd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, teacher_idx, teacher_logits, (float*)dlogits, sum1, V, ld, Kt, lambda, tau, pad, grad_scale);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+
+// ------------------------------------------------------------------ log-softmax rows (generation)
+// out[row][v] = log_softmax(logits[row][:] * inv_temperature)[v] in f32
+// (sequence_generator.py:711-768 EnsembleModel.forward_decoder -> get_normalized_probs(log_probs=True))
+template <typename T>
+__global__ __launch_bounds__(256) void log_softmax_kernel(const T* __restrict__ logits, float* __restrict__ out, int V, int ld, float it) {
+    __shared__ float sh[16];
+    const long row = blockIdx.x;
+    const T* x = logits + row * ld;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) m = fmaxf(m, to_f32(x[v]) * it);
+    m = block_max(m, sh);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) s += expf(to_f32(x[v]) * it - m);
+    s = block_sum(s, sh);
+    const float lse = m + logf(s);
+    for (int v = threadIdx.x; v < V; v += 256) out[row * V + v] = to_f32(x[v]) * it - lse;
+}
+extern "C" int s2t_log_softmax(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream) {
+    if (rows <= 0) return S2T_OK;
+    if (!logits || !out || V <= 0 || ld < V) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(log_softmax_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, out, V, ld, inv_temperature);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(log_softmax_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, out, V, ld, inv_temperature);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

@@ -494,6 +494,61 @@ class S2TEngine:
         logits = self.linear(xn, pfx + "output_projection", bias=False, pad_rows=True)   # [L*B, V] time-major rows
         return logits, ctx
 
+    # ------------------------------------------------------------------ incremental decoding (generation)
+    def decoder_begin(self, enc_out, enc_klen32, max_steps, pfx="decoder."):
+        """Per-hypothesis decoding state (fairseq incremental_state, multihead_attention.py:368-440 / transformer.py:690-760):
+        the encoder-side K/V of every layer (computed once: the reference's static_kv) and a ring of fused q|k|v rows
+        `[max_steps][N][3D]` per layer that the step GEMM writes in place (no concat, no copy)."""
+        hp = self.hp
+        Ts, N, D = enc_out.shape
+        enc2d = enc_out.reshape(Ts * N, D)
+        st = dict(pfx=pfx, N=N, Ts=Ts, klen=enc_klen32, kv_enc=[], cache=[], spare=[], steps=0, max_steps=max_steps)
+        for l in range(hp.dec_layers):
+            lp = pfx + "layers.%d." % l
+            st["kv_enc"].append(self.linear(enc2d, lp + "encoder_attn.kv").view(Ts, N, 2 * D))
+            st["cache"].append(torch.empty((max_steps, N, 3 * D), dtype=self.dtype, device=self.dev))
+            st["spare"].append(torch.empty((max_steps, N, 3 * D), dtype=self.dtype, device=self.dev))
+        return st
+
+    def decoder_reorder(self, st, order):
+        """Beam re-ordering of the self-attention caches (transformer.py:840-852 reorder_incremental_state).  The encoder-side
+        K/V are identical for all hypotheses of a sentence and sentences are never compacted here, so they stay put
+        (multihead_attention.py:385-386 makes the same shortcut).  Pure data movement (gather of rows)."""
+        n = st["steps"]
+        if n == 0:
+            return
+        for l in range(len(st["cache"])):
+            torch.index_select(st["cache"][l][:n], 1, order, out=st["spare"][l][:n])
+            st["cache"][l], st["spare"][l] = st["spare"][l], st["cache"][l]
+
+    def decoder_step(self, st, last_tokens):
+        """One decoding step for N hypotheses: last_tokens int64 [N] -> logits [N, V] (row stride padded).
+        Eval mode (no dropout); the same kernels as training with Tq = 1."""
+        hp = self.hp
+        pfx, N, D, step = st["pfx"], st["N"], hp.D, st["steps"]
+        assert step < st["max_steps"]
+        scale = 1.0 if hp.no_scale_embedding else math.sqrt(D)
+        x = K.embed_fwd(last_tokens.view(N, 1).contiguous(), self.W(pfx + "embed_tokens.weight"),
+                        self.table(hp.pad + 2 + st["max_steps"], hp.pad), scale, hp.pad, pos_offset=step).view(N, D)
+        for l in range(hp.dec_layers):
+            lp = pfx + "layers.%d." % l
+            h, _, _ = K.layernorm_fwd(x, self.P(lp + "self_attn_layer_norm.weight"), self.P(lp + "self_attn_layer_norm.bias"), hp.ln_eps)
+            cache = st["cache"][l]
+            K.gemm(h, self.W(lp + "self_attn.qkv.weight"), bias=self.P(lp + "self_attn.qkv.bias"), out=cache[step])
+            ctx, _ = K.attn_fwd(cache[step:step + 1, :, :D], cache[:step + 1, :, D:2 * D], cache[:step + 1, :, 2 * D:], hp.heads)
+            x = self.linear(ctx.view(N, D), lp + "self_attn.out_proj", residual=x)
+            h, _, _ = K.layernorm_fwd(x, self.P(lp + "encoder_attn_layer_norm.weight"), self.P(lp + "encoder_attn_layer_norm.bias"), hp.ln_eps)
+            q = self.linear(h, lp + "encoder_attn.q_proj").view(1, N, D)
+            kv = st["kv_enc"][l]
+            ctx, _ = K.attn_fwd(q, kv[:, :, :D], kv[:, :, D:], hp.heads, klen=st["klen"])
+            x = self.linear(ctx.view(N, D), lp + "encoder_attn.out_proj", residual=x)
+            h, _, _ = K.layernorm_fwd(x, self.P(lp + "final_layer_norm.weight"), self.P(lp + "final_layer_norm.bias"), hp.ln_eps)
+            a = self.linear(h, lp + "fc1", act=self.act_fwd)
+            x = self.linear(a, lp + "fc2", residual=x)
+        xn, _, _ = K.layernorm_fwd(x, self.P(pfx + "layer_norm.weight"), self.P(pfx + "layer_norm.bias"), hp.ln_eps)
+        st["steps"] = step + 1
+        return self.linear(xn, pfx + "output_projection", bias=False, pad_rows=True)
+
     def decoder_backward(self, ctx, dlogits, denc=None):
         """dlogits [L*B, V] (time-major).  Returns the gradient w.r.t. the encoder output [Ts*B, D]
         (accumulated into `denc` when given: second decoder of the dual-decoder model)."""

@@ -278,12 +278,21 @@ def kd_loss(logits, target, teacher_idx, teacher_logits, lam, tau, pad, want_gra
     return s, dl
 
 
-def embed_fwd(tokens, W, table, scale, pad):
+def embed_fwd(tokens, W, table, scale, pad, pos_offset=0):
     B, Ln = tokens.shape
     D = W.shape[1]
     out = torch.empty((Ln, B, D), dtype=W.dtype, device=W.device)
     L.check(_lib().s2t_embed_fwd(L.dt(W), L.ptr(tokens), L.ptr(W), L.ptr(table), L.ptr(out), B, Ln, D, float(scale), pad,
-                                 L.stream()), "s2t_embed_fwd")
+                                 int(pos_offset), L.stream()), "s2t_embed_fwd")
+    return out
+
+
+def log_softmax(logits, temperature=1.0):
+    """[rows,V] (row stride may be padded) -> f32 [rows,V] log-probabilities"""
+    rows, V = logits.shape
+    out = torch.empty((rows, V), dtype=torch.float32, device=logits.device)
+    L.check(_lib().s2t_log_softmax(L.dt(logits), L.ptr(logits), L.ptr(out), rows, V, _row_ld(logits), 1.0 / float(temperature),
+                                   L.stream()), "s2t_log_softmax")
     return out
 
 

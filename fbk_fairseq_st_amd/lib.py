@@ -50,7 +50,8 @@ SIGNATURES = {
     "s2t_ctc_loss": [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P],
     "s2t_lsce": [c_int, P, P, P, P, c_long, c_int, c_int, c_float, c_int, c_float, P],
     "s2t_kd_loss": [c_int, P, P, P, P, P, P, c_long, c_int, c_int, c_int, c_float, c_float, c_int, c_float, P],
-    "s2t_embed_fwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
+    "s2t_embed_fwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P],
+    "s2t_log_softmax": [c_int, P, P, c_long, c_int, c_int, c_float, P],
     "s2t_embed_bwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
     "s2t_act_bwd": [c_int, P, P, P, c_size_t, c_int, P],
     "s2t_add_inplace": [c_int, P, P, c_size_t, P],

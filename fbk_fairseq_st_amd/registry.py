@@ -261,6 +261,25 @@ class FairseqTask(object):                         # fairseq/tasks/fairseq_task.
             loss, sample_size, logging_output = criterion(model, sample)
         return loss, sample_size, logging_output
 
+    def build_generator(self, models, args):
+        """fairseq_task.py:230-313 (beam search only: sampling / diverse search / scoring are outside the S2T path)."""
+        from .sequence_generator import SequenceGenerator
+        for flag in ("score_reference", "sampling", "match_source_len", "print_alignment"):
+            if getattr(args, flag, False):
+                raise NotImplementedError("--%s is outside the S2T hot path" % flag.replace("_", "-"))
+        if getattr(args, "diverse_beam_groups", -1) > 0 or getattr(args, "diversity_rate", -1) > 0:
+            raise NotImplementedError("diverse beam search is outside the S2T hot path")
+        return SequenceGenerator(models, self.target_dictionary, beam_size=getattr(args, "beam", 5),
+                                 max_len_a=getattr(args, "max_len_a", 0), max_len_b=getattr(args, "max_len_b", 200),
+                                 min_len=getattr(args, "min_len", 1), normalize_scores=(not getattr(args, "unnormalized", False)),
+                                 len_penalty=getattr(args, "lenpen", 1), unk_penalty=getattr(args, "unkpen", 0),
+                                 temperature=getattr(args, "temperature", 1.0),
+                                 no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0))
+
+    def inference_step(self, generator, models, sample, prefix_tokens=None):      # fairseq_task.py:392-394
+        with torch.no_grad():
+            return generator.generate(models, sample, prefix_tokens=prefix_tokens)
+
     def max_positions(self):
         return None
 

@@ -1,0 +1,170 @@
+"""Beam-search generation on the HIP incremental decoder.
+
+Mirrors the observable behaviour of the reference's `SequenceGenerator` with `BeamSearch`
+(fairseq/sequence_generator.py:26-600, fairseq/search.py:50-85): same constructor arguments, same
+`generate(models, sample)` result (per sentence a list of hypotheses sorted by score, each a dict with
+`tokens`, `score`, `positional_scores`, `attention`, `alignment`), same candidate rules (2*beam
+candidates per step, EOS only finalised from the top `beam`, length-normalised scores, forced EOS at
+`max_len`, `min_len`, unk penalty, temperature).
+
+Design differences (results identical): finished sentences are masked instead of compacted out of the
+batch, so the decoder state never needs the `batch_idxs` re-indexing and the encoder-side K/V are never
+re-gathered; every floating-point operation of a step (embedding, the six decoder layers with
+in-place K/V rows, output projection, log-softmax) is a libs2t_hip.so kernel; torch is used for the
+integer selection bookkeeping (top-k, gathers of token/score rows) exactly as the reference does.
+Ensembles, sampling, prefix tokens, n-gram blocking and attention/alignment output are not part of this
+path (they raise).
+"""
+import math
+
+import torch
+
+from . import kernels as K
+
+
+class BeamSearch:
+    """fairseq/search.py:50-85: candidates of one step = top 2*beam of (cumulative score + log-prob) over beam x vocab."""
+
+    def __init__(self, tgt_dict):
+        self.pad, self.unk, self.eos = tgt_dict.pad(), tgt_dict.unk(), tgt_dict.eos()
+        self.vocab_size = len(tgt_dict)
+
+    def step(self, step, lprobs, scores):
+        """lprobs f32 [B, beam, V]; scores [B, beam, >=step] cumulative.  Returns (scores, token ids, beam ids), each [B, k]."""
+        B, beam, V = lprobs.shape
+        if step == 0:
+            cand = lprobs[:, 0, :]                                        # all beams are identical copies of <eos>
+        else:
+            cand = (lprobs + scores[:, :, step - 1].unsqueeze(-1)).view(B, beam * V)
+        k = min(2 * beam, cand.shape[1] - 1)                              # -1: pad is never selected (search.py:71-75)
+        top_s, top_i = torch.topk(cand, k)
+        return top_s, top_i % V, top_i // V
+
+
+class SequenceGenerator:
+    def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, min_len=1, normalize_scores=True, len_penalty=1.0,
+                 unk_penalty=0.0, retain_dropout=False, temperature=1.0, match_source_len=False, no_repeat_ngram_size=0,
+                 search_strategy=None, eos=None):
+        self.models = list(models) if isinstance(models, (list, tuple)) else [models]
+        if len(self.models) != 1:
+            raise NotImplementedError("ensembles are outside the S2T hot path")
+        self.pad, self.unk = tgt_dict.pad(), tgt_dict.unk()
+        self.eos = tgt_dict.eos() if eos is None else eos
+        self.vocab_size = len(tgt_dict)
+        self.beam_size = min(beam_size, self.vocab_size - 1)              # sequence_generator.py:69
+        self.max_len_a, self.max_len_b, self.min_len = max_len_a, max_len_b, min_len
+        self.normalize_scores, self.len_penalty, self.unk_penalty = normalize_scores, len_penalty, unk_penalty
+        self.temperature = temperature
+        assert temperature > 0, "--temperature must be greater than 0"
+        if match_source_len or no_repeat_ngram_size > 0 or retain_dropout:
+            raise NotImplementedError("match_source_len / no_repeat_ngram_size / retain_dropout are outside the S2T hot path")
+        self.search = BeamSearch(tgt_dict) if search_strategy is None else search_strategy
+
+    # ------------------------------------------------------------------ API of the reference
+    @torch.no_grad()
+    def generate(self, models, sample, prefix_tokens=None, bos_token=None, **unused):
+        if prefix_tokens is not None:
+            raise NotImplementedError("prefix_tokens")
+        model = self.models[0]                                            # the reference also ignores `models` here (:149-161)
+        was_training = model.training
+        model.eval()                                                      # sequence_generator.py:86-87
+        try:
+            return self._generate(model, sample, bos_token)
+        finally:
+            model.train(was_training)
+
+    def _generate(self, model, sample, bos_token):
+        net_input = sample["net_input"]
+        src_tokens = net_input["src_tokens"]
+        dev = src_tokens.device
+        B, src_len = src_tokens.shape[0], src_tokens.shape[1]
+        beam, V = self.beam_size, self.vocab_size
+        max_len = min(int(self.max_len_a * src_len + self.max_len_b), model.max_decoder_positions() - 1)
+        assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
+
+        enc = model.encoder.forward_non_torchscript(net_input)
+        order0 = torch.arange(B, device=dev).repeat_interleave(beam)
+        enc = model.encoder.reorder_encoder_out(enc, order0)              # one copy of the encoder output per hypothesis
+        state = model.decoder.begin_incremental(enc, max_len + 1)
+
+        N = B * beam
+        scores = torch.zeros((N, max_len + 1), dtype=torch.float32, device=dev)
+        tokens = torch.full((N, max_len + 2), self.pad, dtype=torch.int64, device=dev)
+        tokens[:, 0] = self.eos if bos_token is None else bos_token
+        blacklist = torch.zeros((B, beam), dtype=torch.bool, device=dev)
+        done = torch.zeros((B,), dtype=torch.bool, device=dev)           # sentence already has `beam` hypotheses
+        finalized = [[] for _ in range(B)]
+        finished = [False] * B
+        cand_size = 2 * beam
+        row0 = (torch.arange(B, device=dev) * beam).unsqueeze(1)
+        cand_rank = torch.arange(cand_size, device=dev)
+
+        reorder = None
+        for step in range(max_len + 1):                                   # one extra step for the EOS marker
+            if reorder is not None:
+                model.decoder.reorder_incremental(state, reorder)
+            logits = model.decoder.step_incremental(state, tokens[:, step])
+            lprobs = K.log_softmax(logits, self.temperature)              # f32 [N, V]
+            lprobs[lprobs != lprobs] = -math.inf
+            lprobs[:, self.pad] = -math.inf
+            lprobs[:, self.unk] -= self.unk_penalty
+            if step >= max_len:
+                lprobs[:, :self.eos] = -math.inf
+                lprobs[:, self.eos + 1:] = -math.inf
+            elif step < self.min_len:
+                lprobs[:, self.eos] = -math.inf
+
+            cand_scores, cand_tok, cand_beam = self.search.step(step, lprobs.view(B, beam, V), scores.view(B, beam, -1))
+            k = cand_scores.shape[1]
+            cand_row = cand_beam + row0                                    # row of the parent hypothesis in tokens/scores
+
+            eos_mask = cand_tok.eq(self.eos) & cand_scores.ne(-math.inf)
+            eos_mask[:, :beam] &= ~blacklist
+            top_eos = eos_mask[:, :beam] & ~done.unsqueeze(1)
+            if bool(top_eos.any()):                                        # the step's only host sync
+                self._finalize(step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len)
+                done = torch.tensor(finished, device=dev)
+                if all(finished):
+                    break
+            assert step < max_len
+
+            # next beam = the first `beam` candidates (rank order) that are not EOS; slots that could only be filled by an
+            # EOS candidate are black-listed for the next step (sequence_generator.py:417-446)
+            eos_mask[:, :beam] |= blacklist
+            key = eos_mask.to(torch.int64) * cand_size + cand_rank[:k]
+            key_top, pick = torch.topk(key, beam, dim=1, largest=False)
+            blacklist = key_top.ge(cand_size)
+            parent = torch.gather(cand_row, 1, pick).view(-1)
+            tokens[:, :step + 1] = tokens.index_select(0, parent)[:, :step + 1]
+            tokens[:, step + 1] = torch.gather(cand_tok, 1, pick).view(-1)
+            if step > 0:
+                scores[:, :step] = scores.index_select(0, parent)[:, :step]
+            scores[:, step] = torch.gather(cand_scores, 1, pick).view(-1)
+            reorder = parent
+
+        out = []
+        for hyps in finalized:                                             # sequence_generator.py:486-496: best first
+            idx = sorted(range(len(hyps)), key=lambda i: hyps[i]["score"].item())
+            out.append([hyps[i] for i in reversed(idx)])
+        return out
+
+    def _finalize(self, step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len):
+        """sequence_generator.py:502-600 finalize_hypos: hypotheses ending in EOS among the top `beam` candidates."""
+        beam = self.beam_size
+        sent, rank = top_eos.nonzero(as_tuple=True)                       # row-major: sentence ascending, rank ascending
+        rows = cand_row[sent, rank]
+        eos_s = cand_scores[sent, rank]
+        toks = tokens.index_select(0, rows)[:, 1:step + 2].clone()
+        toks[:, step] = self.eos
+        pos = scores.index_select(0, rows)[:, :step + 1].clone()
+        pos[:, step] = eos_s
+        pos[:, 1:] = pos[:, 1:] - pos[:, :-1]
+        if self.normalize_scores:
+            eos_s = eos_s / (step + 1) ** self.len_penalty
+        for i, s in enumerate(sent.tolist()):
+            if len(finalized[s]) < beam:
+                finalized[s].append({"tokens": toks[i], "score": eos_s[i], "attention": None, "alignment": None,
+                                     "positional_scores": pos[i]})
+        for s in set(sent.tolist()):
+            if not finished[s] and (len(finalized[s]) == beam or step == max_len):
+                finished[s] = True

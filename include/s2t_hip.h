@@ -160,7 +160,9 @@ int s2t_kd_loss(int dtype, const void* logits, const long long* target, const lo
 
 /* ---- decoder embedding (fairseq/models/transformer.py:720-737) -------------------------------------- */
 int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float* table, void* out,
-                  int B, int L, int D, float scale, int pad, void* stream);
+                  int B, int L, int D, float scale, int pad, int pos_offset, void* stream);
+/* f32 log-probabilities of one decoding step (fairseq/sequence_generator.py:711-768) */
+int s2t_log_softmax(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream);
 int s2t_embed_bwd(int dtype, const long long* tokens, const void* dout, float* dW, int B, int L, int D,
                   float scale, int pad, void* stream);
 /* out = dy * act'(y): act 1 = relu (y = post-activation), act 2 = gelu (y = pre-activation) */

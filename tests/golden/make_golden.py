@@ -431,7 +431,51 @@ def run_dual_case():
     print("dual loss", loss.item(), ss, {k: float(v) for k, v in log.items()})
 
 
+def run_generate_case():
+    """G9: beam search (fairseq/sequence_generator.py + search.py BeamSearch) on eval-mode models with deterministic weights."""
+    from fairseq.sequence_generator import SequenceGenerator
+    out = {}
+    cases = [("a", dict(D=64, H=2, Ff=128, EL=3, DL=2, ctc_layer=2, compress=True, seed=600, lens=[61, 50, 37]),
+              dict(beam_size=5, max_len_a=0, max_len_b=12, min_len=1)),
+             ("b", dict(D=64, H=2, Ff=128, EL=2, DL=2, ctc_layer=0, compress=False, seed=700, lens=[48, 48]),
+              dict(beam_size=3, max_len_a=0.1, max_len_b=5, min_len=2, len_penalty=0.6, unk_penalty=0.5, temperature=1.5))]
+    for tag, m, g in cases:
+        crit = ("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy") if m["compress"] else \
+               ("label_smoothed_cross_entropy", "--label-smoothing", "0.1")
+        args, task, model, criterion, V_src, V_tgt = build("gen" + tag, m["D"], m["H"], m["Ff"], m["EL"], m["DL"], m["ctc_layer"],
+                                                           m["compress"], criterion=crit)
+        cfg = s2t_ref.default_cfg(D=m["D"], heads=m["H"], ffn=m["Ff"], enc_layers=m["EL"], dec_layers=m["DL"],
+                                  ctc_layer=m["ctc_layer"] if m["compress"] else 0)
+        W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=m["compress"]), m["seed"])
+        W["decoder.output_projection.weight"][2] *= 4.0          # make <eos> competitive so hypotheses end at different steps
+        load_weights(model, criterion, W)
+        s = make_sample(m["seed"] + 1, m["lens"], [4] * len(m["lens"]), [3] * len(m["lens"]), V_src, V_tgt, V_src - 1)
+        sample = to_ref_sample(s)
+        model.eval()
+        gen = SequenceGenerator([model], task.target_dictionary, **g)
+        hyps = gen.generate([model], sample)
+        B, beam = len(hyps), g["beam_size"]
+        Lmax = max(len(h["tokens"]) for hs in hyps for h in hs)
+        tok = np.full((B, beam, Lmax), -1, np.int64); sc = np.full((B, beam), np.nan, np.float64)
+        ps = np.zeros((B, beam, Lmax), np.float32); nh = np.zeros((B,), np.int64)
+        for b, hs in enumerate(hyps):
+            nh[b] = len(hs)
+            for i, h in enumerate(hs):
+                n = len(h["tokens"])
+                tok[b, i, :n] = h["tokens"].numpy(); sc[b, i] = float(h["score"]); ps[b, i, :n] = h["positional_scores"].numpy()
+        out.update({tag + "_src_tokens": s["src_tokens"], tag + "_src_lengths": s["src_lengths"],
+                    tag + "_tokens": tok, tag + "_scores": sc, tag + "_pos_scores": ps, tag + "_nhyp": nh,
+                    tag + "_meta": np.array([m["D"], m["H"], m["Ff"], m["EL"], m["DL"], m["ctc_layer"], int(m["compress"]), V_src, V_tgt,
+                                             V_src - 1, m["seed"]], np.int64),
+                    tag + "_gen": np.array([g["beam_size"], g["max_len_a"], g["max_len_b"], g["min_len"], g.get("len_penalty", 1.0),
+                                            g.get("unk_penalty", 0.0), g.get("temperature", 1.0)], np.float64)})
+        print("gen", tag, [[(len(h["tokens"]), round(float(h["score"]), 4)) for h in hs] for hs in hyps])
+    np.savez_compressed(os.path.join(OUT, "generate.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "generate":
+        run_generate_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         run_kd_case(); run_dual_case(); sys.exit(0)
     run_ctc_cases()

@@ -30,3 +30,25 @@ def model_case(name):
         ctc_encoder_layer=ctc_layer)
     return g, cfg, W, sample, dict(V_src=V_src, V_tgt=V_tgt, blank=blank, seed=seed,
                                    ctc_layer=ctc_layer, compress=bool(compress))
+
+
+def generate_case(tag):
+    """cfg, weights, inputs, generator options and expected hypotheses of fixture generate.npz (case `a` or `b`)."""
+    g = load_golden("generate")
+    D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed = [int(v) for v in g[tag + "_meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer if compress else 0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=bool(compress)), seed)
+    W["decoder.output_projection.weight"][2] *= 4.0                 # as make_golden.run_generate_case
+    beam, la, lb, mn, lenpen, unkpen, temp = [float(v) for v in g[tag + "_gen"]]
+    opts = dict(beam_size=int(beam), max_len_a=la, max_len_b=int(lb), min_len=int(mn), len_penalty=lenpen, unk_penalty=unkpen,
+                temperature=temp)
+    exp = []
+    for b in range(g[tag + "_tokens"].shape[0]):
+        hs = []
+        for i in range(int(g[tag + "_nhyp"][b])):
+            t = g[tag + "_tokens"][b, i]
+            n = int((t >= 0).sum())
+            hs.append((t[:n], float(g[tag + "_scores"][b, i]), g[tag + "_pos_scores"][b, i, :n]))
+        exp.append(hs)
+    meta = dict(V_src=V_src, V_tgt=V_tgt, blank=blank, seed=seed, ctc_layer=ctc_layer, compress=bool(compress))
+    return cfg, W, torch.from_numpy(g[tag + "_src_tokens"]), torch.from_numpy(g[tag + "_src_lengths"]), opts, exp, meta

@@ -231,3 +231,93 @@ def test_dual_decoder_matches_reference():
         (lg, _), (la, _) = model(**sample["net_input"])
     close(lg, g["logits"], 1e-4, "logits"); close(la, g["aux_logits"], 1e-4, "aux logits")
     _check_gradnorms_gpu(g, model)
+
+
+# ---------------------------------------------------------------------------------------------- generation (a22)
+def build_gen(tag, dtype=torch.float32):
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import namespace
+    from helpers import generate_case
+    cfg, W, src, lens, opts, exp, meta = generate_case(tag)
+    crit = dict(criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy") if meta["compress"] else \
+        dict(criterion="label_smoothed_cross_entropy")
+    args = namespace(arch="conv_transformer", label_smoothing=0.1, ctc_compress_out=meta["compress"],
+                     ctc_encoder_layer=meta["ctc_layer"], ctc_weight=1.0,
+                     encoder_embed_dim=cfg["D"], encoder_ffn_embed_dim=cfg["ffn"], encoder_attention_heads=cfg["heads"],
+                     encoder_layers=cfg["enc_layers"], decoder_layers=cfg["dec_layers"], no_attn_2d=True,
+                     decoder_embed_dim=cfg["D"], decoder_ffn_embed_dim=cfg["ffn"], decoder_attention_heads=cfg["heads"],
+                     input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0,
+                     sentence_avg=False, max_target_positions=1000, **crit)
+    tgt, sd = Dictionary.synthetic(96), Dictionary.synthetic(59)
+    sd.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationCTCTask(args, tgt, sd)
+    model = task.build_model(args)
+    model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+    model.materialize(DEV, dtype)
+    model.eval()
+    return task, model, src.to(DEV), lens.to(DEV), opts, exp, (cfg, W)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_incremental_decoder_matches_full_decoder(tag):
+    """transformer.py:690-760: feeding tokens one at a time through the K/V cache gives the teacher-forced logits."""
+    task, model, src, lens, opts, exp, _ = build_gen(tag)
+    B, L = src.shape[0], 7
+    rs = np.random.RandomState(3)
+    prev = torch.from_numpy(np.concatenate([np.full((B, 1), 2), rs.randint(4, 96, size=(B, L - 1))], 1)).to(DEV)
+    with torch.no_grad():
+        eo = model.encoder(src, lens)
+        full, _ = model.decoder(prev, encoder_out=eo)
+        inc = {}
+        for t in range(L):
+            step, _ = model.decoder(prev[:, :t + 1], encoder_out=eo, incremental_state=inc)
+            close(step[:, 0], full[:, t].cpu().numpy(), 1e-4, "step %d" % t)
+        # beam re-ordering of the cache: two hypotheses per sentence with different prefixes, swapped after 3 steps
+        dup = torch.arange(B, device=DEV).repeat_interleave(2)
+        eo2 = model.encoder.reorder_encoder_out(eo, dup)
+        prev2 = prev[dup].clone()
+        prev2[1::2, 1:] = torch.from_numpy(rs.randint(4, 96, size=(B, L - 1))).to(DEV)
+        full2, _ = model.decoder(prev2, encoder_out=eo2)
+        st = model.decoder.begin_incremental(eo2, L)
+        for t in range(3):
+            model.decoder.step_incremental(st, prev2[:, t])
+        swap = torch.arange(2 * B, device=DEV).view(B, 2).flip(1).reshape(-1)
+        model.decoder.reorder_incremental(st, swap)
+        out = model.decoder.step_incremental(st, prev2[swap, 3])
+        close(out, full2[swap, 3].cpu().numpy(), 1e-4, "after reorder")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_beam_search_matches_reference_generator(tag):
+    """G9: the HIP generator reproduces the hypotheses of fairseq's SequenceGenerator (tokens exact, scores 1e-4)
+    and agrees with the CPU oracle restatement."""
+    from fbk_fairseq_st_amd.sequence_generator import SequenceGenerator
+    task, model, src, lens, opts, exp, (cfg, W) = build_gen(tag)
+    gen = SequenceGenerator([model], task.target_dictionary, **opts)
+    hyps = gen.generate([model], dict(net_input=dict(src_tokens=src, src_lengths=lens)))
+    orc = s2t_ref.beam_search(W, cfg, src.cpu(), lens.cpu(), opts["beam_size"], opts["max_len_a"], opts["max_len_b"], opts["min_len"],
+                              opts["len_penalty"], opts["unk_penalty"], opts["temperature"])
+    assert len(hyps) == len(exp)
+    for hs, es, os_ in zip(hyps, exp, orc):
+        assert len(hs) == len(es)
+        for h, (et, esc, eps), (ot, osc, ops) in zip(hs, es, os_):
+            assert h["tokens"].tolist() == et.tolist() == ot.tolist()
+            assert abs(float(h["score"]) - esc) < 1e-4 and abs(float(h["score"]) - osc) < 1e-4
+            np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), eps, atol=1e-4)
+
+
+def test_beam_search_bf16_runs_and_is_consistent():
+    """bf16 engine: hypotheses are well-formed (end in eos, sorted, positional scores sum to the unnormalised score)."""
+    from fbk_fairseq_st_amd.sequence_generator import SequenceGenerator
+    task, model, src, lens, opts, exp, _ = build_gen("a", torch.bfloat16)
+    gen = SequenceGenerator([model], task.target_dictionary, **opts)
+    hyps = gen.generate([model], dict(net_input=dict(src_tokens=src, src_lengths=lens)))
+    for hs in hyps:
+        assert len(hs) == opts["beam_size"]
+        sc = [float(h["score"]) for h in hs]
+        assert sc == sorted(sc, reverse=True)
+        for h in hs:
+            assert int(h["tokens"][-1]) == 2 and not bool((h["tokens"][:-1] == 2).any())
+            n = h["tokens"].numel()
+            assert abs(float(h["positional_scores"].sum()) / n ** opts["len_penalty"] - float(h["score"])) < 1e-3

@@ -195,3 +195,19 @@ def test_dual_decoder_loss():
         close(log[k], float(g["log_" + k]), what=k)
     close(lg, g["logits"], what="logits"); close(la, g["aux_logits"], what="aux logits")
     _check_gradnorms(g, Wg)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_beam_search_matches_reference_generator(tag):
+    """G9: hypotheses (tokens exact, scores 1e-4) of the reference SequenceGenerator, fairseq/sequence_generator.py."""
+    from helpers import generate_case
+    cfg, W, src, lens, o, exp, _ = generate_case(tag)
+    got = s2t_ref.beam_search(W, cfg, src, lens, o["beam_size"], o["max_len_a"], o["max_len_b"], o["min_len"], o["len_penalty"],
+                              o["unk_penalty"], o["temperature"])
+    assert len(got) == len(exp)
+    for hs, es in zip(got, exp):
+        assert len(hs) == len(es)
+        for (t, s, ps), (et, es_, eps) in zip(hs, es):
+            assert t.tolist() == et.tolist()
+            assert abs(s - es_) < 1e-4
+            np.testing.assert_allclose(ps.numpy(), eps, atol=1e-4)
