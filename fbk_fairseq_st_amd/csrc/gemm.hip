@@ -267,7 +267,7 @@ template <typename T, int COLS> struct FastTrans {
         for (int i = 0; i < N; ++i) {
             const int it = min((int)threadIdx.x + 256 * i, ITEMS - 1);
             const int kq = it % NKQ, cg = it / NKQ;
-            const int gc = min(col0 + cg * E, ncols - E);
+            const int gc = min(col0 + cg * E, (ncols + E - 1) / E * E - E);   // the last chunk may hang over into the row padding (ld >= roundup(ncols))
             ptr[i] = g + (size_t)(k0 + 4 * kq) * ld + gc;
         }
     }
@@ -400,8 +400,9 @@ static bool fast_ok(const GemmArgs& a) {
     if ((a.lda % E) || (a.ldb % E) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return false;
     const size_t rowsA = TA ? (size_t)a.K : (size_t)a.M, rowsB = TB ? (size_t)a.K : (size_t)a.N;
     if (rowsA * a.lda * sizeof(TI) >= (1ull << 32) || rowsB * a.ldb * sizeof(TI) >= (1ull << 32)) return false;   // 32-bit offsets
-    if (TA && (a.M % E || a.M < E)) return false;          // transposed operands: whole 16-byte column chunks only
-    if (TB && (a.N % E || a.N < E)) return false;
+    // transposed operands are read in whole 16-byte column chunks: the last one may cover row padding, never the next row
+    if (TA && (a.M < E || (a.M + E - 1) / E * E > a.lda)) return false;
+    if (TB && (a.N < E || (a.N + E - 1) / E * E > a.ldb)) return false;
     return true;
 }
 
@@ -454,6 +455,22 @@ extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int tra
     if (mapA && (trans_a || periodA <= 0 || periodA % 8)) return S2T_EINVAL;
     if (mapB && !trans_b) return S2T_EINVAL;
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && splitk > 1)) return S2T_EINVAL;
+    {   // K tail (e.g. K = V_src = 5001 in the CTC head's data gradient): whole k-tiles go through the fast kernel, the
+        // remainder is accumulated by a second, tiny launch instead of sending the whole product down the guarded path
+        const int BKe = in_dtype == S2T_BF16 ? 64 : 32, tail = K % BKe;
+        if (tail && K >= 8 * BKe && !mapA && !mapB && !mapC && splitk == 1 && !bias && !residual && !aux && !aux_out &&
+            act == ACT_NONE && p_drop == 0.f) {
+            const size_t es = in_dtype == S2T_BF16 ? 2 : 4;
+            const int Km = K - tail;
+            int rc = s2t_gemm_gather(in_dtype, out_dtype, trans_a, trans_b, M, N, Km, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0,
+                                     nullptr, nullptr, 0, ACT_NONE, accumulate, 1, alpha, nullptr, 0, nullptr, nullptr, 0.f, 0ull, stream);
+            if (rc != S2T_OK) return rc;
+            const char* At = (const char*)A + (trans_a ? (size_t)Km * lda : (size_t)Km) * es;
+            const char* Bt = (const char*)B + (trans_b ? (size_t)Km * ldb : (size_t)Km) * es;
+            return s2t_gemm_gather(in_dtype, out_dtype, trans_a, trans_b, M, N, tail, At, lda, Bt, ldb, C, ldc, nullptr, nullptr, 0,
+                                   nullptr, nullptr, 0, ACT_NONE, 1, 1, alpha, nullptr, 0, nullptr, nullptr, 0.f, 0ull, stream);
+        }
+    }
     GemmArgs a{A, B, C, bias, residual, aux, aux_out, M, N, K, lda, ldb, ldc, ldr, ldaux, act, accumulate, splitk, alpha,
                mapA, periodA, mapB, mapC, p_drop, seed, 0};
     { static const char* e = getenv("S2T_GEMM_DBG"); if (e) a.dbg = atoi(e); }

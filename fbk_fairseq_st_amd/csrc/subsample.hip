@@ -12,95 +12,155 @@
 //     k = c*F4+f (conv_transformer.py:225-226) to k' = f*C+c (permute kernels below).
 #include "common.hpp"
 
+// ------------------------------------------------------------------ 8-channel vectors
+// Every HBM-bound kernel of this file gives a thread 8 consecutive channels of one pixel (one 16-byte bf16 access),
+// so a wavefront instruction moves 1 KiB and a pixel is spread over LP = C/8 lanes; per-channel reductions first
+// fold the lanes of a wave that own the same channel group (xor shuffles LP, 2LP, .. 32), then the four waves
+// through LDS, then one atomic per channel per workgroup.
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&v)[8]) {
+    bf16 t[8];
+    *reinterpret_cast<u32x4*>(t) = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float (&v)[8]) {
+    bf16 t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16)v[e];
+    *reinterpret_cast<u32x4*>(p) = *reinterpret_cast<const u32x4*>(t);
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ float group_sum(float v, int LP) {          // over the lanes of a wave with equal lane % LP
+    for (int o = LP; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// per-channel pair of sums (s1, s2) of a workgroup of 256 threads -> sums[c] += s1, sums[C+c] += s2 (double atomics)
+__device__ __forceinline__ void chan_pair_reduce(float (&s1)[8], float (&s2)[8], int LP, int g, double* sums, int C,
+                                                 float (*red)[16][16]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = group_sum(s1[e], LP); s2[e] = group_sum(s2[e], LP); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < LP) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[wave][g][e] = s1[e]; red[wave][g][8 + e] = s2[e]; }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        const int which = t / C, c = t % C;
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) a += (double)red[w][c >> 3][which * 8 + (c & 7)];
+        atomicAdd(sums + which * C + c, a);
+    }
+}
+// the 3x3 stride-2 window of output pixel (b, t2, f2) over x[b][Tin][F] (zero padding 1), branch-free
+__device__ __forceinline__ void conv1_window(const float* __restrict__ x, int b, int t2, int f2, int Tin, int F, float (&xv)[9]) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int t = 2 * t2 + kh - 1;
+        const bool okt = (t >= 0) && (t < Tin);
+        const float* xr = x + ((long)b * Tin + min(max(t, 0), Tin - 1)) * F;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int f = 2 * f2 + kw - 1;
+            const float v = xr[min(max(f, 0), F - 1)];
+            xv[kh * 3 + kw] = (okt && f >= 0 && f < F) ? v : 0.f;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ conv1 forward (+ BN statistics)
 // x [B][T][F] f32 -> y [B][T2][F2][C] T, y = relu(conv(x)+bias); sums[c] += y, sums[C+c] += y^2 (double)
 template <typename T>
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 4) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y,
                                                         double* __restrict__ sums, int B, int Tin, int F, int T2,
                                                         int F2, int C, int pos_per_block) {
-    __shared__ float red[2][256];
-    const int c = threadIdx.x % C, slot = threadIdx.x / C, nslot = 256 / C;
-    float wr[9];
+    __shared__ float red[4][16][16];
+    const int LP = C >> 3, g = threadIdx.x % LP, slot = threadIdx.x / LP, nslot = 256 / LP;
+    float wr[8][9], bc[8];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) wr[i] = w[c * 9 + i];
-    const float bc = bias[c];
-    const long P = (long)B * T2 * F2;
-    const long p0 = (long)blockIdx.x * pos_per_block;
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = slot; i < pos_per_block; i += nslot) {
-        const long p = p0 + i;
-        if (p >= P) break;
-        const int f2 = (int)(p % F2), t2 = (int)((p / F2) % T2), b = (int)(p / ((long)F2 * T2));
-        float acc = bc;
+    for (int e = 0; e < 8; ++e) {
+        bc[e] = bias[8 * g + e];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int t = 2 * t2 + kh - 1;
-            if (t < 0 || t >= Tin) continue;
-            const float* xr = x + ((long)b * Tin + t) * F;
+        for (int i = 0; i < 9; ++i) wr[e][i] = w[(8 * g + e) * 9 + i];
+    }
+    const unsigned P = (unsigned)B * T2 * F2;
+    const unsigned p0 = blockIdx.x * (unsigned)pos_per_block, pend = min(P, p0 + (unsigned)pos_per_block);
+    float s1[8], s2[8];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int f = 2 * f2 + kw - 1;
-                if (f >= 0 && f < F) acc += xr[f] * wr[kh * 3 + kw];
-            }
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    for (unsigned p = p0 + slot; p < pend; p += nslot) {
+        const unsigned r = p / (unsigned)F2;
+        const int f2 = (int)(p - r * F2), t2 = (int)(r % (unsigned)T2), b = (int)(r / (unsigned)T2);
+        float xv[9], o[8];
+        conv1_window(x, b, t2, f2, Tin, F, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float acc = bc[e];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc += xv[i] * wr[e][i];
+            o[e] = to_f32(from_f32<T>(fmaxf(acc, 0.f)));           // statistics of the value that is stored
+            s1[e] += o[e]; s2[e] += o[e] * o[e];
         }
-        acc = fmaxf(acc, 0.f);
-        const T o = from_f32<T>(acc);
-        y[p * C + c] = o;
-        const float r = to_f32(o);
-        s1 += r; s2 += r * r;
+        store8<T>(y + (size_t)p * C + 8 * g, o);
     }
-    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
-    __syncthreads();
-    if (slot == 0) {
-        double a = 0.0, q = 0.0;
-        for (int s = 0; s < nslot; ++s) { a += red[0][s * C + c]; q += red[1][s * C + c]; }
-        atomicAdd(sums + c, a);
-        atomicAdd(sums + C + c, q);
-    }
+    chan_pair_reduce(s1, s2, LP, g, sums, C, red);
 }
 
 // ------------------------------------------------------------------ conv1 backward (weights, bias)
 // dpre [B][T2][F2][C] T (gradient w.r.t. conv1 + bias, i.e. after the ReLU mask)
 template <typename T>
-__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dpre,
+__global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dpre,
                                                         float* __restrict__ dw, float* __restrict__ db, int B,
                                                         int Tin, int F, int T2, int F2, int C, int pos_per_block) {
-    __shared__ float red[10][256];
-    const int c = threadIdx.x % C, slot = threadIdx.x / C, nslot = 256 / C;
-    float a[10];
+    __shared__ float red[4][16][80];
+    const int LP = C >> 3, g = threadIdx.x % LP, slot = threadIdx.x / LP, nslot = 256 / LP;
+    float a[8][10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) a[i] = 0.f;
-    const long P = (long)B * T2 * F2;
-    const long p0 = (long)blockIdx.x * pos_per_block;
-    for (int i = slot; i < pos_per_block; i += nslot) {
-        const long p = p0 + i;
-        if (p >= P) break;
-        const int f2 = (int)(p % F2), t2 = (int)((p / F2) % T2), b = (int)(p / ((long)F2 * T2));
-        const float g = to_f32(dpre[p * C + c]);
-        a[9] += g;
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int t = 2 * t2 + kh - 1;
-            if (t < 0 || t >= Tin) continue;
-            const float* xr = x + ((long)b * Tin + t) * F;
+        for (int i = 0; i < 10; ++i) a[e][i] = 0.f;
+    const unsigned P = (unsigned)B * T2 * F2;
+    const unsigned p0 = blockIdx.x * (unsigned)pos_per_block, pend = min(P, p0 + (unsigned)pos_per_block);
+    for (unsigned p = p0 + slot; p < pend; p += nslot) {
+        const unsigned r = p / (unsigned)F2;
+        const int f2 = (int)(p - r * F2), t2 = (int)(r % (unsigned)T2), b = (int)(r / (unsigned)T2);
+        float xv[9], gq[8];
+        load8<T>(dpre + (size_t)p * C + 8 * g, gq);
+        conv1_window(x, b, t2, f2, Tin, F, xv);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int f = 2 * f2 + kw - 1;
-                if (f >= 0 && f < F) a[kh * 3 + kw] += g * xr[f];
-            }
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[e][i] += gq[e] * xv[i];
+            a[e][9] += gq[e];
         }
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) red[i][threadIdx.x] = a[i];
-    __syncthreads();
-    if (slot == 0) {
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            float s = 0.f;
-            for (int k = 0; k < nslot; ++k) s += red[i][k * C + c];
-            if (i < 9) atomicAdd(dw + c * 9 + i, s); else atomicAdd(db + c, s);
+            const float v = group_sum(a[e][i], LP);
+            if (lane < LP) red[wave][g][e * 10 + i] = v;
         }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 10 * C; t += 256) {
+        const int c = t / 10, i = t % 10;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) v += red[wv][c >> 3][(c & 7) * 10 + i];
+        if (i < 9) atomicAdd(dw + c * 9 + i, v); else atomicAdd(db + c, v);
     }
 }
 
@@ -112,26 +172,27 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ y,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         double* __restrict__ sums, long P, int C, int mode,
                                                         int pos_per_block) {
-    __shared__ float red[2][256];
-    const int c = threadIdx.x % C, slot = threadIdx.x / C, nslot = 256 / C;
+    __shared__ float red[4][16][16];
+    const int LP = C >> 3, g = threadIdx.x % LP, slot = threadIdx.x / LP, nslot = 256 / LP;
     const long p0 = (long)blockIdx.x * pos_per_block;
-    float s1 = 0.f, s2 = 0.f;
-    const float mu = mode ? mean[c] : 0.f, rs = mode ? rstd[c] : 0.f;
-    for (int i = slot; i < pos_per_block; i += nslot) {
-        const long p = p0 + i;
-        if (p >= P) break;
-        const float v = to_f32(y[p * C + c]);
-        if (mode == 0) { s1 += v; s2 += v * v; }
-        else { const float d = to_f32(dyn[p * C + c]); s1 += d; s2 += d * (v - mu) * rs; }
+    const long pend = min(P, p0 + (long)pos_per_block);
+    float s1[8], s2[8], mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = s2[e] = 0.f; mu[e] = mode ? mean[8 * g + e] : 0.f; rs[e] = mode ? rstd[8 * g + e] : 0.f; }
+    for (long p = p0 + slot; p < pend; p += nslot) {
+        float v[8];
+        load8<T>(y + p * C + 8 * g, v);
+        if (mode == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+        } else {
+            float d[8];
+            load8<T>(dyn + p * C + 8 * g, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += d[e]; s2[e] += d[e] * (v[e] - mu[e]) * rs[e]; }
+        }
     }
-    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
-    __syncthreads();
-    if (slot == 0) {
-        double a = 0.0, q = 0.0;
-        for (int s = 0; s < nslot; ++s) { a += red[0][s * C + c]; q += red[1][s * C + c]; }
-        atomicAdd(sums + c, a);
-        atomicAdd(sums + C + c, q);
-    }
+    chan_pair_reduce(s1, s2, LP, g, sums, C, red);
 }
 
 // ------------------------------------------------------------------ BatchNorm finalize
@@ -160,13 +221,22 @@ __global__ void bn_finalize_kernel(const double* sums, const float* gamma, const
     shift[c] = beta[c] - mu * gamma[c] * rs;
 }
 
-// yn = y*scale[c] + shift[c]   ([P][C], c contiguous)
+// yn = y*scale[c] + shift[c]   ([P][C], c contiguous): 8 channels per thread; the grid stride is a multiple of C/8
+// vectors, so a thread keeps its channel group (scale/shift stay in registers)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, T* __restrict__ yn, long n, int C) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        yn[i] = from_f32<T>(to_f32(y[i]) * scale[c] + shift[c]);
+    const int LP = C >> 3, g = threadIdx.x % LP;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[8 * g + e]; sh[e] = shift[8 * g + e]; }
+    const long nv = n >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float v[8];
+        load8<T>(y + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        store8<T>(yn + i * 8, v);
     }
 }
 
@@ -179,20 +249,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
                                                            T* __restrict__ dpre, float* dgamma, float* dbeta, long n,
                                                            int C, double count, int training) {
-    if (blockIdx.x == 0 && threadIdx.x < C) {
-        atomicAdd(dbeta + threadIdx.x, (float)sums[threadIdx.x]);
-        atomicAdd(dgamma + threadIdx.x, (float)sums[C + threadIdx.x]);
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            atomicAdd(dbeta + c, (float)sums[c]);
+            atomicAdd(dgamma + c, (float)sums[C + c]);
+        }
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const float v = to_f32(y[i]);
-        const float d = to_f32(dyn[i]);
-        float r;
-        if (training) {
-            const float xh = (v - mean[c]) * rstd[c];
-            r = gamma[c] * rstd[c] * (d - (float)(sums[c] / count) - xh * (float)(sums[C + c] / count));
-        } else r = gamma[c] * rstd[c] * d;
-        dpre[i] = from_f32<T>(v > 0.f ? r : 0.f);
+    const int LP = C >> 3, g = threadIdx.x % LP;
+    float k1[8], mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 8 * g + e;
+        mu[e] = mean[c]; rs[e] = rstd[c]; k1[e] = gamma[c] * rstd[c];
+        m1[e] = training ? (float)(sums[c] / count) : 0.f;
+        m2[e] = training ? (float)(sums[C + c] / count) : 0.f;
+    }
+    const long nv = n >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float v[8], d[8];
+        load8<T>(y + i * 8, v);
+        load8<T>(dyn + i * 8, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = (v[e] - mu[e]) * rs[e];
+            const float r = k1[e] * (d[e] - m1[e] - xh * m2[e]);
+            d[e] = v[e] > 0.f ? r : 0.f;
+        }
+        store8<T>(dpre + i * 8, d);
     }
 }
 
@@ -273,7 +356,7 @@ extern "C" int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float*
     if (!x || !dpre || !dw || !db || (C != 64 && C != 128 && C != 32)) return S2T_EINVAL;
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
-    const int ppb = (int)((P + 511) / 512 < 256 ? 256 : (P + 511) / 512);     // <= ~512 workgroups (10C atomics each)
+    const int ppb = (int)((P + 1023) / 1024 < 256 ? 256 : (P + 1023) / 1024);   // <= 1024 workgroups = 4 per CU, all resident (10C atomics each)
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
@@ -287,7 +370,7 @@ extern "C" int s2t_chan_sums(int dtype, const void* y, const void* dyn, const fl
                              double* sums, long P, int C, int mode, void* stream) {
     if (P <= 0) return S2T_OK;
     if (!y || !sums || (C != 64 && C != 128 && C != 32) || (mode && (!dyn || !mean || !rstd))) return S2T_EINVAL;
-    const int ppb = (int)((P + 511) / 512 < 256 ? 256 : (P + 511) / 512);
+    const int ppb = (int)((P + 1023) / 1024 < 256 ? 256 : (P + 1023) / 1024);
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
@@ -309,7 +392,7 @@ extern "C" int s2t_bn_finalize(const double* sums, const float* gamma, const flo
 
 extern "C" int s2t_bn_apply(int dtype, const void* y, const float* scale, const float* shift, void* yn, long n, int C, void* stream) {
     if (n <= 0) return S2T_OK;
-    if (!y || !scale || !shift || !yn) return S2T_EINVAL;
+    if (!y || !scale || !shift || !yn || (C % 8) || (256 % (C / 8)) || (n % C)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nblocks(n)), dim3(256), 0, st, (const bf16*)y, scale, shift, (bf16*)yn, n, C),
@@ -322,7 +405,7 @@ extern "C" int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const
                                 const float* gamma, const double* sums, void* dpre, float* dgamma, float* dbeta, long n,
                                 int C, double count, int training, void* stream) {
     if (n <= 0) return S2T_OK;
-    if (!dyn || !y || !mean || !rstd || !gamma || !sums || !dpre || !dgamma || !dbeta || C > 256) return S2T_EINVAL;
+    if (!dyn || !y || !mean || !rstd || !gamma || !sums || !dpre || !dgamma || !dbeta || C > 256 || (C % 8) || (256 % (C / 8)) || (n % C)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(nblocks(n)), dim3(256), 0, st, (const bf16*)dyn, (const bf16*)y, mean, rstd, gamma, sums, (bf16*)dpre, dgamma, dbeta, n, C, count, training),

@@ -432,3 +432,27 @@ def test_gemm_v2_direct_to_lds_kernel(M, N, K_, monkeypatch):
     y = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), p_drop=0.25, seed=9)
     y0 = K.dropout(K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV)), 0.25, 9)
     assert rel_err(y, y0) < 2e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("V", [1001, 523])
+def test_gemm_ctc_head_shapes_odd_vocabulary(dtype, V):
+    """The CTC head with V_src = 5001-like vocabularies: logit rows live in a padded buffer (K.alloc_rows).  The weight
+    gradient reads whole 16-byte column chunks that hang over into the row padding, the data gradient has a K tail that
+    is accumulated by a second launch (gemm.hip: s2t_gemm_gather)."""
+    M, D = 3000, 256
+    g = torch.Generator().manual_seed(11)
+    base = torch.full((M, K.padded_cols(V, dtype)), float("nan"), dtype=dtype, device=DEV)      # poisoned row padding
+    dl = base[:, :V]
+    dl_h = (torch.randn(M, V, generator=g) * 0.1).to(dtype)
+    dl.copy_(dl_h)
+    x = rnd(M, D, dtype=dtype, seed=2); w = rnd(V, D, dtype=dtype, seed=3, scale=D ** -0.5)
+    gw = torch.zeros(V, D, device=DEV)
+    K.gemm(dl, x.to(DEV), trans_a=True, trans_b=True, out=gw, accumulate=True, splitk=4)
+    ref = dl_h.float().t() @ x.float()
+    assert float((gw.cpu() - ref).abs().max()) < (1e-3 if dtype == torch.float32 else 3e-2) * max(1.0, float(ref.abs().max()))
+    dx = K.gemm(dl, w.to(DEV), trans_b=True)
+    assert rel_err(dx, dl_h.float() @ w.float()) < tol(dtype)
+    acc = rnd(M, D, dtype=dtype, seed=6)
+    dx = K.gemm(dl, w.to(DEV), trans_b=True, out=acc.clone().to(DEV), accumulate=True)
+    assert rel_err(dx, dl_h.float() @ w.float() + acc.float()) < tol(dtype)

@@ -23,7 +23,7 @@ for dtype in ((torch.bfloat16,) if os.environ.get("BF16_ONLY") else (torch.bfloa
         bias = torch.randn(N, device=dev)
         t = timeit(lambda: K.gemm(a, w, bias=bias))
         print("NT  M=%6d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (mm, N, Kd, t * 1e6, 2 * mm * N * Kd / t / 1e12))
-        dy = torch.randn(mm, N, device=dev).to(dtype)
+        dy = K.alloc_rows((mm,), N, dtype, dev); dy.copy_(torch.randn(mm, N, device=dev))     # padded rows as in the engine
         t = timeit(lambda: K.gemm(dy, w, trans_b=True))
         print("NN  M=%6d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (mm, Kd, N, t * 1e6, 2 * mm * N * Kd / t / 1e12))
         gw = torch.zeros(N, Kd, device=dev)

@@ -1,0 +1,44 @@
+"""Micro-benchmark of the HBM-bound subsampler kernels at the bench shape (B=64, T=1500, F=80, C=64): us + TB/s."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fbk_fairseq_st_amd import kernels as K
+
+
+def timeit(fn, n=20, w=3):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e-3
+
+dev = "cuda"
+B, T, F, C = 64, 1500, 80, 64
+T2, F2 = (T + 1) // 2, (F + 1) // 2
+P = B * T2 * F2
+dt = torch.bfloat16
+x = torch.randn(B, T, F, device=dev)
+w = torch.randn(C, 9, device=dev) * 0.3; bias = torch.zeros(C, device=dev)
+y, sums = K.conv1_fwd(x, w, bias, C, dt)
+ybytes = y.numel() * 2
+t = timeit(lambda: K.conv1_fwd(x, w, bias, C, dt))
+print("conv1_fwd      %8.1f us  %5.2f TB/s (write y + read x)" % (t * 1e6, (ybytes + x.numel() * 4) / t / 1e12))
+gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev)
+rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev); nb = torch.zeros((), dtype=torch.int64, device=dev)
+mean, rstd, scale, shift = K.bn_finalize(sums, gamma, beta, rm, rv, nb, float(P), True)
+t = timeit(lambda: K.bn_apply(y, scale, shift))
+print("bn_apply       %8.1f us  %5.2f TB/s" % (t * 1e6, 2 * ybytes / t / 1e12))
+dyn = torch.randn_like(y)
+t = timeit(lambda: K.chan_sums(y, C))
+print("chan_sums m0   %8.1f us  %5.2f TB/s" % (t * 1e6, ybytes / t / 1e12))
+t = timeit(lambda: K.chan_sums(y, C, dyn=dyn, mean=mean, rstd=rstd))
+print("chan_sums m1   %8.1f us  %5.2f TB/s" % (t * 1e6, 2 * ybytes / t / 1e12))
+s2 = K.chan_sums(y, C, dyn=dyn, mean=mean, rstd=rstd)
+dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+t = timeit(lambda: K.bn_bwd_apply(dyn, y, mean, rstd, gamma, s2, dg, db, float(P)))
+print("bn_bwd_apply   %8.1f us  %5.2f TB/s" % (t * 1e6, 3 * ybytes / t / 1e12))
+dw = torch.zeros(C, 9, device=dev); dbias = torch.zeros(C, device=dev)
+t = timeit(lambda: K.conv1_bwd(x, dyn, dw, dbias))
+print("conv1_bwd      %8.1f us  %5.2f TB/s" % (t * 1e6, (ybytes + x.numel() * 4) / t / 1e12))
