@@ -63,20 +63,30 @@ __device__ __forceinline__ void chan_pair_reduce(float (&s1)[8], float (&s2)[8],
         atomicAdd(sums + which * C + c, a);
     }
 }
-// the 3x3 stride-2 window of output pixel (b, t2, f2) over x[b][Tin][F] (zero padding 1), branch-free
-__device__ __forceinline__ void conv1_window(const float* __restrict__ x, int b, int t2, int f2, int Tin, int F, float (&xv)[9]) {
+// the 3x3 stride-2 window of output pixel (b, t2, f2) over x[b][Tin][F] (zero padding 1).  All nine loads are issued
+// from clamped (always valid) addresses before any is used: left to itself the compiler sinks each load under its
+// bounds test and waits for it there, i.e. nine serial memory latencies per pixel (seen in the ISA).
+struct Conv1Win { float v[9]; float mt0, mt2, mf0, mf2; };
+__device__ __forceinline__ void conv1_window_issue(const float* __restrict__ x, unsigned p, int Tin, int F, int T2, int F2, Conv1Win& w) {
+    const unsigned r = p / (unsigned)F2;
+    const int f2 = (int)(p - r * F2), t2 = (int)(r % (unsigned)T2), b = (int)(r / (unsigned)T2);
+    const int tc = 2 * t2, fc = 2 * f2;                       // centre tap: always inside
+    const float* r1 = x + ((long)b * Tin + tc) * F;
+    const float* r0 = r1 - (tc > 0 ? F : 0);
+    const float* r2 = r1 + (tc + 1 < Tin ? F : 0);
+    const int f0 = max(fc - 1, 0), f2c = min(fc + 1, F - 1);
+    w.v[0] = r0[f0]; w.v[1] = r0[fc]; w.v[2] = r0[f2c];
+    w.v[3] = r1[f0]; w.v[4] = r1[fc]; w.v[5] = r1[f2c];
+    w.v[6] = r2[f0]; w.v[7] = r2[fc]; w.v[8] = r2[f2c];
+    w.mt0 = tc > 0 ? 1.f : 0.f; w.mt2 = tc + 1 < Tin ? 1.f : 0.f;
+    w.mf0 = fc > 0 ? 1.f : 0.f; w.mf2 = fc + 1 < F ? 1.f : 0.f;
+}
+__device__ __forceinline__ void conv1_window_finish(Conv1Win& w, float (&xv)[9]) {
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int t = 2 * t2 + kh - 1;
-        const bool okt = (t >= 0) && (t < Tin);
-        const float* xr = x + ((long)b * Tin + min(max(t, 0), Tin - 1)) * F;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int f = 2 * f2 + kw - 1;
-            const float v = xr[min(max(f, 0), F - 1)];
-            xv[kh * 3 + kw] = (okt && f >= 0 && f < F) ? v : 0.f;
-        }
-    }
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(w.v[i]));
+    xv[0] = w.v[0] * (w.mt0 * w.mf0); xv[1] = w.v[1] * w.mt0; xv[2] = w.v[2] * (w.mt0 * w.mf2);
+    xv[3] = w.v[3] * w.mf0;           xv[4] = w.v[4];         xv[5] = w.v[5] * w.mf2;
+    xv[6] = w.v[6] * (w.mt2 * w.mf0); xv[7] = w.v[7] * w.mt2; xv[8] = w.v[8] * (w.mt2 * w.mf2);
 }
 
 // ------------------------------------------------------------------ conv1 forward (+ BN statistics)
@@ -100,11 +110,14 @@ __global__ __launch_bounds__(256, 4) void conv1_fwd_kernel(const float* __restri
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    // the window of the next pixel is requested before the current one is consumed (one memory latency per two pixels
+    // would otherwise sit exposed between the index arithmetic and the FMAs); the last prefetch re-reads a valid pixel
+    Conv1Win wn;
+    if (p0 + slot < pend) conv1_window_issue(x, p0 + slot, Tin, F, T2, F2, wn);
     for (unsigned p = p0 + slot; p < pend; p += nslot) {
-        const unsigned r = p / (unsigned)F2;
-        const int f2 = (int)(p - r * F2), t2 = (int)(r % (unsigned)T2), b = (int)(r / (unsigned)T2);
         float xv[9], o[8];
-        conv1_window(x, b, t2, f2, Tin, F, xv);
+        conv1_window_finish(wn, xv);
+        conv1_window_issue(x, min(p + nslot, P - 1), Tin, F, T2, F2, wn);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float acc = bc[e];
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256, 4) void conv1_fwd_kernel(const float* __restri
 // ------------------------------------------------------------------ conv1 backward (weights, bias)
 // dpre [B][T2][F2][C] T (gradient w.r.t. conv1 + bias, i.e. after the ReLU mask)
 template <typename T>
-__global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dpre,
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const T* __restrict__ dpre,
                                                         float* __restrict__ dw, float* __restrict__ db, int B,
                                                         int Tin, int F, int T2, int F2, int C, int pos_per_block) {
     __shared__ float red[4][16][80];
@@ -133,12 +146,20 @@ __global__ __launch_bounds__(256, 4) void conv1_bwd_kernel(const float* __restri
         for (int i = 0; i < 10; ++i) a[e][i] = 0.f;
     const unsigned P = (unsigned)B * T2 * F2;
     const unsigned p0 = blockIdx.x * (unsigned)pos_per_block, pend = min(P, p0 + (unsigned)pos_per_block);
+    Conv1Win wn;
+    float gn[8];
+    if (p0 + slot < pend) {
+        conv1_window_issue(x, p0 + slot, Tin, F, T2, F2, wn);
+        load8<T>(dpre + (size_t)(p0 + slot) * C + 8 * g, gn);
+    }
     for (unsigned p = p0 + slot; p < pend; p += nslot) {
-        const unsigned r = p / (unsigned)F2;
-        const int f2 = (int)(p - r * F2), t2 = (int)(r % (unsigned)T2), b = (int)(r / (unsigned)T2);
         float xv[9], gq[8];
-        load8<T>(dpre + (size_t)p * C + 8 * g, gq);
-        conv1_window(x, b, t2, f2, Tin, F, xv);
+        conv1_window_finish(wn, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gq[e] = gn[e];
+        const unsigned pn = min(p + nslot, P - 1);
+        conv1_window_issue(x, pn, Tin, F, T2, F2, wn);
+        load8<T>(dpre + (size_t)pn * C + 8 * g, gn);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -356,7 +377,7 @@ extern "C" int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float*
     if (!x || !dpre || !dw || !db || (C != 64 && C != 128 && C != 32)) return S2T_EINVAL;
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
-    const int ppb = (int)((P + 1023) / 1024 < 256 ? 256 : (P + 1023) / 1024);   // <= 1024 workgroups = 4 per CU, all resident (10C atomics each)
+    const int ppb = (int)((P + 767) / 768 < 256 ? 256 : (P + 767) / 768);       // <= 768 workgroups = 3 per CU at 148 VGPRs, all resident (10C atomics each)
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
