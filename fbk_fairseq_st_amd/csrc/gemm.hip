@@ -310,19 +310,81 @@ template <typename T, int COLS> struct FastTrans {
     }
 };
 
+// bf16 operand whose reduction index is the ROW index in memory (dW = dY^T X, dX = dY W), 128 tile columns: the
+// [64 k][128 col] tile is copied to LDS as it lies in memory (256-byte rows, 16-byte chunks XOR-swizzled) and the MFMA
+// fragments are gathered by the hardware transpose read ds_read_b64_tr_b16 (cdna_hip_programming.md T10, image (b)):
+// no register transposition, no sub-dword packing, half the LDS write instructions of FastTrans.
+__device__ __forceinline__ int tr_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+template <int COLS> struct FastTr {
+    static_assert(COLS == 128, "256-byte LDS rows");
+    static constexpr int N = 4;                                // 64 rows x 16 chunks / 256 threads
+    static constexpr bool kTrRead = true;
+    struct Regs { u32x4 r[N]; };
+    const char* base;
+    uint32_t goff[N];
+    int off[N];
+    uint32_t tile_bytes;                                       // 64 rows further down
+    __device__ __forceinline__ void init(const bf16* g, int ld, int col0, int ncols, int k0) {
+        base = reinterpret_cast<const char*>(g);
+        tile_bytes = (uint32_t)(64u * (uint32_t)ld * 2u);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 4, c = cid & 15;
+            const int gc = min(col0 + c * 8, (ncols + 7) / 8 * 8 - 8);
+            goff[i] = (uint32_t)(((size_t)(k0 + row) * ld + gc) * 2);
+            off[i] = row * 256 + ((c ^ tr_swz(row)) << 4);
+        }
+    }
+    __device__ __forceinline__ void load(Regs& R, int step) {
+        const uint32_t st = step ? tile_bytes : 0u;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { R.r[i] = *reinterpret_cast<const u32x4*>(base + goff[i]); goff[i] += st; }
+    }
+    __device__ __forceinline__ void store(char* lds, const Regs& R) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) *reinterpret_cast<u32x4*>(lds + off[i]) = R.r[i];
+    }
+};
+
 template <typename T, int ROWS, bool TRANS> struct FastSel { typedef FastDirect<T, ROWS> type; };
 template <typename T, int ROWS> struct FastSel<T, ROWS, true> { typedef FastTrans<T, ROWS> type; };
+template <> struct FastSel<bf16, 128, true> { typedef FastTr<128> type; };
+template <typename S> struct UsesTrRead { static constexpr bool value = false; };
+template <int C> struct UsesTrRead<FastTr<C>> { static constexpr bool value = true; };
 
-template <typename TI, int MT, int NT>
-__device__ __forceinline__ void mma_tile(const char* la, const char* lb, int r16, int q, f32x4 (&acc)[MT][NT]) {
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// fragment t (16 tile columns) of k-half s from a FastTr image; cw = first tile column of this wave
+__device__ __forceinline__ u32x4 tr_fragment(const char* img, int cw, int t, int s, int r16, int q) {
+    u32x4 f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 32 * s + 8 * q + 4 * h + (r16 >> 2);
+        const int ch = ((cw + 16 * t) >> 3) + ((r16 & 3) >> 1);
+        const char* a = img + row * 256 + ((ch ^ tr_swz(row)) << 4) + ((r16 & 1) << 3);
+        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+        const u32x2 w = __builtin_bit_cast(u32x2, v);
+        f[2 * h] = w[0]; f[2 * h + 1] = w[1];
+    }
+    return f;
+}
+
+// la / lb: LDS image of the A / B tile; arow / brow: first tile row (= output row / column) of this wave
+template <typename TI, int MT, int NT, bool TRA, bool TRB>
+__device__ __forceinline__ void mma_tile(const char* la, const char* lb, int arow, int brow, int r16, int q, f32x4 (&acc)[MT][NT]) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         u32x4 fa[MT], fb[NT];
         const int sw = ((4 * s + q) ^ (r16 & 7)) << 4;          // (16*i + r16) & 7 == r16 & 7
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const u32x4*>(la + (16 * i + r16) * 128 + sw);
+        for (int i = 0; i < MT; ++i) {
+            if constexpr (TRA) fa[i] = tr_fragment(la, arow, i, s, r16, q);
+            else fa[i] = *reinterpret_cast<const u32x4*>(la + (arow + 16 * i + r16) * 128 + sw);
+        }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const u32x4*>(lb + (16 * j + r16) * 128 + sw);
+        for (int j = 0; j < NT; ++j) {
+            if constexpr (TRB) fb[j] = tr_fragment(lb, brow, j, s, r16, q);
+            else fb[j] = *reinterpret_cast<const u32x4*>(lb + (brow + 16 * j + r16) * 128 + sw);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -364,7 +426,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
 
     char* l0 = smem;
     char* l1 = smem + STAGE;
-    const int aoff = (wr * (BM / 2)) * 128, boff = BM * 128 + (wc * (BN / 2)) * 128;
+    constexpr bool TRA = UsesTrRead<SA>::value, TRB = UsesTrRead<SB>::value;
+    const int arow = wr * (BM / 2), brow = wc * (BN / 2);
+    constexpr int BOFF = BM * 128;
 
     int left = nk;                                  // tiles not yet requested from global memory
     auto step = [&]() { left -= 1; return left > 0 ? 128 : 0; };
@@ -374,11 +438,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
     __syncthreads();
     for (int t = 0; t < ((p.dbg & 2) ? 0 : nk); t += 2) {
         { const int st = step(); sa.load(a0, st); sb.load(b0, st); }  // tile t+2 -> set 0
-        mma_tile<TI, MT, NT>(l0 + aoff, l0 + boff, r16, q, acc);       // tile t
+        mma_tile<TI, MT, NT, TRA, TRB>(l0, l0 + BOFF, arow, brow, r16, q, acc);   // tile t
         sa.store(l1, a1); sb.store(l1 + BM * 128, b1);                 // tile t+1
         __syncthreads();
         { const int st = step(); sa.load(a1, st); sb.load(b1, st); }  // tile t+3 -> set 1
-        if (t + 1 < nk) mma_tile<TI, MT, NT>(l1 + aoff, l1 + boff, r16, q, acc);
+        if (t + 1 < nk) mma_tile<TI, MT, NT, TRA, TRB>(l1, l1 + BOFF, arow, brow, r16, q, acc);
         sa.store(l0, a0); sb.store(l0 + BM * 128, b0);                 // tile t+2
         __syncthreads();
     }
