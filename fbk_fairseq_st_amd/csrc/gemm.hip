@@ -223,10 +223,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 // and global loads run TWO k-tiles ahead of the MFMAs in two named register sets, so a load has two compute
 // phases to land before it is written to LDS (PMC showed the guarded 1-deep variant 54 % parked in s_waitcnt
 // and issuing 9 VALU per MFMA).
-template <typename T, int ROWS> struct FastDirect {
+template <typename T, int ROWS, int NTH = 256> struct FastDirect {
     static constexpr int E = Elem<T>::PER16;
     static constexpr int BK = 128 / (int)sizeof(T);
-    static constexpr int N = ROWS * 8 / 256;
+    static constexpr int N = ROWS * 8 / NTH;
     struct Regs { u32x4 r[N]; };
     const char* base;          // wave-uniform (kernel argument): lets the loads use the saddr + 32-bit voffset form
     uint32_t goff[N];          // byte offsets from base (operands are < 4 GiB)
@@ -235,7 +235,7 @@ template <typename T, int ROWS> struct FastDirect {
         base = reinterpret_cast<const char*>(g);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            const int cid = threadIdx.x + NTH * i, row = cid >> 3, c = cid & 7;
             const int gr = min(row0 + row, nrows - 1);
             goff[i] = (uint32_t)(((size_t)gr * ld + k0 + c * E) * sizeof(T));
             off[i] = row * 128 + ((c ^ (row & 7)) << 4);
@@ -252,12 +252,12 @@ template <typename T, int ROWS> struct FastDirect {
     }
 };
 
-template <typename T, int COLS> struct FastTrans {
+template <typename T, int COLS, int NTH = 256> struct FastTrans {
     static constexpr int E = Elem<T>::PER16;
     static constexpr int BK = 128 / (int)sizeof(T);
     static constexpr int NKQ = BK / 4;
     static constexpr int ITEMS = (COLS / E) * NKQ;
-    static constexpr int N = (ITEMS + 255) / 256;
+    static constexpr int N = (ITEMS + NTH - 1) / NTH;
     struct Regs { u32x4 r[N][4]; };
     const T* ptr[N];
     size_t ld;
@@ -265,7 +265,7 @@ template <typename T, int COLS> struct FastTrans {
         ld = (size_t)ld_;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int it = min((int)threadIdx.x + 256 * i, ITEMS - 1);
+            const int it = min((int)threadIdx.x + NTH * i, ITEMS - 1);
             const int kq = it % NKQ, cg = it / NKQ;
             const int gc = min(col0 + cg * E, (ncols + E - 1) / E * E - E);   // the last chunk may hang over into the row padding (ld >= roundup(ncols))
             ptr[i] = g + (size_t)(k0 + 4 * kq) * ld + gc;
@@ -282,7 +282,7 @@ template <typename T, int COLS> struct FastTrans {
     __device__ __forceinline__ void store(char* lds, const Regs& R) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int it = threadIdx.x + 256 * i;
+            const int it = threadIdx.x + NTH * i;
             if (it >= ITEMS) continue;
             const int kq = it % NKQ, cg = it / NKQ;
             if constexpr (sizeof(T) == 2) {
@@ -315,9 +315,9 @@ template <typename T, int COLS> struct FastTrans {
 // fragments are gathered by the hardware transpose read ds_read_b64_tr_b16 (cdna_hip_programming.md T10, image (b)):
 // no register transposition, no sub-dword packing, half the LDS write instructions of FastTrans.
 __device__ __forceinline__ int tr_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-template <int COLS> struct FastTr {
+template <int COLS, int NTH = 256> struct FastTr {
     static_assert(COLS == 128, "256-byte LDS rows");
-    static constexpr int N = 4;                                // 64 rows x 16 chunks / 256 threads
+    static constexpr int N = 1024 / NTH;                       // 64 rows x 16 chunks over the workgroup
     static constexpr bool kTrRead = true;
     struct Regs { u32x4 r[N]; };
     const char* base;
@@ -329,7 +329,7 @@ template <int COLS> struct FastTr {
         tile_bytes = (uint32_t)(64u * (uint32_t)ld * 2u);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int cid = threadIdx.x + 256 * i, row = cid >> 4, c = cid & 15;
+            const int cid = threadIdx.x + NTH * i, row = cid >> 4, c = cid & 15;
             const int gc = min(col0 + c * 8, (ncols + 7) / 8 * 8 - 8);
             goff[i] = (uint32_t)(((size_t)(k0 + row) * ld + gc) * 2);
             off[i] = row * 256 + ((c ^ tr_swz(row)) << 4);
@@ -346,11 +346,11 @@ template <int COLS> struct FastTr {
     }
 };
 
-template <typename T, int ROWS, bool TRANS> struct FastSel { typedef FastDirect<T, ROWS> type; };
-template <typename T, int ROWS> struct FastSel<T, ROWS, true> { typedef FastTrans<T, ROWS> type; };
-template <> struct FastSel<bf16, 128, true> { typedef FastTr<128> type; };
+template <typename T, int ROWS, bool TRANS, int NTH = 256> struct FastSel { typedef FastDirect<T, ROWS, NTH> type; };
+template <typename T, int ROWS, int NTH> struct FastSel<T, ROWS, true, NTH> { typedef FastTrans<T, ROWS, NTH> type; };
+template <int NTH> struct FastSel<bf16, 128, true, NTH> { typedef FastTr<128, NTH> type; };
 template <typename S> struct UsesTrRead { static constexpr bool value = false; };
-template <int C> struct UsesTrRead<FastTr<C>> { static constexpr bool value = true; };
+template <int C, int NTH> struct UsesTrRead<FastTr<C, NTH>> { static constexpr bool value = true; };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // fragment t (16 tile columns) of k-half s from a FastTr image; cw = first tile column of this wave
@@ -392,10 +392,13 @@ __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int aro
     }
 }
 
-template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
+// NW = 4: waves 2 x 2, each (BM/2) x (BN/2).  NW = 8: waves 2 x 4, each (BM/2) x (BN/4): twice the wavefronts per CU to
+// cover the global-load latency of the k-loop, at 1.5x the LDS fragment traffic per MFMA.
+template <typename TI, typename TO, bool TA, bool TB, int BM, int BN, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
     constexpr int BK = 128 / (int)sizeof(TI);
-    constexpr int MT = BM / 32, NT = BN / 32;
+    constexpr int NTH = NW * 64, WN = NW / 2;
+    constexpr int MT = BM / 32, NT = BN / (16 * WN);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = (BM + BN) * 128;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
@@ -408,8 +411,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
     const int nk = kt1 - kt0;
     if (nk <= 0) return;
 
-    typedef typename FastSel<TI, BM, TA>::type SA;
-    typedef typename FastSel<TI, BN, TB>::type SB;
+    typedef typename FastSel<TI, BM, TA, NTH>::type SA;
+    typedef typename FastSel<TI, BN, TB, NTH>::type SB;
     SA sa; SB sb;
     sa.init(reinterpret_cast<const TI*>(p.A), p.lda, row0, p.M, kt0 * BK);
     sb.init(reinterpret_cast<const TI*>(p.B), p.ldb, col0, p.N, kt0 * BK);
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
     typename SB::Regs b0, b1;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1, r16 = lane & 15, q = lane >> 4;
+    const int wr = wave / WN, wc = wave % WN, r16 = lane & 15, q = lane >> 4;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
     char* l0 = smem;
     char* l1 = smem + STAGE;
     constexpr bool TRA = UsesTrRead<SA>::value, TRB = UsesTrRead<SB>::value;
-    const int arow = wr * (BM / 2), brow = wc * (BN / 2);
+    const int arow = wr * (BM / 2), brow = wc * (BN / WN);
     constexpr int BOFF = BM * 128;
 
     int left = nk;                                  // tiles not yet requested from global memory
@@ -453,7 +456,90 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs p) {
             for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    gemm_epilogue<TO, BM, BN, MT, NT, 256>(p, acc, smem, row0, col0, wr * (BM / 2), wc * (BN / 2), q, r16);
+    gemm_epilogue<TO, BM, BN, MT, NT, NTH>(p, acc, smem, row0, col0, arow, brow, q, r16);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent form of the fast path.  With K = 512 a 128x128 tile has only 8 k-tiles, so the per-tile prologue
+// (first global loads: one full memory latency with nothing to do) and the epilogue (LDS staging + stores) cost as
+// much as the k-loop (ablation in profiles/README.md).  Here a workgroup walks a sequence of work items
+// (tile, k-slice) and the operand stream never stops at an item boundary: the loads that the last two k-tiles of item
+// i issue fetch the first two k-tiles of item i+1 into the two register sets, they travel while the epilogue of
+// item i runs out of LDS, and the epilogue's global stores drain under the next k-loop.  Grid = 2 workgroups per CU,
+// work items are dealt so that the workgroups of one XCD walk neighbouring tiles (shared A rows / W columns in L2).
+// Requires an even number of k-tiles per item (the two register sets / LDS stages alternate in a 2-unrolled loop).
+template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_pers_kernel(GemmArgs p, int per) {
+    constexpr int BK = 128 / (int)sizeof(TI);
+    constexpr int MT = BM / 32, NT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = (BM + BN) * 128;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int nk_total = p.K / BK;
+    const int items = tiles_m * tiles_n * p.splitk;
+    const int G = gridDim.x;
+    int item = xcd_remap(blockIdx.x, G);
+    if (item >= items) return;
+
+    typedef typename FastSel<TI, BM, TA>::type SA;
+    typedef typename FastSel<TI, BN, TB>::type SB;
+    constexpr bool TRA = UsesTrRead<SA>::value, TRB = UsesTrRead<SB>::value;
+    SA sa; SB sb;
+    typename SA::Regs a0, a1;
+    typename SB::Regs b0, b1;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, r16 = lane & 15, q = lane >> 4;
+    const int arow = wr * (BM / 2), brow = wc * (BN / 2);
+    constexpr int BOFF = BM * 128;
+    char* l0 = smem;
+    char* l1 = smem + STAGE;
+
+    // loader state: the item whose k-tiles are being requested
+    int ld_item = item, ld_left = 0;
+    auto open_item = [&](int it) {           // k-slices innermost: the splitk slices of a tile are neighbours
+        const int tile = it / p.splitk, z = it - tile * p.splitk;
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int kt0 = z * per;
+        ld_left = min(per, nk_total - kt0);
+        sa.init(reinterpret_cast<const TI*>(p.A), p.lda, tm * BM, p.M, kt0 * BK);
+        sb.init(reinterpret_cast<const TI*>(p.B), p.ldb, tn * BN, p.N, kt0 * BK);
+    };
+    // request the next k-tile of the stream into (A, B); past the end of the stream the last tile is read again
+    auto request = [&](typename SA::Regs& A, typename SB::Regs& B) {
+        if (ld_left == 0 && ld_item + G < items) { ld_item += G; open_item(ld_item); }
+        const int st = ld_left > 1 ? 128 : 0;
+        sa.load(A, st); sb.load(B, st);
+        ld_left = max(ld_left - 1, 0);
+    };
+    open_item(item);
+    request(a0, b0);
+    request(a1, b1);
+
+    for (; item < items; item += G) {
+        const int tile = item / p.splitk, z = item - tile * p.splitk;
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int nk = min(per, nk_total - z * per);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sa.store(l0, a0); sb.store(l0 + BOFF, b0);
+        __syncthreads();
+        for (int t = 0; t < nk; t += 2) {
+            request(a0, b0);                                                       // stream tile t+2
+            mma_tile<TI, MT, NT, TRA, TRB>(l0, l0 + BOFF, arow, brow, r16, q, acc);   // tile t
+            sa.store(l1, a1); sb.store(l1 + BOFF, b1);                             // tile t+1
+            __syncthreads();
+            request(a1, b1);                                                       // stream tile t+3
+            mma_tile<TI, MT, NT, TRA, TRB>(l1, l1 + BOFF, arow, brow, r16, q, acc);   // tile t+1
+            if (t + 2 < nk) { sa.store(l0, a0); sb.store(l0 + BOFF, b0); }         // tile t+2 (else: the next item's tile 0 stays in registers)
+            __syncthreads();
+        }
+        gemm_epilogue<TO, BM, BN, MT, NT, 256>(p, acc, smem, tm * BM, tn * BN, arow, brow, q, r16);
+        __syncthreads();
+    }
 }
 
 template <typename TI, bool TA, bool TB>
@@ -481,6 +567,38 @@ static int launch(const GemmArgs& a, hipStream_t st) {
         if (lds > 65536) {
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        }
+        constexpr int BKc = 128 / (int)sizeof(TI);
+        const int nk_total = a.K / BKc;
+        int per = (nk_total + a.splitk - 1) / a.splitk;
+        // measured (tools/microbench.py): the persistent form ties or loses by up to 15 % against hardware dispatch of one
+        // tile per workgroup (static dealing of 1.5-6 tiles per workgroup balances worse than the dispatcher and the
+        // per-tile overheads it hides are not what bounds the loop), so it is opt-in: S2T_GEMM_PERS=1
+        static const bool no_pers = getenv("S2T_GEMM_PERS") == nullptr;
+        if (!no_pers && BM == 128 && BN == 128 && nk_total % 2 == 0 && !a.dbg) {
+            per += per & 1;                                                // even slices; the last one may be shorter (still even)
+            GemmArgs b = a;
+            b.splitk = (nk_total + per - 1) / per;
+            const int items = tiles * b.splitk;
+            const int G = items < 512 ? items : 512;                       // 2 resident workgroups per CU
+            static bool attr2 = false;
+            if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
+            hipLaunchKernelGGL((gemm_pers_kernel<TI, TO, TA, TB, BM, BN>), dim3(G), dim3(256), lds, st, b, per);
+            S2T_LAUNCH_CHECK();
+            return S2T_OK;
+        }
+        if constexpr (BM == 128 && BN == 128 && sizeof(TI) == 2) {
+            // measured (tools/microbench.py, M = 24000): 8 waves gain 10-18 % on the NT / NN products (the k-loop is bound by
+            // global-load latency: twice the wavefronts per CU cover more of it), and lose ~10 % on TN where both operands
+            // are gathered by transposed LDS reads (fragment traffic dominates); S2T_GEMM_NW4=1 forces the 4-wave form
+            static const bool nw4 = getenv("S2T_GEMM_NW4") != nullptr;
+            if (!TA && !nw4) {
+                static bool attr3 = false;
+                if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
+                hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), grid, dim3(512), lds, st, a);
+                S2T_LAUNCH_CHECK();
+                return S2T_OK;
+            }
         }
         hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), grid, dim3(256), lds, st, a);
         S2T_LAUNCH_CHECK();
