@@ -369,8 +369,11 @@ __device__ __forceinline__ u32x4 tr_fragment(const char* img, int cw, int t, int
 }
 
 // la / lb: LDS image of the A / B tile; arow / brow: first tile row (= output row / column) of this wave
-template <typename TI, int MT, int NT, bool TRA, bool TRB>
-__device__ __forceinline__ void mma_tile(const char* la, const char* lb, int arow, int brow, int r16, int q, f32x4 (&acc)[MT][NT]) {
+// RSUM: additionally rs[i] += A-fragment x ones, i.e. the row sums of op(A) over this k-tile (every column of the
+// 16x16 result holds the same sum): the bias gradient of a Linear rides on the weight-gradient product's A operand.
+template <typename TI, int MT, int NT, bool TRA, bool TRB, bool RSUM = false>
+__device__ __forceinline__ void mma_tile(const char* la, const char* lb, int arow, int brow, int r16, int q, f32x4 (&acc)[MT][NT],
+                                         f32x4 (*rs)[MT] = nullptr) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         u32x4 fa[MT], fb[NT];
@@ -389,6 +392,12 @@ __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int aro
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = mma16<TI>(fb[j], fa[i], acc[i][j]);   // swapped roles: a lane ends up with 4 consecutive n of one m
+        if constexpr (RSUM) {
+            const u32x4 ones = sizeof(TI) == 2 ? (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u}
+                                               : (u32x4){0x3F800000u, 0x3F800000u, 0x3F800000u, 0x3F800000u};
+#pragma unroll
+            for (int i = 0; i < MT; ++i) (*rs)[i] = mma16<TI>(ones, fa[i], (*rs)[i]);
+        }
     }
 }
 
@@ -439,15 +448,35 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
     { const int st = step(); sa.load(a1, st); sb.load(b1, st); }      // tile 1 (or tile 0 again)
     sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
     __syncthreads();
+    // bias gradient: the first column tile's wc == 0 waves also sum their A rows (wave-uniform choice)
+    const bool do_rs = TA && p.rowsum != nullptr && tn == 0 && wc == 0;
+    f32x4 rs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const char* l) {
+        if constexpr (TA) {
+            if (do_rs) { mma_tile<TI, MT, NT, TRA, TRB, true>(l, l + BOFF, arow, brow, r16, q, acc, &rs); return; }
+        }
+        mma_tile<TI, MT, NT, TRA, TRB>(l, l + BOFF, arow, brow, r16, q, acc);
+    };
     for (int t = 0; t < ((p.dbg & 2) ? 0 : nk); t += 2) {
         { const int st = step(); sa.load(a0, st); sb.load(b0, st); }  // tile t+2 -> set 0
-        mma_tile<TI, MT, NT, TRA, TRB>(l0, l0 + BOFF, arow, brow, r16, q, acc);   // tile t
+        mma(l0);                                                       // tile t
         sa.store(l1, a1); sb.store(l1 + BM * 128, b1);                 // tile t+1
         __syncthreads();
         { const int st = step(); sa.load(a1, st); sb.load(b1, st); }  // tile t+3 -> set 1
-        if (t + 1 < nk) mma_tile<TI, MT, NT, TRA, TRB>(l1, l1 + BOFF, arow, brow, r16, q, acc);
+        if (t + 1 < nk) mma(l1);
         sa.store(l0, a0); sb.store(l0 + BM * 128, b0);                 // tile t+2
         __syncthreads();
+    }
+    if constexpr (TA) {
+        if (do_rs && q == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = row0 + arow + 16 * i + r16;
+                if (row < p.M) atomicAdd(p.rowsum + row, rs[i][0]);
+            }
+        }
     }
     if (p.dbg & 1) {
 #pragma unroll
@@ -556,12 +585,24 @@ static bool fast_ok(const GemmArgs& a) {
     return true;
 }
 
+extern "C" int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float* out, void* stream);
+
 template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
-static int launch(const GemmArgs& a, hipStream_t st) {
+static int launch(const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     dim3 grid(tiles, 1, a.splitk);
     static const bool no_fast = getenv("S2T_GEMM_NOFAST") != nullptr;     // A/B switch for benchmarking
-    if (!no_fast && fast_ok<TI, TA, TB>(a)) {
+    static const bool pers_on = getenv("S2T_GEMM_PERS") != nullptr;
+    const bool fast = !no_fast && fast_ok<TI, TA, TB>(a);
+    if (a.rowsum && !(TA && fast && !pers_on)) {
+        // the row sums ride on gemm_fast_kernel's transposed A operand only: otherwise a separate column-sum pass over A [K][M]
+        if (!TA) return S2T_EINVAL;
+        const int rc = s2t_colsum(sizeof(TI) == 2 ? S2T_BF16 : S2T_F32, a.A, a.lda, a.K, a.M, a.rowsum, st);
+        if (rc != S2T_OK) return rc;
+        a.rowsum = nullptr;
+    }
+    if (fast) {
         size_t lds = 2 * (BM + BN) * 128;
         if ((size_t)BM * (BN * 4 + 16) > lds) lds = (size_t)BM * (BN * 4 + 16);
         if (lds > 65536) {
@@ -574,8 +615,7 @@ static int launch(const GemmArgs& a, hipStream_t st) {
         // measured (tools/microbench.py): the persistent form ties or loses by up to 15 % against hardware dispatch of one
         // tile per workgroup (static dealing of 1.5-6 tiles per workgroup balances worse than the dispatcher and the
         // per-tile overheads it hides are not what bounds the loop), so it is opt-in: S2T_GEMM_PERS=1
-        static const bool no_pers = getenv("S2T_GEMM_PERS") == nullptr;
-        if (!no_pers && BM == 128 && BN == 128 && nk_total % 2 == 0 && !a.dbg) {
+        if (pers_on && BM == 128 && BN == 128 && nk_total % 2 == 0 && !a.dbg) {
             per += per & 1;                                                // even slices; the last one may be shorter (still even)
             GemmArgs b = a;
             b.splitk = (nk_total + per - 1) / per;
@@ -623,12 +663,12 @@ static int launch_t(const GemmArgs& a, int ta, int tb, hipStream_t st) {
     return S2T_ENOTSUP;   // A^T . B^T never occurs on this path
 }
 
-extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
-                               const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                               const float* bias, const void* residual, int ldr, const void* aux, void* aux_out,
-                               int ldaux, int act, int accumulate, int splitk, float alpha,
-                               const int* mapA, int periodA, const int* mapB, const int* mapC,
-                               float p_drop, unsigned long long seed, void* stream) {
+static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
+                    const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                    const float* bias, const void* residual, int ldr, const void* aux, void* aux_out,
+                    int ldaux, int act, int accumulate, int splitk, float alpha,
+                    const int* mapA, int periodA, const int* mapB, const int* mapC,
+                    float p_drop, unsigned long long seed, float* rowsum, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return (M < 0 || N < 0 || K < 0) ? S2T_EINVAL : S2T_OK;
     if (!A || !B || !C) return S2T_EINVAL;
     if (splitk < 1) splitk = 1;
@@ -644,17 +684,18 @@ extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int tra
             act == ACT_NONE && p_drop == 0.f) {
             const size_t es = in_dtype == S2T_BF16 ? 2 : 4;
             const int Km = K - tail;
-            int rc = s2t_gemm_gather(in_dtype, out_dtype, trans_a, trans_b, M, N, Km, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0,
-                                     nullptr, nullptr, 0, ACT_NONE, accumulate, 1, alpha, nullptr, 0, nullptr, nullptr, 0.f, 0ull, stream);
+            int rc = gemm_run(in_dtype, out_dtype, trans_a, trans_b, M, N, Km, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0,
+                              nullptr, nullptr, 0, ACT_NONE, accumulate, 1, alpha, nullptr, 0, nullptr, nullptr, 0.f, 0ull, rowsum, stream);
             if (rc != S2T_OK) return rc;
             const char* At = (const char*)A + (trans_a ? (size_t)Km * lda : (size_t)Km) * es;
             const char* Bt = (const char*)B + (trans_b ? (size_t)Km * ldb : (size_t)Km) * es;
-            return s2t_gemm_gather(in_dtype, out_dtype, trans_a, trans_b, M, N, tail, At, lda, Bt, ldb, C, ldc, nullptr, nullptr, 0,
-                                   nullptr, nullptr, 0, ACT_NONE, 1, 1, alpha, nullptr, 0, nullptr, nullptr, 0.f, 0ull, stream);
+            return gemm_run(in_dtype, out_dtype, trans_a, trans_b, M, N, tail, At, lda, Bt, ldb, C, ldc, nullptr, nullptr, 0,
+                            nullptr, nullptr, 0, ACT_NONE, 1, 1, alpha, nullptr, 0, nullptr, nullptr, 0.f, 0ull, rowsum, stream);
         }
     }
     GemmArgs a{A, B, C, bias, residual, aux, aux_out, M, N, K, lda, ldb, ldc, ldr, ldaux, act, accumulate, splitk, alpha,
-               mapA, periodA, mapB, mapC, p_drop, seed, 0};
+               mapA, periodA, mapB, mapC, p_drop, seed, 0, rowsum};
+    if (rowsum && (!trans_a || mapA || mapB)) return S2T_EINVAL;
     { static const char* e = getenv("S2T_GEMM_DBG"); if (e) a.dbg = atoi(e); }
     hipStream_t st = (hipStream_t)stream;
     const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
@@ -677,6 +718,27 @@ extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int tra
     if (in_dtype == S2T_F32 && out_dtype == S2T_F32) { S2T_PICK(float, float); }
 #undef S2T_PICK
     return S2T_ENOTSUP;
+}
+
+extern "C" int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,
+                               const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                               const float* bias, const void* residual, int ldr, const void* aux, void* aux_out,
+                               int ldaux, int act, int accumulate, int splitk, float alpha,
+                               const int* mapA, int periodA, const int* mapB, const int* mapC,
+                               float p_drop, unsigned long long seed, void* stream) {
+    return gemm_run(in_dtype, out_dtype, trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, aux, aux_out,
+                    ldaux, act, accumulate, splitk, alpha, mapA, periodA, mapB, mapC, p_drop, seed, nullptr, stream);
+}
+
+// Parameter gradients of y = x W^T + b in one pass over dY (autograd of F.linear, fairseq/modules/multihead_attention.py:190-208,
+// transformer_layer.py:132-134):  dW[n_out][n_in] += dY^T X  (f32, split-K atomics)  and, when db is given,
+// db[n_out] += column sums of dY, taken from the same LDS tiles the weight-gradient product reads.
+extern "C" int s2t_linear_wgrad(int in_dtype, int n_out, int n_in, int tokens, const void* dY, int ldy, const void* X, int ldx,
+                                float* dW, int ldw, float* db, int splitk, void* stream) {
+    if (n_out <= 0 || n_in <= 0 || tokens <= 0) return (n_out < 0 || n_in < 0 || tokens < 0) ? S2T_EINVAL : S2T_OK;
+    if (!dY || !X || !dW) return S2T_EINVAL;
+    return gemm_run(in_dtype, S2T_F32, 1, 1, n_out, n_in, tokens, dY, ldy, X, ldx, dW, ldw, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                    ACT_NONE, 1, splitk < 1 ? 1 : splitk, 1.f, nullptr, 0, nullptr, nullptr, 0.f, 0ull, db, stream);
 }
 
 extern "C" int s2t_gemm(int in_dtype, int out_dtype, int trans_a, int trans_b, int M, int N, int K,

@@ -193,10 +193,8 @@ class S2TEngine:
         """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
         w = self.W(name + ".weight")
         gw = self.G(name + ".weight")
-        K.gemm(dy2d, x2d, trans_a=True, trans_b=True, out=gw, accumulate=True,
-               splitk=_splitk(gw.shape[0], gw.shape[1], dy2d.shape[0]))
-        if bias:
-            K.colsum(dy2d, self.G(name + ".bias"))
+        K.linear_wgrad(dy2d, x2d, gw, self.G(name + ".bias") if bias else None,
+                       splitk=_splitk(gw.shape[0], gw.shape[1], dy2d.shape[0]))
         if not need_dx:
             return None
         return K.gemm(dy2d, w, trans_b=True, act=act, aux=aux, alpha=alpha, out=dx_out, accumulate=dx_accumulate)

@@ -45,6 +45,16 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_N
     return out
 
 
+def linear_wgrad(dy, x, dw, db=None, splitk=1):
+    """dw[n_out,n_in] += dy[tokens,n_out]^T x[tokens,n_in]; db[n_out] += column sums of dy (one pass over dy)."""
+    L.require_cuda(dy, x)
+    assert dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0]
+    assert dw.dtype == torch.float32 and dw.stride(1) == 1 and (db is None or db.dtype == torch.float32)
+    L.check(_lib().s2t_linear_wgrad(L.dt(dy), dy.shape[1], x.shape[1], dy.shape[0], L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0),
+                                    L.ptr(dw), dw.stride(0), L.ptr(db), int(splitk), L.stream()), "s2t_linear_wgrad")
+    return dw
+
+
 def colsum(x, out):
     """out[n] += sum_m x[m, n] (f32)."""
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32

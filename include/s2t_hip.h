@@ -69,6 +69,11 @@ int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
                     float p_drop, unsigned long long seed, void* stream);
 
 /* out[n] += sum_m X[m][n]  (bias gradients of every nn.Linear above; f32 atomics) */
+/* Parameter gradients of a Linear in one pass over dY (autograd of F.linear: fairseq/modules/multihead_attention.py:190-208,
+ * fairseq/modules/transformer_layer.py:132-134): dW[n_out][n_in] += dY[tokens][n_out]^T X[tokens][n_in] (f32) and, if db is not
+ * NULL, db[n_out] += column sums of dY. */
+int s2t_linear_wgrad(int in_dtype, int n_out, int n_in, int tokens, const void* dY, int ldy, const void* X, int ldx,
+                     float* dW, int ldw, float* db, int splitk, void* stream);
 int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float* out, void* stream);
 
 /* ---- fused multi-head attention ---------------------------------------------------------------

@@ -456,3 +456,28 @@ def test_gemm_ctc_head_shapes_odd_vocabulary(dtype, V):
     acc = rnd(M, D, dtype=dtype, seed=6)
     dx = K.gemm(dl, w.to(DEV), trans_b=True, out=acc.clone().to(DEV), accumulate=True)
     assert rel_err(dx, dl_h.float() @ w.float() + acc.float()) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n_out,n_in,tokens,split", [(512, 512, 3000, 4), (1536, 512, 2048, 2), (100, 72, 999, 3), (256, 2048, 1280, 1),
+                                                     (1001, 256, 3000, 4)])
+def test_linear_wgrad_fused_bias_gradient(dtype, n_out, n_in, tokens, split):
+    """s2t_linear_wgrad: dW += dY^T X and db += colsum(dY) in one pass (row sums ride on the MFMA A operand); shapes cover the
+    fused kernel, the guarded fallback (+ separate column-sum pass) and an odd vocabulary with padded rows."""
+    g = torch.Generator().manual_seed(5)
+    base = torch.full((tokens, K.padded_cols(n_out, dtype)), float("nan"), dtype=dtype, device=DEV)
+    dy = base[:, :n_out]
+    dy_h = (torch.randn(tokens, n_out, generator=g) * 0.5).to(dtype)
+    dy.copy_(dy_h)
+    x = rnd(tokens, n_in, dtype=dtype, seed=2)
+    gw0 = rnd(n_out, n_in, seed=3); gb0 = rnd(n_out, seed=4)
+    gw = gw0.clone().to(DEV); gb = gb0.clone().to(DEV)
+    K.linear_wgrad(dy, x.to(DEV), gw, gb, splitk=split)
+    rw = dy_h.float().t() @ x.float() + gw0
+    rb = dy_h.float().sum(0) + gb0
+    t = 1e-4 if dtype == torch.float32 else 1e-2
+    assert float((gw.cpu() - rw).abs().max()) < t * max(1.0, float(rw.abs().max()))
+    assert float((gb.cpu() - rb).abs().max()) < t * max(1.0, float(rb.abs().max()))
+    gw2 = gw0.clone().to(DEV)
+    K.linear_wgrad(dy, x.to(DEV), gw2, None, splitk=split)           # no bias: weight gradient only
+    assert float((gw2.cpu() - rw).abs().max()) < t * max(1.0, float(rw.abs().max()))
