@@ -15,6 +15,7 @@
 // tiles) and dQ (one workgroup per 64 queries, loops over key tiles): no atomics, deterministic.
 #include "common.hpp"
 #include "prof.hpp"
+#include <cstdlib>
 
 template <typename T, int DH> struct ACfg {
     static constexpr int E = Elem<T>::PER16;
@@ -218,6 +219,186 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int n = 0; n < C::ND; ++n) Og[(long)qrow * p.o_st + 16 * n + r16] = from_f32<T>(o[n][r] * inv);
         if (r16 == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Tq + qrow] = m[r] + logf(l[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward, bf16 d = 64, long queries
+// Second-generation forward for the encoder shapes (Tq >= 128): a wave owns 32 queries (two 16-query column blocks), a
+// workgroup 128, so every K / V fragment read from LDS feeds two MFMAs.  The products are taken transposed,
+//   S^T = K Q^T   (A = K rows from LDS, B = Q fragments kept in registers)      acc[r] = S[query r16][key 16j + 4q + r]
+//   O^T = V^T P^T (A = V gathered by ds_read_b64_tr_b16, B = P straight from the S^T accumulators)
+// so a query is a lane column in both: the softmax statistics are per lane (two xor-shuffles per reduction instead of
+// a 16-lane butterfly), the rescale of O needs no exchange, and P never travels through LDS: the 8 keys a lane holds
+// for a 32-key block (4q..4q+3 of its two 16-key tiles) are exactly the k-slice of its P^T operand once V's transposed
+// reads fetch the same keys.  V is staged as it lies in memory (no transposing scatter); K/V tiles are double-buffered
+// with register prefetch, one barrier per 64 keys.  Dropout mask = the same per-(query, key) hash as every other kernel.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    const bf16 a = (bf16)lo, b = (bf16)hi;
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+__global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs p) {
+    constexpr int DH = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, qw = blockIdx.x * 128 + wave * 32;
+    const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const bf16* Qg = reinterpret_cast<const bf16*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
+    const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
+    const bf16* Vg = reinterpret_cast<const bf16*>(p.V) + (long)b * p.v_sb + (long)h * DH;
+
+    u32x4 qf[2][2];                                    // [query block][k-group of d]
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int row = qw + 16 * qb + r16;
+            qf[qb][g] = (u32x4){0, 0, 0, 0};
+            if (row < p.Tq) qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + (long)row * p.q_st + (4 * g + q) * 8);
+        }
+    f32x4 o[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) o[qb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+    int kv_end = klen;
+    if (p.causal) kv_end = min(kv_end, (int)blockIdx.x * 128 + 128);
+    const int ntile = (kv_end + 63) / 64;
+
+    // staging: thread -> (row, chunk) of the K and of the V tile, two 16-byte pieces each
+    u32x4 kr[2], vr[2];
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            const bool ok = kv0 + row < klen;
+            const long r = min(kv0 + row, p.Tk - 1);
+            kr[i] = *reinterpret_cast<const u32x4*>(Kg + r * p.k_st + c * 8);
+            vr[i] = *reinterpret_cast<const u32x4*>(Vg + r * p.v_st + c * 8);
+            if (!ok) { kr[i] = (u32x4){0, 0, 0, 0}; vr[i] = (u32x4){0, 0, 0, 0}; }
+        }
+    };
+    auto lstore = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            *reinterpret_cast<u32x4*>(st + row * 128 + ((c ^ (row & 7)) << 4)) = kr[i];                 // K: row reads (b128)
+            *reinterpret_cast<u32x4*>(st + 8192 + row * 128 + ((c ^ (row & 6)) << 4)) = vr[i];          // V: transposed reads
+        }
+    };
+    const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float drop_inv = 1.f / (1.f - p.p_drop);
+
+    if (ntile > 0) { gload(0); lstore(smem); }
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int kv0 = t * 64;
+        const char* sK = smem + (t & 1) * 16384;
+        const char* sV = sK + 8192;
+        if (t + 1 < ntile) gload(kv0 + 64);
+        // ---- S^T = K Q^T
+        f32x4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 kf[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int row = 16 * j + r16;
+                kf[g] = *reinterpret_cast<const u32x4*>(sK + row * 128 + (((4 * g + q) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                s[qb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) s[qb][j] = mma16<bf16>(kf[g], qf[qb][g], s[qb][j]);
+            }
+        }
+        // ---- online softmax, per lane = per query
+        u32x4 pf[2][2];                                // [query block][32-key block]
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qrow = qw + 16 * qb + r16;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + 16 * j + 4 * q + r;
+                    const bool ok = key < klen && (!p.causal || key <= qrow);
+                    s[qb][j][r] = ok ? s[qb][j][r] * p.scale : -INFINITY;
+                    mx = fmaxf(mx, s[qb][j][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m[qb], mx);
+            const float mu = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = __expf(m[qb] - mu);    // m = -inf -> 0
+            m[qb] = mn;
+            float rs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pv[r] = __expf(s[qb][j][r] - mu); rs += pv[r]; }
+                if (p.p_drop > 0.f) {
+                    // element index of key 16j + 4q (+0..3): two keys share one hash (common.hpp dropout_keep)
+                    const uint64_t idx0 = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + (kv0 + 16 * j + 4 * q);
+                    const uint32_t h0 = drop_hash2(p.seed, idx0 >> 1), h1 = drop_hash2(p.seed, (idx0 >> 1) + 1),
+                                   h2 = drop_hash2(p.seed, (idx0 >> 1) + 2);
+                    const int odd = (int)(idx0 & 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = odd + r;         // 0..4
+                        const uint32_t hh = (e >> 1) == 0 ? h0 : ((e >> 1) == 1 ? h1 : h2);
+                        const uint32_t v16 = (e & 1) ? (hh >> 16) : (hh & 0xffffu);
+                        pv[r] = v16 >= drop_th16 ? pv[r] * drop_inv : 0.f;
+                    }
+                }
+                pf[qb][j >> 1][2 * (j & 1)] = pack_bf16(pv[0], pv[1]);
+                pf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(pv[2], pv[3]);
+            }
+            l[qb] = l[qb] * alpha + rs;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) o[qb][n] *= alpha;
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                u32x4 vf;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row = 32 * kb + 16 * hh + 4 * q + (r16 >> 2);
+                    const int ch = 2 * n + ((r16 & 3) >> 1);
+                    const char* a = sV + row * 128 + ((ch ^ (row & 6)) << 4) + ((r16 & 1) << 3);
+                    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
+                    const u32x2 w = __builtin_bit_cast(u32x2, v);
+                    vf[2 * hh] = w[0]; vf[2 * hh + 1] = w[1];
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) o[qb][n] = mma16<bf16>(vf, pf[qb][kb], o[qb][n]);
+            }
+        if (t + 1 < ntile) lstore(smem + ((t + 1) & 1) * 16384);
+        __syncthreads();
+    }
+    bf16* Og = reinterpret_cast<bf16*>(p.O) + (long)b * p.o_sb + (long)h * DH;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = qw + 16 * qb + r16;
+        float lt = l[qb];
+        lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
+        if (qrow >= p.Tq) continue;
+        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            u32x2 w;
+            w[0] = pack_bf16(o[qb][n][0] * inv, o[qb][n][1] * inv);
+            w[1] = pack_bf16(o[qb][n][2] * inv, o[qb][n][3] * inv);
+            *reinterpret_cast<u32x2*>(Og + (long)qrow * p.o_st + 16 * n + 4 * q) = w;
+        }
+        if (q == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Tq + qrow] = m[qb] + logf(lt);
     }
 }
 
@@ -499,6 +680,14 @@ extern "C" int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int T
     if (!strides_ok(dtype, s, 6)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("attn_fwd", st, 4.0 * B * H * (double)Tq * Tk * head_dim * (causal ? 0.5 : 1.0), 0.0);
+    if (dtype == S2T_BF16 && head_dim == 64 && Tq >= 128 && (o_st % 4) == 0 && (o_sb % 4) == 0 && ((uintptr_t)O & 7) == 0) {
+        static const bool v1 = getenv("S2T_ATTN_V1") != nullptr;           // A/B switch for benchmarking
+        if (!v1) {
+            hipLaunchKernelGGL(attn_fwd2_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 32768, st, a);
+            S2T_LAUNCH_CHECK();
+            return S2T_OK;
+        }
+    }
     if (dtype == S2T_BF16) return head_dim == 64 ? fwd_launch<bf16, 64>(a, st) : fwd_launch<bf16, 32>(a, st);
     return head_dim == 64 ? fwd_launch<float, 64>(a, st) : fwd_launch<float, 32>(a, st);
 }

@@ -158,7 +158,8 @@ def attn_ref(q, k, v, heads, klen, causal):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("heads,d", [(2, 64), (4, 32)])
 @pytest.mark.parametrize("Tq,Tk,causal,ragged", [(70, 70, False, True), (16, 16, True, True), (130, 130, True, False),
-                                                  (9, 200, False, True), (375, 375, False, False)])
+                                                  (9, 200, False, True), (375, 375, False, False), (200, 333, False, True),
+                                                  (257, 129, False, True), (300, 300, True, True)])
 def test_attention_fwd_bwd(dtype, heads, d, Tq, Tk, causal, ragged):
     B, D = 3, heads * d
     qkv = rnd(max(Tq, Tk), B, 3 * D, dtype=dtype, seed=1)
@@ -201,6 +202,30 @@ def test_attention_dropout_consistency():
     # <dO, O(V2)> == <dV, V2> for the same mask
     lhs = float((do.double() * o2.double()).sum()); rhs = float((dv.double() * v2.double()).sum())
     assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_attention_dropout_consistency_long_bf16():
+    """Tq >= 128 in bf16 takes the second-generation forward (attn_fwd2_kernel): its dropout mask must be the one the
+    backward kernels rebuild -- <dO, O(V2)> == <dV, V2> only holds if forward and backward drop the same (query, key) pairs."""
+    heads, d, T, B = 2, 64, 203, 2
+    D = heads * d
+    bf = torch.bfloat16
+    q, k = rnd(T, B, D, dtype=bf, seed=1).to(DEV), rnd(T, B, D, dtype=bf, seed=2).to(DEV)
+    v1, v2 = rnd(T, B, D, dtype=bf, seed=3).to(DEV), rnd(T, B, D, dtype=bf, seed=4).to(DEV)
+    klen = torch.tensor([T, T - 37], dtype=torch.int32, device=DEV)
+    o1, lse = K.attn_fwd(q, k, v1, heads, klen=klen, p_drop=0.3, seed=77)
+    o2, _ = K.attn_fwd(q, k, v2, heads, klen=klen, p_drop=0.3, seed=77)
+    o0, _ = K.attn_fwd(q, k, v1, heads, klen=klen)
+    assert rel_err(o0, o1) > 1e-2
+    do = rnd(T, B, D, dtype=bf, seed=5).to(DEV)
+    dq, dk, dv = [torch.empty_like(q) for _ in range(3)]
+    K.attn_bwd(q, k, v1, o1, do, lse, heads, dq, dk, dv, klen=klen, p_drop=0.3, seed=77)
+    lhs = float((do.double() * o2.double()).sum()); rhs = float((dv.double() * v2.double()).sum())
+    assert abs(lhs - rhs) < 2e-2 * max(1.0, abs(lhs))
+    # expectation: the kept fraction is 1 - p (mask statistics), via O(V = ones) = sum of kept P / (1-p)
+    ones = torch.ones_like(v1)
+    oo, _ = K.attn_fwd(q, k, ones, heads, klen=klen, p_drop=0.3, seed=77)
+    assert abs(float(oo.float().mean()) - 1.0) < 0.05
 
 
 # ------------------------------------------------------------------ LayerNorm
