@@ -612,6 +612,279 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------ backward, second generation
+// Same construction as attn_fwd2_kernel (bf16, d = 64): every product is oriented so that the index a wave OWNS is the
+// lane column of its accumulators, P / dS are consumed as MFMA operands straight from the accumulators of the product
+// that made them (the 8 values a lane holds for a 32-long contraction block are its k-slice once the other operand's
+// transposed LDS read fetches the same rows), nothing is round-tripped through LDS, a wave owns 32 rows (two blocks of
+// 16) so each staged fragment feeds two MFMAs, tiles are double-buffered with register prefetch.
+//   dK/dV kernel (owns keys, loops over 64-query tiles of Q and dO):
+//     S  = Q K^T,  dP = dO V^T        acc[r] = X[query 16i+4q+r][key r16]     (A = LDS row reads, B = K / V registers)
+//     dV^T += dO^T (D*P),  dK^T += Q^T dS   acc[r] = Y^T[d 16n+4q+r][key r16]  (A = transposed reads of the same tiles)
+//   dQ kernel (owns queries, loops over 64-key tiles of K and V):
+//     S^T = K Q^T, dP^T = V dO^T      acc[r] = X^T[key 16j+4q+r][query r16]
+//     dQ^T += K^T dS^T                acc[r] = dQ^T[d 16n+4q+r][query r16]
+__device__ __forceinline__ u32x4 row_frag128(const char* tile, int row, int chunk) {
+    return *reinterpret_cast<const u32x4*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+// A operand X^T[d = 16n + r16][rows 32*blk + {4q..4q+3, 16+4q..16+4q+3}] of a [64 rows][64 d] tile (chunk swizzle row & 7)
+__device__ __forceinline__ u32x4 tr_frag128(const char* tile, int blk, int n, int r16, int q) {
+    u32x4 f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int row = 32 * blk + 16 * hh + 4 * q + (r16 >> 2);
+        const int ch = 2 * n + ((r16 & 3) >> 1);
+        const char* a = tile + row * 128 + ((ch ^ (row & 7)) << 4) + ((r16 & 1) << 3);
+        const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
+        const u32x2 w = __builtin_bit_cast(u32x2, v);
+        f[2 * hh] = w[0]; f[2 * hh + 1] = w[1];
+    }
+    return f;
+}
+struct Stage2 {                       // two [64][64] bf16 tiles per stage, register-prefetched
+    u32x4 ra[2], rb[2];
+    __device__ __forceinline__ void gload(const bf16* A, long a_st, const bf16* B, long b_st, int r0, int nvalid, int nrows) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            const bool ok = r0 + row < nvalid;
+            const long r = min(r0 + row, nrows - 1);
+            ra[i] = *reinterpret_cast<const u32x4*>(A + r * a_st + c * 8);
+            rb[i] = *reinterpret_cast<const u32x4*>(B + r * b_st + c * 8);
+            if (!ok) { ra[i] = (u32x4){0, 0, 0, 0}; rb[i] = (u32x4){0, 0, 0, 0}; }
+        }
+    }
+    __device__ __forceinline__ void lstore(char* st) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            *reinterpret_cast<u32x4*>(st + row * 128 + ((c ^ (row & 7)) << 4)) = ra[i];
+            *reinterpret_cast<u32x4*>(st + 8192 + row * 128 + ((c ^ (row & 7)) << 4)) = rb[i];
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
+    constexpr int DH = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (Q 8 KiB | dO 8 KiB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, kw = blockIdx.x * 128 + wave * 32;
+    const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const bf16* Qg = reinterpret_cast<const bf16*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
+    const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
+    const bf16* Vg = reinterpret_cast<const bf16*>(p.V) + (long)b * p.v_sb + (long)h * DH;
+    const bf16* dOg = reinterpret_cast<const bf16*>(p.dO) + (long)b * p.do_sb + (long)h * DH;
+    const float* lse = p.LSE + ((long)b * p.H + h) * p.Tq;
+    const float* dlt = p.Delta + ((long)b * p.H + h) * p.Tq;
+
+    u32x4 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int key = kw + 16 * kb + r16;
+            kf[kb][g] = vf[kb][g] = (u32x4){0, 0, 0, 0};
+            if (key < klen) {
+                kf[kb][g] = *reinterpret_cast<const u32x4*>(Kg + (long)key * p.k_st + (4 * g + q) * 8);
+                vf[kb][g] = *reinterpret_cast<const u32x4*>(Vg + (long)key * p.v_st + (4 * g + q) * 8);
+            }
+        }
+    f32x4 dkT[2][4], dvT[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { dkT[kb][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvT[kb][n] = dkT[kb][n]; }
+    const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float drop_inv = 1.f / (1.f - p.p_drop);
+
+    const int qstart = p.causal ? (int)blockIdx.x * 128 : 0;    // queries before the first key of the workgroup see nothing
+    const int ntile = qstart < p.Tq ? (p.Tq - qstart + 63) / 64 : 0;
+    Stage2 sg;
+    if (ntile > 0) { sg.gload(Qg, p.q_st, dOg, p.do_st, qstart, p.Tq, p.Tq); sg.lstore(smem); }
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int qt = qstart + t * 64;
+        const char* sQ = smem + (t & 1) * 16384;
+        const char* sDO = sQ + 8192;
+        if (t + 1 < ntile) sg.gload(Qg, p.q_st, dOg, p.do_st, qt + 64, p.Tq, p.Tq);
+        u32x4 pf[2][2], sf[2][2];                       // [key block][32-query block]: D*P and dS as B operands
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 qa[2], da[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { qa[g] = row_frag128(sQ, 16 * i + r16, 4 * g + q); da[g] = row_frag128(sDO, 16 * i + r16, 4 * g + q); }
+            float L[4], Dl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qrow = qt + 16 * i + 4 * q + r;
+                L[r] = qrow < p.Tq ? lse[qrow] : 0.f;
+                Dl[r] = qrow < p.Tq ? dlt[qrow] : 0.f;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) { st = mma16<bf16>(qa[g], kf[kb][g], st); dp = mma16<bf16>(da[g], vf[kb][g], dp); }
+                const int key = kw + 16 * kb + r16;
+                float pv[4], ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qrow = qt + 16 * i + 4 * q + r;
+                    const bool ok = qrow < p.Tq && key < klen && (!p.causal || key <= qrow);
+                    const float e = ok ? __expf(st[r] * p.scale - L[r]) : 0.f;
+                    float dsc = 1.f;
+                    if (p.p_drop > 0.f) {
+                        const uint64_t idx = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + key;
+                        const uint32_t hh = drop_hash2(p.seed, idx >> 1);
+                        dsc = ((idx & 1) ? (hh >> 16) : (hh & 0xffffu)) >= drop_th16 ? drop_inv : 0.f;
+                    }
+                    pv[r] = e * dsc;
+                    ds[r] = e * (dsc * dp[r] - Dl[r]) * p.scale;
+                }
+                pf[kb][i >> 1][2 * (i & 1)] = pack_bf16(pv[0], pv[1]); pf[kb][i >> 1][2 * (i & 1) + 1] = pack_bf16(pv[2], pv[3]);
+                sf[kb][i >> 1][2 * (i & 1)] = pack_bf16(ds[0], ds[1]); sf[kb][i >> 1][2 * (i & 1) + 1] = pack_bf16(ds[2], ds[3]);
+            }
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const u32x4 dot = tr_frag128(sDO, ib, n, r16, q), qtf = tr_frag128(sQ, ib, n, r16, q);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    dvT[kb][n] = mma16<bf16>(dot, pf[kb][ib], dvT[kb][n]);
+                    dkT[kb][n] = mma16<bf16>(qtf, sf[kb][ib], dkT[kb][n]);
+                }
+            }
+        if (t + 1 < ntile) sg.lstore(smem + ((t + 1) & 1) * 16384);
+        __syncthreads();
+    }
+    bf16* dKg = reinterpret_cast<bf16*>(p.dK) + (long)b * p.dk_sb + (long)h * DH;
+    bf16* dVg = reinterpret_cast<bf16*>(p.dV) + (long)b * p.dv_sb + (long)h * DH;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = kw + 16 * kb + r16;
+        if (key >= p.Tk) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            u32x2 w;
+            w[0] = pack_bf16(dkT[kb][n][0], dkT[kb][n][1]); w[1] = pack_bf16(dkT[kb][n][2], dkT[kb][n][3]);
+            *reinterpret_cast<u32x2*>(dKg + (long)key * p.dk_st + 16 * n + 4 * q) = w;
+            w[0] = pack_bf16(dvT[kb][n][0], dvT[kb][n][1]); w[1] = pack_bf16(dvT[kb][n][2], dvT[kb][n][3]);
+            *reinterpret_cast<u32x2*>(dVg + (long)key * p.dv_st + 16 * n + 4 * q) = w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
+    constexpr int DH = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, qw = blockIdx.x * 128 + wave * 32;
+    const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const bf16* Qg = reinterpret_cast<const bf16*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
+    const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
+    const bf16* Vg = reinterpret_cast<const bf16*>(p.V) + (long)b * p.v_sb + (long)h * DH;
+    const bf16* dOg = reinterpret_cast<const bf16*>(p.dO) + (long)b * p.do_sb + (long)h * DH;
+    const float* lse = p.LSE + ((long)b * p.H + h) * p.Tq;
+    const float* dlt = p.Delta + ((long)b * p.H + h) * p.Tq;
+
+    u32x4 qf[2][2], dof[2][2];
+    float L[2], Dl[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int row = qw + 16 * qb + r16;
+        L[qb] = row < p.Tq ? lse[row] : 0.f;
+        Dl[qb] = row < p.Tq ? dlt[row] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            qf[qb][g] = dof[qb][g] = (u32x4){0, 0, 0, 0};
+            if (row < p.Tq) {
+                qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + (long)row * p.q_st + (4 * g + q) * 8);
+                dof[qb][g] = *reinterpret_cast<const u32x4*>(dOg + (long)row * p.do_st + (4 * g + q) * 8);
+            }
+        }
+    }
+    f32x4 dqT[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) dqT[qb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float drop_inv = 1.f / (1.f - p.p_drop);
+
+    int kv_end = klen;
+    if (p.causal) kv_end = min(kv_end, (int)blockIdx.x * 128 + 128);
+    const int ntile = (kv_end + 63) / 64;
+    Stage2 sg;
+    if (ntile > 0) { sg.gload(Kg, p.k_st, Vg, p.v_st, 0, klen, p.Tk); sg.lstore(smem); }
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int kv0 = t * 64;
+        const char* sK = smem + (t & 1) * 16384;
+        const char* sV = sK + 8192;
+        if (t + 1 < ntile) sg.gload(Kg, p.k_st, Vg, p.v_st, kv0 + 64, klen, p.Tk);
+        u32x4 sf[2][2];                                 // [query block][32-key block]: dS^T as B operand
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x4 ka[2], va[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { ka[g] = row_frag128(sK, 16 * j + r16, 4 * g + q); va[g] = row_frag128(sV, 16 * j + r16, 4 * g + q); }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) { st = mma16<bf16>(ka[g], qf[qb][g], st); dp = mma16<bf16>(va[g], dof[qb][g], dp); }
+                const int qrow = qw + 16 * qb + r16;
+                const int key0 = kv0 + 16 * j + 4 * q;
+                uint32_t h0 = 0, h1 = 0, h2 = 0; int odd = 0;
+                if (p.p_drop > 0.f) {
+                    const uint64_t idx0 = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + key0;
+                    h0 = drop_hash2(p.seed, idx0 >> 1); h1 = drop_hash2(p.seed, (idx0 >> 1) + 1); h2 = drop_hash2(p.seed, (idx0 >> 1) + 2);
+                    odd = (int)(idx0 & 1);
+                }
+                float ds[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + r;
+                    const bool ok = qrow < p.Tq && key < klen && (!p.causal || key <= qrow);
+                    const float e = ok ? __expf(st[r] * p.scale - L[qb]) : 0.f;
+                    float dsc = 1.f;
+                    if (p.p_drop > 0.f) {
+                        const int ee = odd + r;
+                        const uint32_t hh = (ee >> 1) == 0 ? h0 : ((ee >> 1) == 1 ? h1 : h2);
+                        dsc = ((ee & 1) ? (hh >> 16) : (hh & 0xffffu)) >= drop_th16 ? drop_inv : 0.f;
+                    }
+                    ds[r] = e * (dsc * dp[r] - Dl[qb]) * p.scale;
+                }
+                sf[qb][j >> 1][2 * (j & 1)] = pack_bf16(ds[0], ds[1]); sf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(ds[2], ds[3]);
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const u32x4 kt = tr_frag128(sK, jb, n, r16, q);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) dqT[qb][n] = mma16<bf16>(kt, sf[qb][jb], dqT[qb][n]);
+            }
+        if (t + 1 < ntile) sg.lstore(smem + ((t + 1) & 1) * 16384);
+        __syncthreads();
+    }
+    bf16* dQg = reinterpret_cast<bf16*>(p.dQ) + (long)b * p.dq_sb + (long)h * DH;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = qw + 16 * qb + r16;
+        if (qrow >= p.Tq) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            u32x2 w;
+            w[0] = pack_bf16(dqT[qb][n][0], dqT[qb][n][1]); w[1] = pack_bf16(dqT[qb][n][2], dqT[qb][n][3]);
+            *reinterpret_cast<u32x2*>(dQg + (long)qrow * p.dq_st + 16 * n + 4 * q) = w;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 static bool strides_ok(int dtype, const long* s, int n) {
     const int e = dtype == S2T_BF16 ? 8 : 4;
@@ -632,7 +905,23 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
     const long rows = (long)a.B * a.H * a.Tq;
     hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
     S2T_LAUNCH_CHECK();
-    {
+    bool dkv2 = false, dq2 = false;
+    if constexpr (sizeof(T) == 2 && DH == 64) {
+        static const bool v1 = getenv("S2T_ATTN_V1") != nullptr;           // A/B switch for benchmarking
+        const bool al = !(a.dk_st % 4) && !(a.dk_sb % 4) && !(a.dv_st % 4) && !(a.dv_sb % 4) && !(a.dq_st % 4) && !(a.dq_sb % 4) &&
+                        !((uintptr_t)a.dK & 7) && !((uintptr_t)a.dV & 7) && !((uintptr_t)a.dQ & 7);
+        dkv2 = !v1 && al && a.Tk >= 128;
+        dq2 = !v1 && al && a.Tq >= 128;
+        if (dkv2) {
+            hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((a.Tk + 127) / 128, a.H, a.B), dim3(256), 32768, st, a);
+            S2T_LAUNCH_CHECK();
+        }
+        if (dq2) {
+            hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((a.Tq + 127) / 128, a.H, a.B), dim3(256), 32768, st, a);
+            S2T_LAUNCH_CHECK();
+        }
+    }
+    if (!dkv2) {
         static bool attr = false;
         const size_t lds = 4 * C::TILE + 8 * C::PTILE;
         if (!attr && lds > 65536) {
@@ -642,7 +931,7 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DH>), dim3((a.Tk + 63) / 64, a.H, a.B), dim3(256), lds, st, a);
         S2T_LAUNCH_CHECK();
     }
-    {
+    if (!dq2) {
         static bool attr = false;
         const size_t lds = 3 * C::TILE + 4 * C::PTILE;
         if (!attr && lds > 65536) {
