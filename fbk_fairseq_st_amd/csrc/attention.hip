@@ -108,11 +108,15 @@ struct AttnArgs {
     float scale, p_drop; unsigned long long seed;
 };
 
+// dropout element index of (b, h, query, key): key rows are padded to a multiple of 4 so that 4 consecutive keys from a
+// multiple of 4 form one hash quad (common.hpp drop_hash4) in every kernel's register layout
+__device__ __forceinline__ uint64_t drop_index(const AttnArgs& p, int b, int h, int qrow, int key) {
+    return (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)((p.Tk + 3) & ~3) + key;
+}
 __device__ __forceinline__ float drop_scale(const AttnArgs& p, int b, int h, int qrow, int key) {
     if (p.p_drop <= 0.f) return 1.f;
-    const uint64_t idx = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + key;
     const uint32_t th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
-    return dropout_keep(p.seed, idx, th) ? 1.f / (1.f - p.p_drop) : 0.f;
+    return dropout_keep(p.seed, drop_index(p, b, h, qrow, key), th) ? 1.f / (1.f - p.p_drop) : 0.f;
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -342,18 +346,9 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { pv[r] = __expf(s[qb][j][r] - mu); rs += pv[r]; }
                 if (p.p_drop > 0.f) {
-                    // element index of key 16j + 4q (+0..3): two keys share one hash (common.hpp dropout_keep)
-                    const uint64_t idx0 = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + (kv0 + 16 * j + 4 * q);
-                    const uint32_t h0 = drop_hash2(p.seed, idx0 >> 1), h1 = drop_hash2(p.seed, (idx0 >> 1) + 1),
-                                   h2 = drop_hash2(p.seed, (idx0 >> 1) + 2);
-                    const int odd = (int)(idx0 & 1);
+                    const u32x2 hq = drop_hash4(p.seed, drop_index(p, b, h, qrow, kv0 + 16 * j + 4 * q) >> 2);   // keys 4q .. 4q+3 = one quad
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int e = odd + r;         // 0..4
-                        const uint32_t hh = (e >> 1) == 0 ? h0 : ((e >> 1) == 1 ? h1 : h2);
-                        const uint32_t v16 = (e & 1) ? (hh >> 16) : (hh & 0xffffu);
-                        pv[r] = v16 >= drop_th16 ? pv[r] * drop_inv : 0.f;
-                    }
+                    for (int r = 0; r < 4; ++r) pv[r] = drop_field(hq, r) >= drop_th16 ? pv[r] * drop_inv : 0.f;
                 }
                 pf[qb][j >> 1][2 * (j & 1)] = pack_bf16(pv[0], pv[1]);
                 pf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(pv[2], pv[3]);
@@ -641,6 +636,15 @@ __device__ __forceinline__ u32x4 tr_frag128(const char* tile, int blk, int n, in
     }
     return f;
 }
+// value of lane (lane & ~3) | r of every 4-lane group (DPP quad_perm broadcast: one VALU move, no LDS traffic)
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int r) {
+    switch (r) {
+        case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true);
+        case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, true);
+        case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, true);
+        default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, true);
+    }
+}
 struct Stage2 {                       // two [64][64] bf16 tiles per stage, register-prefetched
     u32x4 ra[2], rb[2];
     __device__ __forceinline__ void gload(const bf16* A, long a_st, const bf16* B, long b_st, int r0, int nvalid, int nrows) {
@@ -726,6 +730,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) { st = mma16<bf16>(qa[g], kf[kb][g], st); dp = mma16<bf16>(da[g], vf[kb][g], dp); }
                 const int key = kw + 16 * kb + r16;
+                u32x2 hq = {0u, 0u};
+                if (p.p_drop > 0.f) hq = drop_hash4(p.seed, drop_index(p, b, h, qt + 16 * i + 4 * q + (r16 & 3), key) >> 2);
                 float pv[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -734,9 +740,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
                     const float e = ok ? __expf(st[r] * p.scale - L[r]) : 0.f;
                     float dsc = 1.f;
                     if (p.p_drop > 0.f) {
-                        const uint64_t idx = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + key;
-                        const uint32_t hh = drop_hash2(p.seed, idx >> 1);
-                        dsc = ((idx & 1) ? (hh >> 16) : (hh & 0xffffu)) >= drop_th16 ? drop_inv : 0.f;
+                        // lane r16 hashed (query 4q + (r16 & 3), key quad r16 >> 2): the quad of (query 4q + r, own key) sits in
+                        // lane (r16 & ~3) | r of the same 4-lane group -> DPP quad broadcast, then take the own key's field
+                        dsc = drop_field((u32x2){quad_bcast(hq[0], r), quad_bcast(hq[1], r)}, r16 & 3) >= drop_th16 ? drop_inv : 0.f;
                     }
                     pv[r] = e * dsc;
                     ds[r] = e * (dsc * dp[r] - Dl[r]) * p.scale;
@@ -837,12 +843,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
                 for (int g = 0; g < 2; ++g) { st = mma16<bf16>(ka[g], qf[qb][g], st); dp = mma16<bf16>(va[g], dof[qb][g], dp); }
                 const int qrow = qw + 16 * qb + r16;
                 const int key0 = kv0 + 16 * j + 4 * q;
-                uint32_t h0 = 0, h1 = 0, h2 = 0; int odd = 0;
-                if (p.p_drop > 0.f) {
-                    const uint64_t idx0 = (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)p.Tk + key0;
-                    h0 = drop_hash2(p.seed, idx0 >> 1); h1 = drop_hash2(p.seed, (idx0 >> 1) + 1); h2 = drop_hash2(p.seed, (idx0 >> 1) + 2);
-                    odd = (int)(idx0 & 1);
-                }
+                u32x2 hq = {0u, 0u};
+                if (p.p_drop > 0.f) hq = drop_hash4(p.seed, drop_index(p, b, h, qrow, key0) >> 2);     // keys 4q .. 4q+3 = one quad
                 float ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -850,11 +852,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
                     const bool ok = qrow < p.Tq && key < klen && (!p.causal || key <= qrow);
                     const float e = ok ? __expf(st[r] * p.scale - L[qb]) : 0.f;
                     float dsc = 1.f;
-                    if (p.p_drop > 0.f) {
-                        const int ee = odd + r;
-                        const uint32_t hh = (ee >> 1) == 0 ? h0 : ((ee >> 1) == 1 ? h1 : h2);
-                        dsc = ((ee & 1) ? (hh >> 16) : (hh & 0xffffu)) >= drop_th16 ? drop_inv : 0.f;
-                    }
+                    if (p.p_drop > 0.f) dsc = drop_field(hq, r) >= drop_th16 ? drop_inv : 0.f;
                     ds[r] = e * (dsc * dp[r] - Dl[qb]) * p.scale;
                 }
                 sf[qb][j >> 1][2 * (j & 1)] = pack_bf16(ds[0], ds[1]); sf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(ds[2], ds[3]);

@@ -74,13 +74,13 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& p, const char* smem,
 #pragma unroll
             for (int e = 0; e < CW; ++e) bv[e] = (p.bias && col + e < p.N) ? p.bias[col + e] : 0.f;
         }
-        // one hash per element pair when rows start on an even element index
-        const bool pair_ok = (p.N & 1) == 0;
-        uint32_t dh[CW / 2];
-        if (p.p_drop > 0.f && pair_ok) {
-            const uint64_t base = ((uint64_t)row * p.N + col) >> 1;
+        // one hash per element quad when rows start on a multiple of four elements
+        const bool quad_ok = (p.N & 3) == 0;
+        u32x2 dh[CW / 4];
+        if (p.p_drop > 0.f && quad_ok) {
+            const uint64_t base = ((uint64_t)row * p.N + col) >> 2;
 #pragma unroll
-            for (int k = 0; k < CW / 2; ++k) dh[k] = drop_hash2(p.seed, base + k);
+            for (int k = 0; k < CW / 4; ++k) dh[k] = drop_hash4(p.seed, base + k);
         }
         TO pre[CW], o[CW];
 #pragma unroll
@@ -92,7 +92,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& p, const char* smem,
             else if constexpr (ACT == ACT_GELU_BWD) x *= gelu_grad_f(to_f32(raux[e]));
             if (p.p_drop > 0.f) {
                 bool keep;
-                if (pair_ok) keep = ((e & 1) ? (dh[e >> 1] >> 16) : (dh[e >> 1] & 0xffffu)) >= (drop_th >> 16);
+                if (quad_ok) keep = drop_field(dh[e >> 2], e & 3) >= (drop_th >> 16);
                 else keep = dropout_keep(p.seed, (uint64_t)row * p.N + col + e, drop_th);
                 x = keep ? x * drop_inv : 0.f;
             }

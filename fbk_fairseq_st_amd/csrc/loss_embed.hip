@@ -114,20 +114,35 @@ extern "C" int s2t_embed_bwd(int dtype, const long long* tokens, const void* dou
 // ------------------------------------------------------------------ dropout (Philox, mask regenerated in backward)
 // y = x * keep/(1-p) with keep from (seed, element index); backward = the same call on the gradient.
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, float p, unsigned long long seed) {
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n, float p, unsigned long long seed, int vec) {
     const uint32_t th = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
     const float inv = 1.f / (1.f - p);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    constexpr int E = 16 / (int)sizeof(T);                      // elements per 16-byte access = E/4 hash quads
+    const size_t nv = vec ? n / E : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        T v[E];
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + i * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            const u32x2 h = drop_hash4(seed, i * (E / 4) + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * k + e] = from_f32<T>(drop_field(h, e) >= (th >> 16) ? to_f32(v[4 * k + e]) * inv : 0.f);
+        }
+        *reinterpret_cast<u32x4*>(y + i * E) = *reinterpret_cast<const u32x4*>(v);
+    }
+    for (size_t i = nv * E + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         y[i] = from_f32<T>(dropout_keep(seed, i, th) ? to_f32(x[i]) * inv : 0.f);
 }
 extern "C" int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p, unsigned long long seed, void* stream) {
     if (n == 0) return S2T_OK;
     if (!x || !y || p < 0.f || p >= 1.f) return S2T_EINVAL;
-    int blocks = (int)((n + 255) / 256);
-    blocks = blocks > 4096 ? 4096 : blocks;
+    const int vec = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    const size_t per = dtype == S2T_BF16 ? 8 : 4;
+    int blocks = (int)((n / (vec ? per : 1) + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, p, seed);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, n, p, seed);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, p, seed, vec);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, n, p, seed, vec);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
