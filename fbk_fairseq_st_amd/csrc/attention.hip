@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "prof.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 template <typename T, int DH> struct ACfg {
     static constexpr int E = Elem<T>::PER16;
@@ -241,7 +242,7 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     const bf16 a = (bf16)lo, b = (bf16)hi;
     return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
 }
-__global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs p) {
     };
     const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
     const float drop_inv = 1.f / (1.f - p.p_drop);
+    const float sc2 = p.scale * 1.44269504088896f;
 
     if (ntile > 0) { gload(0); lstore(smem); }
     __syncthreads();
@@ -319,44 +321,52 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs p) {
                 for (int g = 0; g < 2; ++g) s[qb][j] = mma16<bf16>(kf[g], qf[qb][g], s[qb][j]);
             }
         }
-        // ---- online softmax, per lane = per query
+        // ---- online softmax, per lane = per query (base-2 domain: s2 = s * scale * log2 e); interior tiles carry no masks
         u32x4 pf[2][2];                                // [query block][32-key block]
+        auto softmax_tile = [&](auto masked) {
+            constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int qrow = qw + 16 * qb + r16;
-            float mx = -INFINITY;
+            for (int qb = 0; qb < 2; ++qb) {
+                const int qrow = qw + 16 * qb + r16;
+                float mx = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kv0 + 16 * j + 4 * q + r;
-                    const bool ok = key < klen && (!p.causal || key <= qrow);
-                    s[qb][j][r] = ok ? s[qb][j][r] * p.scale : -INFINITY;
-                    mx = fmaxf(mx, s[qb][j][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        float v = s[qb][j][r] * sc2;
+                        if constexpr (MASK) {
+                            const int key = kv0 + 16 * j + 4 * q + r;
+                            const bool ok = key < klen && (!p.causal || key <= qrow);
+                            v = ok ? v : -INFINITY;
+                        }
+                        s[qb][j][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mn = fmaxf(m[qb], mx);
+                const float mu = (mn == -INFINITY) ? 0.f : mn;
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mu);    // m = -inf -> 0
+                m[qb] = mn;
+                float rs = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float pv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(s[qb][j][r] - mu); rs += pv[r]; }
+                    if (p.p_drop > 0.f) {
+                        const u32x2 hq = drop_hash4(p.seed, drop_index(p, b, h, qrow, kv0 + 16 * j + 4 * q) >> 2);   // keys 4q .. 4q+3 = one quad
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pv[r] = drop_field(hq, r) >= drop_th16 ? pv[r] * drop_inv : 0.f;
+                    }
+                    pf[qb][j >> 1][2 * (j & 1)] = pack_bf16(pv[0], pv[1]);
+                    pf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(pv[2], pv[3]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m[qb], mx);
-            const float mu = (mn == -INFINITY) ? 0.f : mn;
-            const float alpha = __expf(m[qb] - mu);    // m = -inf -> 0
-            m[qb] = mn;
-            float rs = 0.f;
+                l[qb] = l[qb] * alpha + rs;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float pv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { pv[r] = __expf(s[qb][j][r] - mu); rs += pv[r]; }
-                if (p.p_drop > 0.f) {
-                    const u32x2 hq = drop_hash4(p.seed, drop_index(p, b, h, qrow, kv0 + 16 * j + 4 * q) >> 2);   // keys 4q .. 4q+3 = one quad
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pv[r] = drop_field(hq, r) >= drop_th16 ? pv[r] * drop_inv : 0.f;
-                }
-                pf[qb][j >> 1][2 * (j & 1)] = pack_bf16(pv[0], pv[1]);
-                pf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(pv[2], pv[3]);
+                for (int n = 0; n < 4; ++n) o[qb][n] *= alpha;
             }
-            l[qb] = l[qb] * alpha + rs;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) o[qb][n] *= alpha;
-        }
+        };
+        if (p.causal || kv0 + 64 > klen) softmax_tile(std::true_type{}); else softmax_tile(std::false_type{});
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -393,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs p) {
             w[1] = pack_bf16(o[qb][n][2] * inv, o[qb][n][3] * inv);
             *reinterpret_cast<u32x2*>(Og + (long)qrow * p.o_st + 16 * n + 4 * q) = w;
         }
-        if (q == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Tq + qrow] = m[qb] + logf(lt);
+        if (q == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Tq + qrow] = m[qb] * 0.693147180559945f + logf(lt);
     }
 }
 
@@ -668,7 +678,7 @@ struct Stage2 {                       // two [64][64] bf16 tiles per stage, regi
     }
 };
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (Q 8 KiB | dO 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
@@ -681,18 +691,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
     const float* lse = p.LSE + ((long)b * p.H + h) * p.Tq;
     const float* dlt = p.Delta + ((long)b * p.H + h) * p.Tq;
 
-    u32x4 kf[2][2], vf[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int key = kw + 16 * kb + r16;
-            kf[kb][g] = vf[kb][g] = (u32x4){0, 0, 0, 0};
-            if (key < klen) {
-                kf[kb][g] = *reinterpret_cast<const u32x4*>(Kg + (long)key * p.k_st + (4 * g + q) * 8);
-                vf[kb][g] = *reinterpret_cast<const u32x4*>(Vg + (long)key * p.v_st + (4 * g + q) * 8);
-            }
+    // the workgroup's own 128 keys: K and V rows parked in LDS for the whole kernel (B operands of S and dP); holding the
+    // 8 fragments per lane in registers instead pushed the kernel past 256 VGPRs
+    char* sKown = smem + 32768 + 1024;                              // [128 keys][64 d] K, then V
+    char* sVown = sKown + 16384;
+    for (int cid = threadIdx.x; cid < 128 * 8; cid += 256) {
+        const int row = cid >> 3, c = cid & 7, key = blockIdx.x * 128 + row;
+        u32x4 kk = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+        if (key < klen) {
+            kk = *reinterpret_cast<const u32x4*>(Kg + (long)key * p.k_st + c * 8);
+            vv = *reinterpret_cast<const u32x4*>(Vg + (long)key * p.v_st + c * 8);
         }
+        *reinterpret_cast<u32x4*>(sKown + row * 128 + ((c ^ (row & 7)) << 4)) = kk;
+        *reinterpret_cast<u32x4*>(sVown + row * 128 + ((c ^ (row & 7)) << 4)) = vv;
+    }
     f32x4 dkT[2][4], dvT[2][4];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -704,40 +716,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
     const int qstart = p.causal ? (int)blockIdx.x * 128 : 0;    // queries before the first key of the workgroup see nothing
     const int ntile = qstart < p.Tq ? (p.Tq - qstart + 63) / 64 : 0;
     Stage2 sg;
-    if (ntile > 0) { sg.gload(Qg, p.q_st, dOg, p.do_st, qstart, p.Tq, p.Tq); sg.lstore(smem); }
+    // per-query statistics of the tile (LSE pre-multiplied by log2 e, Delta) travel with it: threads 0..63 / 64..127
+    float* sStat = reinterpret_cast<float*>(smem + 32768);          // [2 stages][2][64]
+    float stat = 0.f;
+    auto stat_load = [&](int qt) {
+        if (threadIdx.x < 128) {
+            const int row = qt + (threadIdx.x & 63);
+            stat = 0.f;
+            if (row < p.Tq) stat = threadIdx.x < 64 ? lse[row] * 1.44269504088896f : dlt[row];
+        }
+    };
+    auto stat_store = [&](int stage) { if (threadIdx.x < 128) sStat[stage * 128 + threadIdx.x] = stat; };
+    if (ntile > 0) { sg.gload(Qg, p.q_st, dOg, p.do_st, qstart, p.Tq, p.Tq); stat_load(qstart); sg.lstore(smem); stat_store(0); }
     __syncthreads();
+    const float sc2 = p.scale * 1.44269504088896f;
     for (int t = 0; t < ntile; ++t) {
         const int qt = qstart + t * 64;
         const char* sQ = smem + (t & 1) * 16384;
         const char* sDO = sQ + 8192;
-        if (t + 1 < ntile) sg.gload(Qg, p.q_st, dOg, p.do_st, qt + 64, p.Tq, p.Tq);
-        u32x4 pf[2][2], sf[2][2];                       // [key block][32-query block]: D*P and dS as B operands
+        const float* sL = sStat + (t & 1) * 128;
+        if (t + 1 < ntile) { sg.gload(Qg, p.q_st, dOg, p.do_st, qt + 64, p.Tq, p.Tq); stat_load(qt + 64); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int ib = 0; ib < 2; ++ib) {                  // 32 queries at a time: their P / dS operands are consumed at once
+        u32x4 pf[2], sf[2];                             // [key block]: D*P and dS as B operands
+#pragma unroll
+        for (int i = 2 * ib; i < 2 * ib + 2; ++i) {
             u32x4 qa[2], da[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g) { qa[g] = row_frag128(sQ, 16 * i + r16, 4 * g + q); da[g] = row_frag128(sDO, 16 * i + r16, 4 * g + q); }
-            float L[4], Dl[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = qt + 16 * i + 4 * q + r;
-                L[r] = qrow < p.Tq ? lse[qrow] : 0.f;
-                Dl[r] = qrow < p.Tq ? dlt[qrow] : 0.f;
-            }
+            const f32x4 L = *reinterpret_cast<const f32x4*>(sL + 16 * i + 4 * q);
+            const f32x4 Dl = *reinterpret_cast<const f32x4*>(sL + 64 + 16 * i + 4 * q);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int g = 0; g < 2; ++g) { st = mma16<bf16>(qa[g], kf[kb][g], st); dp = mma16<bf16>(da[g], vf[kb][g], dp); }
+                for (int g = 0; g < 2; ++g) {
+                    const int krow = wave * 32 + 16 * kb + r16;
+                    st = mma16<bf16>(qa[g], row_frag128(sKown, krow, 4 * g + q), st);
+                    dp = mma16<bf16>(da[g], row_frag128(sVown, krow, 4 * g + q), dp);
+                }
                 const int key = kw + 16 * kb + r16;
                 u32x2 hq = {0u, 0u};
                 if (p.p_drop > 0.f) hq = drop_hash4(p.seed, drop_index(p, b, h, qt + 16 * i + 4 * q + (r16 & 3), key) >> 2);
                 float pv[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qrow = qt + 16 * i + 4 * q + r;
-                    const bool ok = qrow < p.Tq && key < klen && (!p.causal || key <= qrow);
-                    const float e = ok ? __expf(st[r] * p.scale - L[r]) : 0.f;
+                    // rows past Tq are zero in Q / dO / statistics and so contribute exactly 0; columns past klen are
+                    // discarded at the store: only the causal triangle needs a per-element mask
+                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - L[r]);
+                    if (p.causal) e = (key <= qt + 16 * i + 4 * q + r) ? e : 0.f;
                     float dsc = 1.f;
                     if (p.p_drop > 0.f) {
                         // lane r16 hashed (query 4q + (r16 & 3), key quad r16 >> 2): the quad of (query 4q + r, own key) sits in
@@ -747,22 +774,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
                     pv[r] = e * dsc;
                     ds[r] = e * (dsc * dp[r] - Dl[r]) * p.scale;
                 }
-                pf[kb][i >> 1][2 * (i & 1)] = pack_bf16(pv[0], pv[1]); pf[kb][i >> 1][2 * (i & 1) + 1] = pack_bf16(pv[2], pv[3]);
-                sf[kb][i >> 1][2 * (i & 1)] = pack_bf16(ds[0], ds[1]); sf[kb][i >> 1][2 * (i & 1) + 1] = pack_bf16(ds[2], ds[3]);
+                pf[kb][2 * (i & 1)] = pack_bf16(pv[0], pv[1]); pf[kb][2 * (i & 1) + 1] = pack_bf16(pv[2], pv[3]);
+                sf[kb][2 * (i & 1)] = pack_bf16(ds[0], ds[1]); sf[kb][2 * (i & 1) + 1] = pack_bf16(ds[2], ds[3]);
             }
         }
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const u32x4 dot = tr_frag128(sDO, ib, n, r16, q), qtf = tr_frag128(sQ, ib, n, r16, q);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    dvT[kb][n] = mma16<bf16>(dot, pf[kb][ib], dvT[kb][n]);
-                    dkT[kb][n] = mma16<bf16>(qtf, sf[kb][ib], dkT[kb][n]);
+                    dvT[kb][n] = mma16<bf16>(dot, pf[kb], dvT[kb][n]);
+                    dkT[kb][n] = mma16<bf16>(qtf, sf[kb], dkT[kb][n]);
                 }
             }
-        if (t + 1 < ntile) sg.lstore(smem + ((t + 1) & 1) * 16384);
+        }
+        if (t + 1 < ntile) { sg.lstore(smem + ((t + 1) & 1) * 16384); stat_store((t + 1) & 1); }
         __syncthreads();
     }
     bf16* dKg = reinterpret_cast<bf16*>(p.dK) + (long)b * p.dk_sb + (long)h * DH;
@@ -771,6 +797,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
     for (int kb = 0; kb < 2; ++kb) {
         const int key = kw + 16 * kb + r16;
         if (key >= p.Tk) continue;
+        const float kz = key < klen ? 1.f : 0.f;          // padded keys get exact zeros
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { dkT[kb][n] *= kz; dvT[kb][n] *= kz; }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             u32x2 w;
@@ -782,7 +811,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(AttnArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
@@ -800,7 +829,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int row = qw + 16 * qb + r16;
-        L[qb] = row < p.Tq ? lse[row] : 0.f;
+        L[qb] = row < p.Tq ? lse[row] * 1.44269504088896f : 0.f;
         Dl[qb] = row < p.Tq ? dlt[row] : 0.f;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -822,6 +851,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
     int kv_end = klen;
     if (p.causal) kv_end = min(kv_end, (int)blockIdx.x * 128 + 128);
     const int ntile = (kv_end + 63) / 64;
+    const float sc2 = p.scale * 1.44269504088896f;
     Stage2 sg;
     if (ntile > 0) { sg.gload(Kg, p.k_st, Vg, p.v_st, 0, klen, p.Tk); sg.lstore(smem); }
     __syncthreads();
@@ -831,6 +861,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
         const char* sV = sK + 8192;
         if (t + 1 < ntile) sg.gload(Kg, p.k_st, Vg, p.v_st, kv0 + 64, klen, p.Tk);
         u32x4 sf[2][2];                                 // [query block][32-key block]: dS^T as B operand
+        auto ds_tile = [&](auto masked) {
+        constexpr bool MASK = decltype(masked)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32x4 ka[2], va[2];
@@ -848,9 +880,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
                 float ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + r;
-                    const bool ok = qrow < p.Tq && key < klen && (!p.causal || key <= qrow);
-                    const float e = ok ? __expf(st[r] * p.scale - L[qb]) : 0.f;
+                    // query rows past Tq are never stored; padded / future keys must not reach dQ
+                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - L[qb]);
+                    if constexpr (MASK) {
+                        const int key = key0 + r;
+                        e = (key < klen && (!p.causal || key <= qrow)) ? e : 0.f;
+                    }
                     float dsc = 1.f;
                     if (p.p_drop > 0.f) dsc = drop_field(hq, r) >= drop_th16 ? drop_inv : 0.f;
                     ds[r] = e * (dsc * dp[r] - Dl[qb]) * p.scale;
@@ -858,6 +893,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs p) {
                 sf[qb][j >> 1][2 * (j & 1)] = pack_bf16(ds[0], ds[1]); sf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(ds[2], ds[3]);
             }
         }
+        };
+        if (p.causal || kv0 + 64 > klen) ds_tile(std::true_type{}); else ds_tile(std::false_type{});
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -911,7 +948,11 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
         dkv2 = !v1 && al && a.Tk >= 128;
         dq2 = !v1 && al && a.Tq >= 128;
         if (dkv2) {
-            hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((a.Tk + 127) / 128, a.H, a.B), dim3(256), 32768, st, a);
+            {
+                static bool attr = false;
+                if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 + 1024 + 32768); attr = true; }
+            }
+            hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((a.Tk + 127) / 128, a.H, a.B), dim3(256), 32768 + 1024 + 32768, st, a);
             S2T_LAUNCH_CHECK();
         }
         if (dq2) {

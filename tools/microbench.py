@@ -43,6 +43,8 @@ for dtype in ((torch.bfloat16,) if os.environ.get("BF16_ONLY") else (torch.bfloa
     print("attn bwd                 %8.1f us  %7.1f TF/s (10*BHT^2d)" % (t * 1e6, 2.5 * fl / t / 1e12))
     t = timeit(lambda: K.attn_fwd(q, k, v, H, p_drop=0.1, seed=1))
     print("attn fwd + dropout       %8.1f us" % (t * 1e6))
+    t = timeit(lambda: K.attn_bwd(q, k, v, o, do, lse, H, dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], p_drop=0.1, seed=1))
+    print("attn bwd + dropout       %8.1f us" % (t * 1e6))
     x = torch.randn(M, 512, device=dev).to(dtype); g = torch.ones(512, device=dev); b = torch.zeros(512, device=dev)
     t = timeit(lambda: K.layernorm_fwd(x, g, b))
     print("layernorm fwd M=%d D=512 %8.1f us  %6.2f TB/s" % (M, t * 1e6, 2 * x.numel() * x.element_size() / t / 1e12))
