@@ -31,6 +31,25 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+# kernel template behind each profiled family (names as they appear in the rocprofv3 kernel trace, profiles/)
+KERNEL_OF = {"gemm_tn": "gemm_fast_kernel<bf16, float, TA=true, TB=true, 128, 128, 4 waves> (dW = dY^T X, split-K)",
+             "gemm_nt": "gemm_fast_kernel<bf16, bf16, false, false, 128, 128, 8 waves> (Y = X W^T)",
+             "gemm_nn": "gemm_fast_kernel<bf16, bf16, false, TB=true, 128, 128, 8 waves> (dX = dY W)",
+             "gemm_gather": "gemm_kernel<..> with row gather (conv2 as implicit GEMM)"}
+
+
+def hbm_traffic(family):
+    """HBM bytes per launch of the family's kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_hbm_traffic.json, made by tools/hbm_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes,
+    MI355X_MICROARCH.md section HBM); None when the file is absent."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_hbm_traffic.json")) as f:
+            t = json.load(f)
+        return t["families"][family]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_F32_TFLOPS = 157.3
 
@@ -156,15 +175,22 @@ def main():
             trainer.train_step([sample])
         torch.cuda.synchronize()
         K.prof_enable(False)
-        fam = {f: K.prof_read(f) for f in ("gemm", "gemm_gather", "attn_fwd", "attn_bwd")}
-        gm = fam["gemm"]
-        if gm["launches"] > 0 and gm["ms"] > 0:
+        names = ("gemm_tn", "gemm_nt", "gemm_nn", "gemm_gather", "attn_fwd", "attn_bwd")
+        fam = {f: K.prof_read(f) for f in names}
+        gemms = {f: v for f, v in fam.items() if f.startswith("gemm") and v["launches"] > 0 and v["ms"] > 0}
+        if gemms:
+            # dominant kernel = the GEMM family with the most time per step (one kernel template per family, see KERNEL_OF)
+            dom = max(gemms, key=lambda f: gemms[f]["ms"])
+            gm = gemms[dom]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
             peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-            roof = {"bound": "mfma", "kernel": "gemm_kernel (libs2t_hip.so, all s2t_gemm launches of a step)",
+            tot_fl = sum(v["flops"] for v in gemms.values()); tot_ms = sum(v["ms"] for v in gemms.values())
+            roof = {"bound": "mfma", "kernel": KERNEL_OF[dom], "family": dom,
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None, "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 2),
+                    "traffic": hbm_traffic(dom), "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 2),
                     "launches_per_step": gm["launches"] // args.prof_steps,
+                    "flop_per_launch": round(gm["flops"] / gm["launches"] / 1e9, 3), "flop_unit": "GFLOP",
+                    "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                     "ms_per_step": {k: round(v["ms"] / args.prof_steps, 3) for k, v in fam.items()}}
     if world > 1:
         torch.distributed.barrier()

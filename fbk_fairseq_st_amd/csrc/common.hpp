@@ -109,7 +109,10 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ u32x2 drop_hash4(uint64_t seed, uint64_t quad) {
-    uint32_t x = mix32((uint32_t)quad ^ (uint32_t)seed);
+    // the seed is scrambled first (wave-uniform: scalar ALU) so that call sites whose seeds differ by small offsets do not
+    // reuse one mask at xor-neighbouring positions
+    const uint32_t ks = mix32((uint32_t)seed * 0x9E3779B9u + 0x7F4A7C15u);
+    uint32_t x = mix32((uint32_t)quad ^ ks);
     const uint32_t hw = (uint32_t)(quad >> 32) + (uint32_t)(seed >> 32);     // almost always zero: no multiply spent on it
     x ^= hw ^ (hw << 13) ^ (hw >> 7) ^ (hw << 27);
     uint32_t y = (x ^ 0x68E31DA4u) * 0xB5297A4Du;

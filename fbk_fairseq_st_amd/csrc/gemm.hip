@@ -411,12 +411,23 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = (BM + BN) * 128;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tiles = tiles_m * tiles_n;
+    int wg, kz;
+    {
+        // Workgroups are dealt to the 8 XCDs round-robin on their linear id.  Without split-K an XCD gets a contiguous run
+        // of tiles (neighbours share A rows / B columns in its L2).  With split-K the k-slices partition the ROWS of both
+        // operands, so all tiles of one slice belong on one XCD: it then streams its slice of the operands from HBM once
+        // (PMC: the dW products read 2.2x their operand bytes with the tile-major deal).
+        const int L = blockIdx.z * tiles + blockIdx.x, xcd = L & 7, j = L >> 3, sk = p.splitk;
+        if (sk > 1 && (sk & 7) == 0) { kz = xcd + 8 * (j / tiles); wg = j % tiles; }
+        else if ((sk == 2 || sk == 4) && tiles % (8 / sk) == 0) { kz = xcd % sk; wg = (xcd / sk) * (tiles / (8 / sk)) + j; }
+        else { kz = blockIdx.z; wg = xcd_remap(blockIdx.x, tiles); }
+    }
     const int tm = wg / tiles_n, tn = wg % tiles_n;
     const int row0 = tm * BM, col0 = tn * BN;
     const int nk_total = p.K / BK;
     const int per = (nk_total + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.z * per, kt1 = min(nk_total, kt0 + per);
+    const int kt0 = kz * per, kt1 = min(nk_total, kt0 + per);
     const int nk = kt1 - kt0;
     if (nk <= 0) return;
 
@@ -699,7 +710,8 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     { static const char* e = getenv("S2T_GEMM_DBG"); if (e) a.dbg = atoi(e); }
     hipStream_t st = (hipStream_t)stream;
     const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
-    ProfScope prof(mapA || mapB ? "gemm_gather" : "gemm", st, 2.0 * M * (double)N * K,
+    // families for the roofline report: dW-shaped (TN), forward (NT), dX-shaped (NN) products and the implicit-GEMM convolution
+    ProfScope prof(mapA || mapB ? "gemm_gather" : (trans_a ? "gemm_tn" : (trans_b ? "gemm_nn" : "gemm_nt")), st, 2.0 * M * (double)N * K,
                    esz * ((double)M * K + (double)N * K) + osz * (double)M * N);
     if (in_dtype == S2T_BF16 && !trans_a && !trans_b) {      // big forward projections: direct-to-LDS 3-stage kernel
         const int r = s2t_gemm_v2_try(a, out_dtype, st);
