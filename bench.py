@@ -35,7 +35,8 @@ sys.path.insert(0, REPO)
 KERNEL_OF = {"gemm_tn": "gemm_fast_kernel<bf16, float, TA=true, TB=true, 128, 128, 4 waves> (dW = dY^T X, split-K)",
              "gemm_nt": "gemm_fast_kernel<bf16, bf16, false, false, 128, 128, 8 waves> (Y = X W^T)",
              "gemm_nn": "gemm_fast_kernel<bf16, bf16, false, TB=true, 128, 128, 8 waves> (dX = dY W)",
-             "gemm_gather": "gemm_kernel<..> with row gather (conv2 as implicit GEMM)"}
+             "gemm_tn_small": "gemm_fast_kernel<.., 64, 64, 4 waves> (small dW)", "gemm_nt_small": "gemm_fast_kernel<.., 64, 64, 4 waves>",
+             "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (conv2 as implicit GEMM)"}
 
 
 def hbm_traffic(family):
@@ -175,7 +176,7 @@ def main():
             trainer.train_step([sample])
         torch.cuda.synchronize()
         K.prof_enable(False)
-        names = ("gemm_tn", "gemm_nt", "gemm_nn", "gemm_gather", "attn_fwd", "attn_bwd")
+        names = ("gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small", "gemm_gather", "attn_fwd", "attn_bwd")
         fam = {f: K.prof_read(f) for f in names}
         gemms = {f: v for f, v in fam.items() if f.startswith("gemm") and v["launches"] > 0 and v["ms"] > 0}
         if gemms:

@@ -237,6 +237,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 // for a 32-key block (4q..4q+3 of its two 16-key tiles) are exactly the k-slice of its P^T operand once V's transposed
 // reads fetch the same keys.  V is staged as it lies in memory (no transposing scatter); K/V tiles are double-buffered
 // with register prefetch, one barrier per 64 keys.  Dropout mask = the same per-(query, key) hash as every other kernel.
+// The workgroups of one (batch, head) read the same K/V (or Q/dO) tiles: put them on one XCD so its L2 serves the re-reads
+// (PMC: the forward fetched 2.1x its operand bytes with the tiles of a head dealt round-robin over the 8 XCDs).
+// Linear id L -> XCD L % 8 (dispatch order x fastest); returns the tile index within the head, sets the head index.
+__device__ __forceinline__ int head_xcd_remap(int& head, int nheads, int ntile) {
+    const int L = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (nheads & 7) { head = (int)blockIdx.z * gridDim.y + blockIdx.y; return blockIdx.x; }
+    const int slot = L >> 3;
+    head = (L & 7) + 8 * (slot / ntile);
+    return slot % ntile;
+}
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     const bf16 a = (bf16)lo, b = (bf16)hi;
@@ -246,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, qw = blockIdx.x * 128 + wave * 32;
+    int head;
+    const int bx = head_xcd_remap(head, p.B * p.H, gridDim.x);
+    const int b = head / p.H, h = head % p.H, qw = bx * 128 + wave * 32;
     const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
     const bf16* Qg = reinterpret_cast<const bf16*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
     const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
 
     int kv_end = klen;
-    if (p.causal) kv_end = min(kv_end, (int)blockIdx.x * 128 + 128);
+    if (p.causal) kv_end = min(kv_end, bx * 128 + 128);
     const int ntile = (kv_end + 63) / 64;
 
     // staging: thread -> (row, chunk) of the K and of the V tile, two 16-byte pieces each
@@ -682,7 +694,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (Q 8 KiB | dO 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, kw = blockIdx.x * 128 + wave * 32;
+    int head;
+    const int bx = head_xcd_remap(head, p.B * p.H, gridDim.x);
+    const int b = head / p.H, h = head % p.H, kw = bx * 128 + wave * 32;
     const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
     const bf16* Qg = reinterpret_cast<const bf16*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
     const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
@@ -696,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     char* sKown = smem + 32768 + 1024;                              // [128 keys][64 d] K, then V
     char* sVown = sKown + 16384;
     for (int cid = threadIdx.x; cid < 128 * 8; cid += 256) {
-        const int row = cid >> 3, c = cid & 7, key = blockIdx.x * 128 + row;
+        const int row = cid >> 3, c = cid & 7, key = bx * 128 + row;
         u32x4 kk = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
         if (key < klen) {
             kk = *reinterpret_cast<const u32x4*>(Kg + (long)key * p.k_st + c * 8);
@@ -713,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
     const float drop_inv = 1.f / (1.f - p.p_drop);
 
-    const int qstart = p.causal ? (int)blockIdx.x * 128 : 0;    // queries before the first key of the workgroup see nothing
+    const int qstart = p.causal ? bx * 128 : 0;                 // queries before the first key of the workgroup see nothing
     const int ntile = qstart < p.Tq ? (p.Tq - qstart + 63) / 64 : 0;
     Stage2 sg;
     // per-query statistics of the tile (LSE pre-multiplied by log2 e, Delta) travel with it: threads 0..63 / 64..127
@@ -815,7 +829,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y, qw = blockIdx.x * 128 + wave * 32;
+    int head;
+    const int bx = head_xcd_remap(head, p.B * p.H, gridDim.x);
+    const int b = head / p.H, h = head % p.H, qw = bx * 128 + wave * 32;
     const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
     const bf16* Qg = reinterpret_cast<const bf16*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
     const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
@@ -849,7 +865,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
     const float drop_inv = 1.f / (1.f - p.p_drop);
 
     int kv_end = klen;
-    if (p.causal) kv_end = min(kv_end, (int)blockIdx.x * 128 + 128);
+    if (p.causal) kv_end = min(kv_end, bx * 128 + 128);
     const int ntile = (kv_end + 63) / 64;
     const float sc2 = p.scale * 1.44269504088896f;
     Stage2 sg;

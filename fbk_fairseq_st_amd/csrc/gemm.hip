@@ -710,17 +710,19 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     { static const char* e = getenv("S2T_GEMM_DBG"); if (e) a.dbg = atoi(e); }
     hipStream_t st = (hipStream_t)stream;
     const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
-    // families for the roofline report: dW-shaped (TN), forward (NT), dX-shaped (NN) products and the implicit-GEMM convolution
-    ProfScope prof(mapA || mapB ? "gemm_gather" : (trans_a ? "gemm_tn" : (trans_b ? "gemm_nn" : "gemm_nt")), st, 2.0 * M * (double)N * K,
+    // small problems: 64x64 tiles so that more workgroups exist than CUs
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
+    const bool small = t128 < 192;
+    const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
+    // families for the roofline report (one kernel template each): dW-shaped (TN), forward (NT), dX-shaped (NN) products on
+    // 128x128 tiles, their small-problem 64x64 forms, and the implicit-GEMM convolution
+    static const char* const kFam[3][2] = {{"gemm_nt", "gemm_nt_small"}, {"gemm_nn", "gemm_nn_small"}, {"gemm_tn", "gemm_tn_small"}};
+    ProfScope prof(mapA || mapB ? "gemm_gather" : kFam[trans_a ? 2 : (trans_b ? 1 : 0)][small ? 1 : 0], st, 2.0 * M * (double)N * K,
                    esz * ((double)M * K + (double)N * K) + osz * (double)M * N);
     if (in_dtype == S2T_BF16 && !trans_a && !trans_b) {      // big forward projections: direct-to-LDS 3-stage kernel
         const int r = s2t_gemm_v2_try(a, out_dtype, st);
         if (r != 0) return r < 0 ? r : S2T_OK;
     }
-    // small problems: 64x64 tiles so that more workgroups exist than CUs
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
-    const bool small = t128 < 192;
-    const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
 #define S2T_PICK(TI_, TO_)                                                                   \
     return small ? launch_t<TI_, TO_, 64, 64>(a, trans_a, trans_b, st)                       \
                  : (narrow ? launch_t<TI_, TO_, 128, 64>(a, trans_a, trans_b, st)            \

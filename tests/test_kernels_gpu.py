@@ -506,3 +506,25 @@ def test_linear_wgrad_fused_bias_gradient(dtype, n_out, n_in, tokens, split):
     gw2 = gw0.clone().to(DEV)
     K.linear_wgrad(dy, x.to(DEV), gw2, None, splitk=split)           # no bias: weight gradient only
     assert float((gw2.cpu() - rw).abs().max()) < t * max(1.0, float(rw.abs().max()))
+
+
+def test_attention_v2_head_to_xcd_mapping():
+    """B*H multiple of 8: the second-generation kernels re-map workgroups so that the tiles of a head share an XCD
+    (attention.hip head_xcd_remap); results must not depend on it."""
+    heads, d, B, Tq, Tk = 4, 64, 4, 260, 200
+    D = heads * d
+    bf = torch.bfloat16
+    q = rnd(Tq, B, D, dtype=bf, seed=1); k = rnd(Tk, B, D, dtype=bf, seed=2); v = rnd(Tk, B, D, dtype=bf, seed=3)
+    klen = torch.tensor([Tk, Tk - 9, 150, 131], dtype=torch.int32)
+    qf, kf, vf = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    ref = attn_ref(qf, kf, vf, heads, klen, False)
+    do = rnd(Tq, B, D, dtype=bf, seed=4)
+    ref.backward(do.float())
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out, lse = K.attn_fwd(qd, kd, vd, heads, klen=klen.to(DEV))
+    assert rel_err(out, ref) < 2e-2
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, out, do.to(DEV), lse, heads, dq, dk, dv, klen=klen.to(DEV))
+    assert rel_err(dq, qf.grad) < 3e-2 and rel_err(dk, kf.grad) < 3e-2 and rel_err(dv, vf.grad) < 3e-2
+    for b in range(1, B):                                # padded keys receive exact zeros
+        assert float(dk[int(klen[b]):, b].abs().max()) == 0.0 and float(dv[int(klen[b]):, b].abs().max()) == 0.0
