@@ -47,13 +47,41 @@ class _LSCEFn(torch.autograd.Function):
 class _CTCFn(torch.autograd.Function):
     """sum over the batch of -log p(target | logits) (zero_infinity) with fused gradient w.r.t. the logits."""
 
+    # The alpha/beta recursion is a latency-bound kernel with one workgroup per utterance: it runs on a side stream, under the
+    # decoder forward that the caller issues next on the main stream; `join()` makes the main stream wait for it.
+    _side = {}
+    _pending = []
+
     @staticmethod
     def forward(ctx, logits, targets, tgt_len, in_len32, blank):
         if logits.stride(2) != 1 or logits.stride(0) != logits.shape[1] * logits.stride(1):
             logits = logits.contiguous()
-        loss, grad, _ = K.ctc_loss(logits, targets.contiguous(), tgt_len.contiguous(), in_len32.contiguous(), blank)
+        targets, tgt_len, in_len32 = targets.contiguous(), tgt_len.contiguous(), in_len32.contiguous()
+        dev = logits.device
+        main = torch.cuda.current_stream(dev)
+        side = _CTCFn._side.get(dev)
+        if side is None:
+            side = _CTCFn._side[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            loss, grad, _ = K.ctc_loss(logits, targets, tgt_len, in_len32, blank)
+            out = loss[0]
+        for t in (logits, targets, tgt_len, in_len32):
+            t.record_stream(side)
+        for t in (loss, grad, out):
+            t.record_stream(main)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        _CTCFn._pending.append((main, ev))
         ctx.grad = grad
-        return loss[0]
+        return out
+
+    @staticmethod
+    def join():
+        """Call before the loss (or anything else produced by forward) is consumed on the main stream."""
+        for main, ev in _CTCFn._pending:
+            main.wait_event(ev)
+        _CTCFn._pending.clear()
 
     @staticmethod
     def backward(ctx, g):
@@ -171,7 +199,6 @@ class CTCMultiLoss(FairseqCriterion):
         k = self.ctc_aware_model.ctc_encoder_layer
         model._ctc_state_layer = k - 1
         encoder_out = enc(ni["src_tokens"], src_lengths=ni["src_lengths"], return_all_hiddens=True)
-        decoder_out = model.decoder(ni["prev_output_tokens"], encoder_out=encoder_out)
         last = enc._last
         if hasattr(encoder_out, "ctc_out"):
             ctc_feat, in_len, in_len_host, pred = encoder_out.ctc_out, last["ctc_lengths"], last["ctc_lengths_host"], last.get("pred_host")
@@ -180,7 +207,8 @@ class CTCMultiLoss(FairseqCriterion):
                                        "criterion.ctc_aware_model.fc_out.weight", "criterion.ctc_aware_model.fc_out.bias")
             in_len, in_len_host, pred = last["lengths"], last["lengths_host"], None
         tr, tr_len = sample["transcript_target"], sample["transcript_target_lengths"]
-        ctc_loss = _CTCFn.apply(ctc_feat, tr, tr_len, in_len.to(torch.int32), self.blank_idx)
+        ctc_loss = _CTCFn.apply(ctc_feat, tr, tr_len, in_len.to(torch.int32), self.blank_idx)      # side stream
+        decoder_out = model.decoder(ni["prev_output_tokens"], encoder_out=encoder_out)               # main stream, concurrently
         # unit error rate (logging only): greedy path + native edit-distance alignment on the host
         if pred is None:
             pred = K.ctc_argmax(ctc_feat.detach())[0].cpu()
@@ -198,6 +226,7 @@ class CTCMultiLoss(FairseqCriterion):
             ctc_sample_size = ctc_ntokens
         real_loss, nll = self.real_criterion.compute_loss(model, decoder_out, sample, reduce=reduce)
         real_ss = sample["target"].size(0) if self.sentence_avg else sample["ntokens"]
+        _CTCFn.join()
         loss = self.ctc_weight * ctc_loss + real_loss
         nframes = sample.get("nframes")
         if nframes is None:
