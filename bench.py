@@ -32,7 +32,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 # kernel template behind each profiled family (names as they appear in the rocprofv3 kernel trace, profiles/)
-KERNEL_OF = {"gemm_tn": "gemm_fast_kernel<bf16, float, TA=true, TB=true, 128, 128, 4 waves> (dW = dY^T X, split-K)",
+KERNEL_OF = {"gemm_tn": "gemm_tn2_kernel (dW = dY^T X: bf16 -> f32, 128x128 tile, two k-slices per workgroup, split-K atomics)",
              "gemm_nt": "gemm_fast_kernel<bf16, bf16, false, false, 128, 128, 8 waves> (Y = X W^T)",
              "gemm_nn": "gemm_fast_kernel<bf16, bf16, false, TB=true, 128, 128, 8 waves> (dX = dY W)",
              "gemm_tn_small": "gemm_fast_kernel<.., 64, 64, 4 waves> (small dW)", "gemm_nt_small": "gemm_fast_kernel<.., 64, 64, 4 waves>",

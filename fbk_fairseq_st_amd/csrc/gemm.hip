@@ -324,12 +324,12 @@ template <int COLS, int NTH = 256> struct FastTr {
     uint32_t goff[N];
     int off[N];
     uint32_t tile_bytes;                                       // 64 rows further down
-    __device__ __forceinline__ void init(const bf16* g, int ld, int col0, int ncols, int k0) {
+    __device__ __forceinline__ void init(const bf16* g, int ld, int col0, int ncols, int k0, int tid = threadIdx.x) {
         base = reinterpret_cast<const char*>(g);
         tile_bytes = (uint32_t)(64u * (uint32_t)ld * 2u);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int cid = threadIdx.x + NTH * i, row = cid >> 4, c = cid & 15;
+            const int cid = tid + NTH * i, row = cid >> 4, c = cid & 15;
             const int gc = min(col0 + c * 8, (ncols + 7) / 8 * 8 - 8);
             goff[i] = (uint32_t)(((size_t)(k0 + row) * ld + gc) * 2);
             off[i] = row * 256 + ((c ^ tr_swz(row)) << 4);
@@ -500,6 +500,127 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// dW = dY^T X with two k-slices per workgroup.  The f32 atomic pass of split-K runs at ~1.4 TB/s (one dword per clock and
+// L2 channel) and cost ~22 us of an 80 us dW launch at 8 slices.  Here a workgroup is two independent 4-wave groups (each the
+// 2x2 / 64x64-per-wave structure of gemm_fast_kernel with its own LDS stages) that walk neighbouring k-slices of the SAME
+// output tile; their accumulators meet in LDS and leave as one atomic pass: half the atomic traffic at the same number of
+// wavefronts per CU (8 waves, one workgroup per CU).  bf16 operands (both by transposed LDS reads), f32 output.
+__global__ __launch_bounds__(512, 1) void gemm_tn2_kernel(GemmArgs p) {
+    constexpr int BM = 128, BN = 128, BK = 64, MT = 4, NT = 4, STAGE = (BM + BN) * 128, BOFF = BM * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x & 255, grp = threadIdx.x >> 8;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, tiles = tiles_m * tiles_n;
+    int wg, kz;
+    {
+        const int L = blockIdx.z * tiles + blockIdx.x, xcd = L & 7, j = L >> 3, sk = p.splitk;     // slices -> XCDs as in gemm_fast_kernel
+        if (sk > 1 && (sk & 7) == 0) { kz = xcd + 8 * (j / tiles); wg = j % tiles; }
+        else if ((sk == 2 || sk == 4) && tiles % (8 / sk) == 0) { kz = xcd % sk; wg = (xcd / sk) * (tiles / (8 / sk)) + j; }
+        else { kz = blockIdx.z; wg = xcd_remap(blockIdx.x, tiles); }
+    }
+    const int tm = wg / tiles_n, tn = wg % tiles_n, row0 = tm * BM, col0 = tn * BN;
+    const int nk_total = p.K / BK;
+    const int per = (nk_total + 2 * p.splitk - 1) / (2 * p.splitk);          // k-tiles per half slice
+    const int kt0 = (2 * kz + grp) * per, nk = max(0, min(nk_total, kt0 + per) - kt0);
+    const int nk_max = min(per, max(0, nk_total - 2 * kz * per));              // group 0's count: the barrier count of both groups
+
+    typedef FastTr<128, 256> S;
+    S sa, sb;
+    const int k0 = min(kt0, nk_total - 1) * BK;                                // an empty half still points at valid memory
+    sa.init(reinterpret_cast<const bf16*>(p.A), p.lda, row0, p.M, k0, tid);
+    sb.init(reinterpret_cast<const bf16*>(p.B), p.ldb, col0, p.N, k0, tid);
+    S::Regs a0, a1, b0, b1;
+
+    const int lane = threadIdx.x & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, r16 = lane & 15, q = lane >> 4;
+    const int arow = wr * 64, brow = wc * 64;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_rs = p.rowsum != nullptr && tn == 0 && wc == 0;
+    f32x4 rs[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    char* l0 = smem + grp * 2 * STAGE;
+    char* l1 = l0 + STAGE;
+    int left = nk;
+    auto step = [&]() { left -= 1; return left > 0 ? 128 : 0; };
+    // B fragments one at a time (4 live fragment registers fewer than mma_tile: this kernel sits at the 256-VGPR limit and a
+    // spill reload in the loop would drain the global prefetch through its vmcnt wait)
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    auto mma = [&](const char* l) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 fa[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = tr_fragment(l, arow, i, s2, r16, q);
+            if (do_rs) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) rs[i] = mma16<bf16>(ones, fa[i], rs[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const u32x4 fb = tr_fragment(l + BOFF, brow, j, s2, r16, q);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i][j] = mma16<bf16>(fb, fa[i], acc[i][j]);
+            }
+        }
+    };
+    { const int st = step(); sa.load(a0, st); sb.load(b0, st); }
+    { const int st = step(); sa.load(a1, st); sb.load(b1, st); }
+    sa.store(l0, a0); sb.store(l0 + BOFF, b0);
+    __syncthreads();
+    for (int t = 0; t < nk_max; t += 2) {
+        { const int st = step(); sa.load(a0, st); sb.load(b0, st); }
+        if (t < nk) mma(l0);
+        sa.store(l1, a1); sb.store(l1 + BOFF, b1);
+        __syncthreads();
+        { const int st = step(); sa.load(a1, st); sb.load(b1, st); }
+        if (t + 1 < nk) mma(l1);
+        sa.store(l0, a0); sb.store(l0 + BOFF, b0);
+        __syncthreads();
+    }
+    if (do_rs && q == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = row0 + arow + 16 * i + r16;
+            if (row < p.M) atomicAdd(p.rowsum + row, rs[i][0]);
+        }
+    }
+    // ---- the two halves meet in LDS (f32 tile, row stride 528 B as in gemm_epilogue), then one pass over the output
+    constexpr int RS = BN * 4 + 16;
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4*>(smem + (arow + 16 * i + r16) * RS + (brow + 16 * j + 4 * q) * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4* d = reinterpret_cast<f32x4*>(smem + (arow + 16 * i + r16) * RS + (brow + 16 * j + 4 * q) * 4);
+                *d = (*d + acc[i][j]) * p.alpha;
+            }
+    }
+    __syncthreads();
+    float* C = reinterpret_cast<float*>(p.C);
+    for (int idx = threadIdx.x; idx < BM * BN; idx += 512) {
+        const int lr = idx / BN, lc = idx % BN, row = row0 + lr, col = col0 + lc;
+        if (row >= p.M || col >= p.N) continue;
+        const float v = *reinterpret_cast<const float*>(smem + lr * RS + lc * 4);
+        float* dst = C + (size_t)row * p.ldc + col;
+        if (p.splitk > 1) atomicAdd(dst, v);
+        else *dst = p.accumulate ? *dst + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Persistent form of the fast path.  With K = 512 a 128x128 tile has only 8 k-tiles, so the per-tile prologue
 // (first global loads: one full memory latency with nothing to do) and the epilogue (LDS staging + stores) cost as
 // much as the k-loop (ablation in profiles/README.md).  Here a workgroup walks a sequence of work items
@@ -637,6 +758,21 @@ static int launch(const GemmArgs& a_in, hipStream_t st) {
             hipLaunchKernelGGL((gemm_pers_kernel<TI, TO, TA, TB, BM, BN>), dim3(G), dim3(256), lds, st, b, per);
             S2T_LAUNCH_CHECK();
             return S2T_OK;
+        }
+        if constexpr (BM == 128 && BN == 128 && sizeof(TI) == 2 && sizeof(TO) == 4 && TA && TB) {
+            // weight-gradient products: two k-slices per workgroup, half the atomic traffic (S2T_GEMM_TN1=1: single-slice form)
+            static const bool tn1 = getenv("S2T_GEMM_TN1") != nullptr;
+            constexpr int BKc2 = 64;
+            const int nk_total2 = a.K / BKc2;
+            if (!tn1 && !a.mapC && !a.dbg && nk_total2 >= 4 * a.splitk && (a.splitk == 1 || a.splitk % 2 == 0)) {
+                GemmArgs b = a;
+                b.splitk = a.splitk > 1 ? a.splitk / 2 : 1;                    // same wavefronts per CU: s slices of 4 waves -> s/2 of 8
+                static bool attr4 = false;
+                if (!attr4) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr4 = true; }
+                hipLaunchKernelGGL(gemm_tn2_kernel, dim3(tiles, 1, b.splitk), dim3(512), 131072, st, b);
+                S2T_LAUNCH_CHECK();
+                return S2T_OK;
+            }
         }
         if constexpr (BM == 128 && BN == 128 && sizeof(TI) == 2) {
             // measured (tools/microbench.py, M = 24000): 8 waves gain 10-18 % on the NT / NN products (the k-loop is bound by

@@ -132,12 +132,12 @@ def conv2_maps(B, T2, F2, device):
 
 def _splitk(n_out, k_in, m_tokens):
     """k-slices of a weight-gradient product: enough workgroups to fill 2 per CU, a multiple of 8 when possible (one slice per
-    XCD: gemm.hip deals slices to XCDs), at most 16 (each slice costs a full f32 atomic pass over the output; measured with
-    tools/tn_sweep.py: 8 for the 48/64-tile outputs, 16 for 512x512)."""
+    XCD: gemm.hip deals slices to XCDs; the dW kernel folds two slices per workgroup before the f32 atomic pass); measured with
+    tools/tn_sweep.py: 8 for the 48/64-tile outputs, 32 for 512x512."""
     tiles = ((n_out + 127) // 128) * ((k_in + 127) // 128)
     if tiles >= 256:
         return 1
-    sk = int(max(1, min(512 // tiles, m_tokens // 256, 16)))
+    sk = int(max(1, min(512 // tiles, m_tokens // 256, 32)))
     return sk - sk % 8 if sk >= 8 else sk
 
 

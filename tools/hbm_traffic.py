@@ -11,7 +11,7 @@ Kernels are grouped into the families bench.py reports (same template -> same fa
 import collections, csv, glob, json, sys
 
 # (family, kernel-name substrings that must ALL occur): the 128x128 templates bench.py names in KERNEL_OF
-FAMILY = [("gemm_tn", ("gemm_fast_kernel", "true, true, 128, 128")), ("gemm_tn", ("gemm_fast_kernel", "Lb1ELb1ELi128ELi128")),
+FAMILY = [("gemm_tn", ("gemm_tn2_kernel",)), ("gemm_tn", ("gemm_fast_kernel", "true, true, 128, 128")), ("gemm_tn", ("gemm_fast_kernel", "Lb1ELb1ELi128ELi128")),
           ("gemm_nt", ("gemm_fast_kernel", "Lb0ELb0ELi128ELi128")), ("gemm_nn", ("gemm_fast_kernel", "Lb0ELb1ELi128ELi128")),
           ("gemm_gather", ("gemm_kernel",)), ("attn_fwd", ("attn_fwd2",)), ("attn_bwd", ("attn_bwd_d",))]
 
