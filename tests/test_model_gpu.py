@@ -321,3 +321,57 @@ def test_beam_search_bf16_runs_and_is_consistent():
             assert int(h["tokens"][-1]) == 2 and not bool((h["tokens"][:-1] == 2).any())
             n = h["tokens"].numel()
             assert abs(float(h["positional_scores"].sum()) / n ** opts["len_penalty"] - float(h["score"])) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE.json configs
+@pytest.mark.parametrize("arch,B,lengths,L,ctc_layer", [("s2t_transformer_xs", 4, [200, 180, 150, 120], 12, 4),
+                                                        ("s2t_transformer_s", 3, [333, 333, 333], 10, 8)])
+def test_baseline_config_shapes_match_oracle(arch, B, lengths, L, ctc_layer):
+    """configs[0] of BASELINE.json (s2t_transformer_xs, 80-mel x 200 frames, batch 4, ragged) and an s-preset batch at the real
+    vocabulary sizes (V_tgt 8000, V_src 5001: unaligned logit rows, K-tail GEMMs, d_head 64): one fp32 update's loss terms and
+    gradient norms of the HIP engine against the CPU oracle run on the same weights and batch (1e-4 loss, 1e-3 gradients)."""
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.conv_transformer import fused_to_reference
+    from fbk_fairseq_st_amd.registry import apply_arch, namespace, setup_task
+    a = namespace(arch=arch, task="dummy_s2t", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+                  label_smoothing=0.1, sentence_avg=False, ctc_compress_out=True, ctc_encoder_layer=ctc_layer, ctc_weight=1.0,
+                  ctc_compress_strategy="avg", input_feat_per_channel=80, no_attn_2d=True, dict_size=8000 - 4, src_dict_size=5000 - 4,
+                  batch_size=B, frames=max(lengths), tgt_len=L, transcript_len=L, dropout=0.0, attention_dropout=0.0,
+                  activation_dropout=0.0, relu_dropout=0.0, seed=1)
+    apply_arch(a)
+    a.dropout = a.attention_dropout = a.activation_dropout = a.relu_dropout = 0.0
+    task = setup_task(a)
+    torch.manual_seed(3)
+    model = task.build_model(a)
+    crit = task.build_criterion(a)
+    W = {k: v.detach().clone().float() for k, v in model.state_dict().items() if torch.is_tensor(v) and v.dtype.is_floating_point}
+    model.hp.sub_dropout = 0.0
+    model.materialize(DEV, torch.float32, extra=crit.arena_params())
+    sample = task.dummy_batch(seed=7, lengths=lengths)
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    loss, ss, log = crit(model, to_dev(sample))
+    loss.backward()
+
+    hp = model.hp
+    cfg = s2t_ref.default_cfg(D=hp.D, heads=hp.heads, ffn=hp.ffn, enc_layers=hp.enc_layers, dec_layers=hp.dec_layers, ctc_layer=ctc_layer,
+                              act=hp.act)
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items() if not k.endswith("_float_tensor") and "running" not in k}
+    Wb = {k: v.clone() for k, v in W.items() if "running" in k}
+    blank = task.source_dictionary.index("<ctc_blank>")
+    rl, rss, rlog, _, _, _ = s2t_ref.ctc_multi_loss({**Wr, **Wb}, cfg, dict(sample, ctc_encoder_layer=ctc_layer), 0.1, 1.0, blank, training=True)
+    rl.backward()
+    close(loss, float(rl), 1e-4, "loss")
+    close(log["ctc_loss"], rlog["ctc_loss"], 1e-4, "ctc_loss")
+    close(log["nll_loss"], rlog["nll_loss"], 1e-4, "nll_loss")
+    assert int(log["ctc_errors"]) == int(rlog["ctc_errors"]) and int(log["ctc_total"]) == int(rlog["ctc_total"])
+    assert ss == rss
+    grads = fused_to_reference({n: model.arena.g(n).detach().cpu().clone() for n in model.arena.slices})
+    worst = 0.0
+    for k, p in Wr.items():
+        if p.grad is None or k not in grads:
+            continue
+        ref = float(p.grad.norm()); mine = float(grads[k].norm())
+        worst = max(worst, abs(mine - ref) / max(1.0, ref))
+        assert abs(mine - ref) <= 1e-3 * max(1.0, ref), (k, mine, ref)
+    assert worst < 1e-3
