@@ -116,3 +116,44 @@ extern "C" int s2t_host_ctc_uer(const int* pred, const long long* input_len, int
     *errors = e; *total = n;
     return S2T_OK;
 }
+
+
+// Frame-budget batching (host): fairseq/data/data_utils_fast.pyx:16-68 batch_by_size_fast.  `indices` is the ordered list of
+// dataset indices, lens[idx] the number of frames of utterance idx.  A batch is closed when adding the next utterance would make
+// (batch size + 1) x (longest member) exceed max_tokens, or the batch holds max_sentences; closed batches are trimmed to a
+// multiple of bsz_mult (the remainder opens the next batch).  Output: the batches concatenated in out_flat[n], their bounds in
+// out_offsets[*n_batches + 1].  max_tokens / max_sentences <= 0 disable the respective limit.
+extern "C" int s2t_host_batch_by_size(const long long* indices, long long n, const long long* lens, long long max_tokens,
+                                      long long max_sentences, int bsz_mult, long long* out_flat, long long* out_offsets,
+                                      long long* n_batches) {
+    if (n < 0 || bsz_mult < 1 || !out_offsets || !n_batches || (n > 0 && (!indices || !lens || !out_flat))) return S2T_EINVAL;
+    std::vector<long long> batch, blen;
+    long long nb = 0, written = 0, sample_len = 0;
+    out_offsets[0] = 0;
+    for (long long i = 0; i < n; ++i) {
+        const long long idx = indices[i], nt = lens[idx];
+        blen.push_back(nt);
+        sample_len = sample_len > nt ? sample_len : nt;
+        if (max_tokens > 0 && sample_len > max_tokens) return S2T_EINVAL;          // "sentence ... exceeds max_tokens limit"
+        const long long num_tokens = ((long long)batch.size() + 1) * sample_len;
+        const bool full = !batch.empty() && ((max_sentences > 0 && (long long)batch.size() == max_sentences) ||
+                                             (max_tokens > 0 && num_tokens > max_tokens));
+        if (full) {
+            const long long sz = (long long)batch.size();
+            const long long a = bsz_mult * (sz / bsz_mult), b = sz % bsz_mult, mod_len = a > b ? a : b;
+            for (long long k = 0; k < mod_len; ++k) out_flat[written++] = batch[k];
+            out_offsets[++nb] = written;
+            batch.erase(batch.begin(), batch.begin() + mod_len);
+            blen.erase(blen.begin(), blen.begin() + mod_len);
+            sample_len = 0;
+            for (long long v : blen) sample_len = sample_len > v ? sample_len : v;
+        }
+        batch.push_back(idx);
+    }
+    if (!batch.empty()) {
+        for (long long v : batch) out_flat[written++] = v;
+        out_offsets[++nb] = written;
+    }
+    *n_batches = nb;
+    return S2T_OK;
+}

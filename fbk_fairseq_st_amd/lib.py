@@ -20,6 +20,7 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD = 0, 1, 2, 3, 4
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
                                                         ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t)
 c_ull = ctypes.c_ulonglong
+c_longlong = ctypes.c_longlong
 P = c_void_p
 
 # name -> argtypes (restype is int unless noted).  Mirrors include/s2t_hip.h one to one.
@@ -64,6 +65,7 @@ SIGNATURES = {
     "s2t_prof_enable": [c_int],
     "s2t_prof_reset": [],
     "s2t_prof_read": [ctypes.c_char_p, P, P, P, P],
+    "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],
     "s2t_host_ctc_uer": [P, P, c_int, c_int, P, P, c_int, c_int, P, P],
 }
 

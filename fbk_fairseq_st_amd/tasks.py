@@ -38,6 +38,20 @@ class SpeechTranslationCTCTask(FairseqTask):
         src.add_symbol("<ctc_blank>")
         return cls(args, tgt, src)
 
+    def load_dataset(self, split, combine=False, **kwargs):
+        """speech_translation_ctc.py:48-72: <split>.npz filterbanks, <split>.<tgt> targets, <split>.<src> transcripts (TNTIDX files)"""
+        from .indexed import load_s2t_split
+        a = self.args
+        self.datasets[split] = load_s2t_split(a.data.split(os.pathsep)[0], split, a.source_lang, a.target_lang, self.src_dict, self.tgt_dict,
+                                              getattr(a, "skip_normalization", False), getattr(a, "legacy_audio_fix_lua_indexing", False))
+
+    def get_batch_iterator(self, dataset, max_tokens=None, max_sentences=None, max_positions=None, ignore_invalid_inputs=False,
+                           required_batch_size_multiple=1, seed=1, num_shards=1, shard_id=0, num_workers=0, epoch=1):
+        """fairseq_task.py:107-199 on the native batcher + pinned-memory prefetch thread (iterators.py)"""
+        from .iterators import get_batch_iterator
+        return get_batch_iterator(dataset, max_tokens, max_sentences, max_positions, ignore_invalid_inputs, required_batch_size_multiple,
+                                  seed, num_shards, shard_id, epoch)
+
     @property
     def source_dictionary(self):
         return self.src_dict

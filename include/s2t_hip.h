@@ -36,6 +36,11 @@ extern "C" {
 #define S2T_ACT_GELU_BWD 4  /* out = acc * gelu'(aux)           (aux = forward pre-activation)  */
 
 /* ---- library info ------------------------------------------------------------------------- */
+/* Host: frame-budget batching of utterance indices (fairseq/data/data_utils_fast.pyx:16-68 batch_by_size_fast; caller
+ * fairseq/data/data_utils.py:200-234).  lens[idx] = frames of utterance idx; out_flat[n], out_offsets[n + 1]. */
+int s2t_host_batch_by_size(const long long* indices, long long n, const long long* lens, long long max_tokens,
+                           long long max_sentences, int bsz_mult, long long* out_flat, long long* out_offsets,
+                           long long* n_batches);
 int s2t_abi_version(void);                       /* bumps when a signature changes */
 const char* s2t_build_info(void);                /* "gfx950 <date> ..." */
 

@@ -182,3 +182,24 @@ def sort_desc_c(lengths):
     order = np.empty_like(lengths)
     _c().orc_sort_desc(_p(lengths), ctypes.c_int32(len(lengths)), _p(order))
     return order
+
+
+def batch_by_size(indices, lens, max_tokens=-1, max_sentences=-1, bsz_mult=1):
+    """fairseq/data/data_utils_fast.pyx:16-68 batch_by_size_fast, restated with plain lists (lens[idx] = frames of item idx)."""
+    batches, batch, blen, sample_len = [], [], [], 0
+    for idx in [int(i) for i in indices]:
+        nt = int(lens[idx])
+        blen.append(nt)
+        sample_len = max(sample_len, nt)
+        assert max_tokens <= 0 or sample_len <= max_tokens, "sentence at index {} of size {} exceeds max_tokens limit of {}!".format(idx, sample_len, max_tokens)
+        num_tokens = (len(batch) + 1) * sample_len
+        full = len(batch) > 0 and ((max_sentences > 0 and len(batch) == max_sentences) or (max_tokens > 0 and num_tokens > max_tokens))
+        if full:
+            mod_len = max(bsz_mult * (len(batch) // bsz_mult), len(batch) % bsz_mult)
+            batches.append(batch[:mod_len])
+            batch, blen = batch[mod_len:], blen[mod_len:]
+            sample_len = max(blen) if blen else 0
+        batch.append(idx)
+    if batch:
+        batches.append(batch)
+    return batches

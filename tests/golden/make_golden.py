@@ -473,7 +473,146 @@ def run_generate_case():
     np.savez_compressed(os.path.join(OUT, "generate.npz"), **out)
 
 
+def run_data_case():
+    """G12: the on-disk TNTIDX format and frame-budget batching.
+    * tests/golden/tntidx/{fbank,tokens}.{idx,bin}: tiny datasets written by the reference's own builders
+      (examples/speech_recognition/preprocess_audio.py AudioIndexedDatasetBuilder, fairseq/data/indexed_dataset.py
+      IndexedDatasetBuilder) + the items as arrays in data.npz;
+    * batches of fairseq/data/data_utils_fast.pyx batch_by_size_fast (built out of tree with cython) for several length
+      distributions and (max_tokens, max_sentences, multiple) settings."""
+    import subprocess, sysconfig, tempfile, importlib.util, shutil
+    from fairseq.data.indexed_dataset import IndexedDatasetBuilder, IndexedDataset
+    sys.modules.setdefault("h5py", type(sys)("h5py"))
+    from examples.speech_recognition.preprocess_audio import AudioIndexedDatasetBuilder
+    from examples.speech_recognition.data.fbank_dataset import FilterBanksDataset
+    d = os.path.join(OUT, "tntidx")
+    os.makedirs(d, exist_ok=True)
+    rs = np.random.RandomState(3)
+    out = {}
+    fb = [rs.randn(l, 8).astype(np.float32) for l in (5, 1, 9, 3)]
+    b = AudioIndexedDatasetBuilder(os.path.join(d, "fbank.bin"))
+    for x in fb:
+        b.add_item(torch.from_numpy(x.copy()))
+    b.finalize(os.path.join(d, "fbank.idx"))
+    ds = FilterBanksDataset(os.path.join(d, "fbank"), cached=False)
+    for i, x in enumerate(fb):
+        assert np.array_equal(ds[i].numpy(), x)
+        out["fbank_%d" % i] = x
+    out["fbank_sizes"] = np.array([ds.size(i) for i in range(len(ds))], np.int64)
+    tk = [rs.randint(4, 90, size=l).astype(np.int64) for l in (7, 2, 11)]
+    b = IndexedDatasetBuilder(os.path.join(d, "tokens.bin"))           # int32, stored +1 (Lua indexing)
+    for x in tk:
+        b.add_item(torch.from_numpy(x.copy()))
+    b.finalize(os.path.join(d, "tokens.idx"))
+    ds = IndexedDataset(os.path.join(d, "tokens"), fix_lua_indexing=True)
+    for i, x in enumerate(tk):
+        assert np.array_equal(ds[i].numpy(), x)
+        out["tokens_%d" % i] = x
+    # ---- batch_by_size (cython module built under /tmp, never inside the reference tree)
+    tmp = tempfile.mkdtemp()
+    shutil.copy(REF + "/fairseq/data/data_utils_fast.pyx", tmp)
+    subprocess.check_call([sys.executable, "-m", "cython", "-3", os.path.join(tmp, "data_utils_fast.pyx")])
+    inc = sysconfig.get_paths()["include"]
+    so = os.path.join(tmp, "data_utils_fast" + sysconfig.get_config_var("EXT_SUFFIX"))
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O2", "-I", inc, "-I", np.get_include(), os.path.join(tmp, "data_utils_fast.c"), "-o", so])
+    spec = importlib.util.spec_from_file_location("data_utils_fast", so)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cases = []
+    for ci, (n, dist, mt, ms, mult) in enumerate([(40, "lognormal", 3000, -1, 1), (40, "lognormal", 3000, 6, 1), (64, "lognormal", 12000, -1, 8),
+                                                  (33, "uniform", 2500, 5, 4), (10, "const", 1000, -1, 1), (50, "lognormal", -1, 7, 1),
+                                                  (0, "const", 100, -1, 1)]):
+        if dist == "lognormal":
+            lens = np.clip(np.exp(rs.normal(np.log(600), 0.7, size=n)), 50, 2000).astype(np.int64)
+        elif dist == "uniform":
+            lens = rs.randint(20, 900, size=n).astype(np.int64)
+        else:
+            lens = np.full(n, 250, np.int64)
+        order = rs.permutation(n).astype(np.int64)
+        batches = mod.batch_by_size_fast(order, lambda i: int(lens[i]), mt, ms, mult)
+        flat = np.array([i for bt in batches for i in bt], np.int64)
+        offs = np.cumsum([0] + [len(bt) for bt in batches]).astype(np.int64)
+        out["bbs%d_lens" % ci] = lens; out["bbs%d_order" % ci] = order
+        out["bbs%d_params" % ci] = np.array([mt, ms, mult], np.int64)
+        out["bbs%d_flat" % ci] = flat; out["bbs%d_offs" % ci] = offs
+        cases.append((n, len(batches)))
+    out["bbs_ncases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(OUT, "data.npz"), **out)
+    print("data", cases, sorted(os.listdir(d)))
+
+
+def _load_fast_batcher():
+    import subprocess, sysconfig, tempfile, importlib.util, shutil
+    tmp = tempfile.mkdtemp()
+    shutil.copy(REF + "/fairseq/data/data_utils_fast.pyx", tmp)
+    subprocess.check_call([sys.executable, "-m", "cython", "-3", os.path.join(tmp, "data_utils_fast.pyx")])
+    so = os.path.join(tmp, "data_utils_fast" + sysconfig.get_config_var("EXT_SUFFIX"))
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O2", "-w", "-I", sysconfig.get_paths()["include"], "-I", np.get_include(),
+                           os.path.join(tmp, "data_utils_fast.c"), "-o", so])
+    spec = importlib.util.spec_from_file_location("fairseq.data.data_utils_fast", so)
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    sys.modules["fairseq.data.data_utils_fast"] = mod
+    return mod
+
+
+def run_iterator_case():
+    """G13: the reference's data pipeline end to end on a tiny on-disk split (tests/golden/s2t_data/, written here with the reference's
+    builders): SpeechTranslationCTCTask.load_dataset + get_batch_iterator (filter_by_size, batch_by_size, epoch shuffle, 2 shards) ->
+    the collated batches of epochs 1 and 2."""
+    from fairseq.data.indexed_dataset import IndexedDatasetBuilder
+    sys.modules.setdefault("h5py", type(sys)("h5py"))
+    from examples.speech_recognition.preprocess_audio import AudioIndexedDatasetBuilder
+    _load_fast_batcher()
+    d = os.path.join(OUT, "s2t_data")
+    os.makedirs(d, exist_ok=True)
+    rs = np.random.RandomState(11)
+    tgt, src = mk_dict(40), mk_dict(30)
+    tgt.save(os.path.join(d, "dict.de.txt")); src.save(os.path.join(d, "dict.en.txt"))
+    n = 14
+    lens = [int(v) for v in rs.randint(18, 64, size=n)]
+    lens[5] = 90                                            # one utterance beyond --max-source-positions 80: filtered out
+    fb = AudioIndexedDatasetBuilder(os.path.join(d, "train.npz.bin"))
+    tb = IndexedDatasetBuilder(os.path.join(d, "train.de.bin")); sb = IndexedDatasetBuilder(os.path.join(d, "train.en.bin"))
+    for l in lens:
+        fb.add_item(torch.from_numpy((rs.randn(l, 80) * 2 + 1).astype(np.float32)))
+        tb.add_item(torch.from_numpy(np.concatenate([rs.randint(4, len(tgt), size=rs.randint(2, 7)), [2]]).astype(np.int64)))
+        sb.add_item(torch.from_numpy(np.concatenate([rs.randint(4, len(src), size=rs.randint(2, 6)), [2]]).astype(np.int64)))
+    fb.finalize(os.path.join(d, "train.npz.idx")); tb.finalize(os.path.join(d, "train.de.idx")); sb.finalize(os.path.join(d, "train.en.idx"))
+    a = [d, "--user-dir", REF + "/examples/speech_recognition", "--task", "speech_translation_with_transcription", "-s", "en", "-t", "de",
+         "--arch", "conv_transformer", "--no-attn-2d", "--criterion", "ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy",
+         "--max-tokens", "150", "--max-source-positions", "80", "--max-target-positions", "50", "--skip-invalid-size-inputs-valid-test", "--cpu"]
+    args = options.parse_args_and_arch(options.get_training_parser(), input_args=a)
+    task = SpeechTranslationCTCTask.setup_task(args)
+    task.load_dataset("train")
+    out = {"lens": np.array(lens, np.int64)}
+    for shard in (0, 1):
+        task.dataset_to_epoch_iter = {}
+        it = task.get_batch_iterator(task.dataset("train"), max_tokens=150, max_sentences=None, max_positions=(80, 50),
+                                     ignore_invalid_inputs=True, required_batch_size_multiple=1, seed=1, num_shards=2, shard_id=shard,
+                                     num_workers=0, epoch=1)
+        for ep in (1, 2):
+            itr = it.next_epoch_itr(shuffle=True)
+            k = 0
+            for batch in itr:
+                pre = "s%d_e%d_b%d_" % (shard, ep, k); k += 1
+                if len(batch) == 0:
+                    out[pre + "empty"] = np.int64(1)
+                    continue
+                out[pre + "id"] = batch["id"].numpy()
+                for kk in ("src_tokens", "src_lengths", "prev_output_tokens", "transcript_prev_output_tokens"):
+                    out[pre + kk] = batch["net_input"][kk].numpy()
+                for kk in ("target", "target_lengths", "transcript_target", "transcript_target_lengths"):
+                    out[pre + kk] = batch[kk].numpy()
+                out[pre + "ntokens"] = np.int64(batch["ntokens"])
+            out["s%d_e%d_n" % (shard, ep)] = np.int64(k)
+    np.savez_compressed(os.path.join(OUT, "iterator.npz"), **out)
+    print("iterator", {k: int(v) for k, v in out.items() if k.endswith("_n")}, sorted(os.listdir(d)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "iterator":
+        run_iterator_case(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "data":
+        run_data_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "generate":
         run_generate_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "extra":

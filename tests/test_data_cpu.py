@@ -1,0 +1,119 @@
+"""SURVEY 8-f N1 on the CPU: the TNTIDX on-disk format (files written by the reference's own builders, tests/golden/tntidx/) and
+frame-budget batching (batches produced by the reference's cython batch_by_size_fast, tests/golden/data.npz): oracle restatement,
+native host function and reader/writer against them -- all bit-exact."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, load_golden
+from oracle import int_ref
+
+
+def _batches(g, ci):
+    flat, offs = g["bbs%d_flat" % ci], g["bbs%d_offs" % ci]
+    return [flat[offs[b]:offs[b + 1]].tolist() for b in range(len(offs) - 1)]
+
+
+def test_oracle_batch_by_size_matches_reference():
+    g = load_golden("data")
+    for ci in range(int(g["bbs_ncases"])):
+        mt, ms, mult = [int(v) for v in g["bbs%d_params" % ci]]
+        got = int_ref.batch_by_size(g["bbs%d_order" % ci], g["bbs%d_lens" % ci], mt, ms, mult)
+        assert got == _batches(g, ci), ci
+
+
+def test_native_batch_by_size_matches_reference_and_oracle():
+    from fbk_fairseq_st_amd.indexed import batch_by_size
+    g = load_golden("data")
+    for ci in range(int(g["bbs_ncases"])):
+        mt, ms, mult = [int(v) for v in g["bbs%d_params" % ci]]
+        lens, order = g["bbs%d_lens" % ci], g["bbs%d_order" % ci]
+        got = batch_by_size(order, lens, mt if mt > 0 else None, ms if ms > 0 else None, mult)
+        assert got == _batches(g, ci), ci
+        assert got == batch_by_size(order, lambda i: int(lens[i]), mt if mt > 0 else None, ms if ms > 0 else None, mult)   # callable form
+    rs = np.random.RandomState(0)                        # larger random cases against the oracle
+    for _ in range(20):
+        n = int(rs.randint(1, 400))
+        lens = rs.randint(1, 2000, size=n).astype(np.int64)
+        order = rs.permutation(n).astype(np.int64)
+        mt, ms, mult = int(rs.choice([2000, 6000, 12000])), int(rs.choice([-1, 3, 16])), int(rs.choice([1, 4, 8]))
+        assert batch_by_size(order, lens, mt, ms if ms > 0 else None, mult) == int_ref.batch_by_size(order, lens, mt, ms, mult)
+    with pytest.raises(AssertionError, match="exceeds max_tokens"):
+        batch_by_size(np.arange(3), np.array([10, 500, 20]), 100)
+
+
+def test_tntidx_reader_on_reference_written_files():
+    from fbk_fairseq_st_amd.indexed import FilterBanksDataset, IndexedDataset
+    g = load_golden("data")
+    fb = FilterBanksDataset(os.path.join(GOLDEN, "tntidx", "fbank"))
+    assert len(fb) == 4 and fb.dtype == np.float32
+    for i in range(len(fb)):
+        assert torch.equal(fb[i], torch.from_numpy(g["fbank_%d" % i]))
+        assert fb.size(i) == g["fbank_sizes"][i] == fb.num_tokens(i)
+    assert fb.frame_lengths.tolist() == g["fbank_sizes"].tolist()
+    tk = IndexedDataset(os.path.join(GOLDEN, "tntidx", "tokens"), fix_lua_indexing=True)
+    assert len(tk) == 3
+    for i in range(len(tk)):
+        assert torch.equal(tk[i], torch.from_numpy(g["tokens_%d" % i]))
+    with pytest.raises(IndexError):
+        tk[3]
+
+
+def test_tntidx_writer_is_byte_identical_to_the_reference(tmp_path):
+    from fbk_fairseq_st_amd.indexed import AudioIndexedDatasetBuilder, IndexedDatasetBuilder
+    g = load_golden("data")
+    b = AudioIndexedDatasetBuilder(str(tmp_path / "fbank.bin"))
+    for i in range(4):
+        b.add_item(torch.from_numpy(g["fbank_%d" % i]))
+    b.finalize(str(tmp_path / "fbank.idx"))
+    b = IndexedDatasetBuilder(str(tmp_path / "tokens.bin"))
+    for i in range(3):
+        b.add_item(torch.from_numpy(g["tokens_%d" % i]))
+    b.finalize(str(tmp_path / "tokens.idx"))
+    for f in ("fbank.bin", "fbank.idx", "tokens.bin", "tokens.idx"):
+        assert filecmp.cmp(str(tmp_path / f), os.path.join(GOLDEN, "tntidx", f), shallow=False), f
+
+
+def _s2t_task():
+    from fbk_fairseq_st_amd import tasks  # noqa: F401
+    from fbk_fairseq_st_amd.registry import namespace, setup_task
+    a = namespace(task="speech_translation_with_transcription", data=os.path.join(GOLDEN, "s2t_data"), source_lang="en", target_lang="de",
+                  criterion="ctc_multi_loss", max_source_positions=80, max_target_positions=50)
+    return setup_task(a)
+
+
+@pytest.mark.parametrize("prefetch", [0, 2])
+def test_data_pipeline_reproduces_the_reference_batches(prefetch):
+    """G13: load_dataset + get_batch_iterator on the on-disk split written by the reference's builders: every batch of epochs 1 and 2
+    on both shards equals the reference's (ids, padded frames after per-utterance CMVN, lengths, targets, eos-shifted inputs, transcripts),
+    including the utterance dropped by max_positions and the empty filler batch of the short shard."""
+    from fbk_fairseq_st_amd.iterators import get_batch_iterator
+    g = load_golden("iterator")
+    task = _s2t_task()
+    assert len(task.source_dictionary) == 35 and task.source_dictionary.index("<ctc_blank>") == 34
+    task.load_dataset("train")
+    ds = task.dataset("train")
+    assert len(ds) == 14
+    for shard in (0, 1):
+        it = get_batch_iterator(ds, max_tokens=150, max_positions=(80, 50), ignore_invalid_inputs=True, seed=1, num_shards=2, shard_id=shard,
+                                epoch=1, prefetch=prefetch, pin_memory=False)
+        for ep in (1, 2):
+            batches = list(it.next_epoch_itr(shuffle=True))
+            assert len(batches) == int(g["s%d_e%d_n" % (shard, ep)]) == len(it)
+            for k, b in enumerate(batches):
+                pre = "s%d_e%d_b%d_" % (shard, ep, k)
+                if pre + "empty" in g:
+                    assert b == {}
+                    continue
+                assert b["id"].tolist() == g[pre + "id"].tolist()
+                assert int(b["ntokens"]) == int(g[pre + "ntokens"])
+                np.testing.assert_allclose(b["net_input"]["src_tokens"].numpy(), g[pre + "src_tokens"], rtol=0, atol=1e-6)
+                for kk in ("src_lengths", "prev_output_tokens", "transcript_prev_output_tokens"):
+                    assert np.array_equal(b["net_input"][kk].numpy(), g[pre + kk]), kk
+                for kk in ("target", "target_lengths", "transcript_target", "transcript_target_lengths"):
+                    assert np.array_equal(b[kk].numpy(), g[pre + kk]), kk
+    with pytest.raises(Exception, match="invalid"):
+        get_batch_iterator(ds, max_tokens=150, max_positions=(80, 50), ignore_invalid_inputs=False)

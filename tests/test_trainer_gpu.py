@@ -65,3 +65,42 @@ def test_bf16_dropout_step_is_finite():
         tr.train_step([sample])
     st = tr.reduce_stats()
     assert all(np.isfinite(v) for v in st.values()), st
+
+
+def test_training_from_the_on_disk_split():
+    """SURVEY 8-f N1 end to end: TNTIDX split (written by the reference's builders) -> load_dataset -> frame-budget batches with
+    pinned prefetch -> Trainer updates; the empty filler batch of a short shard is skipped like the reference's dummy batch."""
+    import os
+    from helpers import GOLDEN
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.registry import apply_arch, namespace, setup_task
+    from fbk_fairseq_st_amd.trainer import Trainer
+    a = namespace(arch="s2t_transformer_xs", task="speech_translation_with_transcription", data=os.path.join(GOLDEN, "s2t_data"),
+                  source_lang="en", target_lang="de", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+                  label_smoothing=0.1, sentence_avg=False, ctc_compress_out=True, ctc_encoder_layer=2, ctc_weight=1.0,
+                  input_feat_per_channel=80, no_attn_2d=True, lr=[1e-3], adam_betas="(0.9, 0.98)", clip_norm=20.0, warmup_updates=1,
+                  warmup_init_lr=1e-3, seed=3, encoder_layers=2, decoder_layers=1, max_source_positions=80, max_target_positions=50,
+                  dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0)
+    apply_arch(a)
+    task = setup_task(a)
+    task.load_dataset("train")
+    torch.manual_seed(0)
+    model, crit = task.build_model(a), task.build_criterion(a)
+    tr = Trainer(a, task, model, crit, device="cuda:0", compute_dtype=torch.float32)
+    itr = task.get_batch_iterator(task.dataset("train"), max_tokens=150, max_positions=(80, 50), ignore_invalid_inputs=True, seed=1,
+                                  num_shards=2, shard_id=1, epoch=1)
+    first = last = None
+    for epoch in range(4):
+        n = frames = 0
+        for batch in itr.next_epoch_itr(shuffle=True):
+            if len(batch):
+                assert batch["net_input"]["src_tokens"].is_pinned()
+            tr.train_step([batch])                         # {} -> no micro-batch: a zero-gradient update
+            if len(batch):
+                st = tr.reduce_stats()
+                assert np.isfinite(st["loss"]) and np.isfinite(st["gnorm"])
+                n += 1; frames += st["nframes"]
+                last = st["loss"] / st["sample_size"]
+                first = last if first is None else first
+        assert n >= 2 and frames > 0
+    assert last < first
