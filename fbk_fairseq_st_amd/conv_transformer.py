@@ -390,8 +390,23 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             fn(part)
 
     # ---- reference-compatible state dict (split q/k/v, `encoder.bn.N.*` buffers, positional placeholders)
+    def _local_attention_keys(self, sd, to_reference):
+        """With --distance-penalty the encoder layers hold LocalAttention (modules/local_attention.py:23-47): ONE in_proj_weight
+        [3D, D] / in_proj_bias [3D] in q|k|v order = exactly the fused layout of the arena, under another name."""
+        if not self.hp.distance_penalty:
+            return sd
+        out = {}
+        for k, v in sd.items():
+            if k.startswith("encoder.layers.") and to_reference and k.endswith((".self_attn.qkv.weight", ".self_attn.qkv.bias")):
+                k = k.replace("qkv.weight", "in_proj_weight").replace("qkv.bias", "in_proj_bias")
+            elif k.startswith("encoder.layers.") and not to_reference and k.endswith((".self_attn.in_proj_weight", ".self_attn.in_proj_bias")):
+                k = k.replace("in_proj_weight", "qkv.weight").replace("in_proj_bias", "qkv.bias")
+            out[k] = v
+        return out
+
     def state_dict(self, destination=None, prefix="", keep_vars=False):
         sd = {n: p.data.detach().float().cpu().clone() for n, p in self.named_arena_params().items()}
+        sd = self._local_attention_keys(sd, True)
         sd = fused_to_reference(sd)
         for i in range(2):
             for n in ("running_mean", "running_var", "num_batches_tracked"):
@@ -403,7 +418,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         return {prefix + k: v for k, v in sd.items()}
 
     def load_state_dict(self, state_dict, strict=True, args=None):
-        sd = reference_to_fused({k: v for k, v in state_dict.items()})
+        sd = reference_to_fused(self._local_attention_keys({k: v for k, v in state_dict.items()}, False))
         mine = self.named_arena_params()
         missing = [n for n in mine if n not in sd]
         if strict and missing:
@@ -466,8 +481,11 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             args.max_target_positions = 100000
         if getattr(args, "attn_2d", False):
             raise NotImplementedError("ConvAttention2D is outside this round's hot path: pass --no-attn-2d (SURVEY.md 8-f N3)")
-        if getattr(args, "distance_penalty", False):
-            raise NotImplementedError("--distance-penalty is outside this round's hot path (SURVEY.md 8-f N4)")
+        if getattr(args, "distance_penalty", False) is True:
+            args.distance_penalty = "log"                                    # conv_transformer.py:160-161
+        if getattr(args, "distance_penalty", False) not in (False, None, "log"):
+            raise NotImplementedError("--distance-penalty gauss (learnable per-head variance; undefined `num_heads` in the reference, "
+                                      "conv_transformer_layer.py:30-38) is not built; `log` is (SURVEY.md 8-f N4)")
         if getattr(args, "share_decoder_input_output_embed", False):
             raise NotImplementedError("--share-decoder-input-output-embed")
         src_dict, tgt_dict = task.source_dictionary, task.target_dictionary
@@ -484,7 +502,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                      act=getattr(args, "activation_fn", "relu"), dropout=args.dropout,
                      attention_dropout=args.attention_dropout, activation_dropout=args.activation_dropout,
                      pad=tgt_dict.pad(), no_scale_embedding=getattr(args, "no_scale_embedding", False),
-                     V_src=len(enc_dict), V_tgt=len(tgt_dict))
+                     V_src=len(enc_dict), V_tgt=len(tgt_dict), distance_penalty=getattr(args, "distance_penalty", False) or False)
         assert args.decoder_ffn_embed_dim == args.encoder_ffn_embed_dim
         encoder = ConvolutionalTransformerEncoder(args, enc_dict, audio_features=args.input_feat_per_channel)
         decoder = TransformerDecoder(args, tgt_dict)

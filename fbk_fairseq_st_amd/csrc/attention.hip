@@ -106,6 +106,7 @@ struct AttnArgs {
     long dq_st, dq_sb, dk_st, dk_sb, dv_st, dv_sb, do_st, do_sb;
     const int* klen;                                       // [B] valid keys (null = Tk)
     int B, H, Tq, Tk, causal;
+    int dist_pen;                                          // 1: scores -= max(0, ln|query - key|)  (LocalAttention + LogPenalty)
     float scale, p_drop; unsigned long long seed;
 };
 
@@ -118,6 +119,18 @@ __device__ __forceinline__ float drop_scale(const AttnArgs& p, int b, int h, int
     if (p.p_drop <= 0.f) return 1.f;
     const uint32_t th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
     return dropout_keep(p.seed, drop_index(p, b, h, qrow, key), th) ? 1.f / (1.f - p.p_drop) : 0.f;
+}
+
+// distance penalty of examples/speech_recognition/modules/local_attention.py:131-133 with LogPenalty
+// (modules/conv_transformer_layer.py:22-27): max(0, ln|i - j|), subtracted from the scaled scores before the softmax.
+// A constant additive bias: the backward pass only sees it through P.
+__device__ __forceinline__ float dist_pen_ln(int qrow, int key) {
+    const int d = qrow > key ? qrow - key : key - qrow;
+    return d > 1 ? __logf((float)d) : 0.f;
+}
+__device__ __forceinline__ float dist_pen_log2(int qrow, int key) {
+    const int d = qrow > key ? qrow - key : key - qrow;
+    return d > 1 ? __builtin_amdgcn_logf((float)d) : 0.f;          // v_log_f32 = log2
 }
 
 // ------------------------------------------------------------------------------------ forward
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int qrow = q0 + 4 * q + r;
                 const bool ok = key < klen && (!p.causal || key <= qrow);
-                s[j][r] = ok ? s[j][r] * p.scale : -INFINITY;
+                s[j][r] = ok ? s[j][r] * p.scale - (p.dist_pen ? dist_pen_ln(qrow, key) : 0.f) : -INFINITY;
                 mx[r] = fmaxf(mx[r], s[j][r]);
             }
         }
@@ -346,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = s[qb][j][r] * sc2;
+                        if (p.dist_pen) v -= dist_pen_log2(qrow, kv0 + 16 * j + 4 * q + r);
                         if constexpr (MASK) {
                             const int key = kv0 + 16 * j + 4 * q + r;
                             const bool ok = key < klen && (!p.causal || key <= qrow);
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + 4 * q + r;
                 const bool ok = qok && key < klen && (!p.causal || key <= qrow);
-                const float pv = ok ? __expf(st[j][r] * p.scale - L) : 0.f;
+                const float pv = ok ? __expf(st[j][r] * p.scale - (p.dist_pen ? dist_pen_ln(qrow, key) : 0.f) - L) : 0.f;
                 const float ds = ok ? drop_scale(p, b, h, qrow, key) : 0.f;
                 st[j][r] = pv * ds;                                  // D*P   (for dV)
                 dp[j][r] = pv * (ds * dp[j][r] - Dl) * p.scale;      // dS    (for dK)
@@ -603,7 +617,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int qrow = q0 + 4 * q + r;
                 const bool ok = qrow < p.Tq && key < klen && (!p.causal || key <= qrow);
-                const float pv = ok ? __expf(s[j][r] * p.scale - L[r]) : 0.f;
+                const float pv = ok ? __expf(s[j][r] * p.scale - (p.dist_pen ? dist_pen_ln(qrow, key) : 0.f) - L[r]) : 0.f;
                 const float ds = ok ? drop_scale(p, b, h, qrow, key) : 0.f;
                 dp[j][r] = pv * (ds * dp[j][r] - Dl[r]) * p.scale;
             }
@@ -777,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     // rows past Tq are zero in Q / dO / statistics and so contribute exactly 0; columns past klen are
                     // discarded at the store: only the causal triangle needs a per-element mask
-                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - L[r]);
+                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - (p.dist_pen ? dist_pen_log2(qt + 16 * i + 4 * q + r, key) : 0.f) - L[r]);
                     if (p.causal) e = (key <= qt + 16 * i + 4 * q + r) ? e : 0.f;
                     float dsc = 1.f;
                     if (p.p_drop > 0.f) {
@@ -897,7 +911,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // query rows past Tq are never stored; padded / future keys must not reach dQ
-                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - L[qb]);
+                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - (p.dist_pen ? dist_pen_log2(qrow, key0 + r) : 0.f) - L[qb]);
                     if constexpr (MASK) {
                         const int key = key0 + r;
                         e = (key < klen && (!p.causal || key <= qrow)) ? e : 0.f;
@@ -1003,16 +1017,17 @@ static int check_common(int dtype, int head_dim, const AttnArgs& a) {
     if (dtype != S2T_F32 && dtype != S2T_BF16) return S2T_ENOTSUP;
     if (head_dim != 64 && head_dim != 32) return S2T_ENOTSUP;
     if (a.B <= 0 || a.H <= 0 || a.Tq <= 0 || a.Tk <= 0) return S2T_EINVAL;
-    if (a.p_drop < 0.f || a.p_drop >= 1.f) return S2T_EINVAL;
+    if (a.p_drop < 0.f || a.p_drop >= 1.f || (a.dist_pen != 0 && a.dist_pen != 1)) return S2T_EINVAL;
     return S2T_OK;
 }
 
 extern "C" int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
                             const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
                             const void* V, long v_st, long v_sb, void* O, long o_st, long o_sb, float* LSE,
-                            const int* klen, int causal, float scale, float p_drop, unsigned long long seed,
+                            const int* klen, int causal, int dist_penalty, float scale, float p_drop, unsigned long long seed,
                             void* stream) {
     AttnArgs a{};
+    a.dist_pen = dist_penalty;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE;
     a.q_st = q_st; a.q_sb = q_sb; a.k_st = k_st; a.k_sb = k_sb; a.v_st = v_st; a.v_sb = v_sb; a.o_st = o_st; a.o_sb = o_sb;
     a.klen = klen; a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.causal = causal; a.scale = scale; a.p_drop = p_drop; a.seed = seed;
@@ -1042,9 +1057,10 @@ extern "C" int s2t_attn_bwd(int dtype, int head_dim, int B, int H, int Tq, int T
                             const void* dO, long do_st, long do_sb, const float* LSE, float* Delta,
                             void* dQ, long dq_st, long dq_sb, void* dK, long dk_st, long dk_sb,
                             void* dV, long dv_st, long dv_sb,
-                            const int* klen, int causal, float scale, float p_drop, unsigned long long seed,
+                            const int* klen, int causal, int dist_penalty, float scale, float p_drop, unsigned long long seed,
                             void* stream) {
     AttnArgs a{};
+    a.dist_pen = dist_penalty;
     a.Q = Q; a.K = K; a.V = V; a.O = const_cast<void*>(O); a.LSE = const_cast<float*>(LSE);
     a.dO = dO; a.dQ = dQ; a.dK = dK; a.dV = dV; a.Delta = Delta;
     a.q_st = q_st; a.q_sb = q_sb; a.k_st = k_st; a.k_sb = k_sb; a.v_st = v_st; a.v_sb = v_sb; a.o_st = o_st; a.o_sb = o_sb;

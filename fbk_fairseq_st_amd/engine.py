@@ -28,6 +28,7 @@ class HParams:
         self.sub_dropout = None                  # None -> max(dropout, 0.1) (conv_transformer.py:214)
         self.pad = 1; self.no_scale_embedding = False
         self.V_src = 0; self.V_tgt = 0
+        self.distance_penalty = False            # 'log': encoder self-attention scores -= max(0, ln|i-j|) (local_attention.py:131-133)
         self.V_aux = 0                           # > 0: second decoder `auxiliary_decoder.*` over this vocabulary (dual-decoder model)
         self.ln_eps = 1e-5; self.bn_eps = 1e-5; self.bn_momentum = 0.1
         for k, v in kw.items():
@@ -301,7 +302,7 @@ class S2TEngine:
                     self.G("encoder.convolutions.0.bias"))
 
     # ------------------------------------------------------------------ transformer blocks
-    def self_attn_block_fwd(self, pfx, x, klen32, causal, training, seed):
+    def self_attn_block_fwd(self, pfx, x, klen32, causal, training, seed, dist_penalty=False):
         """x [T,B,D] -> x + dropout(out_proj(attn(LN(x))))   (pre-LN; transformer_layer.py:103-124)"""
         hp = self.hp
         T, B, D = x.shape
@@ -310,10 +311,11 @@ class S2TEngine:
         qkv = self.linear(h, pfx + "self_attn.qkv").view(T, B, 3 * D)
         pa = hp.attention_dropout if training else 0.0
         ctx, lse = K.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], hp.heads, klen=klen32, causal=causal,
-                              p_drop=pa, seed=seed + 1)
+                              p_drop=pa, seed=seed + 1, dist_penalty=dist_penalty)
         p = hp.dropout if training else 0.0
         y = self.linear(ctx.view(T * B, D), pfx + "self_attn.out_proj", residual=x2, p_drop=p, seed=seed + 2)
-        c = dict(x=x2, h=h, mean=mean, rstd=rstd, qkv=qkv, ctx=ctx, lse=lse, klen=klen32, causal=causal, pa=pa, p=p, seed=seed, T=T, B=B)
+        c = dict(x=x2, h=h, mean=mean, rstd=rstd, qkv=qkv, ctx=ctx, lse=lse, klen=klen32, causal=causal, pa=pa, p=p, seed=seed, T=T, B=B,
+                 dist_penalty=dist_penalty)
         return y.view(T, B, D), c
 
     def self_attn_block_bwd(self, pfx, c, dy):
@@ -326,7 +328,7 @@ class S2TEngine:
         qkv = c["qkv"]
         K.attn_bwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], c["ctx"], dctx.view(T, B, D), c["lse"], hp.heads,
                    dqkv[:, :, :D], dqkv[:, :, D:2 * D], dqkv[:, :, 2 * D:], klen=c["klen"], causal=c["causal"],
-                   p_drop=c["pa"], seed=c["seed"] + 1)
+                   p_drop=c["pa"], seed=c["seed"] + 1, dist_penalty=c["dist_penalty"])
         dh = self.linear_bwd(dqkv.view(T * B, 3 * D), c["h"], pfx + "self_attn.qkv")
         return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "self_attn_layer_norm.weight"),
                                self.G(pfx + "self_attn_layer_norm.weight"), self.G(pfx + "self_attn_layer_norm.bias"), dres=dy)
@@ -404,7 +406,8 @@ class S2TEngine:
         cur_len, cur_len_host, cur_klen = len4, lens_host, klen
         for l in range(hp.enc_layers):
             pfx = "encoder.layers.%d." % l
-            x, ca = self.self_attn_block_fwd(pfx, x, cur_klen, False, training, seed * 1000 + 10 * (l + 1))
+            x, ca = self.self_attn_block_fwd(pfx, x, cur_klen, False, training, seed * 1000 + 10 * (l + 1),
+                                             dist_penalty=bool(hp.distance_penalty))
             x, cf = self.ffn_block_fwd(pfx, x, training, seed * 1000 + 10 * (l + 1))
             ctx["layers"].append((ca, cf))
             if hp.ctc_layer == l + 1:

@@ -67,7 +67,7 @@ def _tb(x):
     return x.stride(0), x.stride(1)
 
 
-def attn_fwd(q, k, v, heads, klen=None, causal=False, scale=None, p_drop=0.0, seed=0, out=None):
+def attn_fwd(q, k, v, heads, klen=None, causal=False, scale=None, p_drop=0.0, seed=0, out=None, dist_penalty=False):
     """q [Tq,B,D'], k/v [Tk,B,D'] views (last dim contiguous, may be slices of a fused QKV buffer)."""
     Tq, B, D = q.shape
     Tk = k.shape[0]
@@ -78,13 +78,13 @@ def attn_fwd(q, k, v, heads, klen=None, causal=False, scale=None, p_drop=0.0, se
         out = torch.empty((Tq, B, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, heads, Tq), dtype=torch.float32, device=q.device)
     rc = _lib().s2t_attn_fwd(L.dt(q), d, B, heads, Tq, Tk, L.ptr(q), *_tb(q), L.ptr(k), *_tb(k), L.ptr(v), *_tb(v),
-                             L.ptr(out), *_tb(out), L.ptr(lse), L.ptr(klen), int(causal), float(scale), float(p_drop),
+                             L.ptr(out), *_tb(out), L.ptr(lse), L.ptr(klen), int(causal), int(bool(dist_penalty)), float(scale), float(p_drop),
                              int(seed), L.stream())
     L.check(rc, "s2t_attn_fwd")
     return out, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, heads, dq, dk, dv, klen=None, causal=False, scale=None, p_drop=0.0, seed=0):
+def attn_bwd(q, k, v, o, do, lse, heads, dq, dk, dv, klen=None, causal=False, scale=None, p_drop=0.0, seed=0, dist_penalty=False):
     Tq, B, D = q.shape
     Tk = k.shape[0]
     d = D // heads
@@ -94,7 +94,7 @@ def attn_bwd(q, k, v, o, do, lse, heads, dq, dk, dv, klen=None, causal=False, sc
     rc = _lib().s2t_attn_bwd(L.dt(q), d, B, heads, Tq, Tk, L.ptr(q), *_tb(q), L.ptr(k), *_tb(k), L.ptr(v), *_tb(v),
                              L.ptr(o), *_tb(o), L.ptr(do), *_tb(do), L.ptr(lse), L.ptr(delta),
                              L.ptr(dq), *_tb(dq), L.ptr(dk), *_tb(dk), L.ptr(dv), *_tb(dv),
-                             L.ptr(klen), int(causal), float(scale), float(p_drop), int(seed), L.stream())
+                             L.ptr(klen), int(causal), int(bool(dist_penalty)), float(scale), float(p_drop), int(seed), L.stream())
     L.check(rc, "s2t_attn_bwd")
     return dq, dk, dv
 

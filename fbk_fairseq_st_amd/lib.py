@@ -31,9 +31,9 @@ SIGNATURES = {
                                        c_float, P, c_int, P, P, c_float, c_ull, P],
     "s2t_linear_wgrad": [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P],
     "s2t_colsum": [c_int, P, c_int, c_int, c_int, P, P],
-    "s2t_attn_fwd": [c_int] * 6 + [P, c_long, c_long] * 4 + [P, P, c_int, c_float, c_float, c_ull, P],
+    "s2t_attn_fwd": [c_int] * 6 + [P, c_long, c_long] * 4 + [P, P, c_int, c_int, c_float, c_float, c_ull, P],
     "s2t_attn_bwd": [c_int] * 6 + [P, c_long, c_long] * 5 + [P, P] + [P, c_long, c_long] * 3 +
-                    [P, c_int, c_float, c_float, c_ull, P],
+                    [P, c_int, c_int, c_float, c_float, c_ull, P],
     "s2t_layernorm_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_float, P],
     "s2t_layernorm_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P],
     "s2t_conv1_fwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P],

@@ -91,14 +91,14 @@ int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float* out, void*
 int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
                  const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
                  const void* V, long v_st, long v_sb, void* O, long o_st, long o_sb, float* LSE,
-                 const int* klen, int causal, float scale, float p_drop, unsigned long long seed, void* stream);
+                 const int* klen, int causal, int dist_penalty, float scale, float p_drop, unsigned long long seed, void* stream);
 /* Backward of the above (flash-style recomputation; Delta [B][H][Tq] f32 is workspace). */
 int s2t_attn_bwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
                  const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
                  const void* V, long v_st, long v_sb, const void* O, long o_st, long o_sb,
                  const void* dO, long do_st, long do_sb, const float* LSE, float* Delta,
                  void* dQ, long dq_st, long dq_sb, void* dK, long dk_st, long dk_sb, void* dV, long dv_st, long dv_sb,
-                 const int* klen, int causal, float scale, float p_drop, unsigned long long seed, void* stream);
+                 const int* klen, int causal, int dist_penalty, float scale, float p_drop, unsigned long long seed, void* stream);
 
 /* ---- LayerNorm (fairseq/modules/layer_norm.py:29-32; eps 1e-5; rows of D <= 1024) ------------------ */
 int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,

@@ -122,7 +122,7 @@ def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
 
 
 # ------------------------------------------------------------------ attention (a7, a13)
-def mha(W, pfx, heads, query, key, key_padding_mask=None, causal=False):
+def mha(W, pfx, heads, query, key, key_padding_mask=None, causal=False, dist_penalty=False):
     """fairseq/modules/multihead_attention.py:108-366 / F.multi_head_attention_forward
     (Appendix B1): q,k,v projections with bias, q * d^-1/2, -inf on padded keys and
     above the diagonal (causal), softmax in fp32, P.V, out-projection.
@@ -142,6 +142,11 @@ def mha(W, pfx, heads, query, key, key_padding_mask=None, causal=False):
     if key_padding_mask is not None:
         s = s.view(B, heads, Tq, Tk).masked_fill(key_padding_mask[:, None, None, :], float("-inf"))
         s = s.view(B * heads, Tq, Tk)
+    if dist_penalty:
+        # LocalAttention + LogPenalty (examples/speech_recognition/modules/local_attention.py:131-133,
+        # modules/conv_transformer_layer.py:22-27): scores -= max(0, ln|i - j|), after the padding mask
+        dist = (torch.arange(Tq).unsqueeze(1) - torch.arange(Tk).unsqueeze(0)).abs().float()
+        s = s - torch.max(torch.zeros_like(dist), torch.log(dist)).unsqueeze(0)
     p = F.softmax(s.float(), dim=-1)
     o = torch.bmm(p, v).transpose(0, 1).contiguous().view(Tq, B, D)
     return F.linear(o, W[pfx + "out_proj.weight"], W[pfx + "out_proj.bias"])
@@ -163,7 +168,7 @@ def encoder_layer(W, cfg, pfx, x, pad_mask):
     r = x
     if pre:
         x = layer_norm(W, pfx + "self_attn_layer_norm.", x)
-    x = r + mha(W, pfx + "self_attn.", cfg["heads"], x, x, pad_mask)
+    x = r + mha(W, pfx + "self_attn.", cfg["heads"], x, x, pad_mask, dist_penalty=bool(cfg.get("distance_penalty", False)))
     if not pre:
         x = layer_norm(W, pfx + "self_attn_layer_norm.", x)
     r = x

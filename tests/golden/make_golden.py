@@ -608,7 +608,52 @@ def run_iterator_case():
     print("iterator", {k: int(v) for k, v in out.items() if k.endswith("_n")}, sorted(os.listdir(d)))
 
 
+def run_distpen_case():
+    """G14: --distance-penalty log.  The reference's LocalAttention is hard-wired to CUDA (`.cuda()` on a fresh CPU
+    tensor, local_attention.py:132) and scales q in place on a chunk view (:98), which autograd rejects: the forward is
+    captured under no_grad with Tensor.cuda patched to the identity (our patch, outside the tree); gradients are pinned through the oracle."""
+    D, H, Ff, EL, DL, seed = 64, 2, 128, 2, 1, 800
+    args, task, model, crit, V_src, V_tgt = build("dp", D, H, Ff, EL, DL, 2, True, extra=("--distance-penalty", "log"))
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=2, distance_penalty="log")
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    sd = model.state_dict()
+    for k in sd:
+        if k in W:
+            sd[k] = W[k].clone()
+        elif k.endswith("self_attn.in_proj_weight") or k.endswith("self_attn.in_proj_bias"):
+            base, kind = k.rsplit("in_proj_", 1)
+            sd[k] = torch.cat([W[base + n + "_proj." + kind] for n in ("q", "k", "v")], 0)
+    model.load_state_dict(sd, strict=True)
+    s = make_sample(seed + 1, [70, 57, 41], [5, 4, 6], [4, 3, 5], V_src, V_tgt, V_src - 1)
+    sample = to_ref_sample(s)
+    out = {("in_" + k): v for k, v in s.items() if isinstance(v, np.ndarray)}
+    out["in_ntokens"] = np.int64(s["ntokens"])
+    out["meta"] = np.array([D, H, Ff, EL, DL, 2, 1, V_src, V_tgt, V_src - 1, seed], np.int64)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            for mode in ("train", "eval"):
+                model.train(mode == "train"); crit.train(mode == "train")
+                load = model.state_dict()
+                loss, ss, log = crit(model, sample)
+                eo = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"]) if mode == "eval" else None
+                out[mode + "_loss"] = np.float64(loss.item()); out[mode + "_sample_size"] = np.int64(ss)
+                for k in ("ctc_loss", "nll_loss"):
+                    out[mode + "_" + k] = np.float64(float(log[k]))
+                if eo is not None:
+                    out["eval_encoder_out"] = eo.encoder_out.numpy(); out["eval_src_lengths_out"] = eo.src_lengths.numpy()
+                model.load_state_dict(sd, strict=True)              # restore the BN running statistics
+    finally:
+        torch.Tensor.cuda = real_cuda
+    out["statedict_keys"] = np.array(sorted(k for k in sd if "layers.0.self_attn" in k and k.startswith("encoder")))
+    np.savez_compressed(os.path.join(OUT, "distpen.npz"), **out)
+    print("distpen", {k: float(v) for k, v in out.items() if k.endswith("loss")}, list(out["statedict_keys"]))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "distpen":
+        run_distpen_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "iterator":
         run_iterator_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "data":

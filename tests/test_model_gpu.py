@@ -375,3 +375,105 @@ def test_baseline_config_shapes_match_oracle(arch, B, lengths, L, ctc_layer):
         worst = max(worst, abs(mine - ref) / max(1.0, ref))
         assert abs(mine - ref) <= 1e-3 * max(1.0, ref), (k, mine, ref)
     assert worst < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- distance penalty (8-f N4)
+def _build_distpen(dtype=torch.float32):
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import namespace
+    from test_oracle_golden import _distpen_case
+    g, cfg, W, sample, blank = _distpen_case()
+    args = namespace(arch="conv_transformer", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+                     label_smoothing=0.1, ctc_compress_out=True, ctc_encoder_layer=cfg["ctc_layer"], ctc_weight=1.0,
+                     encoder_embed_dim=cfg["D"], encoder_ffn_embed_dim=cfg["ffn"], encoder_attention_heads=cfg["heads"],
+                     encoder_layers=cfg["enc_layers"], decoder_layers=cfg["dec_layers"], no_attn_2d=True, distance_penalty="log",
+                     decoder_embed_dim=cfg["D"], decoder_ffn_embed_dim=cfg["ffn"], decoder_attention_heads=cfg["heads"],
+                     input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False)
+    tgt, src = Dictionary.synthetic(96), Dictionary.synthetic(59)
+    src.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationCTCTask(args, tgt, src)
+    model = task.build_model(args)
+    crit = task.build_criterion(args)
+    # weights arrive under the reference's LocalAttention names (one in_proj parameter per encoder layer)
+    sd = {}
+    for k, v in W.items():
+        if k.startswith("criterion."):
+            continue
+        if k.startswith("encoder.layers.") and ".self_attn.q_proj." in k:
+            base, kind = k.split("q_proj.")
+            sd[base + "in_proj_" + kind] = torch.cat([W[base + n + "_proj." + kind] for n in ("q", "k", "v")], 0)
+        elif k.startswith("encoder.layers.") and (".self_attn.k_proj." in k or ".self_attn.v_proj." in k):
+            continue
+        else:
+            sd[k] = v
+    model.load_state_dict(sd)
+    out_keys = set(model.state_dict())
+    assert all(str(k) in out_keys for k in g["statedict_keys"]) and "encoder.layers.0.self_attn.q_proj.weight" not in out_keys
+    model.hp.sub_dropout = 0.0
+    model.materialize(DEV, dtype, extra=crit.arena_params())
+    return g, cfg, W, sample, blank, model, crit
+
+
+def test_distance_penalty_forward_matches_reference_and_gradients_match_oracle():
+    """G14 on the GPU: losses against the reference's LocalAttention forward (train + eval), eval encoder output, and -- the reference
+    cannot back-propagate through its in-place q scaling -- gradients against the oracle that the same fixture pins."""
+    from fbk_fairseq_st_amd.conv_transformer import fused_to_reference
+    g, cfg, W, sample, blank, model, crit = _build_distpen()
+    s = to_dev(sample)
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    loss, ss, log = crit(model, s)
+    loss.backward()
+    close(loss, g["train_loss"], 1e-4, "train loss")
+    close(log["ctc_loss"], g["train_ctc_loss"], 1e-4, "ctc"); close(log["nll_loss"], g["train_nll_loss"], 1e-4, "nll")
+    grads = fused_to_reference({n: model.arena.g(n).detach().cpu().clone() for n in model.arena.slices})
+    Wr = {k: v.clone().requires_grad_(True) for k, v in W.items() if "running" not in k}
+    Wb = {k: v.clone() for k, v in W.items() if "running" in k}
+    rl = s2t_ref.ctc_multi_loss({**Wr, **Wb}, cfg, sample, 0.1, 1.0, blank, training=True)[0]
+    rl.backward()
+    for k, p in Wr.items():
+        if p.grad is None or k not in grads:
+            continue
+        ref = float(p.grad.norm()); mine = float(grads[k].norm())
+        assert abs(mine - ref) <= 5e-4 * max(1.0, ref), (k, mine, ref)
+    close(grads["encoder.layers.0.self_attn.q_proj.weight"], Wr["encoder.layers.0.self_attn.q_proj.weight"].grad, 5e-4, "dq_proj")
+    model.eval(); crit.eval()
+    model.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        # running statistics were updated by the train step: restore the fixture's
+        model.bn0_running_mean.copy_(W["encoder.bn.0.running_mean"]); model.bn0_running_var.copy_(W["encoder.bn.0.running_var"])
+        model.bn1_running_mean.copy_(W["encoder.bn.1.running_mean"]); model.bn1_running_var.copy_(W["encoder.bn.1.running_var"])
+        loss, _, log = crit(model, s)
+        eo = model.encoder(s["net_input"]["src_tokens"], s["net_input"]["src_lengths"])
+    close(loss, g["eval_loss"], 1e-4, "eval loss")
+    close(eo.encoder_out, g["eval_encoder_out"], 1e-4, "eval encoder_out")
+
+
+def test_distance_penalty_long_sequences_bf16_kernels():
+    """the second-generation (bf16, T >= 128) kernels with the penalty against the fp32 torch formula"""
+    from fbk_fairseq_st_amd import kernels as K
+    heads, d, B, T = 2, 64, 2, 200
+    D = heads * d
+    gq = torch.Generator().manual_seed(3)
+    q, k, v, do = [(torch.randn(T, B, D, generator=gq) * 0.7).to(torch.bfloat16) for _ in range(4)]
+    klen = torch.tensor([T, 170], dtype=torch.int32)
+    qf, kf, vf = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    qh = qf.view(T, B * heads, d).transpose(0, 1) * d ** -0.5
+    kh = kf.view(T, B * heads, d).transpose(0, 1); vh = vf.view(T, B * heads, d).transpose(0, 1)
+    sc = torch.bmm(qh, kh.transpose(1, 2))
+    m = torch.arange(T)[None, :] >= klen[:, None]
+    sc = sc.view(B, heads, T, T).masked_fill(m[:, None, None, :], float("-inf")).view(B * heads, T, T)
+    dist = (torch.arange(T)[:, None] - torch.arange(T)[None, :]).abs().float()
+    sc = sc - torch.max(torch.zeros_like(dist), torch.log(dist))
+    ref = torch.bmm(torch.softmax(sc, -1), vh).transpose(0, 1).reshape(T, B, D)
+    ref.backward(do.float())
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out, lse = K.attn_fwd(qd, kd, vd, heads, klen=klen.to(DEV), dist_penalty=True)
+    err = lambda a, b: float((a.float().cpu() - b).abs().max() / b.abs().max())
+    assert err(out, ref.detach()) < 2e-2
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    K.attn_bwd(qd, kd, vd, out, do.to(DEV), lse, heads, dq, dk, dv, klen=klen.to(DEV), dist_penalty=True)
+    assert err(dq, qf.grad) < 3e-2 and err(dk, kf.grad) < 3e-2 and err(dv, vf.grad) < 3e-2
+    out0, _ = K.attn_fwd(qd, kd, vd, heads, klen=klen.to(DEV))
+    assert err(out0, ref.detach()) > 5e-2

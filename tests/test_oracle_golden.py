@@ -211,3 +211,34 @@ def test_beam_search_matches_reference_generator(tag):
             assert t.tolist() == et.tolist()
             assert abs(s - es_) < 1e-4
             np.testing.assert_allclose(ps.numpy(), eps, atol=1e-4)
+
+
+def _distpen_case():
+    g = load_golden("distpen")
+    D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed = [int(v) for v in g["meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer, distance_penalty="log")
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    t = lambda k: torch.from_numpy(g["in_" + k])
+    sample = dict(id=t("id"), ntokens=int(g["in_ntokens"]), nsentences=3,
+                  net_input=dict(src_tokens=t("src_tokens"), src_lengths=t("src_lengths"), prev_output_tokens=t("prev_output_tokens")),
+                  target=t("target"), target_lengths=t("target_lengths"), transcript_target=t("transcript_target"),
+                  transcript_target_lengths=t("transcript_target_lengths"), ctc_encoder_layer=ctc_layer)
+    return g, cfg, W, sample, blank
+
+
+def test_distance_penalty_matches_reference_local_attention():
+    """G14: --distance-penalty log (LocalAttention + LogPenalty): oracle vs the reference's forward, train and eval mode."""
+    g, cfg, W, sample, blank = _distpen_case()
+    for mode in ("train", "eval"):
+        Wm = {k: v.clone() for k, v in W.items()}
+        loss, ss, log, enc, _, _ = s2t_ref.ctc_multi_loss(Wm, cfg, sample, 0.1, 1.0, blank, training=(mode == "train"))
+        assert abs(float(loss) - float(g[mode + "_loss"])) < 1e-4 * abs(float(g[mode + "_loss"]))
+        assert abs(log["ctc_loss"] - float(g[mode + "_ctc_loss"])) < 1e-4 * abs(float(g[mode + "_ctc_loss"]))
+        assert abs(log["nll_loss"] - float(g[mode + "_nll_loss"])) < 1e-4 * abs(float(g[mode + "_nll_loss"]))
+        if mode == "eval":
+            np.testing.assert_allclose(enc.encoder_out.numpy(), g["eval_encoder_out"], atol=1e-4)
+            assert enc.src_lengths.tolist() == g["eval_src_lengths_out"].tolist()
+    # the penalty does something
+    cfg0 = dict(cfg, distance_penalty=False)
+    l0 = s2t_ref.ctc_multi_loss({k: v.clone() for k, v in W.items()}, cfg0, sample, 0.1, 1.0, blank, training=False)[0]
+    assert abs(float(l0) - float(g["eval_loss"])) > 1e-3
