@@ -470,3 +470,37 @@ extern "C" int s2t_add_pos(int dtype, void* x, const float* table, const int* le
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
+
+
+// ------------------------------------------------------------------ input augmentation
+// TimeStretch + SpecAugment of examples/speech_recognition/modules/{time_stretch,specaugment}.py as ONE pass over the batch:
+// out[b][t][f] = x[b][row_map[b][t]][f] (row_map -1 / absent rows = 0), zeroed inside the utterance's time masks [t0, t0+w) and
+// frequency masks [f0, f0+w).  The tables come from the host, which draws them from the same random streams as the reference
+// (augment.py); the reference applies them with per-utterance slice writes from Python.
+__global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ x, float* __restrict__ out, const int* __restrict__ row_map,
+                                                      const int* __restrict__ fmask, const int* __restrict__ tmask, int B, int T, int To,
+                                                      int F, int nF, int nT) {
+    const long row = blockIdx.x;                       // (b, t)
+    const int b = (int)(row / To), t = (int)(row % To);
+    int src = row_map ? row_map[row] : (t < T ? t : -1);
+    for (int i = 0; i < nT; ++i) {
+        const int t0 = tmask[(b * nT + i) * 2], w = tmask[(b * nT + i) * 2 + 1];
+        if (t >= t0 && t < t0 + w) src = -1;
+    }
+    for (int f = threadIdx.x; f < F; f += 256) {
+        bool keep = src >= 0;
+        for (int i = 0; i < nF; ++i) {
+            const int f0 = fmask[(b * nF + i) * 2], w = fmask[(b * nF + i) * 2 + 1];
+            keep = keep && !(f >= f0 && f < f0 + w);
+        }
+        out[row * F + f] = keep ? x[((long)b * T + src) * F + f] : 0.f;
+    }
+}
+extern "C" int s2t_augment(const float* x, float* out, const int* row_map, const int* fmask, const int* tmask, int B, int T, int To,
+                           int F, int nF, int nT, void* stream) {
+    if (B <= 0 || To <= 0 || F <= 0) return (B < 0 || To < 0 || F < 0) ? S2T_EINVAL : S2T_OK;
+    if (!x || !out || x == out || T <= 0 || nF < 0 || nT < 0 || (nF > 0 && !fmask) || (nT > 0 && !tmask)) return S2T_EINVAL;
+    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((long)B * To)), dim3(256), 0, (hipStream_t)stream, x, out, row_map, fmask, tmask, B, T, To, F, nF, nT);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

@@ -22,13 +22,39 @@ class SpeechTranslationCTCTask(FairseqTask):
         a("--max-source-positions", default=1024, type=int, metavar="N")
         a("--max-target-positions", default=1024, type=int, metavar="N")
         a("--skip-normalization", action="store_true")
+        a("--legacy-audio-fix-lua-indexing", action="store_true")
+        # speech_recognition.py:114-133
         a("--specaugment", action="store_true")
+        a("--frequency-masking-pars", type=int, default=13)
+        a("--time-masking-pars", type=int, default=13)
+        a("--frequency-masking-num", type=int, default=2)
+        a("--time-masking-num", type=int, default=2)
+        a("--specaugment-rate", type=float, default=1.0)
+        a("--time-stretch", action="store_true")
+        a("--time-stretch-rate", type=float, default=1.0)
+        a("--time-stretch-w", type=int, default=1)
+        a("--time-stretch-low", type=float, default=0.8)
+        a("--time-stretch-high", type=float, default=1.25)
 
     def __init__(self, args, tgt_dict, src_dict=None):
         super().__init__(args)
         self.tgt_dict = tgt_dict
         self.src_dict = src_dict
         self.is_source_speech = True                     # read by generate.py:61-67
+        from .augment import SpecAugment, TimeStretch
+        g = lambda k, d: getattr(args, k, d)
+        self.specaugment = SpecAugment(g("frequency_masking_pars", 13), g("time_masking_pars", 13), g("frequency_masking_num", 2),
+                                       g("time_masking_num", 2), g("specaugment_rate", 1.0)) if g("specaugment", False) else None
+        self.time_stretch = TimeStretch(g("time_stretch_rate", 1.0), g("time_stretch_w", 1), g("time_stretch_low", 0.8),
+                                        g("time_stretch_high", 1.25)) if g("time_stretch", False) else None
+
+    def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
+        """speech_recognition.py:254-263: TimeStretch, then SpecAugment, then the generic step"""
+        if self.time_stretch is not None:
+            sample = self.time_stretch(sample)
+        if self.specaugment is not None:
+            sample = self.specaugment(sample)
+        return super().train_step(sample, model, criterion, optimizer, update_num, ignore_grad)
 
     @classmethod
     def setup_task(cls, args, **kwargs):

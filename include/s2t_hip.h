@@ -36,6 +36,11 @@ extern "C" {
 #define S2T_ACT_GELU_BWD 4  /* out = acc * gelu'(aux)           (aux = forward pre-activation)  */
 
 /* ---- library info ------------------------------------------------------------------------- */
+/* TimeStretch + SpecAugment in one pass (examples/speech_recognition/modules/time_stretch.py:18-57, specaugment.py:44-112; applied by
+ * tasks/speech_recognition.py:254-258): out[b][t][:] = x[b][row_map[b][t]][:] (row_map NULL = identity, -1 = zero row), zeroed inside
+ * tmask[b][i] = (t0, width) and fmask[b][i] = (f0, width).  x [B][T][F] f32, out [B][To][F] f32 (out != x). */
+int s2t_augment(const float* x, float* out, const int* row_map, const int* fmask, const int* tmask, int B, int T, int To, int F,
+                int nF, int nT, void* stream);
 /* Host: frame-budget batching of utterance indices (fairseq/data/data_utils_fast.pyx:16-68 batch_by_size_fast; caller
  * fairseq/data/data_utils.py:200-234).  lens[idx] = frames of utterance idx; out_flat[n], out_offsets[n + 1]. */
 int s2t_host_batch_by_size(const long long* indices, long long n, const long long* lens, long long max_tokens,

@@ -203,3 +203,24 @@ def batch_by_size(indices, lens, max_tokens=-1, max_sentences=-1, bsz_mult=1):
     if batch:
         batches.append(batch)
     return batches
+
+
+def apply_augment(x, row_map=None, fmask=None, tmask=None):
+    """numpy application of the augmentation tables (s2t_augment's contract): x [B,T,F] -> [B,To,F]; row gather (-1 = zero row),
+    then zero the (t0, width) rows and (f0, width) columns of every utterance (time_stretch.py:42-57, specaugment.py:95-110)."""
+    B, T, F = x.shape
+    if row_map is None:
+        out = x.copy()
+    else:
+        out = np.zeros((B, row_map.shape[1], F), x.dtype)
+        for b in range(B):
+            ok = row_map[b] >= 0
+            out[b, ok] = x[b, row_map[b][ok]]
+    for b in range(B):
+        if fmask is not None:
+            for f0, w in fmask[b]:
+                out[b, :, f0:f0 + w] = 0
+        if tmask is not None:
+            for t0, w in tmask[b]:
+                out[b, t0:t0 + w, :] = 0
+    return out

@@ -651,7 +651,44 @@ def run_distpen_case():
     print("distpen", {k: float(v) for k, v in out.items() if k.endswith("loss")}, list(out["statedict_keys"]))
 
 
+def run_augment_case():
+    """G15: TimeStretch then SpecAugment as SpeechRecognitionTask.train_step applies them (speech_recognition.py:254-258),
+    with Python's `random` and numpy's global RNG seeded: expected batches after each stage."""
+    import random
+    from examples.speech_recognition.modules.specaugment import SpecAugment
+    from examples.speech_recognition.modules.time_stretch import TimeStretch
+    out = {}
+    rs = np.random.RandomState(5)
+    for ci, (lens, F_, sa, ts) in enumerate([([50, 43, 31], 80, dict(frequency_masking_pars=13, time_masking_pars=13, frequency_masking_num=2, time_masking_num=2, rate=1.0), None),
+                                             ([60, 60], 40, dict(frequency_masking_pars=27, time_masking_pars=100, frequency_masking_num=1, time_masking_num=1, rate=0.5), None),
+                                             ([50, 43, 31, 8], 80, dict(frequency_masking_pars=13, time_masking_pars=20, frequency_masking_num=2, time_masking_num=1, rate=0.8),
+                                              dict(rate=0.7, w=5, low=0.8, high=1.25)),
+                                             ([37, 22], 16, None, dict(rate=1.0, w=1, low=0.5, high=1.5))]):
+        B, T = len(lens), max(lens)
+        x = np.zeros((B, T, F_), np.float32)
+        for b, l in enumerate(lens):
+            x[b, :l] = rs.randn(l, F_).astype(np.float32) + 3.0          # non-zero everywhere: masks are visible
+        batch = {"net_input": {"src_tokens": torch.from_numpy(x.copy()), "src_lengths": torch.tensor(lens)}}
+        random.seed(100 + ci); np.random.seed(200 + ci)
+        if ts is not None:
+            batch = TimeStretch(ts["rate"], ts["w"], ts["low"], ts["high"])(batch)
+            out["c%d_ts_tokens" % ci] = batch["net_input"]["src_tokens"].numpy().copy()
+            out["c%d_ts_lengths" % ci] = batch["net_input"]["src_lengths"].numpy().copy()
+        if sa is not None:
+            batch = SpecAugment(**sa)(batch)
+        out["c%d_in" % ci] = x; out["c%d_lens" % ci] = np.array(lens, np.int64)
+        out["c%d_out" % ci] = batch["net_input"]["src_tokens"].numpy().copy()
+        out["c%d_out_lengths" % ci] = batch["net_input"]["src_lengths"].numpy().copy()
+        out["c%d_sa" % ci] = np.array([sa[k] for k in ("frequency_masking_pars", "time_masking_pars", "frequency_masking_num", "time_masking_num", "rate")] if sa else [-1] * 5, np.float64)
+        out["c%d_ts" % ci] = np.array([ts[k] for k in ("rate", "w", "low", "high")] if ts else [-1] * 4, np.float64)
+        print("augment", ci, out["c%d_out" % ci].shape, float((out["c%d_out" % ci] == 0).mean()))
+    out["ncases"] = np.int64(4)
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":
+        run_augment_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "distpen":
         run_distpen_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "iterator":

@@ -117,3 +117,37 @@ def test_data_pipeline_reproduces_the_reference_batches(prefetch):
                     assert np.array_equal(b[kk].numpy(), g[pre + kk]), kk
     with pytest.raises(Exception, match="invalid"):
         get_batch_iterator(ds, max_tokens=150, max_positions=(80, 50), ignore_invalid_inputs=False)
+
+
+def _augment_tables(g, ci):
+    """draw the tables of case ci with the generator seeds the reference run used; returns (row_map, new_lengths, fmask, tmask)"""
+    import random
+    from fbk_fairseq_st_amd.augment import SpecAugment, TimeStretch
+    x, lens = g["c%d_in" % ci], g["c%d_lens" % ci]
+    sa, ts = g["c%d_sa" % ci], g["c%d_ts" % ci]
+    random.seed(100 + ci); np.random.seed(200 + ci)
+    rm = new_len = fm = tm = None
+    B, tau, v = x.shape
+    if ts[0] >= 0:
+        rm, new_len = TimeStretch(float(ts[0]), int(ts[1]), float(ts[2]), float(ts[3])).row_map(lens.tolist())
+        tau = rm.shape[1]
+    if sa[0] >= 0:
+        aug = SpecAugment(int(sa[0]), int(sa[1]), int(sa[2]), int(sa[3]), float(sa[4]))
+        fm, tm = aug.tables(B, tau, v)
+    return rm, new_len, fm, tm
+
+
+def test_augmentation_tables_reproduce_the_reference_batches():
+    """G15: the host side of TimeStretch + SpecAugment draws the reference's random numbers in the reference's order: applying the
+    tables (numpy oracle of the kernel's contract) gives the reference's augmented batches bit for bit."""
+    g = load_golden("augment")
+    for ci in range(int(g["ncases"])):
+        rm, new_len, fm, tm = _augment_tables(g, ci)
+        x = g["c%d_in" % ci]
+        if rm is not None:
+            st = int_ref.apply_augment(x, rm)
+            assert np.array_equal(st, g["c%d_ts_tokens" % ci]) and new_len == g["c%d_ts_lengths" % ci].tolist()
+        out = int_ref.apply_augment(x, rm, fm, tm)
+        assert np.array_equal(out, g["c%d_out" % ci]), ci
+        if new_len is not None:
+            assert new_len == g["c%d_out_lengths" % ci].tolist()

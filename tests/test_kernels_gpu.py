@@ -528,3 +528,24 @@ def test_attention_v2_head_to_xcd_mapping():
     assert rel_err(dq, qf.grad) < 3e-2 and rel_err(dk, kf.grad) < 3e-2 and rel_err(dv, vf.grad) < 3e-2
     for b in range(1, B):                                # padded keys receive exact zeros
         assert float(dk[int(klen[b]):, b].abs().max()) == 0.0 and float(dv[int(klen[b]):, b].abs().max()) == 0.0
+
+
+def test_augment_kernel_reproduces_the_reference_batches():
+    """G15 on the GPU: TimeStretch + SpecAugment through s2t_augment, seeded like the reference run: identical batches (exact)."""
+    import random
+    from helpers import load_golden
+    from fbk_fairseq_st_amd.augment import SpecAugment, TimeStretch
+    g = load_golden("augment")
+    for ci in range(int(g["ncases"])):
+        sa, ts = g["c%d_sa" % ci], g["c%d_ts" % ci]
+        batch = {"net_input": {"src_tokens": torch.from_numpy(g["c%d_in" % ci]).to(DEV), "src_lengths": torch.from_numpy(g["c%d_lens" % ci])},
+                 "nframes": int(g["c%d_lens" % ci].sum())}
+        random.seed(100 + ci); np.random.seed(200 + ci)
+        if ts[0] >= 0:
+            batch = TimeStretch(float(ts[0]), int(ts[1]), float(ts[2]), float(ts[3]))(batch)
+            assert torch.equal(batch["net_input"]["src_tokens"].cpu(), torch.from_numpy(g["c%d_ts_tokens" % ci]))
+            assert batch["net_input"]["src_lengths"].tolist() == g["c%d_ts_lengths" % ci].tolist()
+            assert batch["nframes"] == int(g["c%d_ts_lengths" % ci].sum())
+        if sa[0] >= 0:
+            batch = SpecAugment(int(sa[0]), int(sa[1]), int(sa[2]), int(sa[3]), float(sa[4]))(batch)
+        assert torch.equal(batch["net_input"]["src_tokens"].cpu(), torch.from_numpy(g["c%d_out" % ci])), ci

@@ -104,3 +104,19 @@ def test_training_from_the_on_disk_split():
                 first = last if first is None else first
         assert n >= 2 and frames > 0
     assert last < first
+
+
+def test_train_step_applies_time_stretch_and_specaugment():
+    """the task's train_step runs TimeStretch then SpecAugment on the staged batch (speech_recognition.py:254-258)"""
+    import random
+    a, task, model, crit, tr = _setup(torch.float32, dropout=0.0)
+    from fbk_fairseq_st_amd.augment import SpecAugment, TimeStretch
+    task.specaugment = SpecAugment(13, 13, 2, 2, 1.0)
+    task.time_stretch = TimeStretch(1.0, 5, 0.8, 1.25)
+    sample = tr.prepare(task.dummy_batch(seed=1, lengths=[200, 180, 150, 120]))
+    random.seed(1); np.random.seed(1)
+    tr.train_step([sample])
+    st = tr.reduce_stats()
+    assert np.isfinite(st["loss"]) and np.isfinite(st["gnorm"])
+    assert st["nframes"] != 650                           # stretched lengths are what the step saw
+    assert sample["net_input"]["src_tokens"].shape[1] == 200   # the staged batch itself is untouched
