@@ -404,7 +404,7 @@ __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int aro
 // NW = 4: waves 2 x 2, each (BM/2) x (BN/2).  NW = 8: waves 2 x 4, each (BM/2) x (BN/4): twice the wavefronts per CU to
 // cover the global-load latency of the k-loop, at 1.5x the LDS fragment traffic per MFMA.
 template <typename TI, typename TO, bool TA, bool TB, int BM, int BN, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(GemmArgs p) {   // 2nd argument = min waves per SIMD
     constexpr int BK = 128 / (int)sizeof(TI);
     constexpr int NTH = NW * 64, WN = NW / 2;
     constexpr int MT = BM / 32, NT = BN / (16 * WN);
@@ -457,8 +457,6 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
     auto step = [&]() { left -= 1; return left > 0 ? 128 : 0; };
     { const int st = step(); sa.load(a0, st); sb.load(b0, st); }      // tile 0
     { const int st = step(); sa.load(a1, st); sb.load(b1, st); }      // tile 1 (or tile 0 again)
-    sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
-    __syncthreads();
     // bias gradient: the first column tile's wc == 0 waves also sum their A rows (wave-uniform choice)
     const bool do_rs = TA && p.rowsum != nullptr && tn == 0 && wc == 0;
     f32x4 rs[MT];
@@ -470,6 +468,40 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
         }
         mma_tile<TI, MT, NT, TRA, TRB>(l, l + BOFF, arow, brow, r16, q, acc);
     };
+    if constexpr (NW == 8) {
+        // 8-wave form: a thread stages only 2 + 2 chunks per k-tile, so a THIRD register set fits under 128 VGPRs (4 waves per
+        // SIMD kept): loads run three k-tiles ahead of the MFMAs (PMC: 42 % of the wave cycles were parked in s_waitcnt / barriers
+        // with two).  Tile k lives in set k % 3 and is written to stage k % 2 one step before it is consumed; unrolled by 6.
+        typename SA::Regs a2;
+        typename SB::Regs b2;
+        { const int st = step(); sa.load(a2, st); sb.load(b2, st); }  // tile 2
+        sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
+        __syncthreads();
+#define S2T_STEP(RA, RB, SA_, SB_, LCUR, LNXT)                                                  \
+        { const int st = step(); sa.load(RA, st); sb.load(RB, st); }   /* tile t+3 */            \
+        mma(LCUR);                                                      /* tile t   */            \
+        sa.store(LNXT, SA_); sb.store(LNXT + BM * 128, SB_);            /* tile t+1 */            \
+        __syncthreads();
+        const int nkk = (p.dbg & 2) ? 0 : nk;
+        int t = 0;
+        for (; t + 6 <= nkk; t += 6) {
+            S2T_STEP(a0, b0, a1, b1, l0, l1)
+            S2T_STEP(a1, b1, a2, b2, l1, l0)
+            S2T_STEP(a2, b2, a0, b0, l0, l1)
+            S2T_STEP(a0, b0, a1, b1, l1, l0)
+            S2T_STEP(a1, b1, a2, b2, l0, l1)
+            S2T_STEP(a2, b2, a0, b0, l1, l0)
+        }
+        const int rem = nkk - t;                       // 0..5 steps left, the rotation is back at its start
+        if (rem > 0) { S2T_STEP(a0, b0, a1, b1, l0, l1)
+        if (rem > 1) { S2T_STEP(a1, b1, a2, b2, l1, l0)
+        if (rem > 2) { S2T_STEP(a2, b2, a0, b0, l0, l1)
+        if (rem > 3) { S2T_STEP(a0, b0, a1, b1, l1, l0)
+        if (rem > 4) { S2T_STEP(a1, b1, a2, b2, l0, l1) } } } } }
+#undef S2T_STEP
+    } else {
+    sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
+    __syncthreads();
     for (int t = 0; t < ((p.dbg & 2) ? 0 : nk); t += 2) {
         { const int st = step(); sa.load(a0, st); sb.load(b0, st); }  // tile t+2 -> set 0
         mma(l0);                                                       // tile t
@@ -479,6 +511,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_fast_kernel(GemmArgs p) {
         if (t + 1 < nk) mma(l1);
         sa.store(l0, a0); sb.store(l0 + BM * 128, b0);                 // tile t+2
         __syncthreads();
+    }
     }
     if constexpr (TA) {
         if (do_rs && q == 0) {
