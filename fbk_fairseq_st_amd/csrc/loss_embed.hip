@@ -293,3 +293,44 @@ extern "C" int s2t_log_softmax(int dtype, const void* logits, float* out, long r
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
+
+
+// ------------------------------------------------------------------ top-k of logit rows (teacher dump for knowledge distillation)
+// vals[row][0..K) = the K largest logits of the row in descending order, idx = their columns (ties: lower column first)
+// (scripts/generate_topk.py:64-66 torch.topk(net_output[0], k, dim=-1)).  One wavefront per row, K selection rounds: every round
+// takes the largest element that comes after the previous pick in (value desc, column asc) order.
+template <typename T>
+__global__ __launch_bounds__(256) void topk_kernel(const T* __restrict__ x, float* __restrict__ vals, int* __restrict__ idx, long rows, int V,
+                                                   int ld, int K) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const T* xr = x + row * ld;
+    float pv = INFINITY; int pi = -1;
+    for (int k = 0; k < K; ++k) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int c = lane; c < V; c += 64) {
+            const float v = to_f32(xr[c]);
+            const bool after = v < pv || (v == pv && c > pi);
+            if (after && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        pv = bv; pi = bi;
+        if (lane == 0) { vals[row * K + k] = bv; idx[row * K + k] = bi; }
+    }
+}
+extern "C" int s2t_topk(int dtype, const void* x, float* vals, int* idx, long rows, int V, int ld, int K, void* stream) {
+    if (rows <= 0) return S2T_OK;
+    if (!x || !vals || !idx || V <= 0 || ld < V || K <= 0 || K > V) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(topk_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, vals, idx, rows, V, ld, K);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(topk_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, vals, idx, rows, V, ld, K);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

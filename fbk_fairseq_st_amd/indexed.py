@@ -273,3 +273,96 @@ def load_s2t_split(data_path, split, src_lang, tgt_lang, src_dict, tgt_dict, ski
     tr = IndexedDataset(prefix + "." + src_lang, fix_lua_indexing=True)
     assert len(ds) == len(tr)
     return TranscriptionWrapperDataset(ds, tr, src_dict)
+
+
+# ------------------------------------------------------------------ word-level knowledge distillation: teacher outputs on disk
+class TeacherOutputDataset(IndexedDataset):
+    """fairseq/data/knowledge_distillation.py:26-55: items [L, K] of teacher top-k columns (int32 -> long) or logits (float32)."""
+
+    def __init__(self, prefix, dtype):
+        super().__init__(prefix, fix_lua_indexing=False)
+        self.dtype = np.dtype(dtype)
+
+    @staticmethod
+    def save_bin(prefix, data_list, dtype=np.float32):
+        b = IndexedDatasetBuilder(prefix + ".bin", dtype, lua_offset=0)
+        for d in data_list:
+            b.add_item(np.array(d, dtype=dtype))
+        b.finalize(prefix + ".idx")
+
+    def __getitem__(self, i):
+        item = torch.from_numpy(np.array(self.item_view(i)))
+        return item.long() if self.dtype.kind in "iu" else item.float()
+
+
+class DatasetWithTeacherOutput:
+    """knowledge_distillation.py:58-153: adds `teacher_output` = [columns, logits] to every item and batch"""
+
+    def __init__(self, src, teacher_probs, teacher_idxs, tgt_dict, distill_k):
+        self.src, self.teacher_probs, self.teacher_idxs, self.tgt_dict, self.distill_k = src, teacher_probs, teacher_idxs, tgt_dict, distill_k
+
+    def __getitem__(self, index):
+        item = self.src[index]
+        item["teacher_output"] = [self.teacher_idxs[index], self.teacher_probs[index]]
+        return item
+
+    def __len__(self):
+        return len(self.src)
+
+    def num_tokens(self, index):
+        return self.src.num_tokens(index)
+
+    def size(self, index):
+        return self.src.size(index)
+
+    @property
+    def frame_lengths(self):
+        return self.src.frame_lengths
+
+    def ordered_indices(self):
+        return self.src.ordered_indices()
+
+    def collater(self, samples):
+        batch = self.src.collater(samples)
+        if len(samples) > 0:
+            L_t = batch["target"].shape[1]
+            pad = self.tgt_dict.pad()
+            by_id = {}
+            for s in samples:
+                ti, tp = s["teacher_output"]
+                by_id[s["id"]] = (torch.nn.functional.pad(ti, (0, 0, 0, L_t - ti.shape[0]), value=pad),
+                                  torch.nn.functional.pad(tp, (0, 0, 0, L_t - tp.shape[0])))
+            ids = batch["id"].tolist()
+            batch["teacher_output"] = [torch.stack([by_id[i][0] for i in ids]), torch.stack([by_id[i][1] for i in ids])]
+        return batch
+
+
+def dump_teacher_topk(task, model, dataset, k, max_tokens=12000, max_sentences=None, max_positions=None, required_batch_size_multiple=8):
+    """scripts/generate_topk.py:20-74 on the HIP engine: the teacher's top-k logits at every non-pad target position of `dataset`
+    (target-forced forward in eval mode).  Returns [[columns per position], [logits per position]] per utterance, in dataset order."""
+    from . import kernels as K
+    from .iterators import get_batch_iterator
+    itr = get_batch_iterator(dataset, max_tokens=max_tokens, max_sentences=max_sentences, max_positions=max_positions,
+                             ignore_invalid_inputs=True, required_batch_size_multiple=required_batch_size_multiple).next_epoch_itr(shuffle=False)
+    outputs = [None] * len(dataset)
+    was_training = model.training
+    model.eval()
+    dev = model.device if hasattr(model, "device") else torch.device("cuda")
+    try:
+        with torch.no_grad():
+            for s in itr:
+                if "net_input" not in s:
+                    continue
+                ni = s["net_input"]
+                enc = model.encoder(ni["src_tokens"].to(dev), ni["src_lengths"])
+                logits, _ = model.decoder(ni["prev_output_tokens"].to(dev), encoder_out=enc)          # (B, L, V) view of [L*B, V] rows
+                B, Lt, V = logits.shape
+                rows = logits.transpose(0, 1).reshape(Lt * B, V)                                        # time-major rows, padded stride kept
+                vals, idx = K.topk(rows, k)                                                             # time-major rows
+                vals = vals.view(Lt, B, k).transpose(0, 1).cpu().numpy(); idx = idx.view(Lt, B, k).transpose(0, 1).cpu().numpy()
+                keep = s["target"].ne(task.target_dictionary.pad()).numpy().astype(bool)
+                for i, id_s in enumerate(s["id"].tolist()):
+                    outputs[id_s] = [idx[i, keep[i]].tolist(), vals[i, keep[i]].tolist()]
+    finally:
+        model.train(was_training)
+    return outputs

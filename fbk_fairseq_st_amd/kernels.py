@@ -297,6 +297,15 @@ def embed_fwd(tokens, W, table, scale, pad, pos_offset=0):
     return out
 
 
+def topk(logits, k):
+    """[rows,V] (row stride may be padded) -> (f32 [rows,k] values descending, int32 [rows,k] columns)"""
+    rows, V = logits.shape
+    vals = torch.empty((rows, k), dtype=torch.float32, device=logits.device)
+    idx = torch.empty((rows, k), dtype=torch.int32, device=logits.device)
+    L.check(_lib().s2t_topk(L.dt(logits), L.ptr(logits), L.ptr(vals), L.ptr(idx), rows, V, _row_ld(logits), int(k), L.stream()), "s2t_topk")
+    return vals, idx
+
+
 def log_softmax(logits, temperature=1.0):
     """[rows,V] (row stride may be padded) -> f32 [rows,V] log-probabilities"""
     rows, V = logits.shape

@@ -65,6 +65,7 @@ SIGNATURES = {
     "s2t_prof_enable": [c_int],
     "s2t_prof_reset": [],
     "s2t_prof_read": [ctypes.c_char_p, P, P, P, P],
+    "s2t_topk": [c_int, P, P, P, c_long, c_int, c_int, c_int, P],
     "s2t_augment": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],
     "s2t_host_ctc_uer": [P, P, c_int, c_int, P, P, c_int, c_int, P, P],
@@ -124,7 +125,13 @@ def dt(t):
 
 
 def ptr(t):
-    return 0 if t is None else t.data_ptr()
+    """device pointer of a tensor argument of a kernel entry point; host tensors are refused here (a host pointer handed to a
+    kernel is a GPU memory fault that kills the process) -- host-side entry points take `.data_ptr()` themselves"""
+    if t is None:
+        return 0
+    if not t.is_cuda:
+        raise S2THipError("S2T kernels need device tensors: the hot path has no CPU fallback")
+    return t.data_ptr()
 
 
 def stream():

@@ -61,7 +61,8 @@ class SpeechTranslationCTCTask(FairseqTask):
         """speech_translation_ctc.py:35-47: dict.<tgt>.txt, dict.<src>.txt (+ <ctc_blank> as last symbol)."""
         tgt = Dictionary.load(os.path.join(args.data, "dict.%s.txt" % args.target_lang))
         src = Dictionary.load(os.path.join(args.data, "dict.%s.txt" % args.source_lang))
-        src.add_symbol("<ctc_blank>")
+        if getattr(args, "criterion", None) == "ctc_multi_loss":         # only then (speech_translation_ctc.py:44-45)
+            src.add_symbol("<ctc_blank>")
         return cls(args, tgt, src)
 
     def load_dataset(self, split, combine=False, **kwargs):

@@ -36,6 +36,9 @@ extern "C" {
 #define S2T_ACT_GELU_BWD 4  /* out = acc * gelu'(aux)           (aux = forward pre-activation)  */
 
 /* ---- library info ------------------------------------------------------------------------- */
+/* The K largest logits of every row, descending, with their columns (scripts/generate_topk.py:64-66: the teacher dump of word-level
+ * knowledge distillation).  x [rows][V] with row stride ld; vals f32 [rows][K], idx i32 [rows][K]. */
+int s2t_topk(int dtype, const void* x, float* vals, int* idx, long rows, int V, int ld, int K, void* stream);
 /* TimeStretch + SpecAugment in one pass (examples/speech_recognition/modules/time_stretch.py:18-57, specaugment.py:44-112; applied by
  * tasks/speech_recognition.py:254-258): out[b][t][:] = x[b][row_map[b][t]][:] (row_map NULL = identity, -1 = zero row), zeroed inside
  * tmask[b][i] = (t0, width) and fmask[b][i] = (f0, width).  x [B][T][F] f32, out [B][To][F] f32 (out != x). */

@@ -686,7 +686,67 @@ def run_augment_case():
     np.savez_compressed(os.path.join(OUT, "augment.npz"), **out)
 
 
+def run_teacher_case():
+    """G16 (KD producer/consumer): scripts/generate_topk.py's core (teacher forward on the target-forced batch, top-k of the
+    logits at the non-pad positions, TeacherOutputDataset.save_bin) on the on-disk split of G13, and the batches DatasetWithTeacherOutput
+    collates from the written files (fairseq/data/knowledge_distillation.py)."""
+    from fairseq.data.knowledge_distillation import TeacherOutputDataset, DatasetWithTeacherOutput
+    _load_fast_batcher()
+    d = os.path.join(OUT, "s2t_data")
+    Kk = 4
+    a = [d, "--user-dir", REF + "/examples/speech_recognition", "--task", "speech_translation_with_transcription", "-s", "en", "-t", "de",
+         "--arch", "conv_transformer", "--no-attn-2d", "--criterion", "knowledge_distillation", "--input-feat-per-channel", "80",
+         "--encoder-embed-dim", "64", "--decoder-embed-dim", "64", "--decoder-output-dim", "64", "--encoder-ffn-embed-dim", "128",
+         "--decoder-ffn-embed-dim", "128", "--encoder-attention-heads", "2", "--decoder-attention-heads", "2", "--encoder-layers", "2",
+         "--decoder-layers", "1", "--max-tokens", "150", "--max-source-positions", "100", "--max-target-positions", "50", "--cpu",
+         "--dropout", "0.0", "--attention-dropout", "0.0", "--relu-dropout", "0.0"]
+    args = options.parse_args_and_arch(options.get_training_parser(), input_args=a)
+    task = SpeechTranslationCTCTask.setup_task(args)
+    task.load_dataset("train")
+    torch.manual_seed(1)
+    model = task.build_model(args)
+    V_src, V_tgt = len(task.source_dictionary), len(task.target_dictionary)
+    cfg = s2t_ref.default_cfg(D=64, heads=2, ffn=128, enc_layers=2, dec_layers=1, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt), 900)
+    sd = model.state_dict()
+    for k in sd:
+        if k in W:
+            sd[k] = W[k].clone()
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    ds = task.dataset("train")
+    itr = task.get_batch_iterator(ds, max_tokens=150, max_positions=(100, 50), ignore_invalid_inputs=True, required_batch_size_multiple=8,
+                                  num_shards=1, shard_id=0).next_epoch_itr(shuffle=False)
+    outputs = [None] * len(ds)
+    for s in itr:
+        if "net_input" not in s:
+            continue
+        ni = {k: v for k, v in s["net_input"].items() if k != "transcript_prev_output_tokens"}            # F6
+        with torch.no_grad():
+            net_output = model(**ni)
+            vals, idx = torch.topk(net_output[0], Kk, dim=-1)
+        keep = s["target"].ne(task.target_dictionary.pad()).numpy().astype(bool)
+        for i, id_s in enumerate(s["id"].tolist()):
+            outputs[id_s] = [idx.numpy()[i, keep[i]].tolist(), vals.numpy()[i, keep[i]].tolist()]
+    prefix = os.path.join(d, "train.en-de.de")
+    TeacherOutputDataset.save_bin(prefix + ".top%d_idx" % Kk, [o[0] for o in outputs], np.int32)
+    TeacherOutputDataset.save_bin(prefix + ".top%d_out" % Kk, [o[1] for o in outputs], np.float32)
+    out = {"meta": np.array([64, 2, 128, 2, 1, 0, 0, V_src, V_tgt, V_src - 1, 900], np.int64), "K": np.int64(Kk)}
+    for i, o in enumerate(outputs):
+        out["idx_%d" % i] = np.array(o[0], np.int64); out["out_%d" % i] = np.array(o[1], np.float32)
+    ti = TeacherOutputDataset(prefix + ".top%d_idx" % Kk, np.int32); to = TeacherOutputDataset(prefix + ".top%d_out" % Kk, np.float32)
+    ti.prefetch(range(len(ds))); to.prefetch(range(len(ds)))
+    kd = DatasetWithTeacherOutput(ds, to, ti, task.target_dictionary, Kk)
+    batch = kd.collater([kd[i] for i in (3, 0, 7, 9)])
+    out["batch_id"] = batch["id"].numpy(); out["batch_target"] = batch["target"].numpy()
+    out["batch_teacher_idx"] = batch["teacher_output"][0].numpy(); out["batch_teacher_out"] = batch["teacher_output"][1].numpy()
+    np.savez_compressed(os.path.join(OUT, "teacher.npz"), **out)
+    print("teacher", len(outputs), batch["teacher_output"][0].shape, sorted(f for f in os.listdir(d) if "top" in f))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "teacher":
+        run_teacher_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "augment":
         run_augment_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "distpen":

@@ -151,3 +151,31 @@ def test_augmentation_tables_reproduce_the_reference_batches():
         assert np.array_equal(out, g["c%d_out" % ci]), ci
         if new_len is not None:
             assert new_len == g["c%d_out_lengths" % ci].tolist()
+
+
+def test_teacher_output_files_and_kd_collater():
+    """G16: reader / writer of the teacher top-k files (written by the reference's TeacherOutputDataset.save_bin) and the batch
+    DatasetWithTeacherOutput collates (fairseq/data/knowledge_distillation.py)."""
+    from fbk_fairseq_st_amd.indexed import DatasetWithTeacherOutput, TeacherOutputDataset
+    g = load_golden("teacher")
+    K_ = int(g["K"])
+    pre = os.path.join(GOLDEN, "s2t_data", "train.en-de.de")
+    ti = TeacherOutputDataset(pre + ".top%d_idx" % K_, np.int32); to = TeacherOutputDataset(pre + ".top%d_out" % K_, np.float32)
+    assert len(ti) == len(to) == 14
+    for i in range(14):
+        assert ti[i].dtype == torch.long and torch.equal(ti[i], torch.from_numpy(g["idx_%d" % i]))
+        assert to[i].dtype == torch.float32 and torch.equal(to[i], torch.from_numpy(g["out_%d" % i]))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        TeacherOutputDataset.save_bin(os.path.join(d, "i"), [g["idx_%d" % i].tolist() for i in range(14)], np.int32)
+        TeacherOutputDataset.save_bin(os.path.join(d, "o"), [g["out_%d" % i].tolist() for i in range(14)], np.float32)
+        for a, b in (("i", ".top%d_idx" % K_), ("o", ".top%d_out" % K_)):
+            for ext in (".idx", ".bin"):
+                assert filecmp.cmp(os.path.join(d, a + ext), pre + b + ext, shallow=False), (a, ext)
+    task = _s2t_task()
+    task.load_dataset("train")
+    kd = DatasetWithTeacherOutput(task.dataset("train"), to, ti, task.target_dictionary, K_)
+    batch = kd.collater([kd[i] for i in (3, 0, 7, 9)])
+    assert batch["id"].tolist() == g["batch_id"].tolist() and np.array_equal(batch["target"].numpy(), g["batch_target"])
+    assert np.array_equal(batch["teacher_output"][0].numpy(), g["batch_teacher_idx"])
+    assert np.array_equal(batch["teacher_output"][1].numpy(), g["batch_teacher_out"])

@@ -79,7 +79,7 @@ def test_unsupported_options_fail_loudly():
         a = tiny_args(no_attn_2d=False)
         tiny_task(a).build_model(a)
     with pytest.raises(NotImplementedError):
-        a = tiny_args(distance_penalty="log")
+        a = tiny_args(distance_penalty="gauss")            # `log` is built; the learnable-variance form is not
         tiny_task(a).build_model(a)
     with pytest.raises(AssertionError):          # conv_transformer.py:191
         a = tiny_args(criterion="label_smoothed_cross_entropy")

@@ -43,6 +43,8 @@ def to_dev(s):
         return s.to(DEV)
     if isinstance(s, dict):
         return {k: to_dev(v) for k, v in s.items()}
+    if isinstance(s, (list, tuple)):
+        return type(s)(to_dev(v) for v in s)
     return s
 
 
@@ -477,3 +479,48 @@ def test_distance_penalty_long_sequences_bf16_kernels():
     assert err(dq, qf.grad) < 3e-2 and err(dk, kf.grad) < 3e-2 and err(dv, vf.grad) < 3e-2
     out0, _ = K.attn_fwd(qd, kd, vd, heads, klen=klen.to(DEV))
     assert err(out0, ref.detach()) > 5e-2
+
+
+# ---------------------------------------------------------------------------------------------- KD teacher dump (8-f N5)
+def test_teacher_topk_dump_matches_generate_topk():
+    """G16 on the GPU: the teacher dump (target-forced forward + s2t_topk) reproduces scripts/generate_topk.py on the on-disk split:
+    columns exact, logits 1e-4; the knowledge-distillation criterion then trains from the collated batch."""
+    import os
+    from helpers import GOLDEN, load_golden
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.indexed import DatasetWithTeacherOutput, TeacherOutputDataset, dump_teacher_topk
+    from fbk_fairseq_st_amd.registry import apply_arch, namespace, setup_task
+    g = load_golden("teacher")
+    D, H, Ff, EL, DL, _, _, V_src, V_tgt, _, seed = [int(v) for v in g["meta"]]
+    a = namespace(arch="conv_transformer", task="speech_translation_with_transcription", data=os.path.join(GOLDEN, "s2t_data"),
+                  source_lang="en", target_lang="de", criterion="knowledge_distillation", kd_lambda=0.5, kd_temperature=1.0,
+                  label_smoothing=0.0, sentence_avg=False, input_feat_per_channel=80, no_attn_2d=True, encoder_embed_dim=D,
+                  decoder_embed_dim=D, encoder_ffn_embed_dim=Ff, decoder_ffn_embed_dim=Ff, encoder_attention_heads=H,
+                  decoder_attention_heads=H, encoder_layers=EL, decoder_layers=DL, max_source_positions=100, max_target_positions=50,
+                  dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0)
+    apply_arch(a)
+    task = setup_task(a)
+    assert len(task.source_dictionary) == V_src and len(task.target_dictionary) == V_tgt
+    task.load_dataset("train")
+    model = task.build_model(a)
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt), seed)
+    model.load_state_dict(W)
+    model.hp.sub_dropout = 0.0
+    crit = task.build_criterion(a)
+    model.materialize(DEV, torch.float32)
+    ds = task.dataset("train")
+    K_ = int(g["K"])
+    outs = dump_teacher_topk(task, model, ds, K_, max_tokens=150, max_positions=(100, 50))
+    for i in range(len(ds)):
+        assert outs[i][0] == g["idx_%d" % i].tolist(), i
+        np.testing.assert_allclose(np.array(outs[i][1], np.float32), g["out_%d" % i], atol=1e-4 * max(1.0, float(np.abs(g["out_%d" % i]).max())))
+    pre = os.path.join(GOLDEN, "s2t_data", "train.en-de.de")
+    kd = DatasetWithTeacherOutput(ds, TeacherOutputDataset(pre + ".top%d_out" % K_, np.float32), TeacherOutputDataset(pre + ".top%d_idx" % K_, np.int32),
+                                  task.target_dictionary, K_)
+    batch = kd.collater([kd[i] for i in (3, 0, 7, 9)])
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    loss, ss, log = crit(model, to_dev(batch))
+    loss.backward()
+    assert np.isfinite(float(loss)) and float(model.arena.grad.abs().sum()) > 0
