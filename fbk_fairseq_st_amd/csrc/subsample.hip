@@ -504,3 +504,124 @@ extern "C" int s2t_augment(const float* x, float* out, const int* row_map, const
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
+
+
+// ------------------------------------------------------------------ conv2 weight gradient, all nine taps per workgroup
+// dW[co][tap*64 + ci] += sum over output pixels (t4, b, f4) of dpre[t4][b][f4][co] * y1n[b][2 t4 + kh - 1][2 f4 + kw - 1][ci]
+// (autograd of nn.Conv2d(64, 64, 3, stride 2, padding 1), conv_transformer.py:348-354).  As nine gathered GEMMs (one per tap) the
+// product re-read dpre nine times and y1n nine times through row maps: 0.85 ms per step.  Here a workgroup walks (t4, b) groups:
+// it stages the group's 20 output pixels and the 3 x 40 input pixels they touch ONCE (17.5 KB), and all nine taps read their
+// operands out of that window with transposed LDS reads whose per-lane ROW address is 2 f4 + kw -- the stride-2 gather costs
+// nothing.  Contraction = the f4 axis padded to 32 (one 16x16x32 MFMA step); 9 x 64 x 64 accumulators live in registers
+// (144 VGPRs per lane over 4 waves) for the whole walk and leave as f32 atomics once.  bf16, 64 channels.
+typedef short c2_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 c2_tr_frag(const char* base, int row_lo, int row_hi, int key_lo, int key_hi, int chunk, int r16) {
+    // 16 columns starting at chunk*8 of 8 rows given as two groups of 4 (this lane supplies row (r16>>2) of each), 128-B rows,
+    // chunk swizzle by (row key & 7)
+    const int ch = chunk + ((r16 & 3) >> 1);
+    const char* a0 = base + row_lo * 128 + ((ch ^ (key_lo & 7)) << 4) + ((r16 & 1) << 3);
+    const char* a1 = base + row_hi * 128 + ((ch ^ (key_hi & 7)) << 4) + ((r16 & 1) << 3);
+    const u32x2 w0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c2_s16x4*)a0));
+    const u32x2 w1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c2_s16x4*)a1));
+    return (u32x4){w0[0], w0[1], w1[0], w1[1]};
+}
+__global__ __launch_bounds__(256, 2) void conv2_wgrad_kernel(const bf16* __restrict__ dpre, const bf16* __restrict__ y1n, float* __restrict__ gw,
+                                                             int B, int T2, int F2, int T4, int F4, int groups_per_wg) {
+    constexpr int WROWS = 66, WIN = 3 * WROWS * 128, DYB = 32 * 128;
+    __shared__ __attribute__((aligned(16))) char lds[WIN + DYB];
+    char* win = lds;
+    char* dyt = lds + WIN;
+    for (int i = threadIdx.x; i < (WIN + DYB) / 16; i += 256) reinterpret_cast<u32x4*>(lds)[i] = (u32x4){0, 0, 0, 0};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int wco = wave >> 1, wci = wave & 1;
+    const int ngroups = T4 * B;
+    const int g0 = blockIdx.x * groups_per_wg, g1 = min(ngroups, g0 + groups_per_wg);
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nchunk = 3 * F2 * 8 + F4 * 8;                   // 16-byte pieces of one group's window + dY rows
+    u32x4 regs[5];
+    auto gload = [&](int g) {
+        const int t4 = g / B, b = g - t4 * B;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            u32x4 v = {0, 0, 0, 0};
+            if (c < 3 * F2 * 8) {
+                const int kh = c / (F2 * 8), rem = c - kh * (F2 * 8), px = rem >> 3, ch = rem & 7;
+                const int t2 = 2 * t4 + kh - 1;
+                if (t2 >= 0 && t2 < T2) v = *reinterpret_cast<const u32x4*>(y1n + (((long)b * T2 + t2) * F2 + px) * 64 + ch * 8);
+            } else if (c < nchunk) {
+                const int cc = c - 3 * F2 * 8, px = cc >> 3, ch = cc & 7;
+                v = *reinterpret_cast<const u32x4*>(dpre + ((long)g * F4 + px) * 64 + ch * 8);
+            }
+            regs[i] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = threadIdx.x + 256 * i;
+            if (c < 3 * F2 * 8) {
+                const int kh = c / (F2 * 8), rem = c - kh * (F2 * 8), r = (rem >> 3) + 1, ch = rem & 7;     // window row = f2 + 1
+                *reinterpret_cast<u32x4*>(win + (kh * WROWS + r) * 128 + ((ch ^ (r & 7)) << 4)) = regs[i];
+            } else if (c < nchunk) {
+                const int cc = c - 3 * F2 * 8, px = cc >> 3, ch = cc & 7;
+                *reinterpret_cast<u32x4*>(dyt + px * 128 + ((ch ^ (px & 7)) << 4)) = regs[i];
+            }
+        }
+    };
+    if (g0 < g1) gload(g0);
+    __syncthreads();                                             // zero fill done
+    for (int g = g0; g < g1; ++g) {
+        lstore();
+        __syncthreads();
+        if (g + 1 < g1) gload(g + 1);
+        // A = dY^T (rows = co), contraction over the group's f4 positions 8q .. 8q+7 of this lane's k-slice
+        const int p_lo = 8 * q + (r16 >> 2), p_hi = p_lo + 4;
+        u32x4 fa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = c2_tr_frag(dyt, p_lo, p_hi, p_lo, p_hi, 2 * (2 * wco + i), r16);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int r_lo = 2 * p_lo + kw, r_hi = 2 * p_hi + kw;          // window row of position p under tap column kw
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 fb = c2_tr_frag(win, kh * WROWS + r_lo, kh * WROWS + r_hi, r_lo, r_hi, 2 * (2 * wci + j), r16);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[kh * 3 + kw][i][j] = mma16<bf16>(fa[i], fb, acc[kh * 3 + kw][i][j]);
+                }
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * (2 * wco + i) + 4 * q + r, ci = 16 * (2 * wci + j) + r16;
+                    atomicAdd(gw + (long)co * 576 + t * 64 + ci, acc[t][i][j][r]);
+                }
+}
+extern "C" int s2t_conv2_wgrad(int dtype, const void* dpre, const void* y1n, float* gw, int B, int T2, int F2, int C, void* stream) {
+    if (B <= 0 || T2 <= 0) return S2T_OK;
+    if (!dpre || !y1n || !gw) return S2T_EINVAL;
+    const int T4 = (T2 + 1) / 2, F4 = (F2 + 1) / 2;
+    if (dtype != S2T_BF16 || C != 64 || F4 > 32 || F2 > 64 || 3 * F2 * 8 + F4 * 8 > 1280) return S2T_ENOTSUP;   // callers fall back to the gathered GEMMs
+    const int ngroups = T4 * B;
+    int gpw = (ngroups + 511) / 512;                            // 2 workgroups per CU
+    gpw = gpw < 8 ? 8 : gpw;
+    hipLaunchKernelGGL(conv2_wgrad_kernel, dim3((ngroups + gpw - 1) / gpw), dim3(256), 0, (hipStream_t)stream, (const bf16*)dpre, (const bf16*)y1n,
+                       gw, B, T2, F2, T4, F4, gpw);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

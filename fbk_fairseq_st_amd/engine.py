@@ -279,10 +279,11 @@ class S2TEngine:
         # conv2 weight gradient: 9 gathered TN GEMMs (one per tap) into [Co][tap*Ci+ci], then back to [Co][Ci][3][3]
         y1n2d = c["y1n"].view(-1, C)
         gw2p = torch.zeros((C, 9 * C), dtype=torch.float32, device=self.dev)
-        sk = int(max(1, min(512, c["P2"] // 1024)))           # K = all output pixels: ~16 k-tiles per workgroup
-        for tap in range(9):
-            K.gemm(dpre2, y1n2d, trans_a=True, trans_b=True, K=c["P2"], out=gw2p[:, tap * C:(tap + 1) * C],
-                   accumulate=True, splitk=sk, map_b=mp["fwd"][tap])
+        if not K.conv2_wgrad(dpre2, y1n2d, gw2p, B, c["T2"], c["F2"], C):        # one pass, all taps (bf16, 64 channels)
+            sk = int(max(1, min(512, c["P2"] // 1024)))       # K = all output pixels: ~16 k-tiles per workgroup
+            for tap in range(9):
+                K.gemm(dpre2, y1n2d, trans_a=True, trans_b=True, K=c["P2"], out=gw2p[:, tap * C:(tap + 1) * C],
+                       accumulate=True, splitk=sk, map_b=mp["fwd"][tap])
         K.permute_conv_w(gw2p, self.G("encoder.convolutions.1.weight"), C, C, 2)
         # conv2 data gradient: one gathered GEMM per input-pixel parity class, scattered to the class's pixels
         w2q = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 1)

@@ -297,6 +297,15 @@ def embed_fwd(tokens, W, table, scale, pad, pos_offset=0):
     return out
 
 
+def conv2_wgrad(dpre, y1n, gw, B, T2, F2, C):
+    """all-taps conv2 weight gradient; returns False when the shape / dtype is not covered (caller uses the gathered GEMMs)"""
+    rc = _lib().s2t_conv2_wgrad(L.dt(dpre), L.ptr(dpre), L.ptr(y1n), L.ptr(gw), B, T2, F2, C, L.stream())
+    if rc == -95:
+        return False
+    L.check(rc, "s2t_conv2_wgrad")
+    return True
+
+
 def topk(logits, k):
     """[rows,V] (row stride may be padded) -> (f32 [rows,k] values descending, int32 [rows,k] columns)"""
     rows, V = logits.shape

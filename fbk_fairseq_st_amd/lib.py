@@ -65,6 +65,7 @@ SIGNATURES = {
     "s2t_prof_enable": [c_int],
     "s2t_prof_reset": [],
     "s2t_prof_read": [ctypes.c_char_p, P, P, P, P],
+    "s2t_conv2_wgrad": [c_int, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_topk": [c_int, P, P, P, c_long, c_int, c_int, c_int, P],
     "s2t_augment": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],

@@ -36,6 +36,10 @@ extern "C" {
 #define S2T_ACT_GELU_BWD 4  /* out = acc * gelu'(aux)           (aux = forward pre-activation)  */
 
 /* ---- library info ------------------------------------------------------------------------- */
+/* Weight gradient of the second subsampling convolution (nn.Conv2d(C, C, 3, stride 2, padding 1), conv_transformer.py:348-354), all
+ * nine taps in one pass: gw[co][tap*C + ci] += sum_{t4,b,f4} dpre[t4][b][f4][co] * y1n[b][2 t4+kh-1][2 f4+kw-1][ci].
+ * bf16, C = 64 (S2T_ENOTSUP otherwise: use the gathered s2t_gemm_gather products). */
+int s2t_conv2_wgrad(int dtype, const void* dpre, const void* y1n, float* gw, int B, int T2, int F2, int C, void* stream);
 /* The K largest logits of every row, descending, with their columns (scripts/generate_topk.py:64-66: the teacher dump of word-level
  * knowledge distillation).  x [rows][V] with row stride ld; vals f32 [rows][K], idx i32 [rows][K]. */
 int s2t_topk(int dtype, const void* x, float* vals, int* idx, long rows, int V, int ld, int K, void* stream);

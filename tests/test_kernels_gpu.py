@@ -549,3 +549,23 @@ def test_augment_kernel_reproduces_the_reference_batches():
         if sa[0] >= 0:
             batch = SpecAugment(int(sa[0]), int(sa[1]), int(sa[2]), int(sa[3]), float(sa[4]))(batch)
         assert torch.equal(batch["net_input"]["src_tokens"].cpu(), torch.from_numpy(g["c%d_out" % ci])), ci
+
+
+@pytest.mark.parametrize("B,T2,F2", [(3, 37, 40), (2, 10, 20), (5, 64, 40), (1, 1, 40)])
+def test_conv2_wgrad_all_taps_kernel(B, T2, F2):
+    """s2t_conv2_wgrad (bf16, 64 channels) against torch's conv2d weight gradient in fp32: odd T2 (last output row sees one input
+    row less), a single row, the 40-mel (F2 = 20) geometry."""
+    C = 64
+    T4, F4 = (T2 + 1) // 2, (F2 + 1) // 2
+    bf = torch.bfloat16
+    y1n = rnd(B, T2, F2, C, dtype=bf, seed=1)
+    dpre = rnd(T4, B, F4, C, dtype=bf, seed=2, scale=0.3)
+    gw = torch.zeros(C, 9 * C, device=DEV)
+    assert K.conv2_wgrad(dpre.to(DEV), y1n.to(DEV).view(-1, C), gw, B, T2, F2, C)
+    ref = torch.nn.grad.conv2d_weight(y1n.float().permute(0, 3, 1, 2), (C, C, 3, 3), dpre.float().permute(1, 3, 0, 2), stride=2, padding=1)
+    got = gw.cpu().view(C, 9, C).permute(0, 2, 1).reshape(C, C, 3, 3)          # [co][tap][ci] -> [co][ci][kh][kw]
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 2e-3, err
+    K.conv2_wgrad(dpre.to(DEV), y1n.to(DEV).view(-1, C), gw, B, T2, F2, C)     # accumulates
+    assert float((gw.cpu().view(C, 9, C).permute(0, 2, 1).reshape(C, C, 3, 3) - 2 * ref).abs().max() / ref.abs().max()) < 4e-3
+    assert not K.conv2_wgrad(dpre.float().to(DEV), y1n.float().to(DEV).view(-1, C), gw, B, T2, F2, C)      # fp32: not covered
