@@ -856,19 +856,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
 
     u32x4 qf[2][2], dof[2][2];
     float L[2], Dl[2];
+    const bf16* Og = reinterpret_cast<const bf16*>(p.O) + (long)b * p.o_sb + (long)h * DH;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int row = qw + 16 * qb + r16;
         L[qb] = row < p.Tq ? lse[row] * 1.44269504088896f : 0.f;
-        Dl[qb] = row < p.Tq ? dlt[row] : 0.f;
+        float part = 0.f;                                   // Delta = rowsum(dO * O): this kernel owns the query, so it makes it
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             qf[qb][g] = dof[qb][g] = (u32x4){0, 0, 0, 0};
             if (row < p.Tq) {
                 qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + (long)row * p.q_st + (4 * g + q) * 8);
                 dof[qb][g] = *reinterpret_cast<const u32x4*>(dOg + (long)row * p.do_st + (4 * g + q) * 8);
+                const u32x4 ov = *reinterpret_cast<const u32x4*>(Og + (long)row * p.o_st + (4 * g + q) * 8);
+                const bf16* oe = reinterpret_cast<const bf16*>(&ov);
+                const bf16* de = reinterpret_cast<const bf16*>(&dof[qb][g]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) part += (float)oe[e] * (float)de[e];
             }
         }
+        part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
+        Dl[qb] = part;
+        if (q == 0 && row < p.Tq) const_cast<float*>(dlt)[row] = part;         // the dK/dV kernel, launched after this one, reads it
     }
     f32x4 dqT[2][4];
 #pragma unroll
@@ -968,15 +977,20 @@ template <typename T, int DH> static int fwd_launch(const AttnArgs& a, hipStream
 template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream_t st) {
     typedef ACfg<T, DH> C;
     const long rows = (long)a.B * a.H * a.Tq;
-    hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
-    S2T_LAUNCH_CHECK();
     bool dkv2 = false, dq2 = false;
     if constexpr (sizeof(T) == 2 && DH == 64) {
         static const bool v1 = getenv("S2T_ATTN_V1") != nullptr;           // A/B switch for benchmarking
         const bool al = !(a.dk_st % 4) && !(a.dk_sb % 4) && !(a.dv_st % 4) && !(a.dv_sb % 4) && !(a.dq_st % 4) && !(a.dq_sb % 4) &&
                         !((uintptr_t)a.dK & 7) && !((uintptr_t)a.dV & 7) && !((uintptr_t)a.dQ & 7);
         dkv2 = !v1 && al && a.Tk >= 128;
-        dq2 = !v1 && al && a.Tq >= 128;
+        dq2 = !v1 && al && a.Tq >= 128 && !(a.o_st % 8) && !(a.o_sb % 8) && !((uintptr_t)a.O & 15);
+        if (dq2) {                                       // first: it also writes Delta for the dK/dV kernel
+            hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((a.Tq + 127) / 128, a.H, a.B), dim3(256), 32768, st, a);
+            S2T_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
+            S2T_LAUNCH_CHECK();
+        }
         if (dkv2) {
             {
                 static bool attr = false;
@@ -985,10 +999,9 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
             hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3((a.Tk + 127) / 128, a.H, a.B), dim3(256), 32768 + 1024 + 32768, st, a);
             S2T_LAUNCH_CHECK();
         }
-        if (dq2) {
-            hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((a.Tq + 127) / 128, a.H, a.B), dim3(256), 32768, st, a);
-            S2T_LAUNCH_CHECK();
-        }
+    } else {
+        hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
+        S2T_LAUNCH_CHECK();
     }
     if (!dkv2) {
         static bool attr = false;

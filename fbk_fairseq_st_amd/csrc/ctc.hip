@@ -11,6 +11,33 @@
 // ------------------------------------------------------------------ softmax arg-max per frame
 // logits [T][B][V] (T dtype) -> pred[b][t] = first index of max softmax(logits)[v]; pmax[b][t] = that
 // probability (f32).  One wavefront per (t,b) row, three passes over the row (L2-resident).
+// Row statistics with 16-byte loads (rows start 16-byte aligned: padded row stride, kernels.py alloc_rows): max, then sum of
+// exp(x - max).  The scalar tail covers V % (16 / sizeof(T)) and unaligned rows.
+template <typename T>
+__device__ __forceinline__ void row_max_sumexp(const T* __restrict__ x, int V, int lane, float& m_out, float& s_out) {
+    constexpr int E = 16 / (int)sizeof(T);
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const int nv = vec ? V / E : 0;
+    float m = -INFINITY;
+    for (int c = lane; c < nv; c += 64) {
+        T v[E];
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + c * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) m = fmaxf(m, to_f32(v[e]));
+    }
+    for (int j = nv * E + lane; j < V; j += 64) m = fmaxf(m, to_f32(x[j]));
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < nv; c += 64) {
+        T v[E];
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + c * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s += expf(to_f32(v[e]) - m);
+    }
+    for (int j = nv * E + lane; j < V; j += 64) s += expf(to_f32(x[j]) - m);
+    m_out = m; s_out = wave_sum(s);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_argmax_kernel(const T* __restrict__ logits, int* __restrict__ pred,
                                                          float* __restrict__ pmax, int Tn, int B, int V, int ld) {
@@ -19,17 +46,26 @@ __global__ __launch_bounds__(256) void ctc_argmax_kernel(const T* __restrict__ l
     if (row >= (long)Tn * B) return;
     const int t = (int)(row / B), b = (int)(row % B);
     const T* x = logits + row * ld;
-    float m = -INFINITY;
-    for (int j = lane; j < V; j += 64) m = fmaxf(m, to_f32(x[j]));
-    m = wave_max(m);
-    float s = 0.f;
-    for (int j = lane; j < V; j += 64) s += expf(to_f32(x[j]) - m);
-    s = wave_sum(s);
+    float m, s;
+    row_max_sumexp<T>(x, V, lane, m, s);
+    // arg-max of the softmax VALUES (first index among equal f32 probabilities, as torch compares them): only logits within 1e-3 of
+    // the maximum can round to the top probability, everything else is skipped without evaluating exp / divide
     float best = -1.f; int bi = 0x7fffffff;
-    for (int j = lane; j < V; j += 64) {
-        const float p = expf(to_f32(x[j]) - m) / s;           // the softmax value torch would compare
-        if (p > best) { best = p; bi = j; }                      // strict: keeps the lowest index per lane
+    auto consider = [&](float xv, int j) {
+        if (xv >= m - 1e-3f) {
+            const float p = expf(xv - m) / s;                    // the softmax value torch would compare
+            if (p > best || (p == best && j < bi)) { best = p; bi = j; }
+        }
+    };
+    constexpr int E = 16 / (int)sizeof(T);
+    const int nv = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? V / E : 0;
+    for (int c = lane; c < nv; c += 64) {
+        T v[E];
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + c * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) consider(to_f32(v[e]), c * E + e);
     }
+    for (int j = nv * E + lane; j < V; j += 64) consider(to_f32(x[j]), j);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
@@ -139,12 +175,8 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ logi
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* x = logits + row * ld;
-    float m = -INFINITY;
-    for (int j = lane; j < V; j += 64) m = fmaxf(m, to_f32(x[j]));
-    m = wave_max(m);
-    float s = 0.f;
-    for (int j = lane; j < V; j += 64) s += expf(to_f32(x[j]) - m);
-    s = wave_sum(s);
+    float m, s;
+    row_max_sumexp<T>(x, V, lane, m, s);
     if (lane == 0) lse[row] = m + logf(s);
 }
 
@@ -293,7 +325,17 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < V; c += 256) g[c] = from_f32<T>((expf(to_f32(x[c]) - ls) - occ[c]) * gscale);
+    constexpr int E = 16 / (int)sizeof(T);
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    const int nv = vec ? V / E : 0;
+    for (int c = threadIdx.x; c < nv; c += 256) {
+        T v[E], o[E];
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + c * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = from_f32<T>((expf(to_f32(v[e]) - ls) - occ[c * E + e]) * gscale);
+        *reinterpret_cast<u32x4*>(g + c * E) = *reinterpret_cast<const u32x4*>(o);
+    }
+    for (int c = nv * E + threadIdx.x; c < V; c += 256) g[c] = from_f32<T>((expf(to_f32(x[c]) - ls) - occ[c]) * gscale);
 }
 
 // ------------------------------------------------------------------ C ABI
