@@ -144,6 +144,37 @@ __global__ __launch_bounds__(256) void ctc_compress_fwd_kernel(const T* __restri
     T* o = out + ((long)j * B + b) * D;
     if (j >= new_len[b]) { for (int d = threadIdx.x; d < D; d += 256) o[d] = from_f32<T>(0.f); return; }
     const int s0 = run_start[(long)b * Tn + j], n = run_len[(long)b * Tn + j];
+    constexpr int E = 16 / (int)sizeof(T);
+    if (D % E == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        // a run can span hundreds of frames (every frame of an utterance predicted blank): the frames of the run are dealt to the
+        // four waves (a serial walk is one memory latency per frame), 16 bytes of channels per lane, partial sums meet in LDS
+        __shared__ float part[4][64 * E];
+        const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+        for (int d0 = lane * E; d0 < D; d0 += 64 * E) {
+            float acc[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = 0.f;
+            for (int k = slot; k < n; k += 4) {
+                const float wt = w[(long)b * Tn + s0 + k];
+                T v[E];
+                *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + ((long)(s0 + k) * B + b) * D + d0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] += wt * to_f32(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) part[slot][lane * E + e] = acc[e];
+            __syncthreads();
+            if (slot == 0) {
+                T r[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+                    r[e] = from_f32<T>((part[0][lane * E + e] + part[1][lane * E + e]) + (part[2][lane * E + e] + part[3][lane * E + e]));
+                *reinterpret_cast<u32x4*>(o + d0) = *reinterpret_cast<const u32x4*>(r);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int d = threadIdx.x; d < D; d += 256) {
         float acc = 0.f;
         for (int k = 0; k < n; ++k) acc += w[(long)b * Tn + s0 + k] * to_f32(x[((long)(s0 + k) * B + b) * D + d]);
