@@ -17,7 +17,8 @@ reference's paper script, --max-tokens 12000 x --update-freq 8, README.md:144,15
 accumulation and f32 master weights, dropout ON at the preset rates.  Weak scaling: every rank gets its own batch.
 
 Rank 0 prints ONE JSON line.  `roofline` times the dominant kernel family (the MFMA GEMMs) with HIP events
-inside the library (s2t_prof_*) during extra instrumented steps after the timed region; `cpu_baseline` times the
+inside the library (s2t_prof_*, on the launch stream) during instrumented steps that directly follow the timed region
+(inside it the events themselves cost 12 % of the step; --no-roofline skips them); `cpu_baseline` times the
 CPU oracle (port of the reference path, verified against it) on the host cores on a bounded sample.
 """
 import argparse
@@ -127,7 +128,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--prof-steps", type=int, default=2)
+    ap.add_argument("--prof-steps", type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +172,9 @@ def main():
 
     roof = None
     if args.roofline and rank == 0:
+        # Instrumented steps run right AFTER the timed region, on the same batch and training state: bracketing every GEMM and
+        # attention launch with two HIP events costs 2.2-2.5 ms per update (measured: 20.2-21.1 vs 18.0-18.6 ms), which would
+        # distort `value` by 12 % if they sat inside the timed region.
         K.prof_reset(); K.prof_enable(True)
         for _ in range(args.prof_steps):
             trainer.train_step([sample])
