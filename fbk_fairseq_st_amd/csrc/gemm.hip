@@ -881,7 +881,11 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
     // small problems: 64x64 tiles so that more workgroups exist than CUs
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splitk;
-    const bool small = t128 < 192;
+    // products with a k-strided operand (NN, TN) stage it through transposed LDS reads only in the 128-wide kernels (the 64-wide
+    // form transposes in registers): they switch to 64x64 tiles much later (tools/small_gemm.py: NN 2560 x 512 x 8000 93 -> 67 us,
+    // TN 512 x 512 18 -> 14.6 us with the 128-wide kernels; NT is better off with 64x64 below ~192 tiles)
+    static const long small_thr = getenv("S2T_GEMM_SMALL") ? atol(getenv("S2T_GEMM_SMALL")) : -1;    // benchmarking knob
+    const bool small = t128 < (small_thr >= 0 ? small_thr : ((trans_a || trans_b) ? 40 : 192));
     const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
     // families for the roofline report (one kernel template each): dW-shaped (TN), forward (NT), dX-shaped (NN) products on
     // 128x128 tiles, their small-problem 64x64 forms, and the implicit-GEMM convolution
