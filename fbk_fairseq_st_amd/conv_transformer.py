@@ -6,8 +6,8 @@ encoder/decoder call signatures and output tuples, same state-dict key names (SU
 On top of the reference's presets it registers the build-defined `s2t_transformer{,_xs,_s,_m,_l}`
 presets that BASELINE.json names.
 
-Out of scope here: ConvAttention2D (`--no-attn-2d` is implied and required),
-`--distance-penalty`, learned positions, adaptive softmax, LayerDrop.
+`--distance-penalty log` (LocalAttention) is supported.  Out of scope here: ConvAttention2D
+(`--no-attn-2d` is required), `--distance-penalty gauss`, learned positions, adaptive softmax, LayerDrop.
 """
 import math
 
