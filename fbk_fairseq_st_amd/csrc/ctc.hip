@@ -217,6 +217,17 @@ __device__ __forceinline__ float lae(float a, float b) {          // log(exp a +
     const float m = fmaxf(a, b);
     return m + log1pf(expf(-fabsf(a - b)));
 }
+// log(exp a + exp b [+ exp c]) on the hardware exp2 / log2 units: the alpha / beta recursion is a 375-step dependent chain per
+// utterance, its latency IS the kernel's duration (libm expf + log1pf twice per step cost ~4x this form).  Absolute error ~1e-6
+// per step on values of magnitude 1e2: far inside the 1e-4 relative budget of the loss.
+__device__ __forceinline__ float lae3(float a, float b, float c, bool use_c) {
+    if (!use_c) c = -INFINITY;
+    const float m = fmaxf(fmaxf(a, b), c);
+    if (m == -INFINITY) return -INFINITY;
+    const float L2E = 1.44269504088896f;
+    const float sum = __builtin_amdgcn_exp2f((a - m) * L2E) + __builtin_amdgcn_exp2f((b - m) * L2E) + __builtin_amdgcn_exp2f((c - m) * L2E);
+    return m + __builtin_amdgcn_logf(sum) * 0.693147180559945f;
+}
 
 // Pass 2: alpha (wave 0) and beta (wave 1) recursions of one utterance in log space.
 // Extended target ext[s], s < S = 2L+1 <= 64*SPL; lane owns SPL consecutive s; the two neighbours
@@ -254,12 +265,26 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
         // chunk of time steps handled in this iteration: alpha walks forward, beta backward
         const int ta0 = ch * CTC_CH, tb0 = Tb - 1 - ch * CTC_CH;
         __syncthreads();
-        for (int idx = threadIdx.x; idx < 2 * CTC_CH * S; idx += 128) {
-            const int d = idx / (CTC_CH * S), r = idx % (CTC_CH * S), k = r / S, s = r % S;
-            const int t = d == 0 ? ta0 + k : tb0 - k;
-            float v = -INFINITY;
-            if (t >= 0 && t < Tb) v = to_f32(logits[((long)t * B + b) * ld + ext_s[s]]) - lse[(long)t * B + b];
-            em[d][k][s] = v;
+        for (int s = threadIdx.x; s < S; s += 128) {          // no index divisions: (direction, step) pairs outside, position = thread
+            const int col = ext_s[s];
+            // all 32 gathered loads of this position are issued from clamped (always valid) rows before any is used: guarded loads
+            // get sunk under their bounds test and waited for one by one (seen in the ISA of conv1: one memory latency each)
+            float xv[2 * CTC_CH], lv[2 * CTC_CH];
+#pragma unroll
+            for (int dk = 0; dk < 2 * CTC_CH; ++dk) {
+                const int d = dk / CTC_CH, k = dk % CTC_CH;
+                const int t = min(max(d == 0 ? ta0 + k : tb0 - k, 0), max(Tb - 1, 0));
+                xv[dk] = to_f32(logits[((long)t * B + b) * ld + col]);
+                lv[dk] = lse[(long)t * B + b];
+            }
+#pragma unroll
+            for (int dk = 0; dk < 2 * CTC_CH; ++dk) asm volatile("" : "+v"(xv[dk]), "+v"(lv[dk]));
+#pragma unroll
+            for (int dk = 0; dk < 2 * CTC_CH; ++dk) {
+                const int d = dk / CTC_CH, k = dk % CTC_CH;
+                const int t = d == 0 ? ta0 + k : tb0 - k;
+                em[d][k][s] = (t >= 0 && t < Tb) ? xv[dk] - lv[dk] : -INFINITY;
+            }
         }
         __syncthreads();
         for (int k = 0; k < CTC_CH; ++k) {
@@ -279,8 +304,7 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
                     else {
                         const float m1 = (i >= 1) ? a[i - 1] : (lane > 0 ? p1 : -INFINITY);
                         const float m2 = (i >= 2) ? a[i - 2] : (i == 1 ? (lane > 0 ? p1 : -INFINITY) : (has2 ? p2 : -INFINITY));
-                        v = lae(a[i], m1);
-                        if (skip2[i]) v = lae(v, m2);
+                        v = lae3(a[i], m1, m2, skip2[i]);
                     }
                     n[i] = (s < S) ? v + em[0][k][s] : -INFINITY;
                 }
@@ -296,8 +320,7 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
                     else {
                         const float m1 = (i + 1 < CTC_SPL) ? a[i + 1] : (lane < 63 ? p1 : -INFINITY);
                         const float m2 = (i + 2 < CTC_SPL) ? a[i + 2] : (i + 2 == CTC_SPL ? (lane < 63 ? p1 : -INFINITY) : (has2 ? p2 : -INFINITY));
-                        v = lae(a[i], m1);
-                        if (skip2[i]) v = lae(v, m2);
+                        v = lae3(a[i], m1, m2, skip2[i]);
                     }
                     n[i] = (s < S) ? v + em[1][k][s] : -INFINITY;
                 }
