@@ -97,9 +97,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int D) {
+                                                     float* __restrict__ dbeta, int M, int D,
+                                                     T* __restrict__ dx_drop, float p_drop, unsigned long long seed) {
     typedef RowIO<T, EPL> IO;
     __shared__ float sh[2][4][1024];
+    const uint32_t th16 = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float inv_keep = 1.f / (1.f - p_drop);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float ag[16], ab[16], gm[16];
 #pragma unroll
@@ -132,6 +135,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             dv[i] = r;
         }
         IO::store(dx + (size_t)row * D, lane, D, dv);
+        if (dx_drop) {
+            // second output = dropout(dx) with the consumer block's mask (what s2t_dropout would produce from the stored,
+            // rounded dx: element index row*D + col, one hash per aligned group of four)
+            if constexpr (EPL != 0) {
+#pragma unroll
+                for (int k = 0; k < EPL / 4; ++k) {
+                    const u32x2 h = drop_hash4(seed, (((uint64_t)row * D) >> 2) + (uint64_t)(lane * (EPL / 4) + k));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dv[4 * k + e] = drop_field(h, e) >= th16 ? to_f32(from_f32<T>(dv[4 * k + e])) * inv_keep : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < IO::N; ++i) {
+                    const int j = IO::col(lane, i);
+                    if (j < D) dv[i] = drop_field(drop_hash4(seed, ((uint64_t)row * D + j) >> 2), (int)(((uint64_t)row * D + j) & 3)) >= th16
+                                           ? to_f32(from_f32<T>(dv[i])) * inv_keep : 0.f;
+                }
+            }
+            IO::store(dx_drop + (size_t)row * D, lane, D, dv);
+        }
     }
 #pragma unroll
     for (int i = 0; i < IO::N; ++i) {
@@ -179,17 +203,18 @@ extern "C" int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, c
 
 extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
                                  const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                 int M, int D, void* stream) {
+                                 int M, int D, void* dx_drop, float p_drop, unsigned long long seed, void* stream) {
     if (M <= 0) return M < 0 ? S2T_EINVAL : S2T_OK;
     if (D <= 0 || D > 1024) return S2T_ENOTSUP;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return S2T_EINVAL;
+    if (dx_drop && (p_drop < 0.f || p_drop >= 1.f)) return S2T_EINVAL;
     int blocks = (M + 3) / 4;
     if (blocks > 512) blocks = 512;            // 2 workgroups per CU; each ends in 2*D same-address atomics
     dim3 grid(blocks);
     hipStream_t st = (hipStream_t)stream;
-    const int epl = ln_epl(D, dy, x, dres, dx);
-    if (dtype == S2T_BF16) LN_DISPATCH(ln_bwd_kernel, bf16, epl, grid, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D);
-    else if (dtype == S2T_F32) LN_DISPATCH(ln_bwd_kernel, float, epl, grid, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D);
+    const int epl = ln_epl(D, dy, x, dres, dx, dx_drop);
+    if (dtype == S2T_BF16) LN_DISPATCH(ln_bwd_kernel, bf16, epl, grid, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D, (bf16*)dx_drop, p_drop, seed);
+    else if (dtype == S2T_F32) LN_DISPATCH(ln_bwd_kernel, float, epl, grid, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D, (float*)dx_drop, p_drop, seed);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

@@ -9,6 +9,7 @@ torch only allocates buffers and does integer index bookkeeping.  Gradients of p
 accumulated by the kernels directly into the arena's flat f32 gradient buffer.
 """
 import math
+import os
 
 import torch
 
@@ -153,6 +154,8 @@ class S2TEngine:
         self.bn_buffers = None          # set by the model: dict name -> tensor (running_mean/var, num_batches)
         self.on_grads_ready = None      # callback(prefix): every gradient of parameters named prefix* is final
         self._wg_side, self._wg_on, self._wg_pending = None, False, False
+        # LayerNorm backward also writes dropout(dx) for the block that consumes dx (one pass instead of two; identical bits)
+        self.fuse_bwd_dropout = os.environ.get("S2T_FUSE_BWD_DROPOUT", "1") != "0"
         if hp.act not in ("relu", "gelu"):
             raise NotImplementedError("activation_fn %s" % hp.act)
         self.act_fwd = K.ACT_RELU if hp.act == "relu" else K.ACT_GELU
@@ -348,11 +351,14 @@ class S2TEngine:
                  dist_penalty=dist_penalty)
         return y.view(T, B, D), c
 
-    def self_attn_block_bwd(self, pfx, c, dy):
-        """dy [T*B, D] gradient w.r.t. the block output; returns gradient w.r.t. the block input."""
+    def self_attn_block_bwd(self, pfx, c, dy, d=None, nxt=None):
+        """dy [T*B, D] gradient w.r.t. the block output; returns gradient w.r.t. the block input.
+        d: dropout(dy) with this block's mask when the producer of dy already wrote it; nxt: (p, seed) of the dropout that
+        consumes the result next -> returns (dx, dropout(dx)) from the LayerNorm-backward pass."""
         hp = self.hp
         T, B, D = c["T"], c["B"], self.hp.D
-        d = K.dropout(dy, c["p"], c["seed"] + 2) if c["p"] > 0 else dy
+        if d is None:
+            d = K.dropout(dy, c["p"], c["seed"] + 2) if c["p"] > 0 else dy
         dctx = self.linear_bwd(d, c["ctx"].view(T * B, D), pfx + "self_attn.out_proj")
         dqkv = torch.empty_like(c["qkv"])
         qkv = c["qkv"]
@@ -361,7 +367,7 @@ class S2TEngine:
                    p_drop=c["pa"], seed=c["seed"] + 1, dist_penalty=c["dist_penalty"])
         dh = self.linear_bwd(dqkv.view(T * B, 3 * D), c["h"], pfx + "self_attn.qkv")
         return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "self_attn_layer_norm.weight"),
-                               self.G(pfx + "self_attn_layer_norm.weight"), self.G(pfx + "self_attn_layer_norm.bias"), dres=dy)
+                               self.G(pfx + "self_attn_layer_norm.weight"), self.G(pfx + "self_attn_layer_norm.bias"), dres=dy, drop=nxt)
 
     def cross_attn_block_fwd(self, pfx, x, enc2d, Ts, enc_klen32, training, seed):
         """decoder encoder-attention (transformer_layer.py:324-352): q from x, k/v from the encoder output."""
@@ -378,11 +384,12 @@ class S2TEngine:
         c = dict(x=x2, h=h, mean=mean, rstd=rstd, q=q, kv=kv, ctx=ctx, lse=lse, klen=enc_klen32, pa=pa, p=p, seed=seed, T=T, B=B, Ts=Ts, enc2d=enc2d)
         return y.view(T, B, D), c
 
-    def cross_attn_block_bwd(self, pfx, c, dy, denc):
-        """accumulates the encoder-output gradient into denc [Ts*B, D]; returns dx."""
+    def cross_attn_block_bwd(self, pfx, c, dy, denc, d=None, nxt=None):
+        """accumulates the encoder-output gradient into denc [Ts*B, D]; returns dx (d / nxt as in self_attn_block_bwd)."""
         hp = self.hp
         T, B, D, Ts = c["T"], c["B"], self.hp.D, c["Ts"]
-        d = K.dropout(dy, c["p"], c["seed"] + 2) if c["p"] > 0 else dy
+        if d is None:
+            d = K.dropout(dy, c["p"], c["seed"] + 2) if c["p"] > 0 else dy
         dctx = self.linear_bwd(d, c["ctx"].view(T * B, D), pfx + "encoder_attn.out_proj")
         dq = torch.empty_like(c["q"]); dkv = torch.empty_like(c["kv"])
         kv = c["kv"]
@@ -391,7 +398,7 @@ class S2TEngine:
         self.linear_bwd(dkv.view(Ts * B, 2 * D), c["enc2d"], pfx + "encoder_attn.kv", dx_out=denc, dx_accumulate=True)
         dh = self.linear_bwd(dq.view(T * B, D), c["h"], pfx + "encoder_attn.q_proj")
         return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "encoder_attn_layer_norm.weight"),
-                               self.G(pfx + "encoder_attn_layer_norm.weight"), self.G(pfx + "encoder_attn_layer_norm.bias"), dres=dy)
+                               self.G(pfx + "encoder_attn_layer_norm.weight"), self.G(pfx + "encoder_attn_layer_norm.bias"), dres=dy, drop=nxt)
 
     def ffn_block_fwd(self, pfx, x, training, seed):
         """x + dropout(fc2(dropout_act(act(fc1(LN(x))))))   (transformer_layer.py:128-136)"""
@@ -407,8 +414,9 @@ class S2TEngine:
         c = dict(x=x2, h=h, mean=mean, rstd=rstd, a=a, pre=pre, pact=pact, p=p, seed=seed)
         return y.view(T, B, D), c
 
-    def ffn_block_bwd(self, pfx, c, dy):
-        d = K.dropout(dy, c["p"], c["seed"] + 4) if c["p"] > 0 else dy
+    def ffn_block_bwd(self, pfx, c, dy, d=None, nxt=None):
+        if d is None:
+            d = K.dropout(dy, c["p"], c["seed"] + 4) if c["p"] > 0 else dy
         if self.hp.act == "relu":
             # a = relu(z) * keep/(1-p): a > 0 <=> active and kept; the 1/(1-p) factor goes in alpha
             da = self.linear_bwd(d, c["a"], pfx + "fc2", act=K.ACT_RELU_BWD, aux=c["a"], alpha=1.0 / (1.0 - c["pact"]))
@@ -418,7 +426,7 @@ class S2TEngine:
                 K.dropout(da, c["pact"], c["seed"] + 3, out=da)
         dh = self.linear_bwd(da, c["h"], pfx + "fc1")
         return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "final_layer_norm.weight"),
-                               self.G(pfx + "final_layer_norm.weight"), self.G(pfx + "final_layer_norm.bias"), dres=dy)
+                               self.G(pfx + "final_layer_norm.weight"), self.G(pfx + "final_layer_norm.bias"), dres=dy, drop=nxt)
 
     # ------------------------------------------------------------------ encoder
     def encoder_forward(self, src_tokens, src_lengths, training, seed=0, return_all_hiddens=False):
@@ -476,8 +484,21 @@ class S2TEngine:
         d_out = d_out.reshape(-1, D).contiguous()
         if d_states and (hp.enc_layers - 1) in d_states:
             d_out = K.add_inplace(d_states[hp.enc_layers - 1].reshape(-1, D).contiguous(), d_out.clone())
+        def touched(l):
+            """the gradient entering layer l's output is modified between the blocks (CTC tap / compression): no fused mask"""
+            return l < 0 or bool(d_states and l in d_states and l != hp.enc_layers - 1) or \
+                (ctx["ctc"] is not None and ctx["ctc"]["layer"] == l)
+
+        def ffn_drop(l):
+            cf = ctx["layers"][l][1]
+            return (cf["p"], cf["seed"] + 4) if self.fuse_bwd_dropout and cf["p"] > 0 and not touched(l) else None
+
+        dxd = None
+        nxt = ffn_drop(hp.enc_layers - 1)
         dx = K.layernorm_bwd(d_out.reshape(-1, D).contiguous(), f["x"], f["mean"], f["rstd"], self.P("encoder.layer_norm.weight"),
-                             self.G("encoder.layer_norm.weight"), self.G("encoder.layer_norm.bias"))
+                             self.G("encoder.layer_norm.weight"), self.G("encoder.layer_norm.bias"), drop=nxt)
+        if nxt is not None:
+            dx, dxd = dx
         for l in reversed(range(hp.enc_layers)):
             pfx = "encoder.layers.%d." % l
             if d_states and l in d_states and l != hp.enc_layers - 1:
@@ -491,8 +512,12 @@ class S2TEngine:
                     self.linear_bwd(d_ctc_out.reshape(-1, hp.V_src), cc["x"], "encoder.ctc_fc", dx_out=dxk, dx_accumulate=True)
                 dx = dxk
             ca, cf = ctx["layers"][l]
-            dx = self.ffn_block_bwd(pfx, cf, dx)
-            dx = self.self_attn_block_bwd(pfx, ca, dx)
+            nxt = (ca["p"], ca["seed"] + 2) if self.fuse_bwd_dropout and ca["p"] > 0 else None
+            dx = self.ffn_block_bwd(pfx, cf, dx, d=dxd, nxt=nxt)
+            dx, dxd = dx if nxt is not None else (dx, None)
+            nxt = ffn_drop(l - 1) if l > 0 else None
+            dx = self.self_attn_block_bwd(pfx, ca, dx, d=dxd, nxt=nxt)
+            dx, dxd = dx if nxt is not None else (dx, None)
             if l == hp.enc_layers - 1:
                 self._ready("encoder.layer_norm.")
             if hp.ctc_layer == l + 1:
@@ -591,16 +616,27 @@ class S2TEngine:
         pfx, B, L, D = ctx["pfx"], ctx["B"], ctx["L"], hp.D
         f = ctx["final"]
         dxn = self.linear_bwd(dlogits, f["xn"], pfx + "output_projection", bias=False)
+        def drop_of(c, off):
+            return (c["p"], c["seed"] + off) if self.fuse_bwd_dropout and c["p"] > 0 else None
+
+        nxt = drop_of(ctx["layers"][hp.dec_layers - 1][2], 4)
         dx = K.layernorm_bwd(dxn, f["x"], f["mean"], f["rstd"], self.P(pfx + "layer_norm.weight"),
-                             self.G(pfx + "layer_norm.weight"), self.G(pfx + "layer_norm.bias"))
+                             self.G(pfx + "layer_norm.weight"), self.G(pfx + "layer_norm.bias"), drop=nxt)
+        dx, dxd = dx if nxt is not None else (dx, None)
         if denc is None:
             denc = torch.zeros((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
         for l in reversed(range(hp.dec_layers)):
             lp = pfx + "layers.%d." % l
             c1, c2, c3 = ctx["layers"][l]
-            dx = self.ffn_block_bwd(lp, c3, dx)
-            dx = self.cross_attn_block_bwd(lp, c2, dx, denc)
-            dx = self.self_attn_block_bwd(lp, c1, dx)
+            nxt = drop_of(c2, 2)
+            dx = self.ffn_block_bwd(lp, c3, dx, d=dxd, nxt=nxt)
+            dx, dxd = dx if nxt is not None else (dx, None)
+            nxt = drop_of(c1, 2)
+            dx = self.cross_attn_block_bwd(lp, c2, dx, denc, d=dxd, nxt=nxt)
+            dx, dxd = dx if nxt is not None else (dx, None)
+            nxt = drop_of(ctx["layers"][l - 1][2], 4) if l > 0 else None
+            dx = self.self_attn_block_bwd(lp, c1, dx, d=dxd, nxt=nxt)
+            dx, dxd = dx if nxt is not None else (dx, None)
             if l == hp.dec_layers - 1:
                 self._ready(pfx + "output_projection.")
                 self._ready(pfx + "layer_norm.")

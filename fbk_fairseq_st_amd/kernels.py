@@ -111,14 +111,18 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, drop=None):
+    """drop = (p, seed) of the dropout that consumes dx next: returns (dx, dropout(dx, p, seed)) from one pass."""
     D = x.shape[-1]
     M = x.numel() // D
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if drop is not None else None
+    p, seed = drop if drop is not None else (0.0, 0)
     L.check(_lib().s2t_layernorm_bwd(L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres),
-                                     L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), M, D, L.stream()), "s2t_layernorm_bwd")
-    return dx
+                                     L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), M, D, L.ptr(dxd), float(p), int(seed), L.stream()),
+            "s2t_layernorm_bwd")
+    return dx if drop is None else (dx, dxd)
 
 
 def conv1_fwd(x, w, bias, C, dtype):

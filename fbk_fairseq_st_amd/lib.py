@@ -35,7 +35,7 @@ SIGNATURES = {
     "s2t_attn_bwd": [c_int] * 6 + [P, c_long, c_long] * 5 + [P, P] + [P, c_long, c_long] * 3 +
                     [P, c_int, c_int, c_float, c_float, c_ull, P],
     "s2t_layernorm_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_float, P],
-    "s2t_layernorm_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P],
+    "s2t_layernorm_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_float, c_ull, P],
     "s2t_conv1_fwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_conv1_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_chan_sums": [c_int, P, P, P, P, P, c_long, c_int, c_int, P],

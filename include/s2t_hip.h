@@ -115,10 +115,13 @@ int s2t_attn_bwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
 /* ---- LayerNorm (fairseq/modules/layer_norm.py:29-32; eps 1e-5; rows of D <= 1024) ------------------ */
 int s2t_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                       float* mean, float* rstd, int M, int D, float eps, void* stream);
-/* dx = LN'(dy) + dres (dres optional: the residual branch of a pre-LN block); dgamma/dbeta += (f32) */
+/* dx = LN'(dy) + dres (dres optional: the residual branch of a pre-LN block); dgamma/dbeta += (f32).
+ * dx_drop (optional): a second output = s2t_dropout(dx, p_drop, seed), i.e. the gradient that enters the
+ * residual-branch dropout of the block that consumes dx, written in the same pass (bit-identical to the
+ * separate call). */
 int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
                       const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
-                      int M, int D, void* stream);
+                      int M, int D, void* dx_drop, float p_drop, unsigned long long seed, void* stream);
 
 /* ---- convolutional subsampler (conv_transformer.py:202-232) ----------------------------------------
  * conv1: x [B][T][F] f32 -> y [B][T2][F2][C] (channels-last) = relu(conv3x3 s2 p1 + bias); also the

@@ -247,6 +247,24 @@ def test_layernorm(dtype, M, D):
     assert rel_err(db, bf.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,D", [(333, 512), (1000, 256), (50, 1024), (21, 100)])
+def test_layernorm_bwd_second_output_is_the_consumers_dropout(dtype, M, D):
+    """dx_drop of s2t_layernorm_bwd == s2t_dropout(dx, p, seed), bit for bit (same element index, same rounding)"""
+    x = rnd(M, D, dtype=dtype, seed=1, scale=2.0).to(DEV)
+    g = (1 + 0.1 * rnd(D, seed=2)).to(DEV); b = (0.1 * rnd(D, seed=3)).to(DEV)
+    dy = rnd(M, D, dtype=dtype, seed=4).to(DEV); dres = rnd(M, D, dtype=dtype, seed=5).to(DEV)
+    _, mean, rstd = K.layernorm_fwd(x, g, b)
+    dg = torch.zeros(D, device=DEV); db = torch.zeros(D, device=DEV)
+    dx0 = K.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres)
+    dg2 = torch.zeros(D, device=DEV); db2 = torch.zeros(D, device=DEV)
+    dx1, dxd = K.layernorm_bwd(dy, x, mean, rstd, g, dg2, db2, dres=dres, drop=(0.3, 4242))
+    assert torch.equal(dx0, dx1)
+    assert torch.equal(dxd, K.dropout(dx0, 0.3, 4242))
+    kept = float((dxd != 0).float().mean())
+    assert abs(kept - 0.7) < 0.03
+
+
 # ------------------------------------------------------------------ conv1 + BatchNorm
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,T", [(2, 37), (3, 200)])

@@ -169,6 +169,26 @@ def test_dropout_training_step_runs_and_is_reproducible():
     assert np.isfinite(outs[0][1])
 
 
+def test_fused_backward_dropout_gives_the_same_gradients():
+    """LayerNorm backward writing the next block's dropout(dx) is a pure fusion: gradients equal the unfused chain's"""
+    g, cfg, W, sample, meta, model, crit = build("model_a")
+    model.hp.dropout, model.hp.attention_dropout, model.hp.activation_dropout, model.hp.sub_dropout = 0.2, 0.1, 0.1, None
+    model.train(); crit.train()
+    s = to_dev(sample)
+    grads = []
+    for fuse in (False, True):
+        model.engine.fuse_bwd_dropout = fuse
+        model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+        model.set_seed(123)
+        model.arena.zero_grad()
+        loss, _, _ = crit(model, s)
+        loss.backward()
+        grads.append(model.arena.grad.clone())
+    model.engine.fuse_bwd_dropout = True
+    diff = float((grads[0] - grads[1]).norm()); ref = float(grads[0].norm())
+    assert diff <= 1e-4 * ref, (diff, ref)           # only the order of f32 atomic partial sums differs
+
+
 def _build_extra(name, arch, criterion, dual=False, **crit_args):
     from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
     from fbk_fairseq_st_amd.data import Dictionary
