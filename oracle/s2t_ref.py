@@ -89,9 +89,46 @@ def batch_norm2d(x, w, b, rm, rv, training, momentum, eps):
     return y, new_rm, new_rv
 
 
+ATTN2D_HEADS = 4          # conv_transformer.py:155-157: ConvAttention2D(out_channels, 4, dropout)
+
+
+def conv_attention_2d(W, p, x, cfg, training, stats):
+    """conv_attention_2d.py:46-135 as called by the encoder (query = key = value = x [B,C,T,F], no padding mask,
+    dropout = identity): 3x3 conv -> (q, k, v) of `heads` channels each, q scaled by C^-0.5 (head_dim = embed_dim, :21-23),
+    BatchNorm + ReLU per projection, then per (batch, head) plane [T,F]:
+      time attention       softmax_T'(q k^T) v                       -> [T,F]
+      frequency attention  softmax_F'(q^T k) v^T, transposed back    -> [T,F]
+    the 2*heads planes are concatenated on the channel axis, 3x3 conv back to C channels, BatchNorm, ReLU."""
+    H = ATTN2D_HEADS
+    B, C, T, Fq = x.shape
+    qkv = F.conv2d(x, W[p + "in_proj_weight"], W[p + "in_proj_bias"], padding=1)
+    planes = []
+    for i, n in enumerate(("q", "k", "v")):
+        z = qkv[:, i * H:(i + 1) * H]
+        if n == "q":
+            z = z * (C ** -0.5)
+        b = p + "bn_%s." % n
+        z, rm, rv = batch_norm2d(z.contiguous(), W[b + "weight"], W[b + "bias"], W[b + "running_mean"], W[b + "running_var"],
+                                 training, cfg["bn_momentum"], cfg["bn_eps"])
+        stats[b + "running_mean"], stats[b + "running_var"] = rm, rv
+        planes.append(F.relu(z).reshape(B * H, T, Fq))
+    q, k, v = planes
+    a_t = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)             # [BH,T,T]
+    o_t = torch.bmm(a_t, v)                                                  # [BH,T,F]
+    a_f = torch.softmax(torch.bmm(q.transpose(1, 2), k), dim=-1)             # [BH,F,F]  (sums over every frame, padded ones too)
+    o_f = torch.bmm(a_f, v.transpose(1, 2)).transpose(1, 2)                  # [BH,T,F]
+    cat = torch.cat([o_t.reshape(B, H, T, Fq), o_f.reshape(B, H, T, Fq)], dim=1)
+    y = F.conv2d(cat, W[p + "out_proj.weight"], W[p + "out_proj.bias"], padding=1)
+    b = p + "bn_out."
+    y, rm, rv = batch_norm2d(y, W[b + "weight"], W[b + "bias"], W[b + "running_mean"], W[b + "running_var"],
+                             training, cfg["bn_momentum"], cfg["bn_eps"])
+    stats[b + "running_mean"], stats[b + "running_var"] = rm, rv
+    return F.relu(y)
+
+
 def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
-    """conv_transformer.py:202-232 (no attn_2d): 2x[conv3x3 s2 p1 -> act -> BN] -> flatten
-    (channel-major) -> fc3 -> act -> + positions.  Dropout is identity (parity mode).
+    """conv_transformer.py:202-232: 2x[conv3x3 s2 p1 -> act -> BN] -> (cfg attn_2d: 2x residual ConvAttention2D,
+    :216-222) -> flatten (channel-major) -> fc3 -> act -> + positions.  Dropout is identity (parity mode).
     Returns x (T4,B,D), lengths (B,), dict of updated BN running stats."""
     act = act_fn(cfg["act"])
     x = src_tokens.unsqueeze(1)
@@ -108,6 +145,11 @@ def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
         lengths = torch.ceil(lengths.float() / 2).long()          # :213
         if trace is not None:
             trace["conv%d" % i] = x
+    if cfg.get("attn_2d"):
+        for i in range(2):
+            x = x + conv_attention_2d(W, "encoder.attn_2d.%d." % i, x, cfg, training, stats)               # :216-222
+            if trace is not None:
+                trace["attn2d%d" % i] = x
     B, C, T4, F4 = x.shape
     x = x.transpose(1, 2).contiguous().view(B, T4, C * F4).transpose(0, 1)   # :225-226
     x = act(F.linear(x, W["encoder.fc3.weight"], W["encoder.fc3.bias"]))    # :227
@@ -508,6 +550,15 @@ def param_shapes(cfg, V_src, V_tgt, criterion_fc=False, V_aux=0):
         for n in ("weight", "bias", "running_mean", "running_var"):
             s["encoder.bn.%d.%s" % (i, n)] = (C,)
     s["encoder.fc3.weight"] = (D, C * f4); s["encoder.fc3.bias"] = (D,)
+    if cfg.get("attn_2d"):
+        H = ATTN2D_HEADS
+        for i in range(2):
+            p = "encoder.attn_2d.%d." % i
+            s[p + "in_proj_weight"] = (3 * H, C, 3, 3); s[p + "in_proj_bias"] = (3 * H,)
+            s[p + "out_proj.weight"] = (C, 2 * H, 3, 3); s[p + "out_proj.bias"] = (C,)
+            for bn, n in (("bn_q", H), ("bn_k", H), ("bn_v", H), ("bn_out", C)):
+                for f in ("weight", "bias", "running_mean", "running_var"):
+                    s[p + bn + "." + f] = (n,)
 
     def attn(p):
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
@@ -557,7 +608,7 @@ def make_weights(shapes, seed):
             a = 0.5 + rs.rand(*shp)
         elif k.endswith("running_mean"):
             a = 0.1 * rs.randn(*shp)
-        elif "layer_norm" in k or ".bn." in k:
+        elif "layer_norm" in k or ".bn." in k or ".bn_" in k:
             a = (1.0 + 0.1 * rs.randn(*shp)) if k.endswith("weight") else 0.1 * rs.randn(*shp)
         elif k.endswith("bias"):
             a = 0.05 * rs.randn(*shp)

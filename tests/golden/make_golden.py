@@ -67,10 +67,10 @@ def mk_dict(n):
 
 
 def build(cfgname, D, H, Ff, EL, DL, ctc_layer, compress=True, strategy="avg", arch="conv_transformer",
-          criterion=("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy"), extra=()):
+          criterion=("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy"), extra=(), attn_2d=False):
     a = ["/nonexistent", "--user-dir", REF + "/examples/speech_recognition",
          "--task", "speech_translation_with_transcription", "-s", "en", "-t", "de",
-         "--arch", arch, "--no-attn-2d", "--input-feat-per-channel", "80",
+         "--arch", arch] + ([] if attn_2d else ["--no-attn-2d"]) + ["--input-feat-per-channel", "80",
          "--encoder-embed-dim", str(D), "--decoder-embed-dim", str(D),
          "--decoder-output-dim", str(D),
          "--encoder-ffn-embed-dim", str(Ff), "--decoder-ffn-embed-dim", str(Ff),
@@ -651,6 +651,78 @@ def run_distpen_case():
     print("distpen", {k: float(v) for k, v in out.items() if k.endswith("loss")}, list(out["statedict_keys"]))
 
 
+ATTN2D_GRAD_KEYS = ["encoder.attn_2d.0.in_proj_weight", "encoder.attn_2d.0.in_proj_bias", "encoder.attn_2d.0.out_proj.weight",
+                    "encoder.attn_2d.0.bn_q.weight", "encoder.attn_2d.0.bn_k.bias", "encoder.attn_2d.0.bn_v.weight",
+                    "encoder.attn_2d.0.bn_out.bias", "encoder.attn_2d.1.in_proj_weight", "encoder.attn_2d.1.out_proj.bias",
+                    "encoder.convolutions.1.bias", "encoder.bn.1.weight", "encoder.fc3.bias"]
+
+
+def run_attn2d_case():
+    """G17: the default conv_transformer front end WITH the two residual ConvAttention2D blocks
+    (conv_transformer.py:155-157,216-222; conv_attention_2d.py).  Train-mode loss + gradients, encoder tensors, BN statistics."""
+    D, H, Ff, EL, DL, seed = 64, 2, 128, 2, 1, 900
+    lens, tgt_lens, tr_lens = [70, 57, 41], [5, 4, 6], [4, 3, 5]
+    # conv_attention_2d.py:82 scales q in place on a chunk() view, which current autograd rejects (same class of problem as
+    # SURVEY F7): the projections are cloned first (our patch, outside the tree; values unchanged)
+    from examples.speech_recognition.modules.conv_attention_2d import ConvAttention2D
+    ConvAttention2D.in_proj_qkv = lambda self, query: tuple(t.clone() for t in self._in_proj(query).chunk(3, dim=1))
+
+    def fresh():
+        args, task, model, crit, V_src, V_tgt = build("a2d", D, H, Ff, EL, DL, 2, True, attn_2d=True)
+        cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=2, attn_2d=True)
+        W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+        load_weights(model, crit, W)
+        return model, crit, V_src, V_tgt
+
+    model, crit, V_src, V_tgt = fresh()
+    assert hasattr(model.encoder, "attn_2d")
+    s = make_sample(seed + 1, lens, tgt_lens, tr_lens, V_src, V_tgt, V_src - 1)
+    sample = to_ref_sample(s)
+    out = {("in_" + k): v for k, v in s.items() if isinstance(v, np.ndarray)}
+    out["in_ntokens"] = np.int64(s["ntokens"])
+    out["meta"] = np.array([D, H, Ff, EL, DL, 2, 1, V_src, V_tgt, V_src - 1, seed], np.int64)
+    model.train(); crit.train()
+    trace = {}
+    hooks = [model.encoder.attn_2d[i].register_forward_hook(lambda m, i_, o, i=i: trace.__setitem__("attn2d%d" % i, o[0].detach()))
+             for i in range(2)]
+    model.zero_grad(); crit.zero_grad()
+    loss, ss, log = crit(model, sample)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    out["train_loss"] = np.float64(loss.item()); out["train_sample_size"] = np.int64(ss)
+    for k, v in log.items():
+        out["train_log_" + k] = np.float64(float(v))
+    for k, v in trace.items():
+        out["train_" + k] = v.numpy()                      # the block's output BEFORE the residual add, [B,C,T4,F4]
+    gn = {}
+    for k, p_ in list(model.named_parameters()) + [("criterion." + k, p_) for k, p_ in crit.named_parameters()]:
+        g = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+        gn[k] = float(g.norm())
+        if k in ATTN2D_GRAD_KEYS:
+            out["grad_" + k] = g.numpy().copy()
+    out["gradnorm_keys"] = np.array(sorted(gn)); out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], np.float64)
+    sd = model.state_dict()
+    for k in sd:
+        if "attn_2d" in k and ("running" in k):
+            out["train_stat_" + k] = sd[k].numpy().copy()
+    model2, crit2, _, _ = fresh()
+    model2.train()
+    with torch.no_grad():
+        eo = model2.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+    out["train_encoder_out"] = eo.encoder_out.numpy(); out["train_src_lengths_out"] = eo.src_lengths.numpy()
+    model3, crit3, _, _ = fresh()
+    model3.eval(); crit3.eval()
+    with torch.no_grad():
+        eo = model3.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+        l3, ss3, log3 = crit3(model3, sample)
+    out["eval_encoder_out"] = eo.encoder_out.numpy(); out["eval_src_lengths_out"] = eo.src_lengths.numpy()
+    out["eval_loss"] = np.float64(l3.item())
+    out["statedict_keys"] = np.array(sorted(k for k in sd if "attn_2d.0" in k))
+    np.savez_compressed(os.path.join(OUT, "attn2d.npz"), **out)
+    print("attn2d loss", loss.item(), "eval", l3.item(), list(out["statedict_keys"]))
+
+
 def run_augment_case():
     """G15: TimeStretch then SpecAugment as SpeechRecognitionTask.train_step applies them (speech_recognition.py:254-258),
     with Python's `random` and numpy's global RNG seeded: expected batches after each stage."""
@@ -745,6 +817,8 @@ def run_teacher_case():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "attn2d":
+        run_attn2d_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "teacher":
         run_teacher_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "augment":

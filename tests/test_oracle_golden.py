@@ -242,3 +242,50 @@ def test_distance_penalty_matches_reference_local_attention():
     cfg0 = dict(cfg, distance_penalty=False)
     l0 = s2t_ref.ctc_multi_loss({k: v.clone() for k, v in W.items()}, cfg0, sample, 0.1, 1.0, blank, training=False)[0]
     assert abs(float(l0) - float(g["eval_loss"])) > 1e-3
+
+
+def _attn2d_case():
+    g = load_golden("attn2d")
+    D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed = [int(v) for v in g["meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer, attn_2d=True)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    t = lambda k: torch.from_numpy(g["in_" + k])
+    sample = dict(id=t("id"), ntokens=int(g["in_ntokens"]), nsentences=3,
+                  net_input=dict(src_tokens=t("src_tokens"), src_lengths=t("src_lengths"), prev_output_tokens=t("prev_output_tokens")),
+                  target=t("target"), target_lengths=t("target_lengths"), transcript_target=t("transcript_target"),
+                  transcript_target_lengths=t("transcript_target_lengths"), ctc_encoder_layer=ctc_layer)
+    return g, cfg, W, sample, blank
+
+
+def test_conv_attention_2d_matches_reference():
+    """G17: the front end with the two residual ConvAttention2D blocks: loss, every gradient norm, selected
+    gradients, block outputs, BatchNorm running statistics and the encoder output (train and eval) against the reference."""
+    g, cfg, W, sample, blank = _attn2d_case()
+    assert [str(k) for k in g["statedict_keys"] if "num_batches" not in str(k)] == \
+        sorted(k for k in W if k.startswith("encoder.attn_2d.0."))
+    Wg = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in W.items()}
+    loss, ss, log, enc, logits, stats = s2t_ref.ctc_multi_loss(Wg, cfg, sample, 0.1, 1.0, blank, training=True)
+    loss.backward()
+    close(float(loss), float(g["train_loss"]), what="loss")
+    assert ss == int(g["train_sample_size"])
+    for k in ("ctc_loss", "nll_loss"):
+        close(log[k], float(g["train_log_" + k]), what=k)
+    _check_gradnorms(g, Wg)
+    for k in g:
+        if k.startswith("grad_"):
+            close(Wg[k[5:]].grad, g[k], tol=2e-4, what=k)
+        if k.startswith("train_stat_"):
+            close(stats[k[len("train_stat_"):]], g[k], what=k)
+    close(enc.encoder_out, g["train_encoder_out"], what="train encoder_out")
+    trace = {}
+    with torch.no_grad():
+        ni = sample["net_input"]
+        s2t_ref.subsample({k: v.clone() for k, v in W.items()}, cfg, ni["src_tokens"], ni["src_lengths"], training=True, trace=trace)
+    # golden holds the block output before the residual add; the trace holds x + block(x)
+    close(trace["attn2d0"] - trace["conv1"], g["train_attn2d0"], what="block 0")
+    close(trace["attn2d1"] - trace["attn2d0"], g["train_attn2d1"], what="block 1")
+    with torch.no_grad():
+        l3, _, _, enc3, _, _ = s2t_ref.ctc_multi_loss({k: v.clone() for k, v in W.items()}, cfg, sample, 0.1, 1.0, blank, training=False)
+    close(float(l3), float(g["eval_loss"]), what="eval loss")
+    close(enc3.encoder_out, g["eval_encoder_out"], what="eval encoder_out")
+    assert enc3.src_lengths.tolist() == g["eval_src_lengths_out"].tolist()
