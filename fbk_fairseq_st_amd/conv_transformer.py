@@ -293,10 +293,16 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         for name, shape in hp.param_shapes().items():
             self._register(name, self._init_param(name, shape))
         C = hp.conv_ch
-        for i in range(2):
-            self.register_buffer("bn%d_running_mean" % i, torch.zeros(C))
-            self.register_buffer("bn%d_running_var" % i, torch.ones(C))
-            self.register_buffer("bn%d_num_batches_tracked" % i, torch.zeros(1, dtype=torch.int64))
+        # BatchNorm buffers: reference state-dict prefix -> (buffer attribute prefix, channels)
+        self._bn_refs = {"encoder.bn.%d" % i: ("bn%d" % i, C) for i in range(2)}
+        if hp.attn_2d:
+            for i in range(2):
+                for n, ch in (("bn_q", 4), ("bn_k", 4), ("bn_v", 4), ("bn_out", C)):
+                    self._bn_refs["encoder.attn_2d.%d.%s" % (i, n)] = ("a2d%d_%s" % (i, n), ch)
+        for attr, ch in self._bn_refs.values():
+            self.register_buffer(attr + "_running_mean", torch.zeros(ch))
+            self.register_buffer(attr + "_running_var", torch.ones(ch))
+            self.register_buffer(attr + "_num_batches_tracked", torch.zeros(1, dtype=torch.int64))
         self.anchor = nn.Parameter(torch.zeros(1), requires_grad=True)      # keeps the autograd bridges alive
         self.engine = None
         self.arena = None
@@ -314,10 +320,14 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
     def _init_param(self, name, shape):
         """Reference initialisation."""
         hp = self.hp
-        if name.endswith("layer_norm.weight") or (".bn." in name and name.endswith("weight")):
+        if name.endswith("layer_norm.weight") or ((".bn." in name or ".bn_" in name) and name.endswith("weight")):
             return torch.ones(shape)
         if name.endswith("bias"):
             return torch.zeros(shape)
+        if ".attn_2d." in name:                                  # conv_attention_2d.py:39-44: xavier_uniform on the conv weights
+            w = torch.empty(shape)
+            nn.init.xavier_uniform_(w)
+            return w
         if "convolutions" in name:                               # conv_transformer.py:348-354
             cin = shape[1]
             std = math.sqrt((4 * (1.0 - hp.dropout)) / (3 * cin))
@@ -363,8 +373,8 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         self.arena, self.compute_dtype = arena, compute_dtype
         self.engine = S2TEngine(self.hp, arena)
         self.engine.bn_buffers = {
-            "encoder.bn.%d.%s" % (i, n): getattr(self, "bn%d_%s" % (i, n))
-            for i in range(2) for n in ("running_mean", "running_var", "num_batches_tracked")}
+            "%s.%s" % (ref, n): getattr(self, "%s_%s" % (attr, n))
+            for ref, (attr, _) in self._bn_refs.items() for n in ("running_mean", "running_var", "num_batches_tracked")}
         return arena
 
     def _ensure_engine(self, device):
@@ -408,10 +418,10 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         sd = {n: p.data.detach().float().cpu().clone() for n, p in self.named_arena_params().items()}
         sd = self._local_attention_keys(sd, True)
         sd = fused_to_reference(sd)
-        for i in range(2):
+        for ref, (attr, _) in self._bn_refs.items():
             for n in ("running_mean", "running_var", "num_batches_tracked"):
-                b = getattr(self, "bn%d_%s" % (i, n)).detach().cpu().clone()
-                sd["encoder.bn.%d.%s" % (i, n)] = b.view(()) if n == "num_batches_tracked" else b
+                b = getattr(self, "%s_%s" % (attr, n)).detach().cpu().clone()
+                sd["%s.%s" % (ref, n)] = b.view(()) if n == "num_batches_tracked" else b
         sd["encoder.embed_positions.embeddings._float_tensor"] = torch.FloatTensor(1)
         sd["decoder.embed_positions._float_tensor"] = torch.FloatTensor(1)
         sd["decoder.version"] = torch.Tensor([3])
@@ -427,11 +437,12 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             for n, p in mine.items():
                 if n in sd:
                     p.data.copy_(sd[n].to(p.data.dtype))
-            for i in range(2):
+            for ref, (attr, _) in self._bn_refs.items():
                 for n in ("running_mean", "running_var", "num_batches_tracked"):
-                    k = "encoder.bn.%d.%s" % (i, n)
+                    k = "%s.%s" % (ref, n)
                     if k in sd:
-                        getattr(self, "bn%d_%s" % (i, n)).copy_(sd[k].reshape(getattr(self, "bn%d_%s" % (i, n)).shape))
+                        buf = getattr(self, "%s_%s" % (attr, n))
+                        buf.copy_(sd[k].reshape(buf.shape))
         if self.arena is not None:
             self.arena.refresh_shadow()
         if getattr(args, "freeze_pretrained", False):            # conv_transformer.py:114-121
@@ -479,8 +490,6 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             args.max_source_positions = 100000
         if not hasattr(args, "max_target_positions"):
             args.max_target_positions = 100000
-        if getattr(args, "attn_2d", False):
-            raise NotImplementedError("ConvAttention2D is outside this round's hot path: pass --no-attn-2d (SURVEY.md 8-f N3)")
         if getattr(args, "distance_penalty", False) is True:
             args.distance_penalty = "log"                                    # conv_transformer.py:160-161
         if getattr(args, "distance_penalty", False) not in (False, None, "log"):
@@ -502,7 +511,8 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                      act=getattr(args, "activation_fn", "relu"), dropout=args.dropout,
                      attention_dropout=args.attention_dropout, activation_dropout=args.activation_dropout,
                      pad=tgt_dict.pad(), no_scale_embedding=getattr(args, "no_scale_embedding", False),
-                     V_src=len(enc_dict), V_tgt=len(tgt_dict), distance_penalty=getattr(args, "distance_penalty", False) or False)
+                     V_src=len(enc_dict), V_tgt=len(tgt_dict), distance_penalty=getattr(args, "distance_penalty", False) or False,
+                     attn_2d=bool(getattr(args, "attn_2d", False)))
         assert args.decoder_ffn_embed_dim == args.encoder_ffn_embed_dim
         encoder = ConvolutionalTransformerEncoder(args, enc_dict, audio_features=args.input_feat_per_channel)
         decoder = TransformerDecoder(args, tgt_dict)

@@ -1,0 +1,551 @@
+// ConvAttention2D blocks of the conv_transformer front end (reference:
+// examples/speech_recognition/modules/conv_attention_2d.py:46-135, called from conv_transformer.py:216-222 with
+// query = key = value = x and no padding mask).
+//
+// Layout: every tensor is channels-last over the subsampler's pixel rows r = (t*B + b)*F + f  (the layout conv2 / fc3
+// already use): x [M][64], qkv [M][16] (channels 0-3 q, 4-7 k, 8-11 v, 12-15 zero padding so that rows are 16-byte
+// multiples), cat [M][8] (0-3 time attention, 4-7 frequency attention).  The two 3x3 convolutions run as gathered GEMMs
+// (gemm.hip, row maps built by the host); this file holds what is specific to the block:
+//   * BatchNorm statistics / apply(+ReLU, + residual) / backward for a small generic channel count,
+//   * time attention  softmax_t'(q k^T) v   per (batch, head) plane [T][F]   (head_dim = F = 20 for 80-mel input),
+//   * frequency attention softmax_f'(q^T k) v^T (scores summed over every frame),
+//   * packing of the convolution weights for the three gathered-GEMM forms.
+// All arithmetic is f32; the planes are tiny (4 heads x F <= 32 columns), so these are plain VALU kernels staged
+// through LDS -- HBM-bound element work, not MFMA shapes.
+#include "common.hpp"
+#include "prof.hpp"
+#include "../../include/s2t_hip.h"
+
+namespace {
+
+constexpr int QKV_C = 16, CAT_C = 8, HEADS = 4;
+
+#define A2D_DISPATCH_T(dtype, EXPR_BF16, EXPR_F32) \
+    do { if ((dtype) == S2T_BF16) { EXPR_BF16; } else if ((dtype) == S2T_F32) { EXPR_F32; } else return S2T_ENOTSUP; } while (0)
+
+// ------------------------------------------------------------------ BatchNorm pieces (channels-last, C <= 64, row stride ld)
+// sums layout: channel c of group g = c / Cg  ->  sums[g*2*Cg + (c % Cg)] (first moment) and [.. + Cg] (second):
+// each group is the [C | C] block s2t_bn_finalize expects, so q / k / v finalise separately from one statistics pass.
+// mode 0: moments of z' = prescale[c] * z.   mode 1 (backward): with dyn = dy * [z'*scale + shift > 0] (ReLU after BN):
+// sum dyn and sum dyn * xhat, xhat = (z' - mean) * rstd.
+template <typename T>
+__global__ __launch_bounds__(256) void a2d_stats_kernel(const T* __restrict__ z, const T* __restrict__ dy, const float* __restrict__ prescale,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        double* __restrict__ sums, long M, int C, int ld_z, int ld_dy, int Cg, int mode, int rpb) {
+    __shared__ double sh[2][256];
+    const int CP = C <= 16 ? 16 : (C <= 32 ? 32 : 64);          // threads per row
+    const int c = threadIdx.x % CP, rsub = threadIdx.x / CP, rstep = 256 / CP;
+    const long r0 = (long)blockIdx.x * rpb, r1 = r0 + rpb < M ? r0 + rpb : M;
+    float a0 = 0.f, a1 = 0.f;
+    double d0 = 0.0, d1 = 0.0;
+    if (c < C) {
+        const float ps = prescale ? prescale[c] : 1.f;
+        const float mu = mode ? mean[c] : 0.f, rs = mode ? rstd[c] : 0.f, sc = mode ? scale[c] : 0.f, sf = mode ? shift[c] : 0.f;
+        int n = 0;
+        for (long r = r0 + rsub; r < r1; r += rstep) {
+            const float v = to_f32(z[r * ld_z + c]) * ps;
+            if (mode == 0) { a0 += v; a1 += v * v; }
+            else {
+                const float g = (v * sc + sf > 0.f) ? to_f32(dy[r * ld_dy + c]) : 0.f;
+                a0 += g; a1 += g * (v - mu) * rs;
+            }
+            if (++n == 64) { d0 += a0; d1 += a1; a0 = a1 = 0.f; n = 0; }     // short f32 runs, double totals
+        }
+        d0 += a0; d1 += a1;
+    }
+    sh[0][threadIdx.x] = d0; sh[1][threadIdx.x] = d1;
+    __syncthreads();
+    if (threadIdx.x < CP && c < C) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = 0; k < rstep; ++k) { s0 += sh[0][k * CP + c]; s1 += sh[1][k * CP + c]; }
+        const int g = c / Cg, cc = c % Cg;
+        atomicAdd(sums + g * 2 * Cg + cc, s0);
+        atomicAdd(sums + g * 2 * Cg + Cg + cc, s1);
+    }
+}
+
+// y = relu(prescale*z*scale + shift) [+ res]
+template <typename T>
+__global__ __launch_bounds__(256) void a2d_bn_act_kernel(const T* __restrict__ z, const float* __restrict__ prescale, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res, T* __restrict__ y,
+                                                         long M, int C, int ld_z, int ld_y) {
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / C; const int c = (int)(i % C);
+        float v = to_f32(z[r * ld_z + c]) * (prescale ? prescale[c] : 1.f) * scale[c] + shift[c];
+        v = fmaxf(v, 0.f);
+        if (res) v += to_f32(res[r * ld_y + c]);
+        y[r * ld_y + c] = from_f32<T>(v);
+    }
+}
+
+// dz = prescale * scale * (dyn - mean(dyn) - xhat * mean(dyn*xhat))   (training; scale = gamma*rstd)
+//    = prescale * scale * dyn                                           (eval: running statistics are constants)
+template <typename T>
+__global__ __launch_bounds__(256) void a2d_bn_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ prescale,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const double* __restrict__ sums, T* __restrict__ dz, long M, int C, int ld_dy, int ld_z,
+                                                         int Cg, double count, int training) {
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / C; const int c = (int)(i % C);
+        const float ps = prescale ? prescale[c] : 1.f;
+        const float v = to_f32(z[r * ld_z + c]) * ps;
+        const float g = (v * scale[c] + shift[c] > 0.f) ? to_f32(dy[r * ld_dy + c]) : 0.f;
+        float o = g;
+        if (training) {
+            const int gi = c / Cg, cc = c % Cg;
+            const float m0 = (float)(sums[gi * 2 * Cg + cc] / count), m1 = (float)(sums[gi * 2 * Cg + Cg + cc] / count);
+            o = g - m0 - (v - mean[c]) * rstd[c] * m1;
+        }
+        dz[r * ld_z + c] = from_f32<T>(o * scale[c] * ps);
+    }
+}
+
+__global__ void a2d_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int Cg) {
+    const int c = threadIdx.x;
+    if (c < Cg) { dbeta[c] += (float)sums[c]; dgamma[c] += (float)sums[Cg + c]; }
+}
+
+// ------------------------------------------------------------------ convolution weight packing
+// src / grad: nn.Conv2d layout [Co][Ci][3][3] (f32).  Packed matrices are row-major with row stride ld:
+//  mode 0 (forward,  y = gather(x) W0^T):  dst[co][j*CiP + ci] = W[co][ci][j]
+//  mode 1 (data gradient, dx = gather(dy) W1^T):  dst[ci][j*CoP + co] = W[co][ci][8 - j]     (same row maps, taps mirrored)
+//  mode 2 (weight gradient back to the master layout):  W[co][ci][j] += src[co][j*CiP + ci]   (src f32)
+template <typename T>
+__global__ __launch_bounds__(256) void a2d_pack_w_kernel(const float* __restrict__ src, T* __restrict__ dst, float* __restrict__ grad,
+                                                         int Co, int Ci, int CP, int ld, int mode) {
+    const int n = Co * Ci * 9;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int j = i % 9, ci = (i / 9) % Ci, co = i / (9 * Ci);
+        if (mode == 0) dst[(long)co * ld + j * CP + ci] = from_f32<T>(src[i]);
+        else if (mode == 1) dst[(long)ci * ld + (8 - j) * CP + co] = from_f32<T>(src[i]);
+        else grad[i] += src[(long)co * ld + j * CP + ci];
+    }
+}
+
+// ------------------------------------------------------------------ time attention
+// One thread per query frame i of a (batch b, head h) plane; keys / values stream through LDS in tiles of KT frames.
+// Pass 1: row maximum and normaliser (lse).  Pass 2: P = exp(s - lse), dropout, O += P v.
+template <int F> struct Plane {
+    // element (t, f) of channel ch of a [M][ld] channels-last tensor, plane of batch b
+    static __device__ __forceinline__ long at(int t, int f, int b, int B, int ld, int ch) { return ((long)(t * B + b) * F + f) * ld + ch; }
+};
+
+__device__ __forceinline__ uint64_t tdrop_index(int bh, int i, int j, int T, int Tp) { return ((uint64_t)bh * T + i) * Tp + j; }
+
+constexpr int KT = 64;
+
+template <typename T, int F>
+__global__ __launch_bounds__(128) void a2d_time_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ cat, float* __restrict__ lse_out,
+                                                           int B, int Tn, float p_drop, unsigned long long seed) {
+    __shared__ float sk[KT][F], sv[KT][F];
+    const int bh = blockIdx.y, b = bh / HEADS, h = bh % HEADS;
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    const bool live = i < Tn;
+    const int ii = live ? i : Tn - 1;
+    float q[F], o[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) { q[f] = to_f32(qkv[Plane<F>::at(ii, f, b, B, QKV_C, h)]); o[f] = 0.f; }
+    const int Tp = (Tn + 3) & ~3;
+    const uint32_t th16 = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float inv_keep = 1.f / (1.f - p_drop);
+    float m = -INFINITY, l = 0.f, lse = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j0 = 0; j0 < Tn; j0 += KT) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < KT * F; e += 128) {
+                const int jj = e / F, f = e % F, j = j0 + jj;
+                sk[jj][f] = j < Tn ? to_f32(qkv[Plane<F>::at(j, f, b, B, QKV_C, HEADS + h)]) : 0.f;
+                if (pass) sv[jj][f] = j < Tn ? to_f32(qkv[Plane<F>::at(j, f, b, B, QKV_C, 2 * HEADS + h)]) : 0.f;
+            }
+            __syncthreads();
+            const int nj = min(KT, Tn - j0);
+            u32x2 hq = {0, 0};
+            for (int jj = 0; jj < nj; ++jj) {
+                float s = 0.f;
+#pragma unroll
+                for (int f = 0; f < F; ++f) s += q[f] * sk[jj][f];
+                if (pass == 0) {
+                    const float mn = fmaxf(m, s);
+                    l = l * __expf(m - mn) + __expf(s - mn);
+                    m = mn;
+                } else {
+                    float p = __expf(s - lse);
+                    if (p_drop > 0.f) {
+                        const int j = j0 + jj;
+                        if ((j & 3) == 0) hq = drop_hash4(seed, tdrop_index(bh, ii, j, Tn, Tp) >> 2);
+                        p = drop_field(hq, j & 3) >= th16 ? p * inv_keep : 0.f;
+                    }
+#pragma unroll
+                    for (int f = 0; f < F; ++f) o[f] += p * sv[jj][f];
+                }
+            }
+        }
+        if (pass == 0) lse = m + __logf(l);
+    }
+    if (live) {
+        lse_out[(long)bh * Tn + i] = lse;
+#pragma unroll
+        for (int f = 0; f < F; ++f) cat[Plane<F>::at(i, f, b, B, CAT_C, h)] = from_f32<T>(o[f]);
+    }
+}
+
+// backward, query side: delta_i = dO_i . O_i ; dq_i = sum_j dS_ij k_j, dS = P (dP - delta), dP = mask/(1-p) * (dO_i . v_j)
+template <typename T, int F>
+__global__ __launch_bounds__(128) void a2d_time_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ cat, const T* __restrict__ dcat,
+                                                              const float* __restrict__ lse_in, float* __restrict__ delta_out, T* __restrict__ dqkv,
+                                                              int B, int Tn, float p_drop, unsigned long long seed) {
+    __shared__ float sk[KT][F], sv[KT][F];
+    const int bh = blockIdx.y, b = bh / HEADS, h = bh % HEADS;
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    const bool live = i < Tn;
+    const int ii = live ? i : Tn - 1;
+    float q[F], dO[F], dq[F];
+    float delta = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        q[f] = to_f32(qkv[Plane<F>::at(ii, f, b, B, QKV_C, h)]);
+        dO[f] = to_f32(dcat[Plane<F>::at(ii, f, b, B, CAT_C, h)]);
+        delta += dO[f] * to_f32(cat[Plane<F>::at(ii, f, b, B, CAT_C, h)]);
+        dq[f] = 0.f;
+    }
+    const float lse = lse_in[(long)bh * Tn + ii];
+    const int Tp = (Tn + 3) & ~3;
+    const uint32_t th16 = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float inv_keep = 1.f / (1.f - p_drop);
+    for (int j0 = 0; j0 < Tn; j0 += KT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KT * F; e += 128) {
+            const int jj = e / F, f = e % F, j = j0 + jj;
+            sk[jj][f] = j < Tn ? to_f32(qkv[Plane<F>::at(j, f, b, B, QKV_C, HEADS + h)]) : 0.f;
+            sv[jj][f] = j < Tn ? to_f32(qkv[Plane<F>::at(j, f, b, B, QKV_C, 2 * HEADS + h)]) : 0.f;
+        }
+        __syncthreads();
+        const int nj = min(KT, Tn - j0);
+        u32x2 hq = {0, 0};
+        for (int jj = 0; jj < nj; ++jj) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) { s += q[f] * sk[jj][f]; dp += dO[f] * sv[jj][f]; }
+            const float p = __expf(s - lse);
+            if (p_drop > 0.f) {
+                const int j = j0 + jj;
+                if ((j & 3) == 0) hq = drop_hash4(seed, tdrop_index(bh, ii, j, Tn, Tp) >> 2);
+                dp = drop_field(hq, j & 3) >= th16 ? dp * inv_keep : 0.f;
+            }
+            const float ds = p * (dp - delta);
+#pragma unroll
+            for (int f = 0; f < F; ++f) dq[f] += ds * sk[jj][f];
+        }
+    }
+    if (live) {
+        delta_out[(long)bh * Tn + i] = delta;
+#pragma unroll
+        for (int f = 0; f < F; ++f) dqkv[Plane<F>::at(i, f, b, B, QKV_C, h)] = from_f32<T>(dq[f]);
+    }
+}
+
+// backward, key side: one thread per key frame j; queries (q, dO, lse, delta) stream through LDS.
+template <typename T, int F>
+__global__ __launch_bounds__(128) void a2d_time_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dcat, const float* __restrict__ lse_in,
+                                                               const float* __restrict__ delta_in, T* __restrict__ dqkv, int B, int Tn,
+                                                               float p_drop, unsigned long long seed) {
+    __shared__ float sq[KT][F], sdo[KT][F], sl[KT], sd[KT];
+    const int bh = blockIdx.y, b = bh / HEADS, h = bh % HEADS;
+    const int j = blockIdx.x * 128 + threadIdx.x;
+    const bool live = j < Tn;
+    const int jc = live ? j : Tn - 1;
+    float k[F], v[F], dk[F], dv[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        k[f] = to_f32(qkv[Plane<F>::at(jc, f, b, B, QKV_C, HEADS + h)]);
+        v[f] = to_f32(qkv[Plane<F>::at(jc, f, b, B, QKV_C, 2 * HEADS + h)]);
+        dk[f] = 0.f; dv[f] = 0.f;
+    }
+    const int Tp = (Tn + 3) & ~3;
+    const uint32_t th = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f);
+    const float inv_keep = 1.f / (1.f - p_drop);
+    for (int i0 = 0; i0 < Tn; i0 += KT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < KT * F; e += 128) {
+            const int iq = e / F, f = e % F, i = i0 + iq;
+            sq[iq][f] = i < Tn ? to_f32(qkv[Plane<F>::at(i, f, b, B, QKV_C, h)]) : 0.f;
+            sdo[iq][f] = i < Tn ? to_f32(dcat[Plane<F>::at(i, f, b, B, CAT_C, h)]) : 0.f;
+        }
+        if (threadIdx.x < KT) {
+            const int i = i0 + threadIdx.x;
+            sl[threadIdx.x] = i < Tn ? lse_in[(long)bh * Tn + i] : 0.f;
+            sd[threadIdx.x] = i < Tn ? delta_in[(long)bh * Tn + i] : 0.f;
+        }
+        __syncthreads();
+        const int ni = min(KT, Tn - i0);
+        for (int iq = 0; iq < ni; ++iq) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) { s += sq[iq][f] * k[f]; dp += sdo[iq][f] * v[f]; }
+            const float p = __expf(s - sl[iq]);
+            float pd = p;
+            if (p_drop > 0.f) {
+                const bool keep = dropout_keep(seed, tdrop_index(bh, i0 + iq, jc, Tn, Tp), th);
+                pd = keep ? p * inv_keep : 0.f;
+                dp = keep ? dp * inv_keep : 0.f;
+            }
+            const float ds = p * (dp - sd[iq]);
+#pragma unroll
+            for (int f = 0; f < F; ++f) { dv[f] += pd * sdo[iq][f]; dk[f] += ds * sq[iq][f]; }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            dqkv[Plane<F>::at(j, f, b, B, QKV_C, HEADS + h)] = from_f32<T>(dk[f]);
+            dqkv[Plane<F>::at(j, f, b, B, QKV_C, 2 * HEADS + h)] = from_f32<T>(dv[f]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ frequency attention
+// One workgroup per (b, h) plane.  S[f1][f2] = sum_t q[t][f1] k[t][f2] (all frames), A = softmax over f2, dropout,
+// out[t][f1] = sum_f2 A[f1][f2] v[t][f2].
+constexpr int FT = 64;           // frames per staged chunk
+
+// acc[f1][f2] += sum_t X[t][f1] Y[t][f2] over the whole plane; threads f1*F + f2 < F*F own one entry
+template <typename T, int F>
+__device__ __forceinline__ float plane_outer_sum(const T* __restrict__ X, int ldx, int chx, const T* __restrict__ Y, int ldy, int chy,
+                                                 int b, int B, int Tn, float (*sx)[F], float (*sy)[F]) {
+    const int f1 = threadIdx.x / F, f2 = threadIdx.x % F;
+    float acc = 0.f;
+    for (int t0 = 0; t0 < Tn; t0 += FT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < FT * F; e += blockDim.x) {
+            const int tt = e / F, f = e % F, t = t0 + tt;
+            sx[tt][f] = t < Tn ? to_f32(X[Plane<F>::at(t, f, b, B, ldx, chx)]) : 0.f;
+            sy[tt][f] = t < Tn ? to_f32(Y[Plane<F>::at(t, f, b, B, ldy, chy)]) : 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x < F * F) {
+#pragma unroll 8
+            for (int tt = 0; tt < FT; ++tt) acc += sx[tt][f1] * sy[tt][f2];
+        }
+    }
+    return acc;
+}
+
+template <typename T, int F>
+__global__ __launch_bounds__(512) void a2d_freq_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ cat, float* __restrict__ A_out,
+                                                           int B, int Tn, float p_drop, unsigned long long seed) {
+    static_assert(F * F <= 512, "one thread per score entry");
+    __shared__ float sx[FT][F], sy[FT][F], sA[F][F + 1];
+    const int bh = blockIdx.x, b = bh / HEADS, h = bh % HEADS;
+    const float s = plane_outer_sum<T, F>(qkv, QKV_C, h, qkv, QKV_C, HEADS + h, b, B, Tn, sx, sy);
+    if (threadIdx.x < F * F) sA[threadIdx.x / F][threadIdx.x % F] = s;
+    __syncthreads();
+    if (threadIdx.x < F) {
+        const int f1 = threadIdx.x;
+        float m = -INFINITY, l = 0.f;
+        for (int f2 = 0; f2 < F; ++f2) m = fmaxf(m, sA[f1][f2]);
+        for (int f2 = 0; f2 < F; ++f2) l += __expf(sA[f1][f2] - m);
+        const uint32_t th = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f);
+        const float inv_keep = 1.f / (1.f - p_drop);
+        for (int f2 = 0; f2 < F; ++f2) {
+            const float a = __expf(sA[f1][f2] - m) / l;
+            A_out[((long)bh * F + f1) * F + f2] = a;
+            sA[f1][f2] = (p_drop > 0.f && !dropout_keep(seed, ((uint64_t)bh * F + f1) * F + f2, th)) ? 0.f : a * (p_drop > 0.f ? inv_keep : 1.f);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Tn; t += blockDim.x) {
+        float v[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) v[f] = to_f32(qkv[Plane<F>::at(t, f, b, B, QKV_C, 2 * HEADS + h)]);
+#pragma unroll 1
+        for (int f1 = 0; f1 < F; ++f1) {
+            float o = 0.f;
+#pragma unroll
+            for (int f2 = 0; f2 < F; ++f2) o += sA[f1][f2] * v[f2];
+            cat[Plane<F>::at(t, f1, b, B, CAT_C, HEADS + h)] = from_f32<T>(o);
+        }
+    }
+}
+
+// backward: dAd[f1][f2] = sum_t dO[t][f1] v[t][f2];  dA = mask/(1-p) dAd;  dS = A (dA - rowsum(dA A));
+// dv[t][f2] = sum_f1 Ad[f1][f2] dO[t][f1];  dq[t][f1] = sum_f2 dS[f1][f2] k[t][f2];  dk[t][f2] = sum_f1 dS[f1][f2] q[t][f1].
+// The three results are ADDED to dqkv (the time-attention backward wrote its part first, same stream).
+template <typename T, int F>
+__global__ __launch_bounds__(512) void a2d_freq_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dcat, const float* __restrict__ A_in,
+                                                           T* __restrict__ dqkv, int B, int Tn, float p_drop, unsigned long long seed) {
+    __shared__ float sx[FT][F], sy[FT][F], sAd[F][F + 1], sdS[F][F + 1];
+    const int bh = blockIdx.x, b = bh / HEADS, h = bh % HEADS;
+    const float dAd = plane_outer_sum<T, F>(dcat, CAT_C, HEADS + h, qkv, QKV_C, 2 * HEADS + h, b, B, Tn, sx, sy);
+    if (threadIdx.x < F * F) sdS[threadIdx.x / F][threadIdx.x % F] = dAd;
+    __syncthreads();
+    if (threadIdx.x < F) {
+        const int f1 = threadIdx.x;
+        const uint32_t th = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f);
+        const float inv_keep = 1.f / (1.f - p_drop);
+        float a[F], dA[F], rs = 0.f;
+#pragma unroll
+        for (int f2 = 0; f2 < F; ++f2) {
+            a[f2] = A_in[((long)bh * F + f1) * F + f2];
+            const bool keep = !(p_drop > 0.f) || dropout_keep(seed, ((uint64_t)bh * F + f1) * F + f2, th);
+            const float kf = keep ? (p_drop > 0.f ? inv_keep : 1.f) : 0.f;
+            sAd[f1][f2] = a[f2] * kf;
+            dA[f2] = sdS[f1][f2] * kf;
+            rs += dA[f2] * a[f2];
+        }
+#pragma unroll
+        for (int f2 = 0; f2 < F; ++f2) sdS[f1][f2] = a[f2] * (dA[f2] - rs);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Tn; t += blockDim.x) {
+        float q[F], k[F], dO[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            q[f] = to_f32(qkv[Plane<F>::at(t, f, b, B, QKV_C, h)]);
+            k[f] = to_f32(qkv[Plane<F>::at(t, f, b, B, QKV_C, HEADS + h)]);
+            dO[f] = to_f32(dcat[Plane<F>::at(t, f, b, B, CAT_C, HEADS + h)]);
+        }
+#pragma unroll 1
+        for (int f = 0; f < F; ++f) {
+            float dq = 0.f, dk = 0.f, dv = 0.f;
+#pragma unroll
+            for (int g = 0; g < F; ++g) { dq += sdS[f][g] * k[g]; dk += sdS[g][f] * q[g]; dv += sAd[g][f] * dO[g]; }
+            const long iq = Plane<F>::at(t, f, b, B, QKV_C, h), ik = Plane<F>::at(t, f, b, B, QKV_C, HEADS + h),
+                       iv = Plane<F>::at(t, f, b, B, QKV_C, 2 * HEADS + h);
+            dqkv[iq] = from_f32<T>(to_f32(dqkv[iq]) + dq);
+            dqkv[ik] = from_f32<T>(to_f32(dqkv[ik]) + dk);
+            dqkv[iv] = from_f32<T>(to_f32(dqkv[iv]) + dv);
+        }
+    }
+}
+
+inline int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+#define A2D_DISPATCH_F(F, ...)                      \
+    do {                                            \
+        if ((F) == 20) { constexpr int FQ = 20; __VA_ARGS__; } \
+        else if ((F) == 10) { constexpr int FQ = 10; __VA_ARGS__; } \
+        else if ((F) == 21) { constexpr int FQ = 21; __VA_ARGS__; } \
+        else return S2T_ENOTSUP;                    \
+    } while (0)
+
+}  // namespace
+
+extern "C" int s2t_a2d_chan_stats(int dtype, const void* z, const void* dy, const float* prescale, const float* mean, const float* rstd,
+                                  const float* scale, const float* shift, double* sums, long M, int C, int ld_z, int ld_dy, int Cg,
+                                  int mode, void* stream) {
+    if (M <= 0) return S2T_OK;
+    if (!z || !sums || C <= 0 || C > 64 || Cg <= 0 || C % Cg || ld_z < C || (mode && (!dy || !mean || !rstd || !scale || !shift || ld_dy < C)))
+        return S2T_EINVAL;
+    long rpb = (M + 1023) / 1024; if (rpb < 256) rpb = 256;
+    const dim3 grid((unsigned)((M + rpb - 1) / rpb));
+    hipStream_t st = (hipStream_t)stream;
+    A2D_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(a2d_stats_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)z, (const bf16*)dy, prescale, mean, rstd, scale, shift, sums, M, C, ld_z, ld_dy, Cg, mode, (int)rpb),
+        hipLaunchKernelGGL(a2d_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)z, (const float*)dy, prescale, mean, rstd, scale, shift, sums, M, C, ld_z, ld_dy, Cg, mode, (int)rpb));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_bn_act(int dtype, const void* z, const float* prescale, const float* scale, const float* shift, const void* res,
+                              void* y, long M, int C, int ld_z, int ld_y, void* stream) {
+    if (M <= 0) return S2T_OK;
+    if (!z || !scale || !shift || !y || C <= 0 || ld_z < C || ld_y < C) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    A2D_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(a2d_bn_act_kernel<bf16>, dim3(grid_for(M * C)), dim3(256), 0, st, (const bf16*)z, prescale, scale, shift, (const bf16*)res, (bf16*)y, M, C, ld_z, ld_y),
+        hipLaunchKernelGGL(a2d_bn_act_kernel<float>, dim3(grid_for(M * C)), dim3(256), 0, st, (const float*)z, prescale, scale, shift, (const float*)res, (float*)y, M, C, ld_z, ld_y));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_bn_bwd(int dtype, const void* dy, const void* z, const float* prescale, const float* mean, const float* rstd,
+                              const float* scale, const float* shift, const double* sums, void* dz, long M, int C, int ld_dy, int ld_z,
+                              int Cg, double count, int training, void* stream) {
+    if (M <= 0) return S2T_OK;
+    if (!dy || !z || !mean || !rstd || !scale || !shift || !sums || !dz || C <= 0 || Cg <= 0 || C % Cg || ld_dy < C || ld_z < C || count <= 0)
+        return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    A2D_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(a2d_bn_bwd_kernel<bf16>, dim3(grid_for(M * C)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)z, prescale, mean, rstd, scale, shift, sums, (bf16*)dz, M, C, ld_dy, ld_z, Cg, count, training),
+        hipLaunchKernelGGL(a2d_bn_bwd_kernel<float>, dim3(grid_for(M * C)), dim3(256), 0, st, (const float*)dy, (const float*)z, prescale, mean, rstd, scale, shift, sums, (float*)dz, M, C, ld_dy, ld_z, Cg, count, training));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_param_grads(const double* sums, float* dgamma, float* dbeta, int Cg, void* stream) {
+    if (!sums || !dgamma || !dbeta || Cg <= 0 || Cg > 64) return S2T_EINVAL;
+    hipLaunchKernelGGL(a2d_param_grads_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, dgamma, dbeta, Cg);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_pack_w(int dst_dtype, const float* src, void* dst, float* grad, int Co, int Ci, int CP, int ld, int mode, void* stream) {
+    if (Co <= 0 || Ci <= 0) return S2T_OK;
+    if (!src || mode < 0 || mode > 2 || (mode < 2 && !dst) || (mode == 2 && !grad) || CP < (mode == 1 ? Co : Ci) || ld < 9 * CP) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = grid_for((long)Co * Ci * 9);
+    if (mode == 2) hipLaunchKernelGGL(a2d_pack_w_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)nullptr, grad, Co, Ci, CP, ld, mode);
+    else A2D_DISPATCH_T(dst_dtype,
+        hipLaunchKernelGGL(a2d_pack_w_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, (bf16*)dst, (float*)nullptr, Co, Ci, CP, ld, mode),
+        hipLaunchKernelGGL(a2d_pack_w_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, (float*)nullptr, Co, Ci, CP, ld, mode));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_time_fwd(int dtype, const void* qkv, void* cat, float* lse, int B, int T, int F, float p_drop,
+                                unsigned long long seed, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!qkv || !cat || !lse || p_drop < 0.f || p_drop >= 1.f) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, B * HEADS);
+    ProfScope prof("attn2d", st, 4.0 * B * HEADS * (double)T * T * F, 0.0);
+    A2D_DISPATCH_F(F, A2D_DISPATCH_T(dtype,
+        hipLaunchKernelGGL((a2d_time_fwd_kernel<bf16, FQ>), grid, dim3(128), 0, st, (const bf16*)qkv, (bf16*)cat, lse, B, T, p_drop, seed),
+        hipLaunchKernelGGL((a2d_time_fwd_kernel<float, FQ>), grid, dim3(128), 0, st, (const float*)qkv, (float*)cat, lse, B, T, p_drop, seed)));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_time_bwd(int dtype, const void* qkv, const void* cat, const void* dcat, const float* lse, float* delta, void* dqkv,
+                                int B, int T, int F, float p_drop, unsigned long long seed, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!qkv || !cat || !dcat || !lse || !delta || !dqkv || p_drop < 0.f || p_drop >= 1.f) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((T + 127) / 128, B * HEADS);
+    ProfScope prof("attn2d", st, 10.0 * B * HEADS * (double)T * T * F, 0.0);
+    A2D_DISPATCH_F(F, A2D_DISPATCH_T(dtype,
+        { hipLaunchKernelGGL((a2d_time_bwd_dq_kernel<bf16, FQ>), grid, dim3(128), 0, st, (const bf16*)qkv, (const bf16*)cat, (const bf16*)dcat, lse, delta, (bf16*)dqkv, B, T, p_drop, seed);
+          hipLaunchKernelGGL((a2d_time_bwd_dkv_kernel<bf16, FQ>), grid, dim3(128), 0, st, (const bf16*)qkv, (const bf16*)dcat, lse, delta, (bf16*)dqkv, B, T, p_drop, seed); },
+        { hipLaunchKernelGGL((a2d_time_bwd_dq_kernel<float, FQ>), grid, dim3(128), 0, st, (const float*)qkv, (const float*)cat, (const float*)dcat, lse, delta, (float*)dqkv, B, T, p_drop, seed);
+          hipLaunchKernelGGL((a2d_time_bwd_dkv_kernel<float, FQ>), grid, dim3(128), 0, st, (const float*)qkv, (const float*)dcat, lse, delta, (float*)dqkv, B, T, p_drop, seed); }));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_freq_fwd(int dtype, const void* qkv, void* cat, float* A, int B, int T, int F, float p_drop,
+                                unsigned long long seed, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!qkv || !cat || !A || p_drop < 0.f || p_drop >= 1.f) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    A2D_DISPATCH_F(F, A2D_DISPATCH_T(dtype,
+        hipLaunchKernelGGL((a2d_freq_fwd_kernel<bf16, FQ>), dim3(B * HEADS), dim3(512), 0, st, (const bf16*)qkv, (bf16*)cat, A, B, T, p_drop, seed),
+        hipLaunchKernelGGL((a2d_freq_fwd_kernel<float, FQ>), dim3(B * HEADS), dim3(512), 0, st, (const float*)qkv, (float*)cat, A, B, T, p_drop, seed)));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_freq_bwd(int dtype, const void* qkv, const void* dcat, const float* A, void* dqkv, int B, int T, int F,
+                                float p_drop, unsigned long long seed, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!qkv || !dcat || !A || !dqkv || p_drop < 0.f || p_drop >= 1.f) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    A2D_DISPATCH_F(F, A2D_DISPATCH_T(dtype,
+        hipLaunchKernelGGL((a2d_freq_bwd_kernel<bf16, FQ>), dim3(B * HEADS), dim3(512), 0, st, (const bf16*)qkv, (const bf16*)dcat, A, (bf16*)dqkv, B, T, p_drop, seed),
+        hipLaunchKernelGGL((a2d_freq_bwd_kernel<float, FQ>), dim3(B * HEADS), dim3(512), 0, st, (const float*)qkv, (const float*)dcat, A, (float*)dqkv, B, T, p_drop, seed)));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

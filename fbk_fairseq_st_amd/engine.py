@@ -16,6 +16,9 @@ import torch
 from . import kernels as K
 
 
+A2D_HEADS = 4                # ConvAttention2D(out_channels, 4, dropout) -- conv_transformer.py:155-157
+
+
 class HParams:
     """Static model description (what conv_transformer.py reads from `args`)."""
 
@@ -30,6 +33,7 @@ class HParams:
         self.pad = 1; self.no_scale_embedding = False
         self.V_src = 0; self.V_tgt = 0
         self.distance_penalty = False            # 'log': encoder self-attention scores -= max(0, ln|i-j|) (local_attention.py:131-133)
+        self.attn_2d = False                     # two residual ConvAttention2D blocks after the convolutions (conv_transformer.py:155-157,216-222)
         self.V_aux = 0                           # > 0: second decoder `auxiliary_decoder.*` over this vocabulary (dual-decoder model)
         self.ln_eps = 1e-5; self.bn_eps = 1e-5; self.bn_momentum = 0.1
         for k, v in kw.items():
@@ -49,6 +53,15 @@ class HParams:
         s["encoder.bn.0.weight"] = (C,); s["encoder.bn.0.bias"] = (C,)
         s["encoder.convolutions.1.weight"] = (C, C, 3, 3); s["encoder.convolutions.1.bias"] = (C,)
         s["encoder.bn.1.weight"] = (C,); s["encoder.bn.1.bias"] = (C,)
+        if self.attn_2d:
+            H = A2D_HEADS
+            for i in range(2):
+                p = "encoder.attn_2d.%d." % i
+                s[p + "in_proj_weight"] = (3 * H, C, 3, 3); s[p + "in_proj_bias"] = (3 * H,)
+                for n in ("q", "k", "v"):
+                    s[p + "bn_%s.weight" % n] = (H,); s[p + "bn_%s.bias" % n] = (H,)
+                s[p + "out_proj.weight"] = (C, 2 * H, 3, 3); s[p + "out_proj.bias"] = (C,)
+                s[p + "bn_out.weight"] = (C,); s[p + "bn_out.bias"] = (C,)
         s["encoder.fc3.weight"] = (D, C * self.F4); s["encoder.fc3.bias"] = (D,)
 
         def ln(p):
@@ -132,6 +145,21 @@ def conv2_maps(B, T2, F2, device):
     return dict(fwd=fwd, bwd=bwd, T4=T4, F4=F4)
 
 
+def attn2d_maps(B, T4, F4, device):
+    """Row maps [9][M] of a 3x3 / stride 1 / pad 1 convolution over the pixel rows r = (t*B + b)*F4 + f (index bookkeeping):
+    tap j = 3*kh + kw reads pixel (t + kh - 1, f + kw - 1), -1 outside the plane.  The data gradient uses the same maps with the
+    taps of the weights mirrored (s2t_a2d_pack_w mode 1)."""
+    t = torch.arange(T4).view(T4, 1, 1); b = torch.arange(B).view(1, B, 1); f = torch.arange(F4).view(1, 1, F4)
+    maps = []
+    for kh in range(3):
+        for kw in range(3):
+            ts = t + kh - 1; fs = f + kw - 1
+            ok = (ts >= 0) & (ts < T4) & (fs >= 0) & (fs < F4) & (b >= 0)
+            pix = (ts * B + b) * F4 + fs
+            maps.append(torch.where(ok, pix, torch.full_like(pix, -1)).reshape(-1))
+    return torch.stack(maps).to(torch.int32).contiguous().to(device)
+
+
 def _splitk(n_out, k_in, m_tokens):
     """k-slices of a weight-gradient product: enough workgroups to fill 2 per CU, a multiple of 8 when possible (one slice per
     XCD: gemm.hip deals slices to XCDs; the dW kernel folds two slices per workgroup before the f32 atomic pass); measured with
@@ -154,6 +182,7 @@ class S2TEngine:
         self.bn_buffers = None          # set by the model: dict name -> tensor (running_mean/var, num_batches)
         self.on_grads_ready = None      # callback(prefix): every gradient of parameters named prefix* is final
         self._wg_side, self._wg_on, self._wg_pending = None, False, False
+        self._a2d_prescale = None
         # LayerNorm backward also writes dropout(dx) for the block that consumes dx (one pass instead of two; identical bits)
         self.fuse_bwd_dropout = os.environ.get("S2T_FUSE_BWD_DROPOUT", "1") != "0"
         if hp.act not in ("relu", "gelu"):
@@ -175,6 +204,14 @@ class S2TEngine:
         m = self._maps.get(key)
         if m is None:
             m = conv2_maps(B, T2, F2, self.dev)
+            self._maps[key] = m
+        return m
+
+    def a2d_maps(self, B, T4, F4):
+        key = ("a2d", B, T4, F4)
+        m = self._maps.get(key)
+        if m is None:
+            m = attn2d_maps(B, T4, F4, self.dev)
             self._maps[key] = m
         return m
 
@@ -271,6 +308,12 @@ class S2TEngine:
         z2n = K.bn_apply(z2, sc2, sh2)
         if p_sub > 0:
             K.dropout(z2n, p_sub, seed + 2, out=z2n)
+        a2d = []
+        if hp.attn_2d:                           # x = x + ConvAttention2D(x), twice (conv_transformer.py:216-222)
+            for i in range(2):
+                z2n, ci = self.attn2d_block_fwd(i, z2n, B, T4, F4, training, seed + 10 + 3 * i)
+                a2d.append(ci)
+        c["a2d"] = a2d
         # fc3 on channels-last rows: weight columns re-ordered k = c*F4+f -> k' = f*C+c
         w3p = K.permute_cf(self.P("encoder.fc3.weight"), torch.empty((hp.D, F4 * C), dtype=self.dtype, device=self.dev), hp.D, C, F4, 0)
         h3 = K.gemm(z2n.view(T4 * B, F4 * C), w3p, bias=self.P("encoder.fc3.bias"), act=K.ACT_RELU)
@@ -301,6 +344,8 @@ class S2TEngine:
         K.permute_cf(gw3p, self.G("encoder.fc3.weight"), hp.D, C, F4, 1)
         K.colsum(dh3, self.G("encoder.fc3.bias"))
         dz2n = K.gemm(dh3, c["w3p"], trans_b=True).view(-1, C)
+        for ci in reversed(c["a2d"]):
+            dz2n = self.attn2d_block_bwd(ci, dz2n)
         if c["p_sub"] > 0:
             K.dropout(dz2n, c["p_sub"], c["seed"] + 2, out=dz2n)
         # BN2 backward (+ ReLU mask) -> gradient w.r.t. conv2 + bias
@@ -333,6 +378,94 @@ class S2TEngine:
                                self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"])
         K.conv1_bwd(c["x"], dpre1.view(B, c["T2"], c["F2"], C), self.G("encoder.convolutions.0.weight").view(C, 9),
                     self.G("encoder.convolutions.0.bias"))
+
+    # ------------------------------------------------------------------ ConvAttention2D
+    def _a2d_bn(self, p, names, sums, count, training):
+        """finalise the BatchNorms `names` of block p from grouped sums; returns (mean, rstd, scale, shift) over the concatenated channels"""
+        hp, bufs = self.hp, self.bn_buffers
+        parts = []
+        off = 0
+        for n in names:
+            g, b = self.P(p + n + ".weight"), self.P(p + n + ".bias")
+            Cg = g.numel()
+            parts.append(K.bn_finalize(sums[off:off + 2 * Cg] if sums is not None else None, g, b, bufs[p + n + ".running_mean"],
+                                       bufs[p + n + ".running_var"], bufs[p + n + ".num_batches_tracked"], count, training,
+                                       hp.bn_momentum, hp.bn_eps))
+            off += 2 * Cg
+        if len(parts) == 1:
+            return parts[0]
+        return tuple(torch.cat([pt[k] for pt in parts]) for k in range(4))       # copies of 4-element vectors
+
+    def attn2d_block_fwd(self, i, x, B, T4, F4, training, seed):
+        """x [M, C] channels-last pixel rows (t, b, f) -> x + relu(bn_out(conv(cat(time attention, frequency attention))))
+        (conv_attention_2d.py:46-135 with query = key = value = x, no padding mask)."""
+        hp, C, H = self.hp, self.hp.conv_ch, A2D_HEADS
+        p = "encoder.attn_2d.%d." % i
+        M = x.shape[0]
+        mp = self.a2d_maps(B, T4, F4)
+        pd = hp.dropout if training else 0.0                        # ConvAttention2D(.., dropout=self.dropout) on both attention maps
+        if self._a2d_prescale is None:                              # q *= head_dim^-0.5 with head_dim = embed_dim = C (:21-23,82), before bn_q
+            self._a2d_prescale = torch.tensor([C ** -0.5] * H + [1.0] * (16 - H), dtype=torch.float32, device=self.dev)
+        ps = self._a2d_prescale
+        w_in = K.a2d_pack_w(self.P(p + "in_proj_weight"), 16, C, self.dtype, 0)             # [16, 9C], rows 12..15 zero
+        b16 = torch.zeros(16, dtype=torch.float32, device=self.dev)
+        b16[:3 * H].copy_(self.P(p + "in_proj_bias"))
+        z = K.gemm(x, w_in, M=M, K=9 * C, map_a=mp, period_a=C, bias=b16)                    # [M, 16]
+        sums = K.a2d_chan_stats(z, 3 * H, H, prescale=ps) if training else None
+        bn_qkv = self._a2d_bn(p, ("bn_q", "bn_k", "bn_v"), sums, M, training)
+        qkv = K.a2d_bn_act(z, 3 * H, bn_qkv[2], bn_qkv[3], prescale=ps)
+        cat = torch.empty((M, 2 * H), dtype=self.dtype, device=self.dev)
+        lse = K.a2d_time_fwd(qkv, cat, B, T4, F4, pd, seed + 1)
+        A = K.a2d_freq_fwd(qkv, cat, B, T4, F4, pd, seed + 2)
+        w_out = K.a2d_pack_w(self.P(p + "out_proj.weight"), C, 2 * H, self.dtype, 0)          # [C, 72]
+        y = K.gemm(cat, w_out, M=M, K=18 * H, map_a=mp, period_a=2 * H, bias=self.P(p + "out_proj.bias"))
+        sums_o = K.a2d_chan_stats(y, C, C) if training else None
+        bn_o = self._a2d_bn(p, ("bn_out",), sums_o, M, training)
+        out = K.a2d_bn_act(y, C, bn_o[2], bn_o[3], res=x)
+        ctx = dict(p=p, x=x, z=z, qkv=qkv, cat=cat, lse=lse, A=A, y=y, bn_qkv=bn_qkv, bn_o=bn_o, B=B, T4=T4, F4=F4, pd=pd, seed=seed,
+                   training=training)
+        return out, ctx
+
+    def attn2d_block_bwd(self, c, dout):
+        """dout [M, C]: gradient w.r.t. the block output x + f(x); returns the gradient w.r.t. x."""
+        hp, C, H = self.hp, self.hp.conv_ch, A2D_HEADS
+        p, B, T4, F4 = c["p"], c["B"], c["T4"], c["F4"]
+        M = dout.shape[0]
+        mp = self.a2d_maps(B, T4, F4)
+        ps = self._a2d_prescale
+        sk = int(max(1, min(512, M // 1024)))
+        dout = dout.contiguous()
+        # bn_out + ReLU
+        s_o = K.a2d_chan_stats(c["y"], C, C, dy=dout, bn=c["bn_o"])
+        K.a2d_param_grads(s_o, self.G(p + "bn_out.weight"), self.G(p + "bn_out.bias"))
+        dy = K.a2d_bn_bwd(dout, c["y"], C, C, c["bn_o"], s_o, M, c["training"])
+        # out_proj convolution
+        K.colsum(dy, self.G(p + "out_proj.bias"))
+        gwo = torch.zeros((C, 18 * H), dtype=torch.float32, device=self.dev)
+        for tap in range(9):
+            K.gemm(dy, c["cat"], trans_a=True, trans_b=True, K=M, out=gwo[:, tap * 2 * H:(tap + 1) * 2 * H], accumulate=True,
+                   splitk=sk, map_b=mp[tap])
+        K.a2d_unpack_wgrad(gwo, self.G(p + "out_proj.weight"), 2 * H)
+        w_out_d = K.a2d_pack_w(self.P(p + "out_proj.weight"), 2 * H, C, self.dtype, 1)        # [8, 9C]
+        dcat = K.gemm(dy, w_out_d, M=M, K=9 * C, map_a=mp, period_a=C)
+        # the two attentions
+        dqkv = torch.zeros_like(c["qkv"])
+        K.a2d_time_bwd(c["qkv"], c["cat"], dcat, c["lse"], dqkv, B, T4, F4, c["pd"], c["seed"] + 1)
+        K.a2d_freq_bwd(c["qkv"], dcat, c["A"], dqkv, B, T4, F4, c["pd"], c["seed"] + 2)
+        # bn_q / bn_k / bn_v + ReLU
+        s_q = K.a2d_chan_stats(c["z"], 3 * H, H, prescale=ps, dy=dqkv, bn=c["bn_qkv"])
+        for g, n in enumerate(("bn_q", "bn_k", "bn_v")):
+            K.a2d_param_grads(s_q[2 * H * g:2 * H * (g + 1)], self.G(p + n + ".weight"), self.G(p + n + ".bias"))
+        dz = K.a2d_bn_bwd(dqkv, c["z"], 3 * H, H, c["bn_qkv"], s_q, M, c["training"], prescale=ps)
+        # in_proj convolution (+ the residual branch of x + f(x))
+        K.colsum(dz[:, :3 * H], self.G(p + "in_proj_bias"))
+        gwi = torch.zeros((16, 9 * C), dtype=torch.float32, device=self.dev)
+        for tap in range(9):
+            K.gemm(dz, c["x"], trans_a=True, trans_b=True, K=M, out=gwi[:, tap * C:(tap + 1) * C], accumulate=True, splitk=sk,
+                   map_b=mp[tap])
+        K.a2d_unpack_wgrad(gwi, self.G(p + "in_proj_weight"), C)
+        w_in_d = K.a2d_pack_w(self.P(p + "in_proj_weight"), C, 16, self.dtype, 1)            # [C, 144]
+        return K.gemm(dz, w_in_d, M=M, K=144, map_a=mp, period_a=16, residual=dout)
 
     # ------------------------------------------------------------------ transformer blocks
     def self_attn_block_fwd(self, pfx, x, klen32, causal, training, seed, dist_penalty=False):
@@ -524,7 +657,7 @@ class S2TEngine:
                 self._ready("encoder.ctc_fc.")
             self._ready(pfx)
         self.subsample_bwd(ctx["sub"], dx)
-        for n in ("encoder.fc3.", "encoder.bn.1.", "encoder.convolutions.1.", "encoder.bn.0.", "encoder.convolutions.0."):
+        for n in ("encoder.fc3.", "encoder.attn_2d.", "encoder.bn.1.", "encoder.convolutions.1.", "encoder.bn.0.", "encoder.convolutions.0."):
             self._ready(n)
 
     # ------------------------------------------------------------------ decoder

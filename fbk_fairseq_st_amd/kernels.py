@@ -403,3 +403,78 @@ def prof_read(family):
     n = ctypes.c_longlong(0)
     _lib().s2t_prof_read(family.encode(), ctypes.addressof(ms), ctypes.addressof(n), ctypes.addressof(fl), ctypes.addressof(by))
     return dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+
+
+# ------------------------------------------------------------------ ConvAttention2D pieces (csrc/attn2d.hip)
+def a2d_chan_stats(z, C, Cg, prescale=None, dy=None, bn=None):
+    """z [M, ld] channels-last; returns double sums in groups of Cg ([Cg | Cg] each).  dy + bn=(mean, rstd, scale, shift): backward sums."""
+    M = z.shape[0]
+    sums = torch.zeros((2 * C,), dtype=torch.float64, device=z.device)
+    mean, rstd, scale, shift = bn if bn is not None else (None, None, None, None)
+    L.check(_lib().s2t_a2d_chan_stats(L.dt(z), L.ptr(z), L.ptr(dy), L.ptr(prescale), L.ptr(mean), L.ptr(rstd), L.ptr(scale), L.ptr(shift),
+                                      L.ptr(sums), M, C, z.stride(0), dy.stride(0) if dy is not None else 0, Cg,
+                                      0 if dy is None else 1, L.stream()), "s2t_a2d_chan_stats")
+    return sums
+
+
+def a2d_bn_act(z, C, scale, shift, prescale=None, res=None, out=None):
+    M = z.shape[0]
+    if out is None:
+        out = torch.zeros_like(z) if res is None else torch.empty_like(res)
+    assert res is None or res.stride(0) == out.stride(0)
+    L.check(_lib().s2t_a2d_bn_act(L.dt(z), L.ptr(z), L.ptr(prescale), L.ptr(scale), L.ptr(shift), L.ptr(res), L.ptr(out), M, C,
+                                  z.stride(0), out.stride(0), L.stream()), "s2t_a2d_bn_act")
+    return out
+
+
+def a2d_bn_bwd(dy, z, C, Cg, bn, sums, count, training, prescale=None):
+    mean, rstd, scale, shift = bn
+    dz = torch.zeros_like(z)
+    L.check(_lib().s2t_a2d_bn_bwd(L.dt(z), L.ptr(dy), L.ptr(z), L.ptr(prescale), L.ptr(mean), L.ptr(rstd), L.ptr(scale), L.ptr(shift),
+                                  L.ptr(sums), L.ptr(dz), z.shape[0], C, dy.stride(0), z.stride(0), Cg, float(count), int(training),
+                                  L.stream()), "s2t_a2d_bn_bwd")
+    return dz
+
+
+def a2d_param_grads(sums, dgamma, dbeta):
+    L.check(_lib().s2t_a2d_param_grads(L.ptr(sums), L.ptr(dgamma), L.ptr(dbeta), dgamma.numel(), L.stream()), "s2t_a2d_param_grads")
+
+
+def a2d_pack_w(w, rows, CP, dtype, mode):
+    """mode 0 / 1: packed operand [rows, 9*CP] of the forward / data-gradient gathered GEMM from nn.Conv2d weights [Co,Ci,3,3]."""
+    Co, Ci = w.shape[0], w.shape[1]
+    dst = torch.zeros((rows, 9 * CP), dtype=dtype, device=w.device)
+    L.check(_lib().s2t_a2d_pack_w(L.dt(dst), L.ptr(w), L.ptr(dst), 0, Co, Ci, CP, dst.stride(0), mode, L.stream()), "s2t_a2d_pack_w")
+    return dst
+
+
+def a2d_unpack_wgrad(gp, grad, CP):
+    """grad[Co,Ci,3,3] += gp[Co, 9*CP] (f32)"""
+    Co, Ci = grad.shape[0], grad.shape[1]
+    assert gp.dtype == torch.float32 and grad.dtype == torch.float32
+    L.check(_lib().s2t_a2d_pack_w(L.F32, L.ptr(gp), 0, L.ptr(grad), Co, Ci, CP, gp.stride(0), 2, L.stream()), "s2t_a2d_pack_w")
+
+
+def a2d_time_fwd(qkv, cat, B, T, F, p_drop=0.0, seed=0):
+    lse = torch.empty((B * 4, T), dtype=torch.float32, device=qkv.device)
+    L.check(_lib().s2t_a2d_time_fwd(L.dt(qkv), L.ptr(qkv), L.ptr(cat), L.ptr(lse), B, T, F, float(p_drop), int(seed), L.stream()),
+            "s2t_a2d_time_fwd")
+    return lse
+
+
+def a2d_time_bwd(qkv, cat, dcat, lse, dqkv, B, T, F, p_drop=0.0, seed=0):
+    delta = torch.empty_like(lse)
+    L.check(_lib().s2t_a2d_time_bwd(L.dt(qkv), L.ptr(qkv), L.ptr(cat), L.ptr(dcat), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, F,
+                                    float(p_drop), int(seed), L.stream()), "s2t_a2d_time_bwd")
+
+
+def a2d_freq_fwd(qkv, cat, B, T, F, p_drop=0.0, seed=0):
+    A = torch.empty((B * 4, F, F), dtype=torch.float32, device=qkv.device)
+    L.check(_lib().s2t_a2d_freq_fwd(L.dt(qkv), L.ptr(qkv), L.ptr(cat), L.ptr(A), B, T, F, float(p_drop), int(seed), L.stream()),
+            "s2t_a2d_freq_fwd")
+    return A
+
+
+def a2d_freq_bwd(qkv, dcat, A, dqkv, B, T, F, p_drop=0.0, seed=0):
+    L.check(_lib().s2t_a2d_freq_bwd(L.dt(qkv), L.ptr(qkv), L.ptr(dcat), L.ptr(A), L.ptr(dqkv), B, T, F, float(p_drop), int(seed),
+                                    L.stream()), "s2t_a2d_freq_bwd")

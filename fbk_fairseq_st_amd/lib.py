@@ -68,6 +68,15 @@ SIGNATURES = {
     "s2t_conv2_wgrad": [c_int, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_topk": [c_int, P, P, P, c_long, c_int, c_int, c_int, P],
     "s2t_augment": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_a2d_chan_stats": [c_int, P, P, P, P, P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_a2d_bn_act": [c_int, P, P, P, P, P, P, c_long, c_int, c_int, c_int, P],
+    "s2t_a2d_bn_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_double, c_int, P],
+    "s2t_a2d_param_grads": [P, P, P, c_int, P],
+    "s2t_a2d_pack_w": [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_a2d_time_fwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
+    "s2t_a2d_time_bwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
+    "s2t_a2d_freq_fwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
+    "s2t_a2d_freq_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
     "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],
     "s2t_host_ctc_uer": [P, P, c_int, c_int, P, P, c_int, c_int, P, P],
 }

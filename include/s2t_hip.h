@@ -197,6 +197,40 @@ int s2t_add_inplace(int dtype, const void* x, void* y, size_t n, void* stream);
 /* y = x * keep/(1-p), mask from Philox(seed, index); the backward pass calls it again on the gradient */
 int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p, unsigned long long seed, void* stream);
 
+/* ---- ConvAttention2D blocks of the front end (examples/speech_recognition/modules/conv_attention_2d.py:46-135,
+ * conv_transformer.py:216-222).  Channels-last tensors over pixel rows r = (t*B + b)*F + f:
+ * x [M][C], qkv [M][16] (q 0-3 | k 4-7 | v 8-11 | 4 zero channels), cat [M][8] (time 0-3 | frequency 4-7).
+ * The two 3x3 convolutions are s2t_gemm_gather calls on the packed weights of s2t_a2d_pack_w. ------------------------- */
+/* channel moments (mode 0: sum z', z'^2 with z' = prescale[c]*z; mode 1: sum dyn, dyn*xhat with dyn = dy*[BN(z') > 0]),
+ * accumulated (double) in groups of Cg channels laid out [Cg | Cg] so that each group feeds s2t_bn_finalize */
+int s2t_a2d_chan_stats(int dtype, const void* z, const void* dy, const float* prescale, const float* mean, const float* rstd,
+                       const float* scale, const float* shift, double* sums, long M, int C, int ld_z, int ld_dy, int Cg,
+                       int mode, void* stream);
+/* y = relu(prescale*z*scale + shift) [+ res]   (nn.BatchNorm2d then ReLU, conv_attention_2d.py:92-94,121) */
+int s2t_a2d_bn_act(int dtype, const void* z, const float* prescale, const float* scale, const float* shift, const void* res,
+                   void* y, long M, int C, int ld_z, int ld_y, void* stream);
+/* gradient w.r.t. z of the above given the mode-1 sums (training: batch statistics; eval: running statistics) */
+int s2t_a2d_bn_bwd(int dtype, const void* dy, const void* z, const float* prescale, const float* mean, const float* rstd,
+                   const float* scale, const float* shift, const double* sums, void* dz, long M, int C, int ld_dy, int ld_z,
+                   int Cg, double count, int training, void* stream);
+/* dbeta += sums[0..Cg), dgamma += sums[Cg..2Cg) of one group of mode-1 sums */
+int s2t_a2d_param_grads(const double* sums, float* dgamma, float* dbeta, int Cg, void* stream);
+/* nn.Conv2d weights [Co][Ci][3][3] (f32) <-> gathered-GEMM operands, row stride ld, CP = padded channels per tap:
+ * mode 0: dst[co][j*CP+ci] = W[co][ci][j];  mode 1: dst[ci][j*CP+co] = W[co][ci][8-j];  mode 2: grad[co][ci][j] += src[co][j*CP+ci] */
+int s2t_a2d_pack_w(int dst_dtype, const float* src, void* dst, float* grad, int Co, int Ci, int CP, int ld, int mode, void* stream);
+/* time attention of every (batch, head) plane: cat[.., h] = dropout(softmax_t'(q k^T)) v ; lse [B*4][T] for the backward */
+int s2t_a2d_time_fwd(int dtype, const void* qkv, void* cat, float* lse, int B, int T, int F, float p_drop,
+                     unsigned long long seed, void* stream);
+/* writes dq, dk, dv of the time attention into dqkv (delta [B*4][T] is workspace) */
+int s2t_a2d_time_bwd(int dtype, const void* qkv, const void* cat, const void* dcat, const float* lse, float* delta, void* dqkv,
+                     int B, int T, int F, float p_drop, unsigned long long seed, void* stream);
+/* frequency attention: cat[.., 4+h] = (dropout(softmax_f'(q^T k)) v^T)^T ; A [B*4][F][F] = the probabilities before dropout */
+int s2t_a2d_freq_fwd(int dtype, const void* qkv, void* cat, float* A, int B, int T, int F, float p_drop,
+                     unsigned long long seed, void* stream);
+/* ADDS dq, dk, dv of the frequency attention to dqkv */
+int s2t_a2d_freq_bwd(int dtype, const void* qkv, const void* dcat, const float* A, void* dqkv, int B, int T, int F,
+                     float p_drop, unsigned long long seed, void* stream);
+
 /* ---- optimizer (fairseq/trainer.py:416-443, fairseq/utils.py:253-277, fairseq/optim/adam.py:147-202) ----
  * out2[0] = gnorm = scale*||g||_2 ; out2[1] = scale * min(1, max_norm/(gnorm+1e-6)) (all on device) */
 int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, float scale, float max_norm, float* out2, void* stream);

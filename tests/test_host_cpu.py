@@ -75,9 +75,10 @@ def test_model_refuses_cpu_inputs():
 
 
 def test_unsupported_options_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        a = tiny_args(no_attn_2d=False)
-        tiny_task(a).build_model(a)
+    a = tiny_args(no_attn_2d=False)                       # the default front end (ConvAttention2D blocks) builds
+    m = tiny_task(a).build_model(a)
+    assert m.hp.attn_2d and "encoder.attn_2d.1.bn_out.running_var" in m.state_dict()
+    assert tuple(m.state_dict()["encoder.attn_2d.0.in_proj_weight"].shape) == (12, 64, 3, 3)
     with pytest.raises(NotImplementedError):
         a = tiny_args(distance_penalty="gauss")            # `log` is built; the learnable-variance form is not
         tiny_task(a).build_model(a)

@@ -587,3 +587,117 @@ def test_conv2_wgrad_all_taps_kernel(B, T2, F2):
     K.conv2_wgrad(dpre.to(DEV), y1n.to(DEV).view(-1, C), gw, B, T2, F2, C)     # accumulates
     assert float((gw.cpu().view(C, 9, C).permute(0, 2, 1).reshape(C, C, 3, 3) - 2 * ref).abs().max() / ref.abs().max()) < 4e-3
     assert not K.conv2_wgrad(dpre.float().to(DEV), y1n.float().to(DEV).view(-1, C), gw, B, T2, F2, C)      # fp32: not covered
+
+
+# ------------------------------------------------------------------ ConvAttention2D pieces (csrc/attn2d.hip)
+def _planes(t, B, T, Fq, C, ch):
+    """[M, C] channels-last rows (t, b, f) -> [B, T, Fq] plane of channel ch"""
+    return t.view(T, B, Fq, C)[..., ch].permute(1, 0, 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,Fq", [(2, 37, 20), (3, 150, 20), (1, 70, 10)])
+def test_attn2d_time_and_frequency_attention(dtype, B, T, Fq):
+    """both attentions of conv_attention_2d.py:96-120 (no mask, no dropout), forward and backward, against torch"""
+    H, M = 4, T * B * Fq
+    qkv = torch.zeros(M, 16); qkv[:, :12] = torch.relu(rnd(M, 12, seed=1, scale=0.8))
+    qkv = qkv.to(dtype)
+    dcat = rnd(M, 8, dtype=dtype, seed=2)
+    x = qkv.float().clone().requires_grad_(True)
+    o_t, o_f = [], []
+    for h in range(H):
+        q, k, v = _planes(x, B, T, Fq, 16, h), _planes(x, B, T, Fq, 16, 4 + h), _planes(x, B, T, Fq, 16, 8 + h)
+        o_t.append(torch.softmax(q @ k.transpose(1, 2), -1) @ v)
+        o_f.append((torch.softmax(q.transpose(1, 2) @ k, -1) @ v.transpose(1, 2)).transpose(1, 2))
+    ref = torch.stack(o_t + o_f, -1).permute(1, 0, 2, 3).reshape(M, 8)          # [B,T,F,8] -> rows (t,b,f)
+    ref.backward(dcat.float())
+    qd, dd = qkv.to(DEV), dcat.to(DEV)
+    cat = torch.empty(M, 8, dtype=dtype, device=DEV)
+    lse = K.a2d_time_fwd(qd, cat, B, T, Fq)
+    A = K.a2d_freq_fwd(qd, cat, B, T, Fq)
+    assert rel_err(cat, ref.detach()) < tol(dtype)
+    assert abs(float(A.sum(-1).mean()) - 1.0) < 1e-5
+    dq = torch.zeros_like(qd)
+    K.a2d_time_bwd(qd, cat, dd, lse, dq, B, T, Fq)
+    K.a2d_freq_bwd(qd, dd, A, dq, B, T, Fq)
+    assert rel_err(dq[:, :12], x.grad[:, :12]) < 3 * tol(dtype)
+    assert float(dq[:, 12:].abs().max()) == 0.0
+
+
+def test_attn2d_dropout_is_an_unbiased_mask_and_backward_is_its_adjoint():
+    B, T, Fq, M = 2, 64, 20, 2 * 64 * 20
+    qkv = torch.zeros(M, 16); qkv[:, :12] = torch.relu(rnd(M, 12, seed=3, scale=0.5))
+    qd = qkv.to(DEV)
+    cat0 = torch.empty(M, 8, device=DEV); cat1 = torch.empty(M, 8, device=DEV); cat2 = torch.empty(M, 8, device=DEV)
+    K.a2d_time_fwd(qd, cat0, B, T, Fq); K.a2d_freq_fwd(qd, cat0, B, T, Fq)
+    lse = K.a2d_time_fwd(qd, cat1, B, T, Fq, 0.25, 11); A = K.a2d_freq_fwd(qd, cat1, B, T, Fq, 0.25, 12)
+    K.a2d_time_fwd(qd, cat2, B, T, Fq, 0.25, 11); K.a2d_freq_fwd(qd, cat2, B, T, Fq, 0.25, 12)
+    assert torch.equal(cat1, cat2) and not torch.equal(cat0, cat1)
+    assert abs(float(cat1[:, :4].mean() / cat0[:, :4].mean()) - 1.0) < 0.02        # E[mask/(1-p)] = 1
+    # the outputs are linear in v for a fixed mask: <dO, O(v)> = <dv, v>
+    do = rnd(M, 8, seed=4).to(DEV)
+    dq = torch.zeros_like(qd)
+    K.a2d_time_bwd(qd, cat1, do, lse, dq, B, T, Fq, 0.25, 11)
+    K.a2d_freq_bwd(qd, do, A, dq, B, T, Fq, 0.25, 12)
+    lhs = float((do.double() * cat1.double()).sum()); rhs = float((dq[:, 8:12].double() * qd[:, 8:12].double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attn2d_batchnorm_relu_pieces(dtype):
+    """grouped statistics -> s2t_bn_finalize -> BN + ReLU (+ residual) and its backward against torch batch_norm (training mode)"""
+    M, C, Cg = 1500, 12, 4
+    z = torch.zeros(M, 16); z[:, :C] = rnd(M, C, seed=5, scale=1.5) + 0.3
+    z = z.to(dtype)
+    ps = torch.tensor([0.125] * 4 + [1.0] * 12)
+    gam, bet = 1 + 0.1 * rnd(C, seed=6), 0.1 * rnd(C, seed=7)
+    dy = torch.zeros(M, 16); dy[:, :C] = rnd(M, C, seed=8); dy = dy.to(dtype)
+    zf = z.float().clone().requires_grad_(True); gf = gam.clone().requires_grad_(True); bf = bet.clone().requires_grad_(True)
+    zz = (zf * ps)[:, :C]
+    ref = torch.relu(F.batch_norm(zz.t().reshape(1, C, M), None, None, gf, bf, True, 0.1, 1e-5)).reshape(C, M).t()
+    ref.backward(dy.float()[:, :C])
+    zd, psd = z.to(DEV), ps.to(DEV)
+    sums = K.a2d_chan_stats(zd, C, Cg, prescale=psd)
+    parts = []
+    for gi in range(3):
+        rm, rv = torch.zeros(Cg, device=DEV), torch.ones(Cg, device=DEV)
+        parts.append(K.bn_finalize(sums[8 * gi:8 * gi + 8], gam[4 * gi:4 * gi + 4].to(DEV), bet[4 * gi:4 * gi + 4].to(DEV), rm, rv,
+                                   torch.zeros(1, dtype=torch.int64, device=DEV), M, True))
+        zg = zz[:, 4 * gi:4 * gi + 4].detach()
+        assert rel_err(rm, 0.1 * zg.mean(0)) < 1e-3 and rel_err(rv, 0.9 + 0.1 * zg.var(0, unbiased=True)) < 1e-3
+    bn = tuple(torch.cat([pt[k] for pt in parts] + [torch.zeros(4, device=DEV)]) for k in range(4))
+    y = K.a2d_bn_act(zd, C, bn[2], bn[3], prescale=psd)
+    assert rel_err(y[:, :C], ref.detach()) < tol(dtype) and float(y[:, C:].abs().max()) == 0.0
+    s1 = K.a2d_chan_stats(zd, C, Cg, prescale=psd, dy=dy.to(DEV), bn=bn)
+    dz = K.a2d_bn_bwd(dy.to(DEV), zd, C, Cg, bn, s1, M, True, prescale=psd)
+    assert rel_err(dz[:, :C], zf.grad[:, :C]) < 3 * tol(dtype)
+    dg, db = torch.zeros(Cg, device=DEV), torch.zeros(Cg, device=DEV)
+    K.a2d_param_grads(s1[8:16], dg, db)
+    assert rel_err(dg, gf.grad[4:8]) < (1e-3 if dtype == torch.float32 else 3e-2) and rel_err(db, bf.grad[4:8]) < (1e-3 if dtype == torch.float32 else 3e-2)
+
+
+def test_attn2d_convolutions_as_gathered_gemms():
+    """3x3 / pad 1 convolution forward, data gradient and weight gradient through the row maps + packed weights, against torch"""
+    from fbk_fairseq_st_amd.engine import attn2d_maps
+    B, T, Fq, Ci, Co = 2, 9, 20, 8, 64
+    M = T * B * Fq
+    x = rnd(M, Ci, seed=1); w = rnd(Co, Ci, 3, 3, seed=2, scale=0.3); bias = 0.1 * rnd(Co, seed=3); dy = rnd(M, Co, seed=4)
+    xi = x.view(T, B, Fq, Ci).permute(1, 3, 0, 2).clone().requires_grad_(True)          # [B,Ci,T,F]
+    wf = w.clone().requires_grad_(True)
+    ref = F.conv2d(xi, wf, bias, padding=1)
+    ref.backward(dy.view(T, B, Fq, Co).permute(1, 3, 0, 2))
+    ref_rows = ref.detach().permute(2, 0, 3, 1).reshape(M, Co)
+    mp = attn2d_maps(B, T, Fq, DEV)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    w0 = K.a2d_pack_w(w.to(DEV), Co, Ci, torch.float32, 0)
+    y = K.gemm(xd, w0, M=M, K=9 * Ci, map_a=mp, period_a=Ci, bias=bias.to(DEV))
+    assert rel_err(y, ref_rows) < 1e-4
+    w1 = K.a2d_pack_w(w.to(DEV), Ci, Co, torch.float32, 1)
+    dx = K.gemm(dyd, w1, M=M, K=9 * Co, map_a=mp, period_a=Co)
+    assert rel_err(dx, xi.grad.permute(2, 0, 3, 1).reshape(M, Ci)) < 1e-4
+    gp = torch.zeros(Co, 9 * Ci, device=DEV)
+    for tap in range(9):
+        K.gemm(dyd, xd, trans_a=True, trans_b=True, K=M, out=gp[:, tap * Ci:(tap + 1) * Ci], accumulate=True, splitk=2, map_b=mp[tap])
+    gw = torch.zeros(Co, Ci, 3, 3, device=DEV)
+    K.a2d_unpack_wgrad(gp, gw, Ci)
+    assert rel_err(gw, wf.grad) < 1e-4

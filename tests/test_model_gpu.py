@@ -574,3 +574,85 @@ def test_bf16_long_sequences_match_the_fp32_engine():
     assert abs(l16 - l32) < 2e-2 * abs(l32) and abs(c16 - c32) < 2e-2 * abs(c32), (l16, l32)
     bad = {n: (g16[n], g32[n]) for n in g32 if abs(g16[n] - g32[n]) > 6e-2 * max(g32[n], 1e-3 * max(g32.values()))}
     assert not bad, bad
+
+
+# ------------------------------------------------------------------ ConvAttention2D front end
+def _build_attn2d(dtype=torch.float32):
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import namespace
+    from test_oracle_golden import _attn2d_case
+    g, cfg, W, sample, blank = _attn2d_case()
+    args = namespace(arch="conv_transformer", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+                     label_smoothing=0.1, ctc_compress_out=True, ctc_encoder_layer=cfg["ctc_layer"], ctc_weight=1.0,
+                     encoder_embed_dim=cfg["D"], encoder_ffn_embed_dim=cfg["ffn"], encoder_attention_heads=cfg["heads"],
+                     encoder_layers=cfg["enc_layers"], decoder_layers=cfg["dec_layers"],          # no --no-attn-2d: the default front end
+                     decoder_embed_dim=cfg["D"], decoder_ffn_embed_dim=cfg["ffn"], decoder_attention_heads=cfg["heads"],
+                     input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False)
+    tgt, src = Dictionary.synthetic(96), Dictionary.synthetic(59)
+    src.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationCTCTask(args, tgt, src)
+    model = task.build_model(args)
+    crit = task.build_criterion(args)
+    assert model.hp.attn_2d
+    model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+    model.hp.sub_dropout = 0.0
+    model.materialize(DEV, dtype, extra=crit.arena_params())
+    return g, cfg, W, sample, blank, model, crit
+
+
+def test_conv_attention_2d_front_end_matches_reference():
+    """G17 on the GPU: the default front end (two residual ConvAttention2D blocks) against the reference: loss, every gradient norm,
+    selected gradients, BatchNorm running statistics of the blocks, encoder output in train and eval mode; state-dict names."""
+    from fbk_fairseq_st_amd.conv_transformer import fused_to_reference
+    g, cfg, W, sample, blank, model, crit = _build_attn2d()
+    assert set(str(k) for k in g["statedict_keys"]) <= set(model.state_dict())
+    s = to_dev(sample)
+    model.eval(); crit.eval()
+    with torch.no_grad():
+        loss, _, _ = crit(model, s)
+        eo = model.encoder(s["net_input"]["src_tokens"], s["net_input"]["src_lengths"])
+    close(loss, g["eval_loss"], 1e-4, "eval loss")
+    close(eo.encoder_out, g["eval_encoder_out"], 1e-4, "eval encoder_out")
+    assert eo.src_lengths.tolist() == g["eval_src_lengths_out"].tolist()
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    loss, ss, log = crit(model, s)
+    loss.backward()
+    close(loss, g["train_loss"], 1e-4, "train loss")
+    close(log["ctc_loss"], g["train_log_ctc_loss"], 1e-4, "ctc"); close(log["nll_loss"], g["train_log_nll_loss"], 1e-4, "nll")
+    _check_gradnorms_gpu(g, model)
+    grads = fused_to_reference({n: model.arena.g(n).detach().cpu().clone() for n in model.arena.slices})
+    for k in g:
+        if k.startswith("grad_"):
+            close(grads[k[5:]], g[k], 5e-4, k)
+    sd = model.state_dict()
+    for k in g:
+        if k.startswith("train_stat_"):
+            close(sd[k[len("train_stat_"):]], g[k], 1e-4, k)
+
+
+def test_conv_attention_2d_bf16_and_dropout():
+    """bf16 engine close to the fp32 reference numbers; with dropout the step runs, is reproducible for a seed and changes the loss"""
+    g, cfg, W, sample, blank, model, crit = _build_attn2d(torch.bfloat16)
+    s = to_dev(sample)
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    loss, _, _ = crit(model, s)
+    loss.backward()
+    assert abs(float(loss) - float(g["train_loss"])) < 0.03 * float(g["train_loss"])
+    ref = float(np.sqrt((g["gradnorm_vals"] ** 2).sum())); gn = float(model.arena.grad.norm())
+    assert abs(gn - ref) < 0.1 * ref
+    g, cfg, W, sample, blank, model, crit = _build_attn2d()
+    model.hp.dropout = 0.3
+    model.train(); crit.train()
+    outs = []
+    for rep in range(2):
+        model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+        model.set_seed(77)
+        model.arena.zero_grad()
+        loss, _, _ = crit(model, s)
+        loss.backward()
+        outs.append((float(loss), float(model.arena.grad.norm())))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[0][0]) and abs(outs[0][1] - outs[1][1]) <= 1e-4 * outs[0][1]
+    assert abs(outs[0][0] - float(g["train_loss"])) > 1e-3 and np.isfinite(outs[0][1])
