@@ -63,7 +63,7 @@ def build_all(args, device, dtype):
     a = namespace(arch=args.arch, task="dummy_s2t", criterion="ctc_multi_loss",
                   underlying_criterion="label_smoothed_cross_entropy", label_smoothing=0.1, sentence_avg=True,
                   ctc_compress_out=True, ctc_encoder_layer=args.ctc_layer, ctc_weight=1.0, ctc_compress_strategy="avg",
-                  input_feat_per_channel=80, no_attn_2d=True, dict_size=8000 - 4, src_dict_size=5000 - 4,
+                  input_feat_per_channel=80, no_attn_2d=not args.attn_2d, dict_size=8000 - 4, src_dict_size=5000 - 4,
                   batch_size=args.batch, frames=args.frames, tgt_len=args.tgt_len, transcript_len=args.tgt_len,
                   lr=[5e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=20.0,
                   warmup_updates=4000, warmup_init_lr=3e-4, seed=1, bf16=(dtype == torch.bfloat16), bucket_cap_mb=64)
@@ -129,7 +129,11 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--prof-steps", type=int, default=4)
+    ap.add_argument("--attn-2d", action="store_true", help="diagnostic (not the headline workload, which is --no-attn-2d as in "
+                    "BASELINE.md): keep the two ConvAttention2D blocks of the default front end; skips the CPU baseline")
     args = ap.parse_args()
+    if args.attn_2d:
+        args.cpu_baseline = False
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -206,8 +210,9 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "%s + ctc_multi_loss(ctc-compress-out @ layer %d) full update, %d x %d x 80 fbank per GPU, "
-                                      "tgt/transcript len %d, V_tgt 8000, V_src 5001, dropout on" %
-                                      (args.arch, args.ctc_layer, args.batch, args.frames, args.tgt_len),
+                                      "tgt/transcript len %d, V_tgt 8000, V_src 5001, dropout on%s" %
+                                      (args.arch, args.ctc_layer, args.batch, args.frames, args.tgt_len,
+                                       ", WITH ConvAttention2D (diagnostic)" if args.attn_2d else ""),
                           "global_batch": args.batch * world, "frames_per_step": frames_per_step * world, "parallelism": "dp%d" % world},
                "loss": round(stats.get("loss", float("nan")) / max(stats.get("sample_size", 1), 1), 4),
                "gnorm": round(stats.get("gnorm", float("nan")), 4)}

@@ -633,7 +633,7 @@ def conv_transformer_giant(args):                                  # :549-586
 def _s2t(args, D, Ff, H, EL, DL, p, conv="[(64, 3, 3)] * 2"):
     """Build-defined presets named by BASELINE.json: conv_transformer structure, S2T sizes."""
     args.dropout = getattr(args, "dropout", None) if getattr(args, "dropout", None) is not None else p
-    args.no_attn_2d = True
+    args.no_attn_2d = getattr(args, "no_attn_2d", True)          # off unless asked for explicitly (BASELINE.md workload)
     _common(args); _sizes(args, D, Ff, H, EL, DL, conv)
 
 
