@@ -13,7 +13,8 @@ re-gathered; every floating-point operation of a step (embedding, the six decode
 in-place K/V rows, output projection, log-softmax) is a libs2t_hip.so kernel; torch is used for the
 integer selection bookkeeping (top-k, gathers of token/score rows) exactly as the reference does.
 Ensembles, sampling, prefix tokens, n-gram blocking and attention/alignment output are not part of this
-path (they raise).
+path (they raise).  `TwoPhaseSequenceGenerator` runs the same loop twice for dual-decoder
+models: transcripts with the auxiliary decoder, then translations seeded by the transcript scores.
 """
 import math
 
@@ -37,6 +38,20 @@ class BeamSearch:
         else:
             cand = (lprobs + scores[:, :, step - 1].unsqueeze(-1)).view(B, beam * V)
         k = min(2 * beam, cand.shape[1] - 1)                              # -1: pad is never selected (search.py:71-75)
+        top_s, top_i = torch.topk(cand, k)
+        return top_s, top_i % V, top_i // V
+
+
+class HierarchicalBeamSearch(BeamSearch):
+    """twophase_sequence_generator.py:17-49: at step 0 every beam slot competes, each starting from the score handed over by the
+    previous search (`prev_scores` [B, beam, 1]); later steps are BeamSearch.step."""
+
+    def step(self, step, lprobs, scores, prev_scores=None):
+        if step > 0 or prev_scores is None:
+            return super().step(step, lprobs, scores)
+        B, beam, V = lprobs.shape
+        cand = (lprobs + prev_scores).view(B, beam * V)
+        k = min(2 * beam, cand.shape[1] - 1)
         top_s, top_i = torch.topk(cand, k)
         return top_s, top_i % V, top_i // V
 
@@ -76,21 +91,36 @@ class SequenceGenerator:
     def _generate(self, model, sample, bos_token):
         net_input = sample["net_input"]
         src_tokens = net_input["src_tokens"]
-        dev = src_tokens.device
         B, src_len = src_tokens.shape[0], src_tokens.shape[1]
-        beam, V = self.beam_size, self.vocab_size
         max_len = min(int(self.max_len_a * src_len + self.max_len_b), model.max_decoder_positions() - 1)
         assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
+        enc = self._encode(model, net_input)
+        hyps = self._beam_search(model.decoder, enc, B, src_tokens.device, max_len, self.search, bos_token,
+                                 self.pad, self.unk, self.eos, self.vocab_size)
+        for hs in hyps:
+            for h in hs:
+                h.pop("origin")
+        return hyps
 
+    def _encode(self, model, net_input):
+        """encoder output with one copy per hypothesis slot (sequence_generator.py:176-196)"""
+        B = net_input["src_tokens"].shape[0]
         enc = model.encoder.forward_non_torchscript(net_input)
-        order0 = torch.arange(B, device=dev).repeat_interleave(beam)
-        enc = model.encoder.reorder_encoder_out(enc, order0)              # one copy of the encoder output per hypothesis
-        state = model.decoder.begin_incremental(enc, max_len + 1)
+        order0 = torch.arange(B, device=net_input["src_tokens"].device).repeat_interleave(self.beam_size)
+        return model.encoder.reorder_encoder_out(enc, order0)
+
+    def _beam_search(self, decoder, enc, B, dev, max_len, search, bos_token, pad, unk, eos, V, prev_scores=None):
+        """The search loop of sequence_generator.py:198-500 over `decoder` (incremental HIP decoder).  prev_scores [B, beam, 1]:
+        starting scores of the slots for a HierarchicalBeamSearch.  Every hypothesis also records `origin`, the slot of step 0 it
+        descends from.  Returns per sentence the finalized hypotheses, best first."""
+        beam = self.beam_size
+        state = decoder.begin_incremental(enc, max_len + 1)
 
         N = B * beam
         scores = torch.zeros((N, max_len + 1), dtype=torch.float32, device=dev)
-        tokens = torch.full((N, max_len + 2), self.pad, dtype=torch.int64, device=dev)
-        tokens[:, 0] = self.eos if bos_token is None else bos_token
+        tokens = torch.full((N, max_len + 2), pad, dtype=torch.int64, device=dev)
+        tokens[:, 0] = eos if bos_token is None else bos_token
+        origin = torch.arange(beam, device=dev).repeat(B)
         blacklist = torch.zeros((B, beam), dtype=torch.bool, device=dev)
         done = torch.zeros((B,), dtype=torch.bool, device=dev)           # sentence already has `beam` hypotheses
         finalized = [[] for _ in range(B)]
@@ -102,27 +132,30 @@ class SequenceGenerator:
         reorder = None
         for step in range(max_len + 1):                                   # one extra step for the EOS marker
             if reorder is not None:
-                model.decoder.reorder_incremental(state, reorder)
-            logits = model.decoder.step_incremental(state, tokens[:, step])
+                decoder.reorder_incremental(state, reorder)
+            logits = decoder.step_incremental(state, tokens[:, step])
             lprobs = K.log_softmax(logits, self.temperature)              # f32 [N, V]
             lprobs[lprobs != lprobs] = -math.inf
-            lprobs[:, self.pad] = -math.inf
-            lprobs[:, self.unk] -= self.unk_penalty
+            lprobs[:, pad] = -math.inf
+            lprobs[:, unk] -= self.unk_penalty
             if step >= max_len:
-                lprobs[:, :self.eos] = -math.inf
-                lprobs[:, self.eos + 1:] = -math.inf
+                lprobs[:, :eos] = -math.inf
+                lprobs[:, eos + 1:] = -math.inf
             elif step < self.min_len:
-                lprobs[:, self.eos] = -math.inf
+                lprobs[:, eos] = -math.inf
 
-            cand_scores, cand_tok, cand_beam = self.search.step(step, lprobs.view(B, beam, V), scores.view(B, beam, -1))
+            if prev_scores is not None:
+                cand_scores, cand_tok, cand_beam = search.step(step, lprobs.view(B, beam, V), scores.view(B, beam, -1), prev_scores)
+            else:
+                cand_scores, cand_tok, cand_beam = search.step(step, lprobs.view(B, beam, V), scores.view(B, beam, -1))
             k = cand_scores.shape[1]
             cand_row = cand_beam + row0                                    # row of the parent hypothesis in tokens/scores
 
-            eos_mask = cand_tok.eq(self.eos) & cand_scores.ne(-math.inf)
+            eos_mask = cand_tok.eq(eos) & cand_scores.ne(-math.inf)
             eos_mask[:, :beam] &= ~blacklist
             top_eos = eos_mask[:, :beam] & ~done.unsqueeze(1)
             if bool(top_eos.any()):                                        # the step's only host sync
-                self._finalize(step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len)
+                self._finalize(step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len, eos, origin)
                 done = torch.tensor(finished, device=dev)
                 if all(finished):
                     break
@@ -140,6 +173,7 @@ class SequenceGenerator:
             if step > 0:
                 scores[:, :step] = scores.index_select(0, parent)[:, :step]
             scores[:, step] = torch.gather(cand_scores, 1, pick).view(-1)
+            origin = origin.index_select(0, parent)
             reorder = parent
 
         out = []
@@ -148,14 +182,15 @@ class SequenceGenerator:
             out.append([hyps[i] for i in reversed(idx)])
         return out
 
-    def _finalize(self, step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len):
+    def _finalize(self, step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len, eos, origin):
         """sequence_generator.py:502-600 finalize_hypos: hypotheses ending in EOS among the top `beam` candidates."""
         beam = self.beam_size
         sent, rank = top_eos.nonzero(as_tuple=True)                       # row-major: sentence ascending, rank ascending
         rows = cand_row[sent, rank]
         eos_s = cand_scores[sent, rank]
         toks = tokens.index_select(0, rows)[:, 1:step + 2].clone()
-        toks[:, step] = self.eos
+        toks[:, step] = eos
+        org = origin.index_select(0, rows).tolist()
         pos = scores.index_select(0, rows)[:, :step + 1].clone()
         pos[:, step] = eos_s
         pos[:, 1:] = pos[:, 1:] - pos[:, :-1]
@@ -164,7 +199,52 @@ class SequenceGenerator:
         for i, s in enumerate(sent.tolist()):
             if len(finalized[s]) < beam:
                 finalized[s].append({"tokens": toks[i], "score": eos_s[i], "attention": None, "alignment": None,
-                                     "positional_scores": pos[i]})
+                                     "positional_scores": pos[i], "origin": org[i]})
         for s in set(sent.tolist()):
             if not finished[s] and (len(finalized[s]) == beam or step == max_len):
                 finished[s] = True
+
+
+class TwoPhaseSequenceGenerator(SequenceGenerator):
+    """Generation with the dual-decoder model (examples/speech_recognition/twophase_sequence_generator.py:52-170, built by the
+    `speech_translation_dualdecoding` task): (1) beam search with `model.auxiliary_decoder` over the transcript dictionary ->
+    `beam` transcript hypotheses per sentence (:477-762); (2) HierarchicalBeamSearch with `model.decoder`: slot i starts from the
+    normalised score of transcript hypothesis i (:171-475; the dual-decoder's target decoder does not read the transcript,
+    conv_transformer_dualdecoder.py:83-84).  The target length limit uses the longest transcript hypothesis of the batch as
+    `src_len` (:178,213-218).  Every returned hypothesis carries `aux_tokens`, the transcript it descends from (:966-975)."""
+
+    def __init__(self, models, src_dict, tgt_dict, **kw):
+        super().__init__(models, tgt_dict, **kw)
+        if not hasattr(self.models[0], "auxiliary_decoder"):
+            raise TypeError("TwoPhaseSequenceGenerator needs a model with an auxiliary decoder (conv_transformer_dualdecoder)")
+        self.src_pad, self.src_unk = src_dict.pad(), src_dict.unk()
+        self.src_eos = src_dict.eos() if kw.get("eos") is None else kw["eos"]
+        self.src_vocab_size = len(src_dict)
+        self.src_search = BeamSearch(src_dict)
+        self.search = HierarchicalBeamSearch(tgt_dict)
+        if self.beam_size > self.src_vocab_size - 1:
+            raise ValueError("beam larger than the transcript vocabulary")
+
+    def _generate(self, model, sample, bos_token):
+        net_input = sample["net_input"]
+        src_tokens = net_input["src_tokens"]
+        dev = src_tokens.device
+        B, src_len = src_tokens.shape[0], src_tokens.shape[1]
+        beam = self.beam_size
+        max_pos = model.max_decoder_positions() - 1
+        max_len = min(int(self.max_len_a * src_len + self.max_len_b), max_pos)
+        assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
+        enc = self._encode(model, net_input)
+        aux = self._beam_search(model.auxiliary_decoder, enc, B, dev, max_len, self.src_search, bos_token,
+                                self.src_pad, self.src_unk, self.src_eos, self.src_vocab_size)
+        assert all(len(hs) == beam for hs in aux)
+        max_aux_len = max(h["tokens"].shape[0] for hs in aux for h in hs)
+        max_len2 = min(int(self.max_len_a * max_aux_len + self.max_len_b), max_pos)
+        assert self.min_len <= max_len2, "min_len cannot be larger than max_len, please adjust these!"
+        prev_scores = torch.stack([h["score"] for hs in aux for h in hs]).view(B, beam, 1)
+        hyps = self._beam_search(model.decoder, enc, B, dev, max_len2, self.search, bos_token, self.pad, self.unk, self.eos,
+                                 self.vocab_size, prev_scores=prev_scores)
+        for b, hs in enumerate(hyps):
+            for h in hs:
+                h["aux_tokens"] = aux[b][h.pop("origin")]["tokens"]
+        return hyps

@@ -91,6 +91,22 @@ class SpeechTranslationCTCTask(FairseqTask):
         return (getattr(self.args, "max_source_positions", 1024), getattr(self.args, "max_target_positions", 1024))
 
 
+@register_task("speech_translation_dualdecoding")
+class SpeechTranslationDualDecodingTask(SpeechTranslationCTCTask):
+    """tasks/speech_translation_dualdecoding.py:16-38: the CTC task whose generator is the two-phase one (transcript first, then
+    translation) for dual-decoder models."""
+
+    def build_generator(self, models, args):
+        from .sequence_generator import TwoPhaseSequenceGenerator
+        return TwoPhaseSequenceGenerator(models, self.source_dictionary, self.target_dictionary, beam_size=getattr(args, "beam", 5),
+                                         max_len_a=getattr(args, "max_len_a", 0), max_len_b=getattr(args, "max_len_b", 200),
+                                         min_len=getattr(args, "min_len", 1), normalize_scores=(not getattr(args, "unnormalized", False)),
+                                         len_penalty=getattr(args, "lenpen", 1), unk_penalty=getattr(args, "unkpen", 0),
+                                         temperature=getattr(args, "temperature", 1.0),
+                                         match_source_len=getattr(args, "match_source_len", False),
+                                         no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0))
+
+
 @register_task("dummy_s2t")
 class DummyS2TTask(SpeechTranslationCTCTask):
     """Synthetic 80-mel filterbank batches of a fixed shape; dictionaries of the requested sizes."""

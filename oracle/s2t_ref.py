@@ -300,13 +300,65 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
 
 
 # ------------------------------------------------------------------ generation (a22)
+def _beam_search_sentence(W, cfg, eo, n, beam, max_len, min_len, len_penalty, unk_penalty, temperature, normalize, eos, unk,
+                          pfx="decoder.", prev_scores=None):
+    """One sentence of SequenceGenerator._generate + BeamSearch.step (fairseq/sequence_generator.py:163-500, fairseq/search.py:50-85),
+    without incremental state (the full prefix is re-decoded every step).  prev_scores [beam]: HierarchicalBeamSearch.step
+    (twophase_sequence_generator.py:22-49) -- at step 0 EVERY beam slot competes, each starting from its own score.
+    Returns (tokens, score, positional_scores, origin slot) tuples sorted best first."""
+    pad = cfg["pad"]
+    toks = torch.full((beam, 1), eos, dtype=torch.long)
+    cum = torch.zeros((beam, 0))
+    blacklist = [False] * beam
+    origin = list(range(beam))
+    fin = []
+    for step in range(max_len + 1):
+        logits = decoder_forward(W, cfg, toks, eo.expand(n, beam, eo.shape[2]), None, pfx=pfx)[:, -1, :]
+        lp = torch.log_softmax(logits / temperature, dim=-1)
+        lp[lp != lp] = -math.inf
+        lp[:, pad] = -math.inf
+        lp[:, unk] -= unk_penalty
+        if step >= max_len:
+            keep = lp[:, eos].clone(); lp[:] = -math.inf; lp[:, eos] = keep
+        elif step < min_len:
+            lp[:, eos] = -math.inf
+        V = lp.shape[1]
+        if step == 0:
+            cand = lp[0] if prev_scores is None else (lp + prev_scores.view(-1, 1)).reshape(-1)
+        else:
+            cand = (lp + cum[:, step - 1:step]).reshape(-1)
+        k = min(2 * beam, cand.numel() - 1)
+        cs, ci = torch.topk(cand, k)
+        ctok, cbeam = (ci % V).tolist(), (ci // V).tolist()
+        is_eos = [ctok[i] == eos and cs[i].item() != -math.inf for i in range(k)]
+        for i in range(min(beam, k)):
+            if blacklist[i]:
+                is_eos[i] = False
+        for i in range(min(beam, k)):
+            if is_eos[i] and len(fin) < beam:
+                t = torch.cat([toks[cbeam[i], 1:], torch.tensor([eos])])
+                ps = torch.cat([cum[cbeam[i], :step], cs[i:i + 1]])
+                ps[1:] = ps[1:] - ps[:-1].clone()
+                sc = cs[i].item() / (step + 1) ** len_penalty if normalize else cs[i].item()
+                fin.append((t, sc, ps, origin[cbeam[i]]))
+        if any(is_eos[:beam]) and (len(fin) == beam or step == max_len):
+            break
+        for i in range(min(beam, k)):
+            is_eos[i] = is_eos[i] or blacklist[i]
+        order = [i for i in range(k) if not is_eos[i]] + [i for i in range(k) if is_eos[i]]
+        pick = order[:beam]
+        blacklist = [is_eos[i] for i in pick]
+        toks = torch.cat([toks[[cbeam[i] for i in pick]], torch.tensor([[ctok[i]] for i in pick])], dim=1)
+        cum = torch.cat([cum[[cbeam[i] for i in pick]][:, :step], torch.stack([cs[i] for i in pick]).view(-1, 1)], dim=1)
+        origin = [origin[cbeam[i]] for i in pick]
+    idx = sorted(range(len(fin)), key=lambda i: fin[i][1])
+    return [fin[i] for i in reversed(idx)]
+
+
 def beam_search(W, cfg, src_tokens, src_lengths, beam, max_len_a=0.0, max_len_b=200, min_len=1, len_penalty=1.0,
                 unk_penalty=0.0, temperature=1.0, normalize=True, eos=2, unk=3, max_positions=1000):
-    """SequenceGenerator._generate + BeamSearch.step (fairseq/sequence_generator.py:163-500, fairseq/search.py:50-85),
-    restated one sentence at a time and without incremental state (the full prefix is re-decoded every step), which is
-    what the batched/incremental reference computes.  Returns per sentence a list of (tokens, score, positional_scores)
+    """SequenceGenerator.generate, one sentence at a time.  Returns per sentence a list of (tokens, score, positional_scores)
     sorted best first."""
-    pad = cfg["pad"]
     enc, _ = encoder_forward(W, cfg, src_tokens, src_lengths, training=False)
     B, src_len = src_tokens.shape[0], src_tokens.shape[1]
     max_len = min(int(max_len_a * src_len + max_len_b), max_positions - 1)
@@ -314,47 +366,36 @@ def beam_search(W, cfg, src_tokens, src_lengths, beam, max_len_a=0.0, max_len_b=
     for b in range(B):
         n = int(enc.src_lengths[b])
         eo = enc.encoder_out[:n, b:b + 1]                                            # this sentence's frames only: no padding mask needed
-        toks = torch.full((beam, 1), eos, dtype=torch.long)
-        cum = torch.zeros((beam, 0))
-        blacklist = [False] * beam
-        fin = []
-        for step in range(max_len + 1):
-            logits = decoder_forward(W, cfg, toks, eo.expand(n, beam, eo.shape[2]), None)[:, -1, :]
-            lp = torch.log_softmax(logits / temperature, dim=-1)
-            lp[lp != lp] = -math.inf
-            lp[:, pad] = -math.inf
-            lp[:, unk] -= unk_penalty
-            if step >= max_len:
-                keep = lp[:, eos].clone(); lp[:] = -math.inf; lp[:, eos] = keep
-            elif step < min_len:
-                lp[:, eos] = -math.inf
-            V = lp.shape[1]
-            cand = lp[0] if step == 0 else (lp + cum[:, step - 1:step]).reshape(-1)
-            k = min(2 * beam, cand.numel() - 1)
-            cs, ci = torch.topk(cand, k)
-            ctok, cbeam = (ci % V).tolist(), (ci // V).tolist()
-            is_eos = [ctok[i] == eos and cs[i].item() != -math.inf for i in range(k)]
-            for i in range(min(beam, k)):
-                if blacklist[i]:
-                    is_eos[i] = False
-            for i in range(min(beam, k)):
-                if is_eos[i] and len(fin) < beam:
-                    t = torch.cat([toks[cbeam[i], 1:], torch.tensor([eos])])
-                    ps = torch.cat([cum[cbeam[i], :step], cs[i:i + 1]])
-                    ps[1:] = ps[1:] - ps[:-1].clone()
-                    sc = cs[i].item() / (step + 1) ** len_penalty if normalize else cs[i].item()
-                    fin.append((t, sc, ps))
-            if any(is_eos[:beam]) and (len(fin) == beam or step == max_len):
-                break
-            for i in range(min(beam, k)):
-                is_eos[i] = is_eos[i] or blacklist[i]
-            order = [i for i in range(k) if not is_eos[i]] + [i for i in range(k) if is_eos[i]]
-            pick = order[:beam]
-            blacklist = [is_eos[i] for i in pick]
-            toks = torch.cat([toks[[cbeam[i] for i in pick]], torch.tensor([[ctok[i]] for i in pick])], dim=1)
-            cum = torch.cat([cum[[cbeam[i] for i in pick]][:, :step], torch.stack([cs[i] for i in pick]).view(-1, 1)], dim=1)
-        idx = sorted(range(len(fin)), key=lambda i: fin[i][1])
-        results.append([fin[i] for i in reversed(idx)])
+        hyps = _beam_search_sentence(W, cfg, eo, n, beam, max_len, min_len, len_penalty, unk_penalty, temperature, normalize, eos, unk)
+        results.append([h[:3] for h in hyps])
+    return results
+
+
+def two_phase_beam_search(W, cfg, src_tokens, src_lengths, beam, max_len_a=0.0, max_len_b=200, min_len=1, len_penalty=1.0,
+                          unk_penalty=0.0, temperature=1.0, normalize=True, eos=2, unk=3, max_positions=1000):
+    """TwoPhaseSequenceGenerator._generate on the dual-decoder model (twophase_sequence_generator.py:127-170): (1) beam search with
+    `auxiliary_decoder.*` -> `beam` transcript hypotheses per sentence, best first (:477-762); (2) target beam search whose slot i
+    starts from transcript hypothesis i's (normalised) score (:171-475; the dual-decoder's target decoder does not read the
+    transcript, conv_transformer_dualdecoder.py:83-84).  The target length limit uses the longest transcript hypothesis of the
+    BATCH as `src_len` (:178,213-218).  Returns per sentence a list of (tokens, score, positional_scores, aux_tokens), best first."""
+    enc, _ = encoder_forward(W, cfg, src_tokens, src_lengths, training=False)
+    B, src_len = src_tokens.shape[0], src_tokens.shape[1]
+    max_len1 = min(int(max_len_a * src_len + max_len_b), max_positions - 1)
+    args = (min_len, len_penalty, unk_penalty, temperature, normalize, eos, unk)
+    aux, eos_ = [], []
+    for b in range(B):
+        n = int(enc.src_lengths[b])
+        eo = enc.encoder_out[:n, b:b + 1]
+        aux.append(_beam_search_sentence(W, cfg, eo, n, beam, max_len1, *args, pfx="auxiliary_decoder."))
+        eos_.append((eo, n))
+    max_aux_len = max(len(h[0]) for hs in aux for h in hs)
+    max_len2 = min(int(max_len_a * max_aux_len + max_len_b), max_positions - 1)
+    results = []
+    for b in range(B):
+        eo, n = eos_[b]
+        prev = torch.tensor([h[1] for h in aux[b]], dtype=torch.float32)
+        hyps = _beam_search_sentence(W, cfg, eo, n, beam, max_len2, *args, prev_scores=prev)
+        results.append([(t, sc, ps, aux[b][o][0]) for (t, sc, ps, o) in hyps])
     return results
 
 

@@ -473,6 +473,48 @@ def run_generate_case():
     np.savez_compressed(os.path.join(OUT, "generate.npz"), **out)
 
 
+def run_twophase_case():
+    """G18: TwoPhaseSequenceGenerator (examples/speech_recognition/twophase_sequence_generator.py) on the dual-decoder
+    model: beam search with the auxiliary (transcript) decoder, then HierarchicalBeamSearch with the target decoder seeded by the
+    transcript hypotheses' scores; every target hypothesis carries the transcript it descends from (`aux_tokens`)."""
+    from examples.speech_recognition.twophase_sequence_generator import TwoPhaseSequenceGenerator
+    out = {}
+    cases = [("a", dict(D=64, H=2, Ff=128, EL=2, DL=2, seed=1100, lens=[52, 41, 33]), dict(beam_size=4, max_len_a=0, max_len_b=10, min_len=1)),
+             ("b", dict(D=64, H=2, Ff=128, EL=2, DL=1, seed=1200, lens=[44, 44]),
+              dict(beam_size=3, max_len_a=0.1, max_len_b=4, min_len=2, len_penalty=0.7, unk_penalty=0.3, temperature=1.3))]
+    for tag, m, g in cases:
+        args, task, model, crit, V_src, V_tgt = build("tp" + tag, m["D"], m["H"], m["Ff"], m["EL"], m["DL"], 0, False,
+                                                      arch="conv_transformer_dualdecoder",
+                                                      criterion=("cross_entropy_dualdecoder", "--label-smoothing", "0.1"))
+        cfg = s2t_ref.default_cfg(D=m["D"], heads=m["H"], ffn=m["Ff"], enc_layers=m["EL"], dec_layers=m["DL"], ctc_layer=0)
+        W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, V_aux=V_src), m["seed"])
+        W["decoder.output_projection.weight"][2] *= 4.0           # competitive <eos>: hypotheses end at different steps
+        W["auxiliary_decoder.output_projection.weight"][2] *= 4.0
+        load_weights(model, crit, W)
+        s = make_sample(m["seed"] + 1, m["lens"], [4] * len(m["lens"]), [3] * len(m["lens"]), V_src, V_tgt, V_src - 1)
+        sample = to_ref_sample(s)
+        model.eval()
+        gen = TwoPhaseSequenceGenerator([model], task.source_dictionary, task.target_dictionary, **g)
+        hyps = gen.generate([model], sample)
+        B, beam = len(hyps), g["beam_size"]
+        Lmax = max(len(h["tokens"]) for hs in hyps for h in hs); Amax = max(len(h["aux_tokens"]) for hs in hyps for h in hs)
+        tok = np.full((B, beam, Lmax), -1, np.int64); aux = np.full((B, beam, Amax), -1, np.int64)
+        sc = np.full((B, beam), np.nan, np.float64); ps = np.zeros((B, beam, Lmax), np.float32); nh = np.zeros((B,), np.int64)
+        for b, hs in enumerate(hyps):
+            nh[b] = len(hs)
+            for i, h in enumerate(hs):
+                n = len(h["tokens"]); na = len(h["aux_tokens"])
+                tok[b, i, :n] = h["tokens"].numpy(); aux[b, i, :na] = h["aux_tokens"].numpy()
+                sc[b, i] = float(h["score"]); ps[b, i, :n] = h["positional_scores"].numpy()
+        out.update({tag + "_src_tokens": s["src_tokens"], tag + "_src_lengths": s["src_lengths"], tag + "_tokens": tok, tag + "_aux_tokens": aux,
+                    tag + "_scores": sc, tag + "_pos_scores": ps, tag + "_nhyp": nh,
+                    tag + "_meta": np.array([m["D"], m["H"], m["Ff"], m["EL"], m["DL"], 0, 0, V_src, V_tgt, V_src - 1, m["seed"]], np.int64),
+                    tag + "_gen": np.array([g["beam_size"], g["max_len_a"], g["max_len_b"], g["min_len"], g.get("len_penalty", 1.0),
+                                            g.get("unk_penalty", 0.0), g.get("temperature", 1.0)], np.float64)})
+        print("twophase", tag, [[(len(h["tokens"]), len(h["aux_tokens"]), round(float(h["score"]), 4)) for h in hs] for hs in hyps])
+    np.savez_compressed(os.path.join(OUT, "twophase.npz"), **out)
+
+
 def run_data_case():
     """G12: the on-disk TNTIDX format and frame-budget batching.
     * tests/golden/tntidx/{fbank,tokens}.{idx,bin}: tiny datasets written by the reference's own builders
@@ -817,6 +859,8 @@ def run_teacher_case():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "twophase":
+        run_twophase_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn2d":
         run_attn2d_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "teacher":

@@ -52,3 +52,26 @@ def generate_case(tag):
         exp.append(hs)
     meta = dict(V_src=V_src, V_tgt=V_tgt, blank=blank, seed=seed, ctc_layer=ctc_layer, compress=bool(compress))
     return cfg, W, torch.from_numpy(g[tag + "_src_tokens"]), torch.from_numpy(g[tag + "_src_lengths"]), opts, exp, meta
+
+
+def twophase_case(tag):
+    """fixture twophase.npz (dual-decoder model, TwoPhaseSequenceGenerator): as generate_case, hypotheses carry their transcript"""
+    g = load_golden("twophase")
+    D, H, Ff, EL, DL, _, _, V_src, V_tgt, blank, seed = [int(v) for v in g[tag + "_meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, V_aux=V_src), seed)
+    W["decoder.output_projection.weight"][2] *= 4.0                 # as make_golden.run_twophase_case
+    W["auxiliary_decoder.output_projection.weight"][2] *= 4.0
+    beam, la, lb, mn, lenpen, unkpen, temp = [float(v) for v in g[tag + "_gen"]]
+    opts = dict(beam_size=int(beam), max_len_a=la, max_len_b=int(lb), min_len=int(mn), len_penalty=lenpen, unk_penalty=unkpen,
+                temperature=temp)
+    exp = []
+    for b in range(g[tag + "_tokens"].shape[0]):
+        hs = []
+        for i in range(int(g[tag + "_nhyp"][b])):
+            t, a = g[tag + "_tokens"][b, i], g[tag + "_aux_tokens"][b, i]
+            n, na = int((t >= 0).sum()), int((a >= 0).sum())
+            hs.append((t[:n], float(g[tag + "_scores"][b, i]), g[tag + "_pos_scores"][b, i, :n], a[:na]))
+        exp.append(hs)
+    meta = dict(V_src=V_src, V_tgt=V_tgt, blank=blank, seed=seed, D=D, H=H, Ff=Ff, EL=EL, DL=DL)
+    return cfg, W, torch.from_numpy(g[tag + "_src_tokens"]), torch.from_numpy(g[tag + "_src_lengths"]), opts, exp, meta

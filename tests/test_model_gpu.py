@@ -656,3 +656,48 @@ def test_conv_attention_2d_bf16_and_dropout():
         outs.append((float(loss), float(model.arena.grad.norm())))
     assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * abs(outs[0][0]) and abs(outs[0][1] - outs[1][1]) <= 1e-4 * outs[0][1]
     assert abs(outs[0][0] - float(g["train_loss"])) > 1e-3 and np.isfinite(outs[0][1])
+
+
+# ------------------------------------------------------------------ two-phase generation with the dual-decoder model
+def _build_twophase(tag, dtype=torch.float32):
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import namespace
+    from helpers import twophase_case
+    cfg, W, src, lens, opts, exp, meta = twophase_case(tag)
+    args = namespace(arch="conv_transformer_dualdecoder", task="speech_translation_dualdecoding", criterion="cross_entropy_dualdecoder",
+                     label_smoothing=0.1, encoder_embed_dim=meta["D"], encoder_ffn_embed_dim=meta["Ff"], encoder_attention_heads=meta["H"],
+                     encoder_layers=meta["EL"], decoder_layers=meta["DL"], decoder_embed_dim=meta["D"], decoder_ffn_embed_dim=meta["Ff"],
+                     decoder_attention_heads=meta["H"], no_attn_2d=True, input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0,
+                     activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False, beam=opts["beam_size"], max_len_a=opts["max_len_a"],
+                     max_len_b=opts["max_len_b"], min_len=opts["min_len"], lenpen=opts["len_penalty"], unkpen=opts["unk_penalty"],
+                     temperature=opts["temperature"])
+    tgt, src_d = Dictionary.synthetic(96), Dictionary.synthetic(59)
+    src_d.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationDualDecodingTask(args, tgt, src_d)
+    model = task.build_model(args)
+    model.load_state_dict(W)
+    model.hp.sub_dropout = 0.0
+    model.materialize(DEV, dtype)
+    model.eval()
+    return task, args, model, src.to(DEV), lens.to(DEV), opts, exp, (cfg, W)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_two_phase_generator_matches_reference(tag):
+    """G18: transcript beam search with the auxiliary decoder, then the hierarchical target search: target tokens and the transcript of
+    every hypothesis exact, scores 1e-4 against examples/speech_recognition/twophase_sequence_generator.py and the oracle"""
+    task, args, model, src, lens, opts, exp, (cfg, W) = _build_twophase(tag)
+    gen = task.build_generator([model], args)
+    assert type(gen).__name__ == "TwoPhaseSequenceGenerator"
+    hyps = task.inference_step(gen, [model], dict(net_input=dict(src_tokens=src, src_lengths=lens)))
+    orc = s2t_ref.two_phase_beam_search(W, cfg, src.cpu(), lens.cpu(), opts["beam_size"], opts["max_len_a"], opts["max_len_b"],
+                                        opts["min_len"], opts["len_penalty"], opts["unk_penalty"], opts["temperature"])
+    assert len(hyps) == len(exp)
+    for hs, es, os_ in zip(hyps, exp, orc):
+        assert len(hs) == len(es)
+        for h, (et, esc, eps, ea), (ot, osc, ops, oa) in zip(hs, es, os_):
+            assert h["tokens"].tolist() == et.tolist() == ot.tolist()
+            assert h["aux_tokens"].tolist() == ea.tolist() == oa.tolist()
+            assert abs(float(h["score"]) - esc) < 1e-4 and abs(float(h["score"]) - osc) < 1e-4
+            np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), eps, atol=1e-4)

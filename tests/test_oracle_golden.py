@@ -213,6 +213,23 @@ def test_beam_search_matches_reference_generator(tag):
             np.testing.assert_allclose(ps.numpy(), eps, atol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_two_phase_beam_search_matches_reference_generator(tag):
+    """G18: TwoPhaseSequenceGenerator on the dual-decoder model: target tokens and the transcript each hypothesis descends from
+    exact, scores 1e-4 (examples/speech_recognition/twophase_sequence_generator.py)."""
+    from helpers import twophase_case
+    cfg, W, src, lens, o, exp, _ = twophase_case(tag)
+    got = s2t_ref.two_phase_beam_search(W, cfg, src, lens, o["beam_size"], o["max_len_a"], o["max_len_b"], o["min_len"],
+                                        o["len_penalty"], o["unk_penalty"], o["temperature"])
+    assert len(got) == len(exp)
+    for hs, es in zip(got, exp):
+        assert len(hs) == len(es)
+        for (t, s, ps, a), (et, es_, eps, ea) in zip(hs, es):
+            assert t.tolist() == et.tolist() and a.tolist() == ea.tolist()
+            assert abs(s - es_) < 1e-4
+            np.testing.assert_allclose(ps.numpy(), eps, atol=1e-4)
+
+
 def _distpen_case():
     g = load_golden("distpen")
     D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed = [int(v) for v in g["meta"]]
