@@ -64,16 +64,17 @@ class _CTCFn(torch.autograd.Function):
             side = _CTCFn._side[dev] = torch.cuda.Stream(device=dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            loss, grad, _ = K.ctc_loss(logits, targets, tgt_len, in_len32, blank)
+            # loss only: the gradient pass runs in backward, where the upstream gradient is known (as a device scalar)
+            loss, ws, _ = K.ctc_loss(logits, targets, tgt_len, in_len32, blank, defer_grad=True)
             out = loss[0]
         for t in (logits, targets, tgt_len, in_len32):
             t.record_stream(side)
-        for t in (loss, grad, out):
+        for t in (loss, out) + tuple(w for w in ws if torch.is_tensor(w)):
             t.record_stream(main)
         ev = torch.cuda.Event()
         ev.record(side)
         _CTCFn._pending.append((main, ev))
-        ctx.grad = grad
+        ctx.ws = ws
         return out
 
     @staticmethod
@@ -85,7 +86,8 @@ class _CTCFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return K.scale_by_device_scalar(ctx.grad, g.contiguous().float()), None, None, None, None
+        _CTCFn.join()                                  # normally a no-op: the loss was already consumed on the main stream
+        return K.ctc_loss_grad(ctx.ws, g.contiguous().float().view(1)), None, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):

@@ -356,14 +356,16 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const int* __restrict__ in_len, const float* __restrict__ la,
                                                        const float* __restrict__ lb, const float* __restrict__ nll,
                                                        T* __restrict__ grad, float* __restrict__ loss_sum, int Tn, int B,
-                                                       int V, int ld, int Lmax, int Smax, int blank, float gscale) {
+                                                       int V, int ld, int Lmax, int Smax, int blank, float gscale,
+                                                       const float* __restrict__ gscale_dev) {
     extern __shared__ float occ[];                      // [V]
+    if (gscale_dev) gscale *= gscale_dev[0];            // upstream gradient of the loss (a device scalar produced by autograd)
     const int t = blockIdx.x, b = blockIdx.y;
     const long row = (long)t * B + b;
     T* g = grad + row * ld;
     const float nl = nll[b];
     const bool live = t < min(in_len[b], Tn) && nl < INFINITY;
-    if (t == 0 && threadIdx.x == 0 && nl < INFINITY) atomicAdd(loss_sum, nl);
+    if (loss_sum && t == 0 && threadIdx.x == 0 && nl < INFINITY) atomicAdd(loss_sum, nl);
     if (!live) { for (int c = threadIdx.x; c < V; c += 256) g[c] = from_f32<T>(0.f); return; }
     const float ls = lse[row];
     const T* x = logits + row * ld;
@@ -446,11 +448,23 @@ extern "C" int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w,
 //   logits [T][B][V]; targets [B][Lmax] int64 (first tgt_len[b] entries); in_len [B] int32
 //   workspaces: lse [T*B] f32, la/lb [B*T*Smax] f32 with Smax = 2*Lmax+1, nll [B] f32
 //   outputs: grad [T][B][V] (dtype), loss_sum[0] += sum of finite nll  (caller zeroes it)
+// forward-only calls: loss_sum[0] += sum of the finite nll's (the gradient pass does it when both run in one call)
+__global__ void ctc_loss_sum_kernel(const float* __restrict__ nll, int B, float* __restrict__ loss_sum) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) { const float v = nll[b]; if (v < INFINITY) s += v; }
+    s = wave_sum(s);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, s);
+}
+
 extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len,
                             const int* in_len, float* lse, float* la, float* lb, float* nll, void* grad,
-                            float* loss_sum, int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, void* stream) {
+                            float* loss_sum, int T, int B, int V, int ld, int Lmax, int blank, float grad_scale,
+                            int phase, const float* grad_scale_dev, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
-    if (!logits || !targets || !tgt_len || !in_len || !lse || !la || !lb || !nll || !grad || !loss_sum || ld < V) return S2T_EINVAL;
+    if (!logits || !targets || !tgt_len || !in_len || !lse || !la || !lb || !nll || ld < V || phase < 0 || phase > 2) return S2T_EINVAL;
+    if ((phase != 2 && !loss_sum) || (phase != 1 && !grad)) return S2T_EINVAL;
+    const bool fwd = phase != 2, bwd = phase != 1;
+    float* const lsum_grad = phase == 0 ? loss_sum : nullptr;      // the gradient pass adds up the loss only when it is the same call
     const int Smax = 2 * Lmax + 1;
     if (Smax > 64 * 4) return S2T_ENOTSUP;                // transcripts longer than 127 tokens
     const int spl = Smax <= 64 ? 1 : (Smax <= 128 ? 2 : 4);   // extended-target positions per lane
@@ -460,21 +474,27 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
     dim3 g1((unsigned)((rows + 3) / 4)), g3(T, B);
     const size_t lds = (size_t)V * 4;
     if (dtype == S2T_BF16) {
+        if (fwd) {
         hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V, ld);
         if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 1>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 2>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 4>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        if (phase == 1) hipLaunchKernelGGL(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, st, nll, B, loss_sum);
+        }
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
-        hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, loss_sum, T, B, V, ld, Lmax, Smax, blank, grad_scale);
+        if (bwd) hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, lsum_grad, T, B, V, ld, Lmax, Smax, blank, grad_scale, grad_scale_dev);
     } else if (dtype == S2T_F32) {
+        if (fwd) {
         hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V, ld);
         if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 1>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 2>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 4>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        if (phase == 1) hipLaunchKernelGGL(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, st, nll, B, loss_sum);
+        }
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
-        hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, loss_sum, T, B, V, ld, Lmax, Smax, blank, grad_scale);
+        if (bwd) hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, lsum_grad, T, B, V, ld, Lmax, Smax, blank, grad_scale, grad_scale_dev);
     } else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

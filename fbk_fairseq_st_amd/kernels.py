@@ -249,8 +249,9 @@ def ctc_compress_bwd(dout, w, seg, dx, accumulate=False):
     return dx
 
 
-def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0):
-    """Returns (loss_sum f32[1], grad like logits)."""
+def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0, defer_grad=False):
+    """Returns (loss_sum f32[1], grad like logits, nll).  defer_grad: the forward pass only; the second result is then the workspace
+    tuple for ctc_loss_grad (called from backward with the upstream gradient as a device scalar: no separate scaling pass)."""
     T, B, V = logits.shape
     Lmax = targets.shape[1]
     dev = logits.device
@@ -260,12 +261,27 @@ def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0):
     lb = torch.empty((B * T * S,), dtype=torch.float32, device=dev)
     nll = torch.empty((B,), dtype=torch.float32, device=dev)
     ld = _row_ld(logits)
-    grad = torch.empty((T, B, ld), dtype=logits.dtype, device=dev)[..., :V]
+    grad = None if defer_grad else torch.empty((T, B, ld), dtype=logits.dtype, device=dev)[..., :V]
     loss = torch.zeros((1,), dtype=torch.float32, device=dev)
     L.check(_lib().s2t_ctc_loss(L.dt(logits), L.ptr(logits), L.ptr(targets), L.ptr(tgt_len), L.ptr(in_len32), L.ptr(lse),
                                 L.ptr(la), L.ptr(lb), L.ptr(nll), L.ptr(grad), L.ptr(loss), T, B, V, ld, Lmax, blank,
-                                float(grad_scale), L.stream()), "s2t_ctc_loss")
+                                float(grad_scale), 1 if defer_grad else 0, 0, L.stream()), "s2t_ctc_loss")
+    if defer_grad:
+        return loss, (logits, targets, tgt_len, in_len32, lse, la, lb, nll, blank, float(grad_scale)), nll
     return loss, grad, nll
+
+
+def ctc_loss_grad(ws, upstream):
+    """gradient w.r.t. the logits from the workspaces of ctc_loss(defer_grad=True), times the device scalar `upstream` (f32[1])"""
+    logits, targets, tgt_len, in_len32, lse, la, lb, nll, blank, grad_scale = ws
+    T, B, V = logits.shape
+    ld = _row_ld(logits)
+    grad = torch.empty((T, B, ld), dtype=logits.dtype, device=logits.device)[..., :V]
+    assert upstream.dtype == torch.float32 and upstream.numel() == 1
+    L.check(_lib().s2t_ctc_loss(L.dt(logits), L.ptr(logits), L.ptr(targets), L.ptr(tgt_len), L.ptr(in_len32), L.ptr(lse),
+                                L.ptr(la), L.ptr(lb), L.ptr(nll), L.ptr(grad), 0, T, B, V, ld, targets.shape[1], blank,
+                                grad_scale, 2, L.ptr(upstream), L.stream()), "s2t_ctc_loss")
+    return grad
 
 
 def lsce(logits, target, eps, pad, want_grad=True, grad_scale=1.0):

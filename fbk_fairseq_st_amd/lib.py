@@ -49,7 +49,7 @@ SIGNATURES = {
     "s2t_ctc_rle": [P] * 8 + [c_int, c_int, c_int, P],
     "s2t_ctc_compress_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_ctc_compress_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
-    "s2t_ctc_loss": [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P],
+    "s2t_ctc_loss": [c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P],
     "s2t_lsce": [c_int, P, P, P, P, c_long, c_int, c_int, c_float, c_int, c_float, P],
     "s2t_kd_loss": [c_int, P, P, P, P, P, P, c_long, c_int, c_int, c_int, c_float, c_float, c_int, c_float, P],
     "s2t_embed_fwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P],

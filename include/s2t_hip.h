@@ -168,10 +168,13 @@ int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int*
 /* ---- losses ------------------------------------------------------------------------------------
  * F.log_softmax + F.ctc_loss(reduction="sum", zero_infinity=True) (CTC_loss.py:143-151) and its gradient
  * w.r.t. the logits [T][B][V].  Workspaces: lse [T*B], la/lb [B*T*(2*Lmax+1)], nll [B] (all f32).
- * loss_sum[0] += sum_b nll_b (caller zeroes). grad is multiplied by grad_scale. */
+ * loss_sum[0] += sum_b nll_b (caller zeroes). grad is multiplied by grad_scale and, if given, by the device scalar
+ * grad_scale_dev[0] (the upstream gradient autograd hands to backward).  phase 0: loss and gradient in one call;
+ * phase 1: loss only (workspaces kept by the caller); phase 2: the gradient from the workspaces of a phase-1 call. */
 int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len, const int* in_len,
                  float* lse, float* la, float* lb, float* nll, void* grad, float* loss_sum,
-                 int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, void* stream);
+                 int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, int phase, const float* grad_scale_dev,
+                 void* stream);
 /* label_smoothed_nll_loss over log_softmax(logits.float()) (label_smoothed_cross_entropy.py:12-29), fused
  * with its gradient: sums2[0] += loss, sums2[1] += nll (caller zeroes); dlogits may be NULL. */
 int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2,

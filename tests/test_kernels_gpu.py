@@ -373,6 +373,13 @@ def test_ctc_loss(dtype):
     assert abs(float(loss) - float(ref)) < (1e-4 if dtype == torch.float32 else 2e-3) * abs(float(ref))
     assert rel_err(grad, lf.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
     assert not math.isfinite(float(nll[3]))
+    # two-call form: loss in forward, gradient in backward times the upstream device scalar
+    loss2, ws, _ = K.ctc_loss(logits.to(DEV), tgt.to(DEV), tl.to(DEV), il.to(torch.int32).to(DEV), blank, defer_grad=True)
+    assert float(loss2) == float(loss)
+    g1 = K.ctc_loss_grad(ws, torch.ones(1, device=DEV))
+    assert torch.equal(g1, grad)
+    g2 = K.ctc_loss_grad(ws, torch.full((1,), 0.25, device=DEV))
+    assert rel_err(g2, 0.25 * lf.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
