@@ -78,7 +78,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& p, const char* smem,
         const bool quad_ok = (p.N & 3) == 0;
         u32x2 dh[CW / 4];
         if (p.p_drop > 0.f && quad_ok) {
-            const uint64_t base = ((uint64_t)row * p.N + col) >> 2;
+            const uint64_t base = ((uint64_t)orow * p.N + col) >> 2;        // element index in the OUTPUT tensor (scattered rows too)
 #pragma unroll
             for (int k = 0; k < CW / 4; ++k) dh[k] = drop_hash4(p.seed, base + k);
         }
@@ -93,7 +93,7 @@ __device__ __forceinline__ void gemm_finish(const GemmArgs& p, const char* smem,
             if (p.p_drop > 0.f) {
                 bool keep;
                 if (quad_ok) keep = drop_field(dh[e >> 2], e & 3) >= (drop_th >> 16);
-                else keep = dropout_keep(p.seed, (uint64_t)row * p.N + col + e, drop_th);
+                else keep = dropout_keep(p.seed, (uint64_t)orow * p.N + col + e, drop_th);
                 x = keep ? x * drop_inv : 0.f;
             }
             if (R) x += to_f32(rres[e]);

@@ -246,17 +246,28 @@ __global__ void bn_finalize_kernel(const double* sums, const float* gamma, const
 // vectors, so a thread keeps its channel group (scale/shift stay in registers)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, T* __restrict__ yn, long n, int C) {
+                                                       const float* __restrict__ shift, T* __restrict__ yn, long n, int C,
+                                                       float p_drop, unsigned long long seed) {
     const int LP = C >> 3, g = threadIdx.x % LP;
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc[e] = scale[8 * g + e]; sh[e] = shift[8 * g + e]; }
     const long nv = n >> 3;
+    const uint32_t th16 = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float inv_keep = 1.f / (1.f - p_drop);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
         float v[8];
         load8<T>(y + i * 8, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (p_drop > 0.f) {                  // the dropout that follows the BatchNorm (conv_transformer.py:214): same mask and rounding as s2t_dropout on yn
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const u32x2 h = drop_hash4(seed, (uint64_t)i * 2 + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * k + e] = drop_field(h, e) >= th16 ? to_f32(from_f32<T>(v[4 * k + e])) * inv_keep : 0.f;
+            }
+        }
         store8<T>(yn + i * 8, v);
     }
 }
@@ -411,13 +422,14 @@ extern "C" int s2t_bn_finalize(const double* sums, const float* gamma, const flo
     return S2T_OK;
 }
 
-extern "C" int s2t_bn_apply(int dtype, const void* y, const float* scale, const float* shift, void* yn, long n, int C, void* stream) {
+extern "C" int s2t_bn_apply(int dtype, const void* y, const float* scale, const float* shift, void* yn, long n, int C,
+                            float p_drop, unsigned long long seed, void* stream) {
     if (n <= 0) return S2T_OK;
-    if (!y || !scale || !shift || !yn || (C % 8) || (256 % (C / 8)) || (n % C)) return S2T_EINVAL;
+    if (!y || !scale || !shift || !yn || (C % 8) || (256 % (C / 8)) || (n % C) || p_drop < 0.f || p_drop >= 1.f) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nblocks(n)), dim3(256), 0, st, (const bf16*)y, scale, shift, (bf16*)yn, n, C),
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, (const float*)y, scale, shift, (float*)yn, n, C));
+        hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nblocks(n)), dim3(256), 0, st, (const bf16*)y, scale, shift, (bf16*)yn, n, C, p_drop, seed),
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, (const float*)y, scale, shift, (float*)yn, n, C, p_drop, seed));
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

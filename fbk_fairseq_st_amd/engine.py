@@ -293,9 +293,7 @@ class S2TEngine:
         mean1, rstd1, sc1, sh1 = K.bn_finalize(sums1, self.P("encoder.bn.0.weight"), self.P("encoder.bn.0.bias"),
                                                bufs["encoder.bn.0.running_mean"], bufs["encoder.bn.0.running_var"],
                                                bufs["encoder.bn.0.num_batches_tracked"], cnt1, training, hp.bn_momentum, hp.bn_eps)
-        y1n = K.bn_apply(y1, sc1, sh1)
-        if p_sub > 0:
-            K.dropout(y1n, p_sub, seed + 1, out=y1n)
+        y1n = K.bn_apply(y1, sc1, sh1, p_sub, seed + 1)
         # conv2 as implicit GEMM + BN2
         w2p = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 0)
         P2 = T4 * B * F4
@@ -305,9 +303,7 @@ class S2TEngine:
         mean2, rstd2, sc2, sh2 = K.bn_finalize(sums2, self.P("encoder.bn.1.weight"), self.P("encoder.bn.1.bias"),
                                                bufs["encoder.bn.1.running_mean"], bufs["encoder.bn.1.running_var"],
                                                bufs["encoder.bn.1.num_batches_tracked"], P2, training, hp.bn_momentum, hp.bn_eps)
-        z2n = K.bn_apply(z2, sc2, sh2)
-        if p_sub > 0:
-            K.dropout(z2n, p_sub, seed + 2, out=z2n)
+        z2n = K.bn_apply(z2, sc2, sh2, p_sub, seed + 2)
         a2d = []
         if hp.attn_2d:                           # x = x + ConvAttention2D(x), twice (conv_transformer.py:216-222)
             for i in range(2):
@@ -343,11 +339,14 @@ class S2TEngine:
                       splitk=_splitk(hp.D, F4 * C, dh3.shape[0]))
         K.permute_cf(gw3p, self.G("encoder.fc3.weight"), hp.D, C, F4, 1)
         K.colsum(dh3, self.G("encoder.fc3.bias"))
-        dz2n = K.gemm(dh3, c["w3p"], trans_b=True).view(-1, C)
-        for ci in reversed(c["a2d"]):
-            dz2n = self.attn2d_block_bwd(ci, dz2n)
-        if c["p_sub"] > 0:
-            K.dropout(dz2n, c["p_sub"], c["seed"] + 2, out=dz2n)
+        if c["a2d"]:
+            dz2n = K.gemm(dh3, c["w3p"], trans_b=True).view(-1, C)
+            for ci in reversed(c["a2d"]):
+                dz2n = self.attn2d_block_bwd(ci, dz2n)
+            if c["p_sub"] > 0:
+                K.dropout(dz2n, c["p_sub"], c["seed"] + 2, out=dz2n)
+        else:                                   # the dropout mask of z2n rides on the epilogue of the data-gradient product
+            dz2n = K.gemm(dh3, c["w3p"], trans_b=True, p_drop=c["p_sub"], seed=c["seed"] + 2).view(-1, C)
         # BN2 backward (+ ReLU mask) -> gradient w.r.t. conv2 + bias
         s2 = K.chan_sums(c["z2"], C, dyn=dz2n, mean=c["mean2"], rstd=c["rstd2"])
         dpre2 = K.bn_bwd_apply(dz2n, c["z2"], c["mean2"], c["rstd2"], self.P("encoder.bn.1.weight"), s2,
@@ -364,15 +363,16 @@ class S2TEngine:
         K.permute_conv_w(gw2p, self.G("encoder.convolutions.1.weight"), C, C, 2)
         # conv2 data gradient: one gathered GEMM per input-pixel parity class, scattered to the class's pixels
         w2q = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 1)
-        dy1n = torch.zeros_like(c["y1n"]).view(-1, C)
+        # every input pixel belongs to exactly one parity class: the four products write all of dy1n, each with the dropout mask
+        # of y1n in its epilogue (the mask index follows the scattered output row)
+        dy1n = torch.empty_like(c["y1n"]).view(-1, C)
         for ci, (pt, pf, taps) in enumerate(_TAPS_BY_CLASS):
             if mp["bwd"][ci] is None:
                 continue
             rows, maps = mp["bwd"][ci]
             s0, nt = _CLASS_SLOT0[ci], len(taps)
-            K.gemm(dpre2, w2q[:, s0 * C:(s0 + nt) * C], M=rows.numel(), K=nt * C, map_a=maps, period_a=C, map_c=rows, out=dy1n)
-        if c["p_sub"] > 0:
-            K.dropout(dy1n, c["p_sub"], c["seed"] + 1, out=dy1n)
+            K.gemm(dpre2, w2q[:, s0 * C:(s0 + nt) * C], M=rows.numel(), K=nt * C, map_a=maps, period_a=C, map_c=rows, out=dy1n,
+                   p_drop=c["p_sub"], seed=c["seed"] + 1)
         s1 = K.chan_sums(c["y1"], C, dyn=dy1n, mean=c["mean1"], rstd=c["rstd1"])
         dpre1 = K.bn_bwd_apply(dy1n, c["y1"].view(-1, C), c["mean1"], c["rstd1"], self.P("encoder.bn.0.weight"), s1,
                                self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"])

@@ -159,10 +159,11 @@ def bn_finalize(sums, gamma, beta, run_mean, run_var, num_batches, count, traini
     return o[0], o[1], o[2], o[3]            # mean, rstd, scale, shift
 
 
-def bn_apply(y, scale, shift):
+def bn_apply(y, scale, shift, p_drop=0.0, seed=0):
+    """yn = dropout(y*scale + shift, p_drop, seed) in one pass (same bits as dropout(bn_apply(y)))"""
     yn = torch.empty_like(y)
-    L.check(_lib().s2t_bn_apply(L.dt(y), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(yn), y.numel(), scale.numel(), L.stream()),
-            "s2t_bn_apply")
+    L.check(_lib().s2t_bn_apply(L.dt(y), L.ptr(y), L.ptr(scale), L.ptr(shift), L.ptr(yn), y.numel(), scale.numel(), float(p_drop),
+                                int(seed), L.stream()), "s2t_bn_apply")
     return yn
 
 

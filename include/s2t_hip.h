@@ -138,7 +138,10 @@ int s2t_chan_sums(int dtype, const void* y, const void* dyn, const float* mean, 
 int s2t_bn_finalize(const double* sums, const float* gamma, const float* beta, float* run_mean, float* run_var,
                     long long* num_batches, float* mean, float* rstd, float* scale, float* shift,
                     double count, int C, int training, float momentum, float eps, void* stream);
-int s2t_bn_apply(int dtype, const void* y, const float* scale, const float* shift, void* yn, long n, int C, void* stream);
+/* yn = dropout(y*scale + shift, p_drop, seed): the normalisation and the dropout that follows it (conv_transformer.py:212-214)
+ * in one pass; the mask / rounding are those of s2t_dropout on the normalised tensor */
+int s2t_bn_apply(int dtype, const void* y, const float* scale, const float* shift, void* yn, long n, int C,
+                 float p_drop, unsigned long long seed, void* stream);
 /* BatchNorm backward fused with the ReLU mask; sums from s2t_chan_sums(mode 1); dgamma/dbeta += */
 int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const float* mean, const float* rstd,
                      const float* gamma, const double* sums, void* dpre, float* dgamma, float* dbeta,

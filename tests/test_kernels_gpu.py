@@ -708,3 +708,25 @@ def test_attn2d_convolutions_as_gathered_gemms():
     gw = torch.zeros(Co, Ci, 3, 3, device=DEV)
     K.a2d_unpack_wgrad(gp, gw, Ci)
     assert rel_err(gw, wf.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_fused_into_bn_apply_and_scattered_gemm_epilogue(dtype):
+    """the fused forms produce the bits of the separate s2t_dropout pass over the same tensor"""
+    C, P = 64, 4096
+    y = rnd(P, C, dtype=dtype, seed=1).to(DEV)
+    sc, sh = (1 + 0.1 * rnd(C, seed=2)).to(DEV), (0.1 * rnd(C, seed=3)).to(DEV)
+    assert torch.equal(K.bn_apply(y, sc, sh, 0.2, 99), K.dropout(K.bn_apply(y, sc, sh), 0.2, 99))
+    # scattered output rows (map_c): the mask index is the element index of the destination tensor
+    M, Kd, rows_out = 300, 128, 700
+    a = rnd(M, Kd, dtype=dtype, seed=4).to(DEV); w = rnd(C, Kd, dtype=dtype, seed=5, scale=0.2).to(DEV)
+    perm = torch.randperm(rows_out, generator=torch.Generator().manual_seed(6))[:M].to(torch.int32).to(DEV)
+    o1 = torch.zeros(rows_out, C, dtype=dtype, device=DEV); o2 = torch.zeros(rows_out, C, dtype=dtype, device=DEV)
+    K.gemm(a, w, map_c=perm, out=o1, p_drop=0.3, seed=7)
+    K.gemm(a, w, map_c=perm, out=o2)
+    ref = K.dropout(o2, 0.3, 7)
+    assert torch.equal(o1 == 0, ref == 0)                       # the same mask ...
+    if dtype == torch.float32:
+        assert torch.equal(o1, ref)
+    else:                                                       # ... the epilogue scales the f32 accumulator (one rounding instead of two)
+        assert rel_err(o1, ref) < 1e-2
