@@ -36,6 +36,31 @@ struct StageDirect {
     u32x4 r[N];
     __device__ __forceinline__ void load(const T* g, int ld, int row0, int nrows, int k0, int K, bool vec,
                                          const int* map = nullptr, int period = 0) {
+        if (map && vec && k0 + 8 * E <= K) {
+            // gathered rows, branch-free: a guarded load compiles to a branch around it and the N chunks of a thread then run as N
+            // dependent (map -> data) round trips one after the other.  Here every map entry is fetched first (clamped index), then
+            // every row (clamped source), and out-of-range / -1 chunks are zeroed by a select afterwards.
+            int src[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+                const int gr = min(row0 + row, nrows - 1), gk = k0 + c * E;
+                src[i] = map[(size_t)(gk / period) * nrows + gr];
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int cid = threadIdx.x + 256 * i, c = cid & 7;
+                const int gk = k0 + c * E, kk = gk % period;
+                r[i] = *reinterpret_cast<const u32x4*>(g + (size_t)max(src[i], 0) * ld + kk);
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int cid = threadIdx.x + 256 * i, row = cid >> 3;
+                asm volatile("" : "+v"(r[i]));
+                if (row0 + row >= nrows || src[i] < 0) r[i] = (u32x4){0, 0, 0, 0};
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;

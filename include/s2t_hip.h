@@ -148,7 +148,8 @@ int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const float* mea
                      long n, int C, double count, int training, void* stream);
 /* fc3 weight [N][C*F] (k = c*F+f, conv_transformer.py:225-226) <-> channels-last k' = f*C+c */
 int s2t_permute_cf(int dst_dtype, const float* src, void* dst, int N, int C, int F, int mode, void* stream);
-/* conv2 weight [Co][Ci][3][3] <-> implicit-GEMM operand layouts (see subsample.hip) */
+/* conv2 weight [Co][Ci][3][3] <-> implicit-GEMM operand layouts (see subsample.hip): 0 forward, 1 data gradient by parity
+ * class, 2 weight gradient back to the master layout */
 int s2t_permute_conv_w(int dst_dtype, const float* src, void* dst, int Co, int Ci, int mode, void* stream);
 /* x[t][b][:] += sinusoid[(t < len[b]) ? t+1 : 0][:]  (positional_embedding_audio.py:21-27) */
 int s2t_add_pos(int dtype, void* x, const float* table, const int* len, int T, int B, int D, void* stream);
