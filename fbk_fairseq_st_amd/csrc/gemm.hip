@@ -99,6 +99,26 @@ struct StageTrans {
     u32x4 r[N][4];
     __device__ __forceinline__ void load(const T* g, int ld, int col0, int ncols, int k0, int K, bool vec,
                                          const int* map = nullptr, int period = 0) {
+        if (map && vec && k0 + BK <= K && ncols % E == 0) {
+            // gathered k-rows, branch-free (see StageDirect::load): all map entries, then all rows, then the zero select
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int it = min((int)threadIdx.x + 256 * i, ITEMS - 1);
+                const int kq = it % NKQ, cg = it / NKQ;
+                const int gc = col0 + cg * E;
+                int src[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) src[rr] = map[k0 + 4 * kq + rr];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) r[i][rr] = *reinterpret_cast<const u32x4*>(g + (size_t)max(src[rr], 0) * ld + min(gc, ncols - E));
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    asm volatile("" : "+v"(r[i][rr]));
+                    if (src[rr] < 0 || gc >= ncols) r[i][rr] = (u32x4){0, 0, 0, 0};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int it = threadIdx.x + 256 * i;
@@ -965,35 +985,42 @@ extern "C" int s2t_gemm(int in_dtype, int out_dtype, int trans_a, int trans_b, i
 // out[n] (+)= sum_m X[m][n].  Each lane owns 16 bytes of columns (8 bf16 / 4 f32), a workgroup = 4 row slots x
 // 64 lanes; rows are grid-strided in chunks, partial sums meet in LDS, one f32 atomic per column per workgroup.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int ld, int M, int N, float* out, int rows_per_block, int vec) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* X, int ld, int M, int N, float* out, int rows_per_block, int vec, int lpr) {
+    // lpr = lanes per row (power of two <= 64): a narrow matrix (N <= 64*E/2 columns) puts 64/lpr rows on one wave-instruction
+    // instead of leaving most lanes idle
     constexpr int E = Elem<T>::PER16;
-    __shared__ float sh[4][64 * 8];
+    __shared__ float sh[256][E + 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c0 = (blockIdx.x * 64 + lane) * E;
+    const int rpw = 64 / lpr;                                   // rows per wave-instruction
+    const int c0 = (blockIdx.x * lpr + (lane % lpr)) * E;
     const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
     float s[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) s[e] = 0.f;
     if (c0 < N) {
         if (vec && c0 + E <= N) {
-            for (int m = m0 + w; m < m1; m += 4) {
+            for (int m = m0 + w * rpw + lane / lpr; m < m1; m += 4 * rpw) {
                 T tmp[E];
                 *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(X + (size_t)m * ld + c0);
 #pragma unroll
                 for (int e = 0; e < E; ++e) s[e] += to_f32(tmp[e]);
             }
         } else {
-            for (int m = m0 + w; m < m1; m += 4)
+            for (int m = m0 + w * rpw + lane / lpr; m < m1; m += 4 * rpw)
 #pragma unroll
                 for (int e = 0; e < E; ++e) if (c0 + e < N) s[e] += to_f32(X[(size_t)m * ld + c0 + e]);
         }
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e) sh[w][lane * E + e] = s[e];
+    for (int e = 0; e < E; ++e) sh[threadIdx.x][e] = s[e];
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * E; i += 256) {
-        const int c = blockIdx.x * 64 * E + i;
-        if (c < N) atomicAdd(out + c, sh[0][i] + sh[1][i] + sh[2][i] + sh[3][i]);
+    for (int i = threadIdx.x; i < lpr * E; i += 256) {
+        const int cl = i / E, e = i % E;
+        const int c = (blockIdx.x * lpr + cl) * E + e;
+        if (c >= N) continue;
+        float t = 0.f;
+        for (int k = cl; k < 256; k += lpr) t += sh[k][e];         // every thread whose lane % lpr == cl (lpr divides 64)
+        atomicAdd(out + c, t);
     }
 }
 
@@ -1002,12 +1029,14 @@ extern "C" int s2t_colsum(int dtype, const void* X, int ld, int M, int N, float*
     if (!X || !out) return S2T_EINVAL;
     const int E = dtype == S2T_BF16 ? 8 : 4;
     const int vec = (ld % E == 0) && (((uintptr_t)X & 15) == 0);
-    const int col_blocks = (N + 64 * E - 1) / (64 * E);
-    int rpb = (int)(((long)M * col_blocks + 511) / 512);         // aim at ~512 workgroups (atomic contention per column)
-    rpb = rpb < 64 ? 64 : rpb;
+    int lpr = 64;
+    while (lpr > 1 && (lpr / 2) * E >= N) lpr /= 2;             // fewest lanes (power of two) that cover one row
+    const int col_blocks = (N + lpr * E - 1) / (lpr * E);
+    int rpb = (int)(((long)M * col_blocks + 1023) / 1024);       // aim at ~1024 workgroups (atomic contention per column)
+    rpb = rpb < 256 ? 256 : rpb;
     dim3 grid(col_blocks, (M + rpb - 1) / rpb);
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)X, ld, M, N, out, rpb, vec);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ld, M, N, out, rpb, vec);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)X, ld, M, N, out, rpb, vec, lpr);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ld, M, N, out, rpb, vec, lpr);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

@@ -225,12 +225,13 @@ class S2TEngine:
     # (MI355X, 20 updates): 21.6 / 20.6 ms per update with the side stream against 18.5 / 18.7 ms without -- every big kernel here
     # already fills the machine and is laid out for XCD-local L2 reuse, two of them at once only thrash it.  Opt-in
     # (S2T_WGRAD_STREAM=1) for shapes whose kernels leave the GPU mostly empty.
-    def _wgrad_stream(self):
+    def _wgrad_stream(self, tokens=0):
         if self._wg_side is None:
-            import os
-            self._wg_on = os.environ.get("S2T_WGRAD_STREAM", "0") == "1" and torch.device(self.dev).type == "cuda"
+            self._wg_all = os.environ.get("S2T_WGRAD_STREAM", "0") == "1"
+            self._wg_maxtok = int(os.environ.get("S2T_WGRAD_STREAM_MAXTOK", "0"))     # side stream only for products over <= this many rows
+            self._wg_on = (self._wg_all or self._wg_maxtok > 0) and torch.device(self.dev).type == "cuda"
             self._wg_side = torch.cuda.Stream(device=self.dev) if self._wg_on else False
-        return self._wg_side if self._wg_on else None
+        return self._wg_side if self._wg_on and (self._wg_all or tokens <= self._wg_maxtok) else None
 
     def join_wgrad(self):
         if self._wg_pending:
@@ -257,7 +258,7 @@ class S2TEngine:
         """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
         w = self.W(name + ".weight")
         gw = self.G(name + ".weight")
-        side = self._wgrad_stream()
+        side = self._wgrad_stream(dy2d.shape[0])
         if side is None:
             K.linear_wgrad(dy2d, x2d, gw, self.G(name + ".bias") if bias else None,
                            splitk=_splitk(gw.shape[0], gw.shape[1], dy2d.shape[0]))

@@ -133,11 +133,13 @@ def test_gemm_gather_scatter():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_colsum(dtype):
-    x = rnd(1234, 200, dtype=dtype, seed=1)
-    out = torch.ones(200, device=DEV)
-    K.colsum(x.to(DEV), out)
-    assert rel_err(out, x.float().sum(0) + 1) < (1e-4 if dtype == torch.float32 else 1e-3)
+@pytest.mark.parametrize("M,N,ld", [(1234, 200, 200), (5000, 64, 64), (3001, 12, 16), (777, 8, 8), (50, 1000, 1000), (300, 3, 5)])
+def test_colsum(dtype, M, N, ld):
+    """wide, narrow (several rows per wave-instruction), strided-view and unaligned column counts"""
+    x = rnd(M, ld, dtype=dtype, seed=1)
+    out = torch.ones(N, device=DEV)
+    K.colsum(x.to(DEV)[:, :N], out)
+    assert rel_err(out, x.float()[:, :N].sum(0) + 1) < (1e-4 if dtype == torch.float32 else 1e-3)
 
 
 # ------------------------------------------------------------------ attention
