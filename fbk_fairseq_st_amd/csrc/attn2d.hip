@@ -14,6 +14,7 @@
 // through LDS -- HBM-bound element work, not MFMA shapes.
 #include "common.hpp"
 #include "prof.hpp"
+#include <cstdlib>
 #include "../../include/s2t_hip.h"
 
 namespace {
@@ -134,6 +135,17 @@ template <int F> struct Plane {
     static __device__ __forceinline__ long at(int t, int f, int b, int B, int ld, int ch) { return ((long)(t * B + b) * F + f) * ld + ch; }
 };
 
+// dot product over F with four independent accumulation chains (a single chain of 20 dependent FMAs halves the VALU rate)
+template <int F>
+__device__ __forceinline__ float dotF(const float (&a)[F], const float* __restrict__ b) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int f = 0; f + 3 < F; f += 4) { s0 += a[f] * b[f]; s1 += a[f + 1] * b[f + 1]; s2 += a[f + 2] * b[f + 2]; s3 += a[f + 3] * b[f + 3]; }
+#pragma unroll
+    for (int f = F & ~3; f < F; ++f) s0 += a[f] * b[f];
+    return (s0 + s1) + (s2 + s3);
+}
+
 __device__ __forceinline__ uint64_t tdrop_index(int bh, int i, int j, int T, int Tp) { return ((uint64_t)bh * T + i) * Tp + j; }
 
 constexpr int KT = 64;
@@ -164,10 +176,9 @@ __global__ __launch_bounds__(128) void a2d_time_fwd_kernel(const T* __restrict__
             __syncthreads();
             const int nj = min(KT, Tn - j0);
             u32x2 hq = {0, 0};
+#pragma unroll 4
             for (int jj = 0; jj < nj; ++jj) {
-                float s = 0.f;
-#pragma unroll
-                for (int f = 0; f < F; ++f) s += q[f] * sk[jj][f];
+                const float s = dotF<F>(q, sk[jj]);
                 if (pass == 0) {
                     const float mn = fmaxf(m, s);
                     l = l * __expf(m - mn) + __expf(s - mn);
@@ -226,10 +237,10 @@ __global__ __launch_bounds__(128) void a2d_time_bwd_dq_kernel(const T* __restric
         __syncthreads();
         const int nj = min(KT, Tn - j0);
         u32x2 hq = {0, 0};
+#pragma unroll 4
         for (int jj = 0; jj < nj; ++jj) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) { s += q[f] * sk[jj][f]; dp += dO[f] * sv[jj][f]; }
+            const float s = dotF<F>(q, sk[jj]);
+            float dp = dotF<F>(dO, sv[jj]);
             const float p = __expf(s - lse);
             if (p_drop > 0.f) {
                 const int j = j0 + jj;
@@ -283,9 +294,8 @@ __global__ __launch_bounds__(128) void a2d_time_bwd_dkv_kernel(const T* __restri
         __syncthreads();
         const int ni = min(KT, Tn - i0);
         for (int iq = 0; iq < ni; ++iq) {
-            float s = 0.f, dp = 0.f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) { s += sq[iq][f] * k[f]; dp += sdo[iq][f] * v[f]; }
+            const float s = dotF<F>(k, sq[iq]);
+            float dp = dotF<F>(v, sdo[iq]);
             const float p = __expf(s - sl[iq]);
             float pd = p;
             if (p_drop > 0.f) {
@@ -422,6 +432,120 @@ __global__ __launch_bounds__(512) void a2d_freq_bwd_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ weight gradient of the two 3x3 convolutions, all nine taps in one pass
+//   dW[co][ci][kh][kw] += sum over pixels (t, b, f) of dY[(t,b,f)][co] * X[(t + kh - 1, b, f + kw - 1)][ci]
+// (as nine gathered TN products this read both operands nine times and took 2.0 ms per update for the two blocks).
+// A workgroup walks units (batch b, TT consecutive frames): X with a one-pixel halo and dY are staged in LDS as f32; a thread owns
+// a 4 (co) x 4 (ci) block for the three taps of one kernel row kh (48 accumulators) and, when CO*CI is small, one of PS frame
+// subsets.  Accumulators live across units; the workgroup's partial sums go to a workspace that a second kernel reduces into the
+// master layout [CO][CI][3][3].
+template <typename T, int CO, int CI>
+__global__ __launch_bounds__(256) void a2d_conv_wgrad_kernel(const T* __restrict__ dY, int ld_dy, const T* __restrict__ X, int ld_x,
+                                                             float* __restrict__ ws, int B, int Tn, int F, int TT, int units, int dbg) {
+    extern __shared__ float a2d_lds[];
+    constexpr int NCI4 = CI / 4, NCO4 = CO / 4, NCOMBO = NCI4 * NCO4, PS = 256 / (NCOMBO * 3) > 0 ? 256 / (NCOMBO * 3) : 1;
+    static_assert(NCOMBO * 3 <= 256, "one thread per (4x4 block, kernel row)");
+    const int FW = F + 2;
+    float* sx = a2d_lds;                                   // [(TT+2)][FW][CI]
+    float* sdy = a2d_lds + (TT + 2) * FW * CI;             // [TT][F][CO]
+    const int tid = threadIdx.x;
+    const bool active = tid < NCOMBO * 3 * PS;
+    const int ps = tid / (NCOMBO * 3), rem = tid % (NCOMBO * 3), kh = rem / NCOMBO, combo = rem % NCOMBO;
+    const int ci4 = combo % NCI4, co4 = combo / NCI4;
+    float acc[3][4][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][i][j] = 0.f;
+    for (int e = tid; e < (TT + 2) * FW * CI; e += 256) sx[e] = 0.f;          // halo columns stay zero for the whole kernel
+    const int nchunk = (Tn + TT - 1) / TT;
+    constexpr int E = Elem<T>::PER16;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int b = u / nchunk, t0 = (u % nchunk) * TT;
+        __syncthreads();
+        // X rows t0-1 .. t0+TT of batch b (zeros outside the plane), channels in 16-byte chunks
+        if (!(dbg & 1))
+        for (int e = tid; e < (TT + 2) * F * (CI / E); e += 256) {
+            const int ch = e % (CI / E), f = (e / (CI / E)) % F, tr = e / ((CI / E) * F);
+            const int t = t0 - 1 + tr;
+            T tmp[E];
+            if (t >= 0 && t < Tn) *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(X + ((size_t)(t * B + b) * F + f) * ld_x + ch * E);
+            float* dst = sx + ((size_t)tr * FW + f + 1) * CI + ch * E;
+#pragma unroll
+            for (int k = 0; k < E; ++k) dst[k] = (t >= 0 && t < Tn) ? to_f32(tmp[k]) : 0.f;
+        }
+        for (int e = tid; e < TT * F * (CO / E); e += 256) {
+            const int ch = e % (CO / E), f = (e / (CO / E)) % F, tt = e / ((CO / E) * F);
+            const int t = t0 + tt;
+            T tmp[E];
+            if (t < Tn) *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(dY + ((size_t)(t * B + b) * F + f) * ld_dy + ch * E);
+            float* dst = sdy + ((size_t)tt * F + f) * CO + ch * E;
+#pragma unroll
+            for (int k = 0; k < E; ++k) dst[k] = t < Tn ? to_f32(tmp[k]) : 0.f;
+        }
+        __syncthreads();
+        if (active && !(dbg & 2)) {
+            for (int tt = ps; tt < TT; tt += PS) {                       // pixel subsets split the frames; f runs with a sliding window
+                const float* dyr = sdy + (size_t)tt * F * CO + co4 * 4;
+                const float* xr = sx + (size_t)(tt + kh) * FW * CI + ci4 * 4;
+                f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + CI);
+#pragma unroll 4
+                for (int f = 0; f < F; ++f) {
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dyr + (size_t)f * CO);
+                    const f32x4 x2 = *reinterpret_cast<const f32x4*>(xr + (size_t)(f + 2) * CI);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[0][i][j] += d4[i] * x0[j];
+                            acc[1][i][j] += d4[i] * x1[j];
+                            acc[2][i][j] += d4[i] * x2[j];
+                        }
+                    x0 = x1; x1 = x2;
+                }
+            }
+        }
+    }
+    // partial sums of this workgroup -> ws[blockIdx.x][CO][CI][9]; PS frame subsets add up through LDS first.  (One f32 atomic per
+    // weight per workgroup was 4.7 M atomics on 9 K addresses: 200-280 us of same-address contention, measured.)
+    __syncthreads();
+    float* red = a2d_lds;                                  // [CO*CI*9] floats (<= 36 KB, fits in the staging area)
+    for (int rep = 0; rep < PS; ++rep) {
+        if (active && ps == rep) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int idx = ((co4 * 4 + i) * CI + ci4 * 4 + j) * 9 + kh * 3 + kw;
+                        red[idx] = (rep == 0 ? 0.f : red[idx]) + acc[kw][i][j];
+                    }
+        }
+        __syncthreads();
+    }
+    float* dst = ws + (size_t)blockIdx.x * CO * CI * 9;
+    for (int e = tid; e < CO * CI * 9; e += 256) dst[e] = red[e];
+}
+
+__global__ __launch_bounds__(256) void a2d_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int n_ws, int n_out, int groups) {
+    // dW[i] += sum_g ws[g][i] for the first n_out (real output channels come first in the [CO][CI][9] order); blockIdx.y takes a
+    // slice of 32 groups (16 atomics per weight in total)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const int g0 = blockIdx.y * 32, g1 = min(groups, g0 + 32);
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int g = g0;
+    for (; g + 3 < g1; g += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += ws[(size_t)(g + k) * n_ws + i];
+    }
+    for (; g < g1; ++g) s[0] += ws[(size_t)g * n_ws + i];
+    if (g0 < g1) atomicAdd(dW + i, (s[0] + s[1]) + (s[2] + s[3]));
+}
+
 inline int grid_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
 
 #define A2D_DISPATCH_F(F, ...)                      \
@@ -546,6 +670,34 @@ extern "C" int s2t_a2d_freq_bwd(int dtype, const void* qkv, const void* dcat, co
     A2D_DISPATCH_F(F, A2D_DISPATCH_T(dtype,
         hipLaunchKernelGGL((a2d_freq_bwd_kernel<bf16, FQ>), dim3(B * HEADS), dim3(512), 0, st, (const bf16*)qkv, (const bf16*)dcat, A, (bf16*)dqkv, B, T, p_drop, seed),
         hipLaunchKernelGGL((a2d_freq_bwd_kernel<float, FQ>), dim3(B * HEADS), dim3(512), 0, st, (const float*)qkv, (const float*)dcat, A, (float*)dqkv, B, T, p_drop, seed)));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_conv_wgrad(int dtype, const void* dY, int ld_dy, const void* X, int ld_x, float* dW, float* ws, int CO, int CI,
+                                  int B, int T, int F, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!dY || !X || !dW || !ws || F <= 0 || ld_dy < CO || ld_x < CI) return S2T_EINVAL;
+    const int E = dtype == S2T_BF16 ? 8 : 4;
+    if ((ld_dy % E) || (ld_x % E) || (((uintptr_t)dY | (uintptr_t)X) & 15)) return S2T_ENOTSUP;
+    static const int dbg = getenv("S2T_A2D_DBG") ? atoi(getenv("S2T_A2D_DBG")) : 0;
+    const int TT = 6;
+    const int units = B * ((T + TT - 1) / TT);
+    const int grid = units < S2T_A2D_WGRAD_GROUPS ? units : S2T_A2D_WGRAD_GROUPS;
+    hipStream_t st = (hipStream_t)stream;
+    // (CO padded to 16, CI) = (16, 64): in_proj with its 12 real output channels; (64, 8): out_proj
+#define A2D_WGRAD(TT_, COp, CIp, co_real)                                                                                              \
+    do {                                                                                                                               \
+        const size_t lds = ((size_t)(TT + 2) * (F + 2) * CIp + (size_t)TT * F * COp) * 4;                                              \
+        if (lds > 150 * 1024) return S2T_ENOTSUP;                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&a2d_conv_wgrad_kernel<TT_, COp, CIp>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((a2d_conv_wgrad_kernel<TT_, COp, CIp>), dim3(grid), dim3(256), lds, st, (const TT_*)dY, ld_dy, (const TT_*)X, ld_x, ws, B, T, F, TT, units, dbg); \
+        hipLaunchKernelGGL(a2d_wgrad_reduce_kernel, dim3((co_real * CIp * 9 + 255) / 256, (grid + 31) / 32), dim3(256), 0, st, ws, dW, COp * CIp * 9, co_real * CIp * 9, grid); \
+    } while (0)
+    if (CO <= 16 && CI == 64 && ld_dy >= 16) { A2D_DISPATCH_T(dtype, A2D_WGRAD(bf16, 16, 64, CO), A2D_WGRAD(float, 16, 64, CO)); }
+    else if (CO == 64 && CI == 8) { A2D_DISPATCH_T(dtype, A2D_WGRAD(bf16, 64, 8, CO), A2D_WGRAD(float, 64, 8, CO)); }
+    else return S2T_ENOTSUP;
+#undef A2D_WGRAD
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

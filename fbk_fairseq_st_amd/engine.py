@@ -443,11 +443,12 @@ class S2TEngine:
         dy = K.a2d_bn_bwd(dout, c["y"], C, C, c["bn_o"], s_o, M, c["training"])
         # out_proj convolution
         K.colsum(dy, self.G(p + "out_proj.bias"))
-        gwo = torch.zeros((C, 18 * H), dtype=torch.float32, device=self.dev)
-        for tap in range(9):
-            K.gemm(dy, c["cat"], trans_a=True, trans_b=True, K=M, out=gwo[:, tap * 2 * H:(tap + 1) * 2 * H], accumulate=True,
-                   splitk=sk, map_b=mp[tap])
-        K.a2d_unpack_wgrad(gwo, self.G(p + "out_proj.weight"), 2 * H)
+        if not K.a2d_conv_wgrad(dy, c["cat"], self.G(p + "out_proj.weight"), B, T4, F4):       # one pass, all taps
+            gwo = torch.zeros((C, 18 * H), dtype=torch.float32, device=self.dev)
+            for tap in range(9):
+                K.gemm(dy, c["cat"], trans_a=True, trans_b=True, K=M, out=gwo[:, tap * 2 * H:(tap + 1) * 2 * H], accumulate=True,
+                       splitk=sk, map_b=mp[tap])
+            K.a2d_unpack_wgrad(gwo, self.G(p + "out_proj.weight"), 2 * H)
         w_out_d = K.a2d_pack_w(self.P(p + "out_proj.weight"), 2 * H, C, self.dtype, 1)        # [8, 9C]
         dcat = K.gemm(dy, w_out_d, M=M, K=9 * C, map_a=mp, period_a=C)
         # the two attentions
@@ -461,11 +462,12 @@ class S2TEngine:
         dz = K.a2d_bn_bwd(dqkv, c["z"], 3 * H, H, c["bn_qkv"], s_q, M, c["training"], prescale=ps)
         # in_proj convolution (+ the residual branch of x + f(x))
         K.colsum(dz[:, :3 * H], self.G(p + "in_proj_bias"))
-        gwi = torch.zeros((16, 9 * C), dtype=torch.float32, device=self.dev)
-        for tap in range(9):
-            K.gemm(dz, c["x"], trans_a=True, trans_b=True, K=M, out=gwi[:, tap * C:(tap + 1) * C], accumulate=True, splitk=sk,
-                   map_b=mp[tap])
-        K.a2d_unpack_wgrad(gwi, self.G(p + "in_proj_weight"), C)
+        if not K.a2d_conv_wgrad(dz, c["x"], self.G(p + "in_proj_weight"), B, T4, F4):
+            gwi = torch.zeros((16, 9 * C), dtype=torch.float32, device=self.dev)
+            for tap in range(9):
+                K.gemm(dz, c["x"], trans_a=True, trans_b=True, K=M, out=gwi[:, tap * C:(tap + 1) * C], accumulate=True, splitk=sk,
+                       map_b=mp[tap])
+            K.a2d_unpack_wgrad(gwi, self.G(p + "in_proj_weight"), C)
         w_in_d = K.a2d_pack_w(self.P(p + "in_proj_weight"), C, 16, self.dtype, 1)            # [C, 144]
         return K.gemm(dz, w_in_d, M=M, K=144, map_a=mp, period_a=16, residual=dout)
 

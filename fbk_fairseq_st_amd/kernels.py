@@ -495,3 +495,16 @@ def a2d_freq_fwd(qkv, cat, B, T, F, p_drop=0.0, seed=0):
 def a2d_freq_bwd(qkv, dcat, A, dqkv, B, T, F, p_drop=0.0, seed=0):
     L.check(_lib().s2t_a2d_freq_bwd(L.dt(qkv), L.ptr(qkv), L.ptr(dcat), L.ptr(A), L.ptr(dqkv), B, T, F, float(p_drop), int(seed),
                                     L.stream()), "s2t_a2d_freq_bwd")
+
+
+def a2d_conv_wgrad(dy, x, grad, B, T, F):
+    """grad[Co,Ci,3,3] += conv-weight gradient from dy [M, >=Co] and x [M, Ci] (pixel rows (t, b, f)); False when the shape is not built"""
+    Co, Ci = grad.shape[0], grad.shape[1]
+    assert grad.dtype == torch.float32 and grad.is_contiguous() and dy.dtype == x.dtype
+    ws = torch.empty((512, max(Co, 16) * Ci * 9), dtype=torch.float32, device=x.device)      # S2T_A2D_WGRAD_GROUPS partial sums
+    rc = _lib().s2t_a2d_conv_wgrad(L.dt(x), L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(grad), L.ptr(ws), Co, Ci, B, T, F,
+                                   L.stream())
+    if rc == -95:
+        return False
+    L.check(rc, "s2t_a2d_conv_wgrad")
+    return True

@@ -225,6 +225,13 @@ int s2t_a2d_param_grads(const double* sums, float* dgamma, float* dbeta, int Cg,
 /* nn.Conv2d weights [Co][Ci][3][3] (f32) <-> gathered-GEMM operands, row stride ld, CP = padded channels per tap:
  * mode 0: dst[co][j*CP+ci] = W[co][ci][j];  mode 1: dst[ci][j*CP+co] = W[co][ci][8-j];  mode 2: grad[co][ci][j] += src[co][j*CP+ci] */
 int s2t_a2d_pack_w(int dst_dtype, const float* src, void* dst, float* grad, int Co, int Ci, int CP, int ld, int mode, void* stream);
+/* weight gradient of a 3x3 / pad 1 convolution over the pixel rows, all nine taps in one pass, added to the master layout
+ * dW [CO][CI][3][3] (f32): (CO <= 16 with ld_dy >= 16, CI = 64) or (CO = 64, CI = 8); other shapes: S2T_ENOTSUP (callers fall
+ * back to nine gathered s2t_gemm_gather products).  ws: S2T_A2D_WGRAD_GROUPS x max(CO,16) x CI x 9 floats of workspace
+ * (per-workgroup partial sums, reduced by a second kernel: 16 instead of 512 atomics per weight) */
+#define S2T_A2D_WGRAD_GROUPS 512
+int s2t_a2d_conv_wgrad(int dtype, const void* dY, int ld_dy, const void* X, int ld_x, float* dW, float* ws, int CO, int CI,
+                       int B, int T, int F, void* stream);
 /* time attention of every (batch, head) plane: cat[.., h] = dropout(softmax_t'(q k^T)) v ; lse [B*4][T] for the backward */
 int s2t_a2d_time_fwd(int dtype, const void* qkv, void* cat, float* lse, int B, int T, int F, float p_drop,
                      unsigned long long seed, void* stream);

@@ -710,6 +710,24 @@ def test_attn2d_convolutions_as_gathered_gemms():
     gw = torch.zeros(Co, Ci, 3, 3, device=DEV)
     K.a2d_unpack_wgrad(gp, gw, Ci)
     assert rel_err(gw, wf.grad) < 1e-4
+    gw1 = torch.ones(Co, Ci, 3, 3, device=DEV)                  # the one-pass kernel adds to the master layout
+    assert K.a2d_conv_wgrad(dyd, xd, gw1, B, T, Fq)
+    assert rel_err(gw1 - 1, wf.grad) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T", [(2, 9), (3, 40), (1, 6)])
+def test_attn2d_in_projection_weight_gradient_one_pass(dtype, B, T):
+    """12 real output channels stored with row stride 16, 64 input channels (the in_proj convolution)"""
+    Fq, Ci, Co = 20, 64, 12
+    M = T * B * Fq
+    x = rnd(M, Ci, dtype=dtype, seed=1); dy16 = torch.zeros(M, 16); dy16[:, :Co] = rnd(M, Co, seed=2); dy16 = dy16.to(dtype)
+    xi = x.float().view(T, B, Fq, Ci).permute(1, 3, 0, 2)
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(xi, w, None, padding=1).backward(dy16.float()[:, :Co].reshape(T, B, Fq, Co).permute(1, 3, 0, 2))
+    gw = torch.zeros(Co, Ci, 3, 3, device=DEV)
+    assert K.a2d_conv_wgrad(dy16.to(DEV), x.to(DEV), gw, B, T, Fq)
+    assert rel_err(gw, w.grad) < (1e-4 if dtype == torch.float32 else 1e-3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -1,0 +1,21 @@
+"""Times s2t_a2d_conv_wgrad at the bench shape (diagnostic; S2T_A2D_DBG bits: 1 no X staging, 2 no FMA loop, 4 no atomics)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fbk_fairseq_st_amd import kernels as K
+B, T, F = 64, 375, 20
+M = B * T * F
+dt = torch.bfloat16
+x = torch.randn(M, 64, device="cuda").to(dt); dz = torch.randn(M, 16, device="cuda").to(dt)
+dy = torch.randn(M, 64, device="cuda").to(dt); cat = torch.randn(M, 8, device="cuda").to(dt)
+gi = torch.zeros(12, 64, 3, 3, device="cuda"); go = torch.zeros(64, 8, 3, 3, device="cuda")
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+print("dbg=%s in_proj %.1f us  out_proj %.1f us" % (os.environ.get("S2T_A2D_DBG", "0"), timeit(lambda: K.a2d_conv_wgrad(dz, x, gi, B, T, F)),
+                                                     timeit(lambda: K.a2d_conv_wgrad(dy, cat, go, B, T, F))))
