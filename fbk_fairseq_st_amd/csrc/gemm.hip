@@ -18,6 +18,7 @@
 #include "gemm_epilogue.hpp"
 int s2t_gemm_v2_try(const GemmArgs& a, int out_dtype, hipStream_t st);   // gemm_v2.hip
 #include <cstdlib>
+#include <type_traits>
 
 template <typename T> __device__ __forceinline__ u32x4 load16_guard(const T* p, int valid) {
     // element-wise guarded load of up to 16 bytes (valid = number of in-bounds elements)
@@ -295,6 +296,27 @@ template <typename T, int ROWS, int NTH = 256> struct FastDirect {
 #pragma unroll
         for (int i = 0; i < N; ++i) *reinterpret_cast<u32x4*>(lds + off[i]) = R.r[i];
     }
+    // ---- direct-to-LDS form (global_load_lds_dwordx4): one wave-instruction writes 64 x 16 bytes CONTIGUOUSLY (wave-uniform LDS
+    // base + 16 * lane), i.e. 8 whole rows of the image; the XOR swizzle therefore moves to the SOURCE address: the lane that fills
+    // position p of row r fetches chunk p ^ (r & 7) (the same image, XOR being an involution).
+    __device__ __forceinline__ void init_glds(const T* g, int ld, int row0, int nrows, int k0) {
+        base = reinterpret_cast<const char*>(g);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = threadIdx.x + NTH * i, row = cid >> 3, pcol = cid & 7;
+            const int gr = min(row0 + row, nrows - 1);
+            goff[i] = (uint32_t)(((size_t)gr * ld + k0 + (pcol ^ (row & 7)) * E) * sizeof(T));
+            off[i] = (cid & ~63) * 16;                          // LDS offset of this wave's 1-KiB piece
+        }
+    }
+    __device__ __forceinline__ void issue(char* lds, int step) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
+                                             (__attribute__((address_space(3))) void*)(lds + __builtin_amdgcn_readfirstlane(off[i])), 16, 0, 0);
+            goff[i] += step;
+        }
+    }
 };
 
 template <typename T, int COLS, int NTH = 256> struct FastTrans {
@@ -388,6 +410,27 @@ template <int COLS, int NTH = 256> struct FastTr {
     __device__ __forceinline__ void store(char* lds, const Regs& R) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) *reinterpret_cast<u32x4*>(lds + off[i]) = R.r[i];
+    }
+    // direct-to-LDS form: a wave-instruction fills 4 whole 256-byte rows; position p of row r takes source chunk p ^ tr_swz(r)
+    __device__ __forceinline__ void init_glds(const bf16* g, int ld, int col0, int ncols, int k0) {
+        base = reinterpret_cast<const char*>(g);
+        tile_bytes = (uint32_t)(64u * (uint32_t)ld * 2u);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int cid = threadIdx.x + NTH * i, row = cid >> 4, pcol = cid & 15;
+            const int gc = min(col0 + (pcol ^ tr_swz(row)) * 8, (ncols + 7) / 8 * 8 - 8);
+            goff[i] = (uint32_t)(((size_t)(k0 + row) * ld + gc) * 2);
+            off[i] = (cid & ~63) * 16;
+        }
+    }
+    __device__ __forceinline__ void issue(char* lds, int step) {
+        const uint32_t st = step ? tile_bytes : 0u;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
+                                             (__attribute__((address_space(3))) void*)(lds + __builtin_amdgcn_readfirstlane(off[i])), 16, 0, 0);
+            goff[i] += st;
+        }
     }
 };
 
@@ -574,6 +617,57 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
             for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
+    gemm_epilogue<TO, BM, BN, MT, NT, NTH>(p, acc, smem, row0, col0, arow, brow, q, r16);
+}
+
+// Direct-to-LDS variant of the 8-wave 128x128 kernel (A direct; B direct or transposed-read), opt-in (S2T_GEMM_GLDS=1):
+// both operands arrive by global_load_lds (no staging registers, no ds_write pass).  A (the activation rows: streamed from HBM) has
+// THREE LDS stages and runs two k-tiles ahead, B (the weights: L2 hits) two stages and one tile ahead: 80 KB per workgroup, two
+// workgroups per CU.  The DMAs stay in flight across the barrier: counted s_waitcnt vmcnt(2) (the two youngest = A(t+2)) + raw
+// s_barrier; tail iterations re-issue the last tile into a free slot so that the count is a constant.
+template <typename TO, bool TB, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_glds_kernel(GemmArgs p) {
+    typedef bf16 TI;
+    constexpr int BM = 128, BN = 128, BK = 64, NTH = NW * 64, WN = NW / 2, MT = 4, NT = BN / (16 * WN);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ASZ = BM * 128, BSZ = BN * 128, BBASE = 3 * ASZ;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = wg / tiles_n, tn = wg % tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nk = p.K / BK;
+    typedef FastDirect<TI, BM, NTH> SA;
+    typedef typename FastSel<TI, BN, TB, NTH>::type SB;
+    SA sa; SB sb;
+    sa.init_glds(reinterpret_cast<const TI*>(p.A), p.lda, row0, p.M, 0);
+    sb.init_glds(reinterpret_cast<const TI*>(p.B), p.ldb, col0, p.N, 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave / WN, wc = wave % WN, r16 = lane & 15, q = lane >> 4;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr bool TRB = UsesTrRead<SB>::value;
+    const int arow = wr * (BM / 2), brow = wc * (BN / WN);
+    int ia = 0, ib = 0;                                   // next A / B tile to request
+    auto issue_a = [&](int slot) { sa.issue(smem + slot * ASZ, ia + 1 < nk ? 128 : 0); ++ia; };
+    auto issue_b = [&](int slot) { sb.issue(smem + BBASE + slot * BSZ, ib + 1 < nk ? 128 : 0); ++ib; };
+    issue_a(0); issue_b(0); issue_a(1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int sa_cur = 0, sa_nxt2 = 2;                          // A slot of tile t, of tile t+2 (mod 3 without a division)
+    for (int t = 0; t < nk; ++t) {
+        issue_b((t + 1) & 1);
+        issue_a(sa_nxt2);
+        mma_tile<TI, MT, NT, false, TRB>(smem + sa_cur * ASZ, smem + BBASE + (t & 1) * BSZ, arow, brow, r16, q, acc);
+        asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        sa_cur = sa_cur == 2 ? 0 : sa_cur + 1;
+        sa_nxt2 = sa_nxt2 == 2 ? 0 : sa_nxt2 + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-issued tail tiles must land before the epilogue reuses the LDS
+    __syncthreads();
     gemm_epilogue<TO, BM, BN, MT, NT, NTH>(p, acc, smem, row0, col0, arow, brow, q, r16);
 }
 
@@ -857,6 +951,23 @@ static int launch(const GemmArgs& a_in, hipStream_t st) {
             // global-load latency: twice the wavefronts per CU cover more of it), and lose ~10 % on TN where both operands
             // are gathered by transposed LDS reads (fragment traffic dominates); S2T_GEMM_NW4=1 forces the 4-wave form
             static const bool nw4 = getenv("S2T_GEMM_NW4") != nullptr;
+            static const bool glds = getenv("S2T_GEMM_GLDS") != nullptr;
+            if constexpr (!TA && std::is_same<TI, bf16>::value) {
+                if (glds && a.splitk == 1 && !a.mapA && !a.mapB && (a.K % 64) == 0 && (!TB || UsesTrRead<typename FastSel<TI, BN, TB, 512>::type>::value)) {
+                    static bool attrg = false;
+                    const size_t ldsg = 5 * 128 * 128;                               // 3 A stages + 2 B stages (>= the epilogue's f32 tile)
+                    static const bool g4 = getenv("S2T_GEMM_GLDS4") != nullptr;      // 4 waves of 64x64 instead of 8 of 64x32
+                    if (!attrg) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TO, TB, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TO, TB, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
+                        attrg = true;
+                    }
+                    if (g4) hipLaunchKernelGGL((gemm_glds_kernel<TO, TB, 4>), grid, dim3(256), ldsg, st, a);
+                    else hipLaunchKernelGGL((gemm_glds_kernel<TO, TB, 8>), grid, dim3(512), ldsg, st, a);
+                    S2T_LAUNCH_CHECK();
+                    return S2T_OK;
+                }
+            }
             if (!TA && !nw4) {
                 static bool attr3 = false;
                 if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
