@@ -210,7 +210,9 @@ def _row_ld(x):
     assert x.stride(-1) == 1
     ld = x.stride(-2)
     if x.dim() == 3:
-        assert x.stride(0) == x.shape[1] * ld
+        if x.shape[1] == 1:                    # batch of one: the stride torch reports for a size-1 dimension is arbitrary
+            return x.stride(0) if x.shape[0] > 1 else max(ld, x.shape[2])
+        assert x.shape[0] == 1 or x.stride(0) == x.shape[1] * ld
     return ld
 
 

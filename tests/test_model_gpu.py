@@ -346,9 +346,13 @@ def test_beam_search_bf16_runs_and_is_consistent():
 
 
 # ---------------------------------------------------------------------------------------------- BASELINE.json configs
-@pytest.mark.parametrize("arch,B,lengths,L,ctc_layer", [("s2t_transformer_xs", 4, [200, 180, 150, 120], 12, 4),
-                                                        ("s2t_transformer_s", 3, [333, 333, 333], 10, 8)])
-def test_baseline_config_shapes_match_oracle(arch, B, lengths, L, ctc_layer):
+@pytest.mark.parametrize("arch,B,lengths,L,ctc_layer,feat,attn_2d", [("s2t_transformer_xs", 4, [200, 180, 150, 120], 12, 4, 80, False),
+                                                                     ("s2t_transformer_s", 3, [333, 333, 333], 10, 8, 80, False),
+                                                                     ("s2t_transformer_xs", 2, [150, 97], 8, 4, 40, True),
+                                                                     ("s2t_transformer_xs", 1, [61], 6, 2, 80, True),
+                                                                     ("s2t_transformer_xs", 2, [9, 5], 3, 2, 80, False),
+                                                                     ("s2t_transformer_xs", 3, [13, 4, 1], 2, 2, 80, True)])
+def test_baseline_config_shapes_match_oracle(arch, B, lengths, L, ctc_layer, feat, attn_2d):
     """configs[0] of BASELINE.json (s2t_transformer_xs, 80-mel x 200 frames, batch 4, ragged) and an s-preset batch at the real
     vocabulary sizes (V_tgt 8000, V_src 5001: unaligned logit rows, K-tail GEMMs, d_head 64): one fp32 update's loss terms and
     gradient norms of the HIP engine against the CPU oracle run on the same weights and batch (1e-4 loss, 1e-3 gradients)."""
@@ -357,9 +361,9 @@ def test_baseline_config_shapes_match_oracle(arch, B, lengths, L, ctc_layer):
     from fbk_fairseq_st_amd.registry import apply_arch, namespace, setup_task
     a = namespace(arch=arch, task="dummy_s2t", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
                   label_smoothing=0.1, sentence_avg=False, ctc_compress_out=True, ctc_encoder_layer=ctc_layer, ctc_weight=1.0,
-                  ctc_compress_strategy="avg", input_feat_per_channel=80, no_attn_2d=True, dict_size=8000 - 4, src_dict_size=5000 - 4,
-                  batch_size=B, frames=max(lengths), tgt_len=L, transcript_len=L, dropout=0.0, attention_dropout=0.0,
-                  activation_dropout=0.0, relu_dropout=0.0, seed=1)
+                  ctc_compress_strategy="avg", input_feat_per_channel=feat, no_attn_2d=not attn_2d, dict_size=8000 - 4,
+                  src_dict_size=5000 - 4, batch_size=B, frames=max(lengths), tgt_len=L, transcript_len=L, dropout=0.0,
+                  attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0, seed=1)
     apply_arch(a)
     a.dropout = a.attention_dropout = a.activation_dropout = a.relu_dropout = 0.0
     task = setup_task(a)
@@ -377,7 +381,8 @@ def test_baseline_config_shapes_match_oracle(arch, B, lengths, L, ctc_layer):
 
     hp = model.hp
     cfg = s2t_ref.default_cfg(D=hp.D, heads=hp.heads, ffn=hp.ffn, enc_layers=hp.enc_layers, dec_layers=hp.dec_layers, ctc_layer=ctc_layer,
-                              act=hp.act)
+                              act=hp.act, feat=feat, attn_2d=attn_2d)
+    assert hp.attn_2d == attn_2d
     Wr = {k: v.clone().requires_grad_(True) for k, v in W.items() if not k.endswith("_float_tensor") and "running" not in k}
     Wb = {k: v.clone() for k, v in W.items() if "running" in k}
     blank = task.source_dictionary.index("<ctc_blank>")
