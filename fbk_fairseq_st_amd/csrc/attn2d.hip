@@ -682,6 +682,23 @@ __global__ __launch_bounds__(256) void a2d_wgrad_reduce_kernel(const float* __re
     if (g0 < g1) atomicAdd(dW + i, (s[0] + s[1]) + (s[2] + s[3]));
 }
 
+// ------------------------------------------------------------------ (batch, head) planes <-> the head-major layout of the MFMA attention kernels
+// chl: channels-last [M][ld] over pixel rows (t, b, f); pl: [G][T][B][HEADS*32], plane of head h in columns 32h .. 32h+F-1 (zero beyond F).
+// dir 0: pl = planes of channels ch0 + 4g + h of chl;  dir 1: chl channels <- pl.  With these the time attention of a block is
+// s2t_attn_fwd / s2t_attn_bwd at head_dim 32, scale 1 (attention.hip) instead of the one-thread-per-query kernels above.
+template <typename T>
+__global__ __launch_bounds__(256) void a2d_planes_kernel(T* __restrict__ chl, T* __restrict__ pl, int G, int ch0, int ld, int B, int Tn, int F, int dir) {
+    const long n = (long)G * Tn * B * HEADS * 32;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int f = (int)(i & 31), h = (int)((i >> 5) & 3);
+        const long tb = (i >> 7) % ((long)Tn * B);
+        const int g = (int)((i >> 7) / ((long)Tn * B));
+        const long src = (tb * F + f) * ld + ch0 + 4 * g + h;
+        if (dir == 0) pl[i] = f < F ? chl[src] : from_f32<T>(0.f);
+        else if (f < F) chl[src] = pl[i];
+    }
+}
+
 // rows of 16 / 32 / 64 channels (8-channel chunks, a power-of-two number of them), both tensors 16-byte aligned
 inline bool a2d_vec_ok(int ld_a, const void* a, int ld_b, const void* b) {
     const bool shape = (ld_a == 16 || ld_a == 32 || ld_a == 64 || ld_a == 8) && ld_b == ld_a;
@@ -866,6 +883,18 @@ extern "C" int s2t_a2d_conv_wgrad(int dtype, const void* dY, int ld_dy, const vo
     else if (CO == 64 && CI == 8) { A2D_DISPATCH_T(dtype, A2D_WGRAD(bf16, 64, 8, CO), A2D_WGRAD(float, 64, 8, CO)); }
     else return S2T_ENOTSUP;
 #undef A2D_WGRAD
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_a2d_planes(int dtype, void* chl, void* planes, int G, int ch0, int ld, int B, int T, int F, int dir, void* stream) {
+    if (B <= 0 || T <= 0 || G <= 0) return S2T_OK;
+    if (!chl || !planes || F <= 0 || F > 32 || ch0 < 0 || ch0 + 4 * G > ld || (dir != 0 && dir != 1)) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = grid_for((long)G * T * B * HEADS * 32);
+    A2D_DISPATCH_T(dtype,
+        hipLaunchKernelGGL(a2d_planes_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (bf16*)chl, (bf16*)planes, G, ch0, ld, B, T, F, dir),
+        hipLaunchKernelGGL(a2d_planes_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)chl, (float*)planes, G, ch0, ld, B, T, F, dir));
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

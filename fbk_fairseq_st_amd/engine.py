@@ -183,6 +183,7 @@ class S2TEngine:
         self.on_grads_ready = None      # callback(prefix): every gradient of parameters named prefix* is final
         self._wg_side, self._wg_on, self._wg_pending = None, False, False
         self._a2d_prescale = None
+        self.a2d_time_mfma = os.environ.get("S2T_A2D_TIME_VALU", "0") != "1"     # time attention of ConvAttention2D on the MFMA attention kernels
         # LayerNorm backward also writes dropout(dx) for the block that consumes dx (one pass instead of two; identical bits)
         self.fuse_bwd_dropout = os.environ.get("S2T_FUSE_BWD_DROPOUT", "1") != "0"
         if hp.act not in ("relu", "gelu"):
@@ -417,7 +418,14 @@ class S2TEngine:
         bn_qkv = self._a2d_bn(p, ("bn_q", "bn_k", "bn_v"), sums, M, training)
         qkv = K.a2d_bn_act(z, 3 * H, bn_qkv[2], bn_qkv[3], prescale=ps)
         cat = torch.empty((M, 2 * H), dtype=self.dtype, device=self.dev)
-        lse = K.a2d_time_fwd(qkv, cat, B, T4, F4, pd, seed + 1)
+        pl = o_pl = None
+        if self.a2d_time_mfma:
+            # time attention on the MFMA attention kernels: planes [3][T][B][4 heads x 32 columns] (F4 <= 32 real), head_dim 32, scale 1
+            pl = K.a2d_planes(qkv, torch.empty((3, T4, B, 32 * H), dtype=self.dtype, device=self.dev), 0, B, T4, F4, True)
+            o_pl, lse = K.attn_fwd(pl[0], pl[1], pl[2], H, scale=1.0, p_drop=pd, seed=seed + 1)
+            K.a2d_planes(cat, o_pl.view(1, T4, B, 32 * H), 0, B, T4, F4, False)
+        else:
+            lse = K.a2d_time_fwd(qkv, cat, B, T4, F4, pd, seed + 1)
         A = K.a2d_freq_fwd(qkv, cat, B, T4, F4, pd, seed + 2)
         w_out = K.a2d_pack_w(self.P(p + "out_proj.weight"), C, 2 * H, self.dtype, 0)          # [C, 72]
         y = K.gemm(cat, w_out, M=M, K=18 * H, map_a=mp, period_a=2 * H, bias=self.P(p + "out_proj.bias"))
@@ -425,7 +433,7 @@ class S2TEngine:
         bn_o = self._a2d_bn(p, ("bn_out",), sums_o, M, training)
         out = K.a2d_bn_act(y, C, bn_o[2], bn_o[3], res=x)
         ctx = dict(p=p, x=x, z=z, qkv=qkv, cat=cat, lse=lse, A=A, y=y, bn_qkv=bn_qkv, bn_o=bn_o, B=B, T4=T4, F4=F4, pd=pd, seed=seed,
-                   training=training)
+                   training=training, pl=pl, o_pl=o_pl)
         return out, ctx
 
     def attn2d_block_bwd(self, c, dout):
@@ -453,7 +461,15 @@ class S2TEngine:
         dcat = K.gemm(dy, w_out_d, M=M, K=9 * C, map_a=mp, period_a=C)
         # the two attentions
         dqkv = torch.zeros_like(c["qkv"])
-        K.a2d_time_bwd(c["qkv"], c["cat"], dcat, c["lse"], dqkv, B, T4, F4, c["pd"], c["seed"] + 1)
+        if c["pl"] is not None:
+            pl = c["pl"]
+            do_pl = K.a2d_planes(dcat, torch.empty((1, T4, B, 32 * H), dtype=self.dtype, device=self.dev), 0, B, T4, F4, True)
+            dpl = torch.empty_like(pl)
+            K.attn_bwd(pl[0], pl[1], pl[2], c["o_pl"], do_pl[0], c["lse"], H, dpl[0], dpl[1], dpl[2], scale=1.0, p_drop=c["pd"],
+                       seed=c["seed"] + 1)
+            K.a2d_planes(dqkv, dpl, 0, B, T4, F4, False)
+        else:
+            K.a2d_time_bwd(c["qkv"], c["cat"], dcat, c["lse"], dqkv, B, T4, F4, c["pd"], c["seed"] + 1)
         K.a2d_freq_bwd(c["qkv"], dcat, c["A"], dqkv, B, T4, F4, c["pd"], c["seed"] + 2)
         # bn_q / bn_k / bn_v + ReLU
         s_q = K.a2d_chan_stats(c["z"], 3 * H, H, prescale=ps, dy=dqkv, bn=c["bn_qkv"])

@@ -510,3 +510,12 @@ def a2d_conv_wgrad(dy, x, grad, B, T, F):
         return False
     L.check(rc, "s2t_a2d_conv_wgrad")
     return True
+
+
+def a2d_planes(chl, planes, ch0, B, T, F, to_planes):
+    """chl [M, ld] channels-last pixel rows <-> planes [G, T, B, 128] (head-major, F columns of 32 used per head)"""
+    G = planes.shape[0]
+    assert planes.is_contiguous() and planes.shape[1:] == (T, B, 128) and chl.stride(1) == 1 and planes.dtype == chl.dtype
+    L.check(_lib().s2t_a2d_planes(L.dt(chl), L.ptr(chl), L.ptr(planes), G, ch0, chl.stride(0), B, T, F, 0 if to_planes else 1, L.stream()),
+            "s2t_a2d_planes")
+    return planes if to_planes else chl

@@ -74,6 +74,7 @@ SIGNATURES = {
     "s2t_a2d_param_grads": [P, P, P, c_int, P],
     "s2t_a2d_pack_w": [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "s2t_a2d_conv_wgrad": [c_int, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_a2d_planes": [c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "s2t_a2d_time_fwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
     "s2t_a2d_time_bwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
     "s2t_a2d_freq_fwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],

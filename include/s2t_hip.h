@@ -232,6 +232,10 @@ int s2t_a2d_pack_w(int dst_dtype, const float* src, void* dst, float* grad, int 
 #define S2T_A2D_WGRAD_GROUPS 512
 int s2t_a2d_conv_wgrad(int dtype, const void* dY, int ld_dy, const void* X, int ld_x, float* dW, float* ws, int CO, int CI,
                        int B, int T, int F, void* stream);
+/* channels-last pixel rows [M][ld] <-> head-major planes [G][T][B][4*32] (plane of head h of group g = channel ch0 + 4g + h,
+ * columns 32h .. 32h+F-1, zero padded): dir 0 gathers the planes, dir 1 scatters them back.  The time attention of a block then
+ * runs on s2t_attn_fwd / s2t_attn_bwd at head_dim 32 */
+int s2t_a2d_planes(int dtype, void* chl, void* planes, int G, int ch0, int ld, int B, int T, int F, int dir, void* stream);
 /* time attention of every (batch, head) plane: cat[.., h] = dropout(softmax_t'(q k^T)) v ; lse [B*4][T] for the backward */
 int s2t_a2d_time_fwd(int dtype, const void* qkv, void* cat, float* lse, int B, int T, int F, float p_drop,
                      unsigned long long seed, void* stream);
