@@ -6,7 +6,7 @@ import bench
 
 
 class A:
-    arch = "s2t_transformer_m"; ctc_layer = 8; batch = int(os.environ.get("B", 64)); frames = 1500; tgt_len = 40; cpu_baseline = False
+    arch = "s2t_transformer_m"; ctc_layer = 8; batch = int(os.environ.get("B", 64)); frames = 1500; tgt_len = 40; cpu_baseline = False; attn_2d = bool(int(os.environ.get("ATTN2D", "0")))
 
 
 dev = torch.device("cuda", 0)
