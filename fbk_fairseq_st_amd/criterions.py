@@ -53,9 +53,10 @@ class _CTCFn(torch.autograd.Function):
     _pending = []
 
     @staticmethod
-    def forward(ctx, logits, targets, tgt_len, in_len32, blank):
-        if logits.stride(2) != 1 or logits.stride(0) != logits.shape[1] * logits.stride(1):
+    def forward(ctx, logits, targets, tgt_len, in_len32, blank, lse=None):
+        if logits.stride(2) != 1 or (logits.shape[1] > 1 and logits.stride(0) != logits.shape[1] * logits.stride(1)):
             logits = logits.contiguous()
+            lse = None
         targets, tgt_len, in_len32 = targets.contiguous(), tgt_len.contiguous(), in_len32.contiguous()
         dev = logits.device
         main = torch.cuda.current_stream(dev)
@@ -65,9 +66,9 @@ class _CTCFn(torch.autograd.Function):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             # loss only: the gradient pass runs in backward, where the upstream gradient is known (as a device scalar)
-            loss, ws, _ = K.ctc_loss(logits, targets, tgt_len, in_len32, blank, defer_grad=True)
+            loss, ws, _ = K.ctc_loss(logits, targets, tgt_len, in_len32, blank, defer_grad=True, lse=lse)
             out = loss[0]
-        for t in (logits, targets, tgt_len, in_len32):
+        for t in (logits, targets, tgt_len, in_len32) + ((lse,) if lse is not None else ()):
             t.record_stream(side)
         for t in (loss, out) + tuple(w for w in ws if torch.is_tensor(w)):
             t.record_stream(main)
@@ -87,7 +88,7 @@ class _CTCFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         _CTCFn.join()                                  # normally a no-op: the loss was already consumed on the main stream
-        return K.ctc_loss_grad(ctx.ws, g.contiguous().float().view(1)), None, None, None, None
+        return K.ctc_loss_grad(ctx.ws, g.contiguous().float().view(1)), None, None, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):
@@ -204,12 +205,13 @@ class CTCMultiLoss(FairseqCriterion):
         last = enc._last
         if hasattr(encoder_out, "ctc_out"):
             ctc_feat, in_len, in_len_host, pred = encoder_out.ctc_out, last["ctc_lengths"], last["ctc_lengths_host"], last.get("pred_host")
+            ctc_lse = last.get("ctc_lse")                # row log-sum-exps of ctc_out, by-product of the compression's arg-max pass
         else:
             ctc_feat = _LinearFn.apply(encoder_out.encoder_states[k - 1], model,
                                        "criterion.ctc_aware_model.fc_out.weight", "criterion.ctc_aware_model.fc_out.bias")
-            in_len, in_len_host, pred = last["lengths"], last["lengths_host"], None
+            in_len, in_len_host, pred, ctc_lse = last["lengths"], last["lengths_host"], None, None
         tr, tr_len = sample["transcript_target"], sample["transcript_target_lengths"]
-        ctc_loss = _CTCFn.apply(ctc_feat, tr, tr_len, in_len.to(torch.int32), self.blank_idx)      # side stream
+        ctc_loss = _CTCFn.apply(ctc_feat, tr, tr_len, in_len.to(torch.int32), self.blank_idx, ctc_lse)      # side stream
         decoder_out = model.decoder(ni["prev_output_tokens"], encoder_out=encoder_out)               # main stream, concurrently
         # unit error rate (logging only): greedy path + native edit-distance alignment on the host
         if pred is None:

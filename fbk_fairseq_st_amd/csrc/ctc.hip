@@ -40,7 +40,7 @@ __device__ __forceinline__ void row_max_sumexp(const T* __restrict__ x, int V, i
 
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_argmax_kernel(const T* __restrict__ logits, int* __restrict__ pred,
-                                                         float* __restrict__ pmax, int Tn, int B, int V, int ld) {
+                                                         float* __restrict__ pmax, float* __restrict__ lse_out, int Tn, int B, int V, int ld) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)Tn * B) return;
@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void ctc_argmax_kernel(const T* __restrict__ l
         const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (lane == 0) { pred[(long)b * Tn + t] = bi; pmax[(long)b * Tn + t] = best; }
+    if (lane == 0) {
+        pred[(long)b * Tn + t] = bi; pmax[(long)b * Tn + t] = best;
+        if (lse_out) lse_out[row] = m + logf(s);              // what row_lse_kernel would store: the CTC loss over the same logits reuses it
+    }
 }
 
 // ------------------------------------------------------------------ run-length collapse + weights
@@ -395,14 +398,14 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
 }
 
 // ------------------------------------------------------------------ C ABI
-extern "C" int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, int ld, void* stream) {
+extern "C" int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, float* lse, int T, int B, int V, int ld, void* stream) {
     const long rows = (long)T * B;
     if (rows <= 0) return S2T_OK;
     if (!logits || !pred || !pmax || V <= 0 || ld < V) return S2T_EINVAL;
     dim3 grid((unsigned)((rows + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, T, B, V, ld);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, pred, pmax, T, B, V, ld);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, lse, T, B, V, ld);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, pred, pmax, lse, T, B, V, ld);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
@@ -461,6 +464,8 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
                             float* loss_sum, int T, int B, int V, int ld, int Lmax, int blank, float grad_scale,
                             int phase, const float* grad_scale_dev, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
+    const bool lse_given = (phase & 4) != 0;               // lse already holds the rows' log-sum-exps (s2t_ctc_argmax wrote them)
+    phase &= 3;
     if (!logits || !targets || !tgt_len || !in_len || !lse || !la || !lb || !nll || ld < V || phase < 0 || phase > 2) return S2T_EINVAL;
     if ((phase != 2 && !loss_sum) || (phase != 1 && !grad)) return S2T_EINVAL;
     const bool fwd = phase != 2, bwd = phase != 1;
@@ -475,7 +480,7 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
     const size_t lds = (size_t)V * 4;
     if (dtype == S2T_BF16) {
         if (fwd) {
-        hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V, ld);
+        if (!lse_given) hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V, ld);
         if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 1>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 2>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 4>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
@@ -486,7 +491,7 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
         if (bwd) hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, lsum_grad, T, B, V, ld, Lmax, Smax, blank, grad_scale, grad_scale_dev);
     } else if (dtype == S2T_F32) {
         if (fwd) {
-        hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V, ld);
+        if (!lse_given) hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V, ld);
         if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 1>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 2>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 4>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);

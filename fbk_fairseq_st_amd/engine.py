@@ -605,14 +605,14 @@ class S2TEngine:
                 Tn = x.shape[0]
                 x2 = x.view(Tn * B, D)
                 x_ctc = self.linear(x2, "encoder.ctc_fc", pad_rows=True).view(Tn, B, hp.V_src)   # row stride padded to 16 B
-                pred, pmax = K.ctc_argmax(x_ctc)
+                pred, pmax, ctc_lse = K.ctc_argmax(x_ctc, want_lse=True)     # the CTC loss over x_ctc reuses the row log-sum-exps
                 seg, rs, rl, new_len, w = K.ctc_rle(pred, pmax, cur_len, hp.ctc_strategy)
                 new_len_host = new_len.tolist()                     # the one host sync of the forward pass
                 out["pred_host"] = pred.cpu()                       # greedy path for the host-side UER (logging)
                 Tout = max(new_len_host)
                 xc = K.ctc_compress_fwd(x, w, rs, rl, new_len, Tout)
                 ctx["ctc"] = dict(layer=l, x=x2, seg=seg, w=w, Tn=Tn, Tout=Tout)
-                out.update(ctc_out=x_ctc, ctc_lengths=cur_len, ctc_lengths_host=cur_len_host, ctc_klen=cur_klen, pred=pred)
+                out.update(ctc_out=x_ctc, ctc_lengths=cur_len, ctc_lengths_host=cur_len_host, ctc_klen=cur_klen, pred=pred, ctc_lse=ctc_lse)
                 x = xc
                 cur_len, cur_len_host = new_len, new_len_host
                 cur_klen = new_len.to(torch.int32) if min(new_len_host) < Tout else None

@@ -216,12 +216,15 @@ def _row_ld(x):
     return ld
 
 
-def ctc_argmax(logits):
+def ctc_argmax(logits, want_lse=False):
+    """(pred, pmax) [B, T]; want_lse: also the rows' log-sum-exps [T*B] (same pass), which ctc_loss(lse=...) reuses"""
     T, B, V = logits.shape
     pred = torch.empty((B, T), dtype=torch.int32, device=logits.device)
     pmax = torch.empty((B, T), dtype=torch.float32, device=logits.device)
-    L.check(_lib().s2t_ctc_argmax(L.dt(logits), L.ptr(logits), L.ptr(pred), L.ptr(pmax), T, B, V, _row_ld(logits), L.stream()), "s2t_ctc_argmax")
-    return pred, pmax
+    lse = torch.empty((T * B,), dtype=torch.float32, device=logits.device) if want_lse else None
+    L.check(_lib().s2t_ctc_argmax(L.dt(logits), L.ptr(logits), L.ptr(pred), L.ptr(pmax), L.ptr(lse), T, B, V, _row_ld(logits), L.stream()),
+            "s2t_ctc_argmax")
+    return (pred, pmax, lse) if want_lse else (pred, pmax)
 
 
 def ctc_rle(pred, pmax, len64, strategy=0):
@@ -252,14 +255,17 @@ def ctc_compress_bwd(dout, w, seg, dx, accumulate=False):
     return dx
 
 
-def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0, defer_grad=False):
+def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0, defer_grad=False, lse=None):
     """Returns (loss_sum f32[1], grad like logits, nll).  defer_grad: the forward pass only; the second result is then the workspace
     tuple for ctc_loss_grad (called from backward with the upstream gradient as a device scalar: no separate scaling pass)."""
     T, B, V = logits.shape
     Lmax = targets.shape[1]
     dev = logits.device
     S = 2 * Lmax + 1
-    lse = torch.empty((T * B,), dtype=torch.float32, device=dev)
+    lse_given = lse is not None                     # row log-sum-exps of THESE logits from ctc_argmax(want_lse=True)
+    if lse is None:
+        lse = torch.empty((T * B,), dtype=torch.float32, device=dev)
+    assert lse.numel() == T * B and lse.dtype == torch.float32
     la = torch.empty((B * T * S,), dtype=torch.float32, device=dev)
     lb = torch.empty((B * T * S,), dtype=torch.float32, device=dev)
     nll = torch.empty((B,), dtype=torch.float32, device=dev)
@@ -268,7 +274,7 @@ def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0, defer_gr
     loss = torch.zeros((1,), dtype=torch.float32, device=dev)
     L.check(_lib().s2t_ctc_loss(L.dt(logits), L.ptr(logits), L.ptr(targets), L.ptr(tgt_len), L.ptr(in_len32), L.ptr(lse),
                                 L.ptr(la), L.ptr(lb), L.ptr(nll), L.ptr(grad), L.ptr(loss), T, B, V, ld, Lmax, blank,
-                                float(grad_scale), 1 if defer_grad else 0, 0, L.stream()), "s2t_ctc_loss")
+                                float(grad_scale), (1 if defer_grad else 0) | (4 if lse_given else 0), 0, L.stream()), "s2t_ctc_loss")
     if defer_grad:
         return loss, (logits, targets, tgt_len, in_len32, lse, la, lb, nll, blank, float(grad_scale)), nll
     return loss, grad, nll

@@ -45,7 +45,7 @@ SIGNATURES = {
     "s2t_permute_cf": [c_int, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_permute_conv_w": [c_int, P, P, c_int, c_int, c_int, P],
     "s2t_add_pos": [c_int, P, P, P, c_int, c_int, c_int, P],
-    "s2t_ctc_argmax": [c_int, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_ctc_argmax": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_ctc_rle": [P] * 8 + [c_int, c_int, c_int, P],
     "s2t_ctc_compress_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_ctc_compress_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],

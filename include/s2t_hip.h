@@ -158,7 +158,8 @@ int s2t_add_pos(int dtype, void* x, const float* table, const int* len, int T, i
  * pred[b][t] = first arg-max of softmax(logits[t][b][:]) (bit-exact integer path), pmax = its probability.
  * Logit rows have a stride of ld >= V elements (here and in the two loss kernels): the producer GEMM pads the
  * row stride to a multiple of 8 so that every GEMM touching the logits can use 16-byte loads. */
-int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, int T, int B, int V, int ld, void* stream);
+/* lse (optional, [T*B] f32): the rows' log-sum-exps, for s2t_ctc_loss over the same logits (phase | 4) */
+int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* pmax, float* lse, int T, int B, int V, int ld, void* stream);
 /* run-length collapse inside len[b]; seg/run_start/run_len [B][T] int32, new_len [B] int64, w [B][T] f32
  * strategy 0 avg, 1 weighted, 2 softmax */
 int s2t_ctc_rle(const int* pred, const float* pmax, const long long* len, int* seg, int* run_start, int* run_len,
@@ -174,7 +175,8 @@ int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int*
  * w.r.t. the logits [T][B][V].  Workspaces: lse [T*B], la/lb [B*T*(2*Lmax+1)], nll [B] (all f32).
  * loss_sum[0] += sum_b nll_b (caller zeroes). grad is multiplied by grad_scale and, if given, by the device scalar
  * grad_scale_dev[0] (the upstream gradient autograd hands to backward).  phase 0: loss and gradient in one call;
- * phase 1: loss only (workspaces kept by the caller); phase 2: the gradient from the workspaces of a phase-1 call. */
+ * phase 1: loss only (workspaces kept by the caller); phase 2: the gradient from the workspaces of a phase-1 call;
+ * phase | 4: `lse` already holds the row log-sum-exps of these logits (written by s2t_ctc_argmax), skip that pass. */
 int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len, const int* in_len,
                  float* lse, float* la, float* lb, float* nll, void* grad, float* loss_sum,
                  int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, int phase, const float* grad_scale_dev,
