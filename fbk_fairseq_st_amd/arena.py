@@ -34,6 +34,30 @@ class ParamArena:
         self.shadow = (torch.zeros(off, dtype=torch.bfloat16, device=self.device)
                        if compute_dtype == torch.bfloat16 else None)
         self._views = {}
+        self.frozen = []               # [start, end) element ranges excluded from the optimizer (--freeze-pretrained)
+
+    # ---- frozen parameters (conv_transformer.py:114-121: loaded weights get requires_grad = False and so never reach the
+    # optimizer or the gradient norm, fairseq/trainer.py:143).  Here the kernels write gradients for everything; the optimizer
+    # zeroes the frozen slices before the norm and launches Adam on the trainable segments only.
+    def freeze(self, names):
+        r = sorted((self.slices[n][0], self.slices[n][0] + (self.slices[n][1] + ALIGN - 1) // ALIGN * ALIGN) for n in names)
+        merged = []
+        for a, b in sorted(self.frozen + r):
+            if merged and a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        self.frozen = merged
+
+    def trainable_segments(self):
+        segs, pos = [], 0
+        for a, b in self.frozen:
+            if a > pos:
+                segs.append((pos, a))
+            pos = max(pos, b)
+        if pos < self.numel:
+            segs.append((pos, self.numel))
+        return segs
 
     def _view(self, buf, name):
         off, n, shape = self.slices[name]

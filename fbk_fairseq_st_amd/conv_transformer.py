@@ -370,6 +370,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         for b in self.buffers():
             b.data = b.data.to(device)
         arena.refresh_shadow()
+        arena.freeze(getattr(self, "_frozen_names", ()))
         self.arena, self.compute_dtype = arena, compute_dtype
         self.engine = S2TEngine(self.hp, arena)
         self.engine.bn_buffers = {
@@ -445,10 +446,12 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                         buf.copy_(sd[k].reshape(buf.shape))
         if self.arena is not None:
             self.arena.refresh_shadow()
-        if getattr(args, "freeze_pretrained", False):            # conv_transformer.py:114-121
-            for n, p in mine.items():
-                if n in sd:
-                    p.requires_grad = False
+        if getattr(args, "freeze_pretrained", False):            # conv_transformer.py:114-121: every loaded parameter leaves the optimizer
+            self._frozen_names = [n for n in mine if n in sd]
+            for n in self._frozen_names:
+                mine[n].requires_grad = False
+            if self.arena is not None:
+                self.arena.freeze(self._frozen_names)
         return self
 
     def raw_state_dict_upgrade(self, state_dict):                   # conv_transformer.py:105-112
@@ -477,7 +480,11 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         a("--no-scale-embedding", action="store_true")
         a("--encoder-convolutions", type=str, metavar="EXPR")
         a("--normalization-constant", type=float, default=1.0)
-        a("--no-attn-2d", action="store_true", default=False)
+        # no explicit default: inside fairseq's model-specific group (argument_default=SUPPRESS, options.py:158-164) the attribute is
+        # then absent unless the flag is given, so the arch function decides -- ON for the reference's conv_transformer* names
+        # (conv_transformer.py:65,455), OFF for the build-defined s2t_transformer* presets; --attn-2d forces it on
+        a("--no-attn-2d", action="store_true")
+        a("--attn-2d", action="store_true", help="keep the two ConvAttention2D blocks with an s2t_transformer* preset")
         a("--distance-penalty", type=str, default=False, choices=["log", "gauss"])
         a("--ctc-compress-out", action="store_true", default=False)
         a("--ctc-compress-strategy", type=str, default="avg", choices=["avg", "weighted", "softmax"])
@@ -633,7 +640,7 @@ def conv_transformer_giant(args):                                  # :549-586
 def _s2t(args, D, Ff, H, EL, DL, p, conv="[(64, 3, 3)] * 2"):
     """Build-defined presets named by BASELINE.json: conv_transformer structure, S2T sizes."""
     args.dropout = getattr(args, "dropout", None) if getattr(args, "dropout", None) is not None else p
-    args.no_attn_2d = getattr(args, "no_attn_2d", True)          # off unless asked for explicitly (BASELINE.md workload)
+    args.no_attn_2d = getattr(args, "no_attn_2d", True) and not getattr(args, "attn_2d", False)   # off unless --attn-2d (BASELINE.md workload)
     _common(args); _sizes(args, D, Ff, H, EL, DL, conv)
 
 

@@ -45,46 +45,61 @@ def distributed_init(backend=None, device=None):
     return dist.get_rank()
 
 
-class BucketedGradReducer:
-    """Sum-all-reduce of the flat gradient buffer in contiguous buckets, launched from backward.
+def bucket_plan(n, bucket_elems):
+    """Static bucket boundaries of a flat gradient buffer of `n` elements: contiguous [start, end) ranges cut from the TAIL
+    (backward finishes the arena last-parameter-first), every one `bucket_elems` long except the head remainder.  A pure
+    function of the arena size and the bucket size, so every rank issues the same collectives of the same sizes in the same
+    order whatever its backward reported and whenever (the reference keeps its ranks aligned the same way: one fixed flat
+    buffer walk, legacy_distributed_data_parallel.py:120-170)."""
+    plan, end = [], n
+    while end > 0:
+        start = max(0, end - bucket_elems)
+        plan.append((start, end))
+        end = start
+    return plan
 
-    The engine reports finished parameter groups through notify(start, end) (element ranges of the
-    arena, arriving in descending address order because the arena is laid out in forward order).
-    Whenever at least `bucket_elems` contiguous finished elements have accumulated below the last
-    launched position, that slice is all-reduced asynchronously; finish() reduces whatever is left
-    (including ranges that were never reported) and waits for all handles."""
+
+class BucketedGradReducer:
+    """Sum-all-reduce of the flat gradient buffer in STATIC contiguous buckets (bucket_plan), launched from backward.
+
+    The engine reports finished parameter groups through notify(start, end) (element ranges of the arena, arriving in
+    descending address order because the arena is laid out in forward order).  A bucket is all-reduced asynchronously as
+    soon as everything at or above its start is final; finish() launches the buckets that are left, in plan order, and
+    waits for all handles.  notify() only decides WHEN a bucket goes out, never its boundaries or its position in the
+    sequence: a rank whose backward reported nothing (or ran on a dummy batch) still issues the identical collectives."""
 
     def __init__(self, flat_grad, bucket_bytes=64 << 20, group=None):
         self.flat = flat_grad
         self.n = flat_grad.numel()
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
+        self.plan = bucket_plan(self.n, self.bucket_elems)
         self.group = group
         self.reset()
 
     def reset(self):
-        self.low = self.n          # everything in [low, n) has been handed to RCCL
+        self.next = 0              # index into the plan: buckets [0, next) have been handed to RCCL
         self.ready_low = self.n    # everything in [ready_low, n) is final
         self.handles = []
         self.launched = []
 
-    def _launch(self, start, end):
-        if end <= start:
-            return
+    def _launch_next(self):
+        start, end = self.plan[self.next]
+        self.next += 1
         self.launched.append((start, end))
         if get_world_size() > 1:
             self.handles.append(dist.all_reduce(self.flat[start:end], group=self.group, async_op=True))
 
     def notify(self, start, end):
-        """Gradients of arena elements [start, end) are final."""
+        """Gradients of arena elements [start, end) are final (no kernel of this update writes them again)."""
         if end >= self.ready_low and start < self.ready_low:
             self.ready_low = start
-        if self.low - self.ready_low >= self.bucket_elems:
-            self._launch(self.ready_low, self.low)
-            self.low = self.ready_low
+        while self.next < len(self.plan) and self.plan[self.next][0] >= self.ready_low:
+            self._launch_next()
 
     def finish(self):
-        self._launch(0, self.low)
-        self.low = self.ready_low = 0
+        while self.next < len(self.plan):
+            self._launch_next()
+        self.ready_low = 0
         for h in self.handles:
             h.wait()
         self.handles = []

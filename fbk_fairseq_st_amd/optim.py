@@ -31,6 +31,8 @@ class ArenaAdam:
 
     def clip_grad_norm(self, max_norm):
         """Returns the (device) gradient norm after multiply_grads; the clip coefficient stays on the device."""
+        for a, b in self.arena.frozen:                # frozen parameters carry no gradient (memset of their slices)
+            self.arena.grad[a:b].zero_()
         K.grad_norm_clip(self.arena.grad, self._scale, float(max_norm), self._ws, self._out2)
         self._have_mult = True
         return self._out2[0]
@@ -40,8 +42,11 @@ class ArenaAdam:
         if not self._have_mult:
             self._out2[1] = self._scale
         a = self.arena
-        K.adam_step(a.master, a.grad, a.exp_avg, a.exp_avg_sq, a.shadow, self._out2, self.lr, self.betas[0], self.betas[1],
-                    self.eps, self.weight_decay, self.step_count)
+        # one launch over the whole arena, or one per trainable segment when parameters are frozen (no moments, no weight decay,
+        # no update for those: they are not in the reference's optimizer at all)
+        for s, e in (a.trainable_segments() if a.frozen else [(0, a.numel)]):
+            K.adam_step(a.master[s:e], a.grad[s:e], a.exp_avg[s:e], a.exp_avg_sq[s:e], a.shadow[s:e] if a.shadow is not None else None,
+                        self._out2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count)
         self._scale, self._have_mult = 1.0, False
 
     def zero_grad(self):

@@ -29,28 +29,39 @@ class Trainer:
     def __init__(self, args, task, model, criterion, device=None, compute_dtype=None):
         self.args, self.task, self.model, self.criterion = args, task, model, criterion
         self.device = torch.device(device if device is not None else "cuda:%d" % getattr(args, "device_id", 0))
+        if self.device.type == "cuda":
+            # one process drives one GPU: the kernels are launched on the CURRENT device's stream (lib.stream caches it), so the
+            # trainer's device must be the current one before anything is allocated or launched (fairseq_cli/train.py:36-37)
+            torch.cuda.set_device(self.device)
         if compute_dtype is None:
             compute_dtype = torch.bfloat16 if getattr(args, "bf16", False) else torch.float32
         extra = criterion.arena_params() if hasattr(criterion, "arena_params") else None
         self.arena = model.materialize(self.device, compute_dtype, extra=extra)
-        betas = eval(args.adam_betas) if isinstance(getattr(args, "adam_betas", None), str) else getattr(args, "adam_betas", (0.9, 0.999))
         lr = args.lr[0] if isinstance(args.lr, (list, tuple)) else args.lr
-        self.optimizer = ArenaAdam(self.arena, lr=lr, betas=betas, eps=getattr(args, "adam_eps", 1e-8),
-                                   weight_decay=getattr(args, "weight_decay", 0.0))
+        self.optimizer = self.build_optimizer(lr)
         self.lr_scheduler = InverseSquareRootSchedule(self.optimizer, lr, getattr(args, "warmup_updates", 4000),
                                                       getattr(args, "warmup_init_lr", -1))
         self.num_updates = 0
         self.world = D.get_world_size()
-        self.reducer = D.BucketedGradReducer(self.arena.grad, getattr(args, "bucket_cap_mb", 64) << 20)
+        cap = getattr(args, "bucket_cap_bytes", None)                     # tests: buckets of a few KB
+        self.reducer = D.BucketedGradReducer(self.arena.grad, int(cap) if cap else getattr(args, "bucket_cap_mb", 64) << 20)
         model.engine.on_grads_ready = self._grads_ready
         self._ranges = {}
+        self._sync_grads = True         # False while a non-final micro-batch accumulates locally (the reference's no_sync)
+        self._dummy_batch = None
         self.last_stats = {}
+
+    def build_optimizer(self, lr):
+        args = self.args
+        betas = eval(args.adam_betas) if isinstance(getattr(args, "adam_betas", None), str) else getattr(args, "adam_betas", (0.9, 0.999))
+        return ArenaAdam(self.arena, lr=lr, betas=betas, eps=getattr(args, "adam_eps", 1e-8),
+                         weight_decay=getattr(args, "weight_decay", 0.0))
 
     # ---- overlap of the gradient all-reduce with backward
     def _grads_ready(self, prefix):
         """Called by the engine as backward finishes a parameter group (last layer first): hand the finished,
         contiguous tail of the flat gradient buffer to the reducer, which launches RCCL on it asynchronously."""
-        if self.world <= 1:
+        if self.world <= 1 or not self._sync_grads:
             return
         r = self._ranges.get(prefix)
         if r is None:
@@ -89,19 +100,40 @@ class Trainer:
         return self._prepare_sample(sample)
 
     def train_step(self, samples):
-        """One optimizer update over a list of micro-batches (`--update-freq`).  Returns the reduced stats."""
+        """One optimizer update over a list of micro-batches (`--update-freq`).  Returns the reduced stats.
+
+        Data-parallel semantics of the reference (fairseq/trainer.py:334-430):
+          * gradients of micro-batches 0..n-2 accumulate locally; only the LAST micro-batch's backward hands finished slices to
+            the reducer (maybe_no_sync, trainer.py:359-375; legacy_distributed_data_parallel.py:78-83,138), so every element is
+            all-reduced exactly once, after all local contributions have landed;
+          * an empty micro-batch (a short shard padded by the iterator) runs the cached dummy batch with ignore_grad, so that
+            every rank executes the same backward and launches the same collectives (trainer.py:337-357,412-418); as in the
+            reference, a rank whose LAST micro-batch was a dummy reports sample_size 0 and no logging outputs."""
+        if self._dummy_batch is None:
+            self._dummy_batch = next((s for s in samples if s is not None and len(s) > 0), None)
         self.model.set_seed(getattr(self.args, "seed", 1) + self.num_updates)        # trainer.py:655-661
         self.model.train(); self.criterion.train()
         self.optimizer.zero_grad()
         self.reducer.reset()
-        logs, sample_size = [], 0
+        logs, sample_size, is_dummy = [], 0, False
         for i, sample in enumerate(samples):
             s = self._prepare_sample(sample)
-            if s is None:
-                continue
-            loss, ss, log = self.task.train_step(s, self.model, self.criterion, self.optimizer, self.num_updates)
+            is_dummy = s is None
+            if is_dummy:
+                if self._dummy_batch is None:
+                    raise RuntimeError("an empty batch arrived before any real one: there is no dummy batch to keep the ranks aligned")
+                s = self._dummy_batch = self._prepare_sample(self._dummy_batch)
+            self._sync_grads = i == len(samples) - 1
+            try:
+                loss, ss, log = self.task.train_step(s, self.model, self.criterion, self.optimizer, self.num_updates,
+                                                     ignore_grad=is_dummy)
+            finally:
+                self._sync_grads = True
             logs.append(log)
             sample_size += ss
+            self._log_keys = sorted(log)
+        if is_dummy:                                                                # trainer.py:412-418
+            sample_size, logs = 0, []
         self.reducer.finish()                                                       # R2
         stats = {"sample_size": float(sample_size)}
         if self.world > 1:
@@ -118,7 +150,7 @@ class Trainer:
     def reduce_stats(self):
         """Materialise (one sync) and sum the logging outputs of the last update."""
         logs, gnorm, total_ss = self._pending
-        agg = {}
+        agg = {k: 0.0 for k in getattr(self, "_log_keys", ())}     # same keys on every rank, also on one whose update was a dummy
         for l in logs:
             for k, v in l.items():
                 agg[k] = agg.get(k, 0.0) + (float(v) if not torch.is_tensor(v) else float(v.item()))
