@@ -101,7 +101,7 @@ __device__ __forceinline__ void put_tile(char* lds, const f32x4 (&acc)[4], int q
 
 // short query blocks over long key ranges (the decoder's encoder-attention: Tq = 40, Tk = 368) also take the second-generation
 // kernels: a workgroup is mostly padding rows there, but each key tile costs a fraction of what the first-generation kernels spend
-static const int S2T_ATTN_V2_MIN_TQ = getenv("S2T_ATTN_V2_MIN_TQ") ? atoi(getenv("S2T_ATTN_V2_MIN_TQ")) : 16;
+#define S2T_ATTN_V2_MIN_TQ g_s2t_opt_attn_v2_min_tq      /* s2t_set_option("attn_v2_min_tq") */
 
 struct AttnArgs {
     const void *Q, *K, *V; void* O; float* LSE;          // LSE [B][H][Tq]
@@ -983,7 +983,7 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
     const long rows = (long)a.B * a.H * a.Tq;
     bool dkv2 = false, dq2 = false;
     if constexpr (sizeof(T) == 2 && DH == 64) {
-        static const bool v1 = getenv("S2T_ATTN_V1") != nullptr;           // A/B switch for benchmarking
+        const bool v1 = g_s2t_opt_attn_v1 != 0;                            // s2t_set_option("attn_v1")
         const bool al = !(a.dk_st % 4) && !(a.dk_sb % 4) && !(a.dv_st % 4) && !(a.dv_sb % 4) && !(a.dq_st % 4) && !(a.dq_sb % 4) &&
                         !((uintptr_t)a.dK & 7) && !((uintptr_t)a.dV & 7) && !((uintptr_t)a.dQ & 7);
         dkv2 = !v1 && al && a.Tk >= 128;
@@ -1057,7 +1057,7 @@ extern "C" int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int T
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("attn_fwd", st, 4.0 * B * H * (double)Tq * Tk * head_dim * (causal ? 0.5 : 1.0), 0.0);
     if (dtype == S2T_BF16 && head_dim == 64 && (Tq >= 128 || (Tq >= S2T_ATTN_V2_MIN_TQ && Tk >= 128)) && (o_st % 4) == 0 && (o_sb % 4) == 0 && ((uintptr_t)O & 7) == 0) {
-        static const bool v1 = getenv("S2T_ATTN_V1") != nullptr;           // A/B switch for benchmarking
+        const bool v1 = g_s2t_opt_attn_v1 != 0;                            // s2t_set_option("attn_v1")
         if (!v1) {
             hipLaunchKernelGGL(attn_fwd2_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 32768, st, a);
             S2T_LAUNCH_CHECK();

@@ -16,7 +16,7 @@
 #include "common.hpp"
 #include "prof.hpp"
 #include "gemm_epilogue.hpp"
-int s2t_gemm_v2_try(const GemmArgs& a, int out_dtype, hipStream_t st);   // gemm_v2.hip
+int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st);   // gemm256.hip
 #include <cstdlib>
 #include <type_traits>
 
@@ -253,13 +253,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    if (p.dbg & 1) {                                 // ablation: keep the accumulators live, store nothing
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
     gemm_epilogue<TO, BM, BN, MT, NT, 256>(p, acc, smem, row0, col0, wr * (BM / 2), wc * (BN / 2), q, r16);
 }
 
@@ -295,27 +288,6 @@ template <typename T, int ROWS, int NTH = 256> struct FastDirect {
     __device__ __forceinline__ void store(char* lds, const Regs& R) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) *reinterpret_cast<u32x4*>(lds + off[i]) = R.r[i];
-    }
-    // ---- direct-to-LDS form (global_load_lds_dwordx4): one wave-instruction writes 64 x 16 bytes CONTIGUOUSLY (wave-uniform LDS
-    // base + 16 * lane), i.e. 8 whole rows of the image; the XOR swizzle therefore moves to the SOURCE address: the lane that fills
-    // position p of row r fetches chunk p ^ (r & 7) (the same image, XOR being an involution).
-    __device__ __forceinline__ void init_glds(const T* g, int ld, int row0, int nrows, int k0) {
-        base = reinterpret_cast<const char*>(g);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int cid = threadIdx.x + NTH * i, row = cid >> 3, pcol = cid & 7;
-            const int gr = min(row0 + row, nrows - 1);
-            goff[i] = (uint32_t)(((size_t)gr * ld + k0 + (pcol ^ (row & 7)) * E) * sizeof(T));
-            off[i] = (cid & ~63) * 16;                          // LDS offset of this wave's 1-KiB piece
-        }
-    }
-    __device__ __forceinline__ void issue(char* lds, int step) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
-                                             (__attribute__((address_space(3))) void*)(lds + __builtin_amdgcn_readfirstlane(off[i])), 16, 0, 0);
-            goff[i] += step;
-        }
     }
 };
 
@@ -410,27 +382,6 @@ template <int COLS, int NTH = 256> struct FastTr {
     __device__ __forceinline__ void store(char* lds, const Regs& R) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) *reinterpret_cast<u32x4*>(lds + off[i]) = R.r[i];
-    }
-    // direct-to-LDS form: a wave-instruction fills 4 whole 256-byte rows; position p of row r takes source chunk p ^ tr_swz(r)
-    __device__ __forceinline__ void init_glds(const bf16* g, int ld, int col0, int ncols, int k0) {
-        base = reinterpret_cast<const char*>(g);
-        tile_bytes = (uint32_t)(64u * (uint32_t)ld * 2u);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int cid = threadIdx.x + NTH * i, row = cid >> 4, pcol = cid & 15;
-            const int gc = min(col0 + (pcol ^ tr_swz(row)) * 8, (ncols + 7) / 8 * 8 - 8);
-            goff[i] = (uint32_t)(((size_t)(k0 + row) * ld + gc) * 2);
-            off[i] = (cid & ~63) * 16;
-        }
-    }
-    __device__ __forceinline__ void issue(char* lds, int step) {
-        const uint32_t st = step ? tile_bytes : 0u;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + goff[i]),
-                                             (__attribute__((address_space(3))) void*)(lds + __builtin_amdgcn_readfirstlane(off[i])), 16, 0, 0);
-            goff[i] += st;
-        }
     }
 };
 
@@ -570,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         mma(LCUR);                                                      /* tile t   */            \
         sa.store(LNXT, SA_); sb.store(LNXT + BM * 128, SB_);            /* tile t+1 */            \
         __syncthreads();
-        const int nkk = (p.dbg & 2) ? 0 : nk;
+        const int nkk = nk;
         int t = 0;
         for (; t + 6 <= nkk; t += 6) {
             S2T_STEP(a0, b0, a1, b1, l0, l1)
@@ -590,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
     } else {
     sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
     __syncthreads();
-    for (int t = 0; t < ((p.dbg & 2) ? 0 : nk); t += 2) {
+    for (int t = 0; t < nk; t += 2) {
         { const int st = step(); sa.load(a0, st); sb.load(b0, st); }  // tile t+2 -> set 0
         mma(l0);                                                       // tile t
         sa.store(l1, a1); sb.store(l1 + BM * 128, b1);                 // tile t+1
@@ -610,64 +561,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
             }
         }
     }
-    if (p.dbg & 1) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
-        return;
-    }
-    gemm_epilogue<TO, BM, BN, MT, NT, NTH>(p, acc, smem, row0, col0, arow, brow, q, r16);
-}
-
-// Direct-to-LDS variant of the 8-wave 128x128 kernel (A direct; B direct or transposed-read), opt-in (S2T_GEMM_GLDS=1):
-// both operands arrive by global_load_lds (no staging registers, no ds_write pass).  A (the activation rows: streamed from HBM) has
-// THREE LDS stages and runs two k-tiles ahead, B (the weights: L2 hits) two stages and one tile ahead: 80 KB per workgroup, two
-// workgroups per CU.  The DMAs stay in flight across the barrier: counted s_waitcnt vmcnt(2) (the two youngest = A(t+2)) + raw
-// s_barrier; tail iterations re-issue the last tile into a free slot so that the count is a constant.
-template <typename TO, bool TB, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_glds_kernel(GemmArgs p) {
-    typedef bf16 TI;
-    constexpr int BM = 128, BN = 128, BK = 64, NTH = NW * 64, WN = NW / 2, MT = 4, NT = BN / (16 * WN);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ASZ = BM * 128, BSZ = BN * 128, BBASE = 3 * ASZ;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int wg = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = wg / tiles_n, tn = wg % tiles_n;
-    const int row0 = tm * BM, col0 = tn * BN;
-    const int nk = p.K / BK;
-    typedef FastDirect<TI, BM, NTH> SA;
-    typedef typename FastSel<TI, BN, TB, NTH>::type SB;
-    SA sa; SB sb;
-    sa.init_glds(reinterpret_cast<const TI*>(p.A), p.lda, row0, p.M, 0);
-    sb.init_glds(reinterpret_cast<const TI*>(p.B), p.ldb, col0, p.N, 0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave / WN, wc = wave % WN, r16 = lane & 15, q = lane >> 4;
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr bool TRB = UsesTrRead<SB>::value;
-    const int arow = wr * (BM / 2), brow = wc * (BN / WN);
-    int ia = 0, ib = 0;                                   // next A / B tile to request
-    auto issue_a = [&](int slot) { sa.issue(smem + slot * ASZ, ia + 1 < nk ? 128 : 0); ++ia; };
-    auto issue_b = [&](int slot) { sb.issue(smem + BBASE + slot * BSZ, ib + 1 < nk ? 128 : 0); ++ib; };
-    issue_a(0); issue_b(0); issue_a(1);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int sa_cur = 0, sa_nxt2 = 2;                          // A slot of tile t, of tile t+2 (mod 3 without a division)
-    for (int t = 0; t < nk; ++t) {
-        issue_b((t + 1) & 1);
-        issue_a(sa_nxt2);
-        mma_tile<TI, MT, NT, false, TRB>(smem + sa_cur * ASZ, smem + BBASE + (t & 1) * BSZ, arow, brow, r16, q, acc);
-        asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        sa_cur = sa_cur == 2 ? 0 : sa_cur + 1;
-        sa_nxt2 = sa_nxt2 == 2 ? 0 : sa_nxt2 + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the re-issued tail tiles must land before the epilogue reuses the LDS
-    __syncthreads();
     gemm_epilogue<TO, BM, BN, MT, NT, NTH>(p, acc, smem, row0, col0, arow, brow, q, r16);
 }
 
@@ -792,89 +685,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn2_kernel(GemmArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Persistent form of the fast path.  With K = 512 a 128x128 tile has only 8 k-tiles, so the per-tile prologue
-// (first global loads: one full memory latency with nothing to do) and the epilogue (LDS staging + stores) cost as
-// much as the k-loop (ablation in profiles/README.md).  Here a workgroup walks a sequence of work items
-// (tile, k-slice) and the operand stream never stops at an item boundary: the loads that the last two k-tiles of item
-// i issue fetch the first two k-tiles of item i+1 into the two register sets, they travel while the epilogue of
-// item i runs out of LDS, and the epilogue's global stores drain under the next k-loop.  Grid = 2 workgroups per CU,
-// work items are dealt so that the workgroups of one XCD walk neighbouring tiles (shared A rows / W columns in L2).
-// Requires an even number of k-tiles per item (the two register sets / LDS stages alternate in a 2-unrolled loop).
-template <typename TI, typename TO, bool TA, bool TB, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_pers_kernel(GemmArgs p, int per) {
-    constexpr int BK = 128 / (int)sizeof(TI);
-    constexpr int MT = BM / 32, NT = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = (BM + BN) * 128;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int nk_total = p.K / BK;
-    const int items = tiles_m * tiles_n * p.splitk;
-    const int G = gridDim.x;
-    int item = xcd_remap(blockIdx.x, G);
-    if (item >= items) return;
-
-    typedef typename FastSel<TI, BM, TA>::type SA;
-    typedef typename FastSel<TI, BN, TB>::type SB;
-    constexpr bool TRA = UsesTrRead<SA>::value, TRB = UsesTrRead<SB>::value;
-    SA sa; SB sb;
-    typename SA::Regs a0, a1;
-    typename SB::Regs b0, b1;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1, r16 = lane & 15, q = lane >> 4;
-    const int arow = wr * (BM / 2), brow = wc * (BN / 2);
-    constexpr int BOFF = BM * 128;
-    char* l0 = smem;
-    char* l1 = smem + STAGE;
-
-    // loader state: the item whose k-tiles are being requested
-    int ld_item = item, ld_left = 0;
-    auto open_item = [&](int it) {           // k-slices innermost: the splitk slices of a tile are neighbours
-        const int tile = it / p.splitk, z = it - tile * p.splitk;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int kt0 = z * per;
-        ld_left = min(per, nk_total - kt0);
-        sa.init(reinterpret_cast<const TI*>(p.A), p.lda, tm * BM, p.M, kt0 * BK);
-        sb.init(reinterpret_cast<const TI*>(p.B), p.ldb, tn * BN, p.N, kt0 * BK);
-    };
-    // request the next k-tile of the stream into (A, B); past the end of the stream the last tile is read again
-    auto request = [&](typename SA::Regs& A, typename SB::Regs& B) {
-        if (ld_left == 0 && ld_item + G < items) { ld_item += G; open_item(ld_item); }
-        const int st = ld_left > 1 ? 128 : 0;
-        sa.load(A, st); sb.load(B, st);
-        ld_left = max(ld_left - 1, 0);
-    };
-    open_item(item);
-    request(a0, b0);
-    request(a1, b1);
-
-    for (; item < items; item += G) {
-        const int tile = item / p.splitk, z = item - tile * p.splitk;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int nk = min(per, nk_total - z * per);
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        sa.store(l0, a0); sb.store(l0 + BOFF, b0);
-        __syncthreads();
-        for (int t = 0; t < nk; t += 2) {
-            request(a0, b0);                                                       // stream tile t+2
-            mma_tile<TI, MT, NT, TRA, TRB>(l0, l0 + BOFF, arow, brow, r16, q, acc);   // tile t
-            sa.store(l1, a1); sb.store(l1 + BOFF, b1);                             // tile t+1
-            __syncthreads();
-            request(a1, b1);                                                       // stream tile t+3
-            mma_tile<TI, MT, NT, TRA, TRB>(l1, l1 + BOFF, arow, brow, r16, q, acc);   // tile t+1
-            if (t + 2 < nk) { sa.store(l0, a0); sb.store(l0 + BOFF, b0); }         // tile t+2 (else: the next item's tile 0 stays in registers)
-            __syncthreads();
-        }
-        gemm_epilogue<TO, BM, BN, MT, NT, 256>(p, acc, smem, tm * BM, tn * BN, arow, brow, q, r16);
-        __syncthreads();
-    }
-}
-
 template <typename TI, bool TA, bool TB>
 static bool fast_ok(const GemmArgs& a) {
     constexpr int E = Elem<TI>::PER16;
@@ -896,47 +706,21 @@ static int launch(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     dim3 grid(tiles, 1, a.splitk);
-    static const bool no_fast = getenv("S2T_GEMM_NOFAST") != nullptr;     // A/B switch for benchmarking
-    static const bool pers_on = getenv("S2T_GEMM_PERS") != nullptr;
-    const bool fast = !no_fast && fast_ok<TI, TA, TB>(a);
-    if (a.rowsum && !(TA && fast && !pers_on)) {
-        // the row sums ride on gemm_fast_kernel's transposed A operand only: otherwise a separate column-sum pass over A [K][M]
+    const bool fast = fast_ok<TI, TA, TB>(a);
+    if (a.rowsum && !(TA && fast)) {
+        // the row sums ride on the fast kernels' transposed A operand only: otherwise a separate column-sum pass over A [K][M]
         if (!TA) return S2T_EINVAL;
         const int rc = s2t_colsum(sizeof(TI) == 2 ? S2T_BF16 : S2T_F32, a.A, a.lda, a.K, a.M, a.rowsum, st);
         if (rc != S2T_OK) return rc;
         a.rowsum = nullptr;
     }
+    size_t lds = 2 * (BM + BN) * 128;
+    if ((size_t)BM * (BN * 4 + 16) > lds) lds = (size_t)BM * (BN * 4 + 16);   // epilogue staging of the f32 tile
     if (fast) {
-        size_t lds = 2 * (BM + BN) * 128;
-        if ((size_t)BM * (BN * 4 + 16) > lds) lds = (size_t)BM * (BN * 4 + 16);
-        if (lds > 65536) {
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        }
-        constexpr int BKc = 128 / (int)sizeof(TI);
-        const int nk_total = a.K / BKc;
-        int per = (nk_total + a.splitk - 1) / a.splitk;
-        // measured (tools/microbench.py): the persistent form ties or loses by up to 15 % against hardware dispatch of one
-        // tile per workgroup (static dealing of 1.5-6 tiles per workgroup balances worse than the dispatcher and the
-        // per-tile overheads it hides are not what bounds the loop), so it is opt-in: S2T_GEMM_PERS=1
-        if (pers_on && BM == 128 && BN == 128 && nk_total % 2 == 0 && !a.dbg) {
-            per += per & 1;                                                // even slices; the last one may be shorter (still even)
-            GemmArgs b = a;
-            b.splitk = (nk_total + per - 1) / per;
-            const int items = tiles * b.splitk;
-            const int G = items < 512 ? items : 512;                       // 2 resident workgroups per CU
-            static bool attr2 = false;
-            if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
-            hipLaunchKernelGGL((gemm_pers_kernel<TI, TO, TA, TB, BM, BN>), dim3(G), dim3(256), lds, st, b, per);
-            S2T_LAUNCH_CHECK();
-            return S2T_OK;
-        }
         if constexpr (BM == 128 && BN == 128 && sizeof(TI) == 2 && sizeof(TO) == 4 && TA && TB) {
-            // weight-gradient products: two k-slices per workgroup, half the atomic traffic (S2T_GEMM_TN1=1: single-slice form)
-            static const bool tn1 = getenv("S2T_GEMM_TN1") != nullptr;
-            constexpr int BKc2 = 64;
-            const int nk_total2 = a.K / BKc2;
-            if (!tn1 && !a.mapC && !a.dbg && nk_total2 >= 4 * a.splitk && (a.splitk == 1 || a.splitk % 2 == 0)) {
+            // weight-gradient products: two k-slices per workgroup, half the atomic traffic
+            const int nk_total2 = a.K / 64;
+            if (!a.mapC && nk_total2 >= 4 * a.splitk && (a.splitk == 1 || a.splitk % 2 == 0)) {
                 GemmArgs b = a;
                 b.splitk = a.splitk > 1 ? a.splitk / 2 : 1;                    // same wavefronts per CU: s slices of 4 waves -> s/2 of 8
                 static bool attr4 = false;
@@ -946,42 +730,24 @@ static int launch(const GemmArgs& a_in, hipStream_t st) {
                 return S2T_OK;
             }
         }
-        if constexpr (BM == 128 && BN == 128 && sizeof(TI) == 2) {
+        if constexpr (BM == 128 && BN == 128 && sizeof(TI) == 2 && !TA) {
             // measured (tools/microbench.py, M = 24000): 8 waves gain 10-18 % on the NT / NN products (the k-loop is bound by
             // global-load latency: twice the wavefronts per CU cover more of it), and lose ~10 % on TN where both operands
-            // are gathered by transposed LDS reads (fragment traffic dominates); S2T_GEMM_NW4=1 forces the 4-wave form
-            static const bool nw4 = getenv("S2T_GEMM_NW4") != nullptr;
-            static const bool glds = getenv("S2T_GEMM_GLDS") != nullptr;
-            if constexpr (!TA && std::is_same<TI, bf16>::value) {
-                if (glds && a.splitk == 1 && !a.mapA && !a.mapB && (a.K % 64) == 0 && (!TB || UsesTrRead<typename FastSel<TI, BN, TB, 512>::type>::value)) {
-                    static bool attrg = false;
-                    const size_t ldsg = 5 * 128 * 128;                               // 3 A stages + 2 B stages (>= the epilogue's f32 tile)
-                    static const bool g4 = getenv("S2T_GEMM_GLDS4") != nullptr;      // 4 waves of 64x64 instead of 8 of 64x32
-                    if (!attrg) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TO, TB, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<TO, TB, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg);
-                        attrg = true;
-                    }
-                    if (g4) hipLaunchKernelGGL((gemm_glds_kernel<TO, TB, 4>), grid, dim3(256), ldsg, st, a);
-                    else hipLaunchKernelGGL((gemm_glds_kernel<TO, TB, 8>), grid, dim3(512), ldsg, st, a);
-                    S2T_LAUNCH_CHECK();
-                    return S2T_OK;
-                }
-            }
-            if (!TA && !nw4) {
-                static bool attr3 = false;
-                if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
-                hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), grid, dim3(512), lds, st, a);
-                S2T_LAUNCH_CHECK();
-                return S2T_OK;
-            }
+            // are gathered by transposed LDS reads (fragment traffic dominates)
+            static bool attr3 = false;
+            if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
+            hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), grid, dim3(512), lds, st, a);
+            S2T_LAUNCH_CHECK();
+            return S2T_OK;
+        }
+        if (lds > 65536) {
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         }
         hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), grid, dim3(256), lds, st, a);
         S2T_LAUNCH_CHECK();
         return S2T_OK;
     }
-    size_t lds = 2 * (BM + BN) * 128;
-    if ((size_t)BM * (BN * 4 + 16) > lds) lds = (size_t)BM * (BN * 4 + 16);   // epilogue staging of the f32 tile
     if (lds > 65536) {
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
@@ -1030,9 +796,8 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
         }
     }
     GemmArgs a{A, B, C, bias, residual, aux, aux_out, M, N, K, lda, ldb, ldc, ldr, ldaux, act, accumulate, splitk, alpha,
-               mapA, periodA, mapB, mapC, p_drop, seed, 0, rowsum};
+               mapA, periodA, mapB, mapC, p_drop, seed, rowsum};
     if (rowsum && (!trans_a || mapA || mapB)) return S2T_EINVAL;
-    { static const char* e = getenv("S2T_GEMM_DBG"); if (e) a.dbg = atoi(e); }
     hipStream_t st = (hipStream_t)stream;
     const double esz = in_dtype == S2T_BF16 ? 2.0 : 4.0, osz = out_dtype == S2T_BF16 ? 2.0 : 4.0;
     // small problems: 64x64 tiles so that more workgroups exist than CUs
@@ -1040,17 +805,18 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     // products with a k-strided operand (NN, TN) stage it through transposed LDS reads only in the 128-wide kernels (the 64-wide
     // form transposes in registers): they switch to 64x64 tiles much later (tools/small_gemm.py: NN 2560 x 512 x 8000 93 -> 67 us,
     // TN 512 x 512 18 -> 14.6 us with the 128-wide kernels; NT is better off with 64x64 below ~192 tiles)
-    static const long small_thr = getenv("S2T_GEMM_SMALL") ? atol(getenv("S2T_GEMM_SMALL")) : -1;    // benchmarking knob
-    const bool small = t128 < (small_thr >= 0 ? small_thr : ((trans_a || trans_b) ? 40 : 192));
+    const bool small = t128 < ((trans_a || trans_b) ? 40 : 192);
     const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
     // families for the roofline report (one kernel template each): dW-shaped (TN), forward (NT), dX-shaped (NN) products on
     // 128x128 tiles, their small-problem 64x64 forms, and the implicit-GEMM convolution
     static const char* const kFam[3][2] = {{"gemm_nt", "gemm_nt_small"}, {"gemm_nn", "gemm_nn_small"}, {"gemm_tn", "gemm_tn_small"}};
     ProfScope prof(mapA || mapB ? "gemm_gather" : kFam[trans_a ? 2 : (trans_b ? 1 : 0)][small ? 1 : 0], st, 2.0 * M * (double)N * K,
                    esz * ((double)M * K + (double)N * K) + osz * (double)M * N);
-    if (in_dtype == S2T_BF16 && !trans_a && !trans_b) {      // big forward projections: direct-to-LDS 3-stage kernel
-        const int r = s2t_gemm_v2_try(a, out_dtype, st);
-        if (r != 0) return r < 0 ? r : S2T_OK;
+    if (in_dtype == S2T_BF16 && !trans_a && !small) {         // big forward / data-gradient products: 256 x 256 x 64 LDS-DMA kernel
+        if (g_s2t_opt_gemm256) {
+            const int r = s2t_gemm256_try(a, out_dtype, trans_b, st);
+            if (r != 0) return r < 0 ? r : S2T_OK;
+        }
     }
 #define S2T_PICK(TI_, TO_)                                                                   \
     return small ? launch_t<TI_, TO_, 64, 64>(a, trans_a, trans_b, st)                       \

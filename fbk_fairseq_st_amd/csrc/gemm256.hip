@@ -1,0 +1,435 @@
+// 256 x 256 x 64 MFMA GEMM for the big bf16 products of the Transformer blocks (M = tokens of the batch):
+//   NT  Y  = epi(X  . W^T)   X [M][K], W [N][K]      forward projections / FFN      (F.linear, multihead_attention.py:190-208,
+//   NN  dX = epi(dY . W)     dY [M][K], W [K][N]      their data gradients            transformer_layer.py:132-134 + autograd)
+//
+// Structure (cdna_hip_programming.md section 5, "256^2 8-phase template", rebuilt here from its description):
+//   * 8 waves = 2 (M) x 4 (N), each 128 x 64 of the output as 8 x 4 tiles of v_mfma_f32_16x16x32_bf16: 128 accumulator VGPRs,
+//     one workgroup per CU (two waves per SIMD);
+//   * operands travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass; the ablation of
+//     round 1 put 16 us of a 77 us launch into the register -> LDS writes).  The LDS image is lane-linear per wave-instruction
+//     (1 KiB = 8 rows x 128 B, or 4 k-rows x 256 B for a k-strided operand), so the XOR swizzle that keeps the fragment reads
+//     conflict-free sits on the per-lane SOURCE address (rule 21);
+//   * two K-tile buffers of 64 KiB, each cut into four 16 KiB half-tiles (A-h0, A-h1, B-h0, B-h1) = what ONE of the four compute
+//     phases of a K-tile reads.  A K-tile is four phases, each 16 MFMAs per wave on one 64 x 32 quadrant of the wave's tile:
+//         P1 (A-h0, B-h0)   P2 (A-h0, B-h1)   P3 (A-h1, B-h1)   P4 (A-h1, B-h0)        reads per wave: 12 / 4 / 8 / 4 fragments
+//     and every phase re-stages ONE half-tile that became free two phases earlier:
+//         P1: A-h1(t+1)   P2: B-h0(t+1)   P3: A-h0(t+2)   P4: B-h1(t+2)
+//     One counted s_waitcnt vmcnt(4) per K-tile (in P4: everything but the two youngest half-tiles has landed = all of tile
+//     t+1), never vmcnt(0) in the loop; raw s_barrier (a __syncthreads() would drain the DMA queue);
+//   * the two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run one barrier apart: while one group issues its LDS
+//     reads and DMA the other runs its MFMA cluster, so the matrix pipe of a SIMD always has one wave's MFMAs to issue.
+// Hazards, by barrier count (group 0 runs phase p's memory segment in barrier interval 2p and its MFMAs in 2p+1, group 1 one
+// interval later): a half-tile read in phase p is re-staged in phase p+2 -- every wave passed the s_waitcnt lgkmcnt(0) that
+// follows its phase-p reads before barrier 2p+3, the first DMA into it issues in interval 2p+4; a half-tile is read one phase or
+// more after the phase whose vmcnt retired it -- both groups' waits precede barrier 2w+2, the first read is in interval 2w+2.
+#include "common.hpp"
+#include "prof.hpp"
+#include "gemm_epilogue.hpp"
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int HALF = 16384;            // bytes of one half-tile
+constexpr int BUF = 65536;             // one K-tile buffer: A-h0 | A-h1 | B-h0 | B-h1
+constexpr int BK = 64;
+
+__device__ __forceinline__ int trswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+// fragment of a k-strided operand from a [64 k][128 col] image (256-byte rows, chunks XOR-swizzled by trswz): 16 columns from
+// `col`, k-half s; two ds_read_b64_tr_b16 (cdna_hip_programming.md T10, image (b))
+__device__ __forceinline__ u32x4 tr_frag(const char* img, int col, int s, int r16, int q) {
+    u32x4 f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 32 * s + 8 * q + 4 * h + (r16 >> 2);
+        const int ch = (col >> 3) + ((r16 & 3) >> 1);
+        const char* a = img + row * 256 + ((ch ^ trswz(row)) << 4) + ((r16 & 1) << 3);
+        const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a);
+        const u32x2 w = __builtin_bit_cast(u32x2, v);
+        f[2 * h] = w[0]; f[2 * h + 1] = w[1];
+    }
+    return f;
+}
+}  // namespace
+
+// ---- epilogue straight from the accumulators (the LDS ring keeps filling for the next tile meanwhile): the MFMAs ran as
+// (W rows x X rows), so a lane holds 4 consecutive columns of one row: C[row][col .. col + 3] -> one 8-byte (bf16) or 16-byte (f32)
+// access per operand.  Same arithmetic, in the same order, as gemm_finish (gemm_epilogue.hpp): alpha, bias, activation, dropout
+// (one hash per aligned element quad = exactly the mask of the standalone kernel), residual / accumulate.
+// EXT: the one extra operand stream an epilogue may read besides the bias: 0 none, 1 residual, 2 the old C (accumulate), 3 aux (the
+// activation-backward operand).  Its 16 loads of a half tile are issued together and waited for once (one memory round trip per half
+// tile: with one workgroup per CU nothing else hides that latency).
+enum { EXT_NONE = 0, EXT_RES = 1, EXT_OLD = 2, EXT_AUX = 3 };
+template <typename TO> struct Pack4 { typedef u32x2 type; };
+template <> struct Pack4<float> { typedef u32x4 type; };
+
+// arithmetic of one output quad (row, col .. col + 3); `pre` receives the GELU pre-activation (aux_out)
+template <typename TO, int ACT, int EXT>
+__device__ __forceinline__ typename Pack4<TO>::type epi_quad(const GemmArgs& p, f32x4 v, f32x4 b4, typename Pack4<TO>::type ext,
+                                                             uint64_t quad, uint32_t drop_th, float drop_inv,
+                                                             typename Pack4<TO>::type& pre_out) {
+    typedef typename Pack4<TO>::type PK;
+    float x[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = v[e] * p.alpha + b4[e];
+    TO xe[4];
+    *reinterpret_cast<PK*>(xe) = ext;
+    TO pre[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if constexpr (ACT == ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+        else if constexpr (ACT == ACT_GELU) { pre[e] = from_f32<TO>(x[e]); x[e] = gelu_f(x[e]); }
+        else if constexpr (ACT == ACT_RELU_BWD) x[e] = (to_f32(xe[e]) > 0.f) ? x[e] : 0.f;
+        else if constexpr (ACT == ACT_GELU_BWD) x[e] *= gelu_grad_f(to_f32(xe[e]));
+    }
+    if constexpr (ACT == ACT_GELU) pre_out = *reinterpret_cast<const PK*>(pre);
+    if (p.p_drop > 0.f) {
+        const u32x2 dh = drop_hash4(p.seed, quad);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = (drop_field(dh, e) >= (drop_th >> 16)) ? x[e] * drop_inv : 0.f;
+    }
+    if constexpr (EXT == EXT_RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] += to_f32(xe[e]);
+    }
+    TO o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = from_f32<TO>(x[e]);
+    if constexpr (EXT == EXT_OLD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f32<TO>(to_f32(o[e]) + to_f32(xe[e]));
+    }
+    return *reinterpret_cast<const PK*>(o);
+}
+
+// buffer-addressed 8 / 16-byte accesses: per-lane 32-bit voffset + wave-uniform soffset (no 64-bit address arithmetic per access);
+// offsets past the descriptor's size (rows >= M; the voffset of a column >= N is forced there) load zeros / store nothing
+template <typename PK> __device__ __forceinline__ PK buf_load(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff);
+template <> __device__ __forceinline__ u32x2 buf_load<u32x2>(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+template <> __device__ __forceinline__ u32x4 buf_load<u32x4>(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store(u32x2 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store(u32x4 v, __amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
+// TB = false: B stored [N][K] (k contiguous);  TB = true: B stored [K][N] (k strided, transposed LDS reads)
+// MT = 16-row tiles per wave along M: 8 (256-row tile) or 6 (192-row tile: picked when it fills the 256 CUs better, e.g. N = 512 at
+// M = 24,000: 250 tiles of 192 x 256 instead of 188 of 256 x 256)
+// Persistent: gridDim.x workgroups (one per CU) walk the output tiles; the operand stream never stops at a tile boundary (the
+// half-tiles staged in the last two K-tiles of a tile are the first ones of the next tile), and the stores of a tile drain under
+// the next tile's K-loop.
+template <typename TO, bool TB, int MT, int ACT, int EXT>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QM = MT / 2;                       // row tiles of one phase's quadrant (4 / 3)
+    constexpr int HR = 16 * QM;                      // rows a wave group owns in one A half-tile (64 / 48)
+    constexpr int BM = 4 * HR, BN = 256;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, tiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    int tile = xcd_remap(blockIdx.x, G);             // then tile += G: every round is a contiguous run of tiles, an XCD's share contiguous inside it
+    if (tile >= tiles) return;
+    const int nk = p.K / BK;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, q = lane >> 4;
+    const int grp = wr;                                                // the stagger group = the M half this wave owns
+
+    // ---- staging: this wave fills pieces 2*wave and 2*wave+1 (1 KiB each) of every half-tile.  An A half-tile = 2 * HR rows =
+    // HR / 4 pieces of 8 rows: 16 pieces (two per wave) at MT = 8; 12 at MT = 6 (two for waves 0-3, one for waves 4-7).
+    // B half-tile h = the 128 columns [128 h, 128 h + 128) of the tile; wave column wc owns columns 32 wc .. 32 wc + 31 of each.
+    const char* Ab = reinterpret_cast<const char*>(p.A);
+    const char* Bb = reinterpret_cast<const char*>(p.B);
+    constexpr bool A2 = (MT == 8);
+    const bool a_two = A2 || wave < 4;                                 // wave-uniform
+    struct Offs { uint32_t a[2][2], b[2][2]; };                        // [half][piece] byte offsets of this lane's 16 bytes at k = 0
+    auto offsets = [&](int tl, Offs& o) {
+        const int row0 = (tl / tiles_n) * BM, col0 = (tl % tiles_n) * BN;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int piece = 2 * wave + i;
+                {   // A: image row r' = 8 piece + lane/8 <-> tile row (r'/HR) * 2 HR + h * HR + r' % HR
+                    const int pa = A2 ? piece : (wave < 4 ? piece : 8 + (wave - 4));
+                    const int rp = 8 * pa + (lane >> 3), pos = lane & 7;
+                    const int trow = (rp / HR) * (2 * HR) + h * HR + (rp % HR);
+                    const int gr = min(row0 + trow, p.M - 1);
+                    o.a[h][i] = (uint32_t)(((size_t)gr * p.lda + ((pos ^ (rp & 7)) << 3)) * 2);
+                }
+                if constexpr (!TB) {   // B [N][K]: image row r' <-> tile column 128 h + r'
+                    const int rp = 8 * piece + (lane >> 3), pos = lane & 7;
+                    const int gc = min(col0 + 128 * h + rp, p.N - 1);
+                    o.b[h][i] = (uint32_t)(((size_t)gc * p.ldb + ((pos ^ (rp & 7)) << 3)) * 2);
+                } else {               // B [K][N]: image k-row 4 piece + lane/16, image column c' <-> tile column 128 h + c'
+                    const int kr = 4 * piece + (lane >> 4), pos = lane & 15;
+                    const int cp = (pos ^ trswz(kr)) << 3;
+                    const int gc = min(col0 + 128 * h + cp, ((p.N + 7) & ~7) - 8);
+                    o.b[h][i] = (uint32_t)(((size_t)kr * p.ldb + gc) * 2);
+                }
+            }
+    };
+    Offs cur, nxt;
+    offsets(tile, cur);
+    const uint32_t kstepA = BK * 2, kstepB = TB ? (uint32_t)BK * (uint32_t)p.ldb * 2u : (uint32_t)BK * 2u;
+    const int a_dst = A2 ? wave * 2048 : (wave < 4 ? wave * 2048 : 8192 + (wave - 4) * 1024);
+    int sbase = 0;                                                      // K-tiles consumed by earlier tiles: LDS buffer parity of the stream
+    bool has_next = false;
+    // stream position u = t + 1 or t + 2 of the CURRENT tile: past its last K-tile it is K-tile u - nk of the next tile (nk >= 2);
+    // with no next tile the source is clamped to the last K-tile (in bounds) and the destination stays the half-tile the schedule
+    // says is free: the DMA count per phase is a constant and nothing reads those bytes afterwards
+    auto stageA = [&](int h, int u) {
+        char* dst = smem + __builtin_amdgcn_readfirstlane(((sbase + u) & 1) * BUF + h * HALF + a_dst);
+        const bool roll = u >= nk && has_next;
+        const uint32_t ko = (uint32_t)(roll ? u - nk : min(u, nk - 1)) * kstepA;
+        const uint32_t o0 = roll ? nxt.a[h][0] : cur.a[h][0], o1 = roll ? nxt.a[h][1] : cur.a[h][1];
+        glds16(Ab + o0 + ko, dst);
+        if (a_two) glds16(Ab + o1 + ko, dst + 1024);
+    };
+    auto stageB = [&](int h, int u) {
+        char* dst = smem + __builtin_amdgcn_readfirstlane(((sbase + u) & 1) * BUF + 2 * HALF + h * HALF + wave * 2048);
+        const bool roll = u >= nk && has_next;
+        const uint32_t ko = (uint32_t)(roll ? u - nk : min(u, nk - 1)) * kstepB;
+        const uint32_t o0 = roll ? nxt.b[h][0] : cur.b[h][0], o1 = roll ? nxt.b[h][1] : cur.b[h][1];
+        glds16(Bb + o0 + ko, dst);
+        glds16(Bb + o1 + ko, dst + 1024);
+    };
+    // the two youngest half-tiles at the P4 wait are A-h0(t+2) and B-h1(t+2): 4 DMA instructions, 3 for a one-piece wave
+#define S2T_WAIT_TILE() do { if (a_two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } while (0)
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses (bytes inside a half-tile)
+    const int swz0 = ((0 + q) ^ (r16 & 7)) << 4, swz1 = ((4 + q) ^ (r16 & 7)) << 4;
+    const int a_off = (wr * HR + r16) * 128;                            // + i * 2048
+    const int b_off = (wc * 32 + r16) * 128;                            // + j * 2048 (direct image)
+
+    u32x4 fa[QM][2], fb[2][2];
+    // fragment reads of one phase, k-half 0 first: the MFMAs of k-half 0 start when those have landed (counted lgkmcnt, placed by
+    // the compiler) while the k-half 1 fragments are still on their way
+    auto readAs = [&](const char* buf, int h, int s_) {
+        const char* base = buf + h * HALF + a_off + (s_ ? swz1 : swz0);
+#pragma unroll
+        for (int i = 0; i < QM; ++i) fa[i][s_] = *reinterpret_cast<const u32x4*>(base + i * 2048);
+    };
+    auto readBs = [&](const char* buf, int h, int s_) {
+        const char* base = buf + 2 * HALF + h * HALF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (!TB) fb[j][s_] = *reinterpret_cast<const u32x4*>(base + b_off + j * 2048 + (s_ ? swz1 : swz0));
+            else fb[j][s_] = tr_frag(base, wc * 32 + 16 * j, s_, r16, q);
+        }
+    };
+#define S2T_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define S2T_MMA(MI, NI)                                                                                      \
+    do {                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                       \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                        \
+            _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                   \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+                    acc[QM * (MI) + i][2 * (NI) + j] = mma16<bf16>(fb[j][s], fa[i][s], acc[QM * (MI) + i][2 * (NI) + j]); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+
+    // ---- prologue: K-tile 0 completely, then the two half-tiles of K-tile 1 that the steady state stages in P3 / P4 of "tile -1"
+    stageA(0, 0); stageB(0, 0); stageB(1, 0); stageA(1, 0);
+    stageA(0, 1); stageB(1, 1);
+    S2T_WAIT_TILE();
+    S2T_BAR();
+    if (grp == 1) S2T_BAR();                                            // group 1 runs one barrier behind from here on
+
+    const uint32_t drop_th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
+    const float drop_inv = 1.f / (1.f - p.p_drop);
+    // buffer descriptors of the output, the extra operand stream and aux_out: M rows each (rows >= M fall outside)
+    const void* Eptr = EXT == EXT_RES ? p.residual : EXT == EXT_OLD ? (const void*)p.C : p.aux;
+    const int lde = EXT == EXT_RES ? p.ldr : EXT == EXT_OLD ? p.ldc : p.ldaux;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((size_t)p.M * p.ldc * sizeof(TO)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(Eptr ? Eptr : (const void*)p.C), 0,
+                                                                         (int)((size_t)p.M * lde * sizeof(TO)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.aux_out ? p.aux_out : p.C, 0,
+                                                                         (int)((size_t)p.M * p.ldaux * sizeof(TO)), 0x00020000);
+    for (;;) {
+        has_next = tile + G < tiles;
+        if (has_next) offsets(tile + G, nxt);
+        for (int t = 0; t < nk; ++t) {
+            const char* buf = smem + ((sbase + t) & 1) * BUF;
+            // P1
+            readBs(buf, 0, 0); readAs(buf, 0, 0); readBs(buf, 0, 1); readAs(buf, 0, 1);
+            stageA(1, t + 1);
+            S2T_BAR();
+            S2T_MMA(0, 0);
+            S2T_BAR();
+            // P2
+            readBs(buf, 1, 0); readBs(buf, 1, 1);
+            stageB(0, t + 1);
+            S2T_BAR();
+            S2T_MMA(0, 1);
+            S2T_BAR();
+            // P3
+            readAs(buf, 1, 0); readAs(buf, 1, 1);
+            stageA(0, t + 2);
+            S2T_BAR();
+            S2T_MMA(1, 1);
+            S2T_BAR();
+            // P4
+            readBs(buf, 0, 0); readBs(buf, 0, 1);
+            stageB(1, t + 2);
+            S2T_WAIT_TILE();
+            S2T_BAR();
+            S2T_MMA(1, 0);
+            S2T_BAR();
+        }
+        // ---- this tile's epilogue (no barrier inside: the other group is one interval away in its own stream)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            typedef typename Pack4<TO>::type PK;
+            constexpr uint32_t ES = sizeof(TO);
+            const int row0 = (tile / tiles_n) * BM, col0 = (tile % tiles_n) * BN;
+            const int colw = col0 + wc * 32 + 4 * q;                      // column of this lane's quad in tile j: + 128 (j >> 1) + 16 (j & 1)
+            const int roww = row0 + wr * (2 * HR) + r16;                  // + HR hm + 16 ii
+            f32x4 b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = colw + (j >> 1) * 128 + 16 * (j & 1);
+                b4[j] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            static_assert(sizeof(TO) == 2, "bf16 outputs");
+            {
+                // bf16: a store of one quad is 8 bytes per lane = sixteen 32-byte row segments per wave-instruction, and the store tail
+                // is bound by the NUMBER of such instructions (cdna_hip_programming.md T21).  The quads of two neighbouring 16-column
+                // tiles are exchanged between lane rows q and q ^ 1 (v_permlane16_swap) so that every lane holds 8 consecutive columns:
+                // 16-byte accesses, half the instructions, 64-byte row segments.  Operand loads come in the same shape and are swapped back.
+                uint32_t vC[2], vE[2], vX[2];                             // per-lane byte offsets of (roww, this lane's 8 columns of pair pp)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int col = col0 + wc * 32 + pp * 128 + 16 * (q & 1) + 8 * (q >> 1);
+                    const bool ok = col < p.N;
+                    vC[pp] = ok ? (uint32_t)(((size_t)roww * p.ldc + col) * ES) : 0xFFFFFFF0u;
+                    vE[pp] = ok ? (uint32_t)(((size_t)roww * lde + col) * ES) : 0xFFFFFFF0u;
+                    vX[pp] = ok ? (uint32_t)(((size_t)roww * p.ldaux + col) * ES) : 0xFFFFFFF0u;
+                }
+                auto swap2 = [](uint32_t& x, uint32_t& y) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+                    x = r[0]; y = r[1];
+                };
+#pragma unroll
+                for (int hm = 0; hm < 2; ++hm) {
+                    u32x4 e16[QM][2];
+#pragma unroll
+                    for (int ii = 0; ii < QM; ++ii)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            e16[ii][pp] = u32x4{};
+                            if constexpr (EXT != EXT_NONE) e16[ii][pp] = buf_load<u32x4>(rE, vE[pp], (uint32_t)((hm * HR + 16 * ii) * lde) * ES);
+                        }
+#pragma unroll
+                    for (int ii = 0; ii < QM; ++ii)
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            const int row = roww + hm * HR + 16 * ii;
+                            uint32_t e0 = e16[ii][pp][0], e1 = e16[ii][pp][1], e2 = e16[ii][pp][2], e3 = e16[ii][pp][3];
+                            if constexpr (EXT != EXT_NONE) { swap2(e0, e2); swap2(e1, e3); }
+                            const uint64_t qa = ((uint64_t)row * p.N + (colw + pp * 128)) >> 2;
+                            PK pa, pb;
+                            const PK oa = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp], b4[2 * pp], PK{e0, e1}, qa, drop_th, drop_inv, pa);
+                            const PK ob = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp + 1], b4[2 * pp + 1], PK{e2, e3}, qa + 4, drop_th, drop_inv, pb);
+                            uint32_t s0 = oa[0], s1 = oa[1], s2 = ob[0], s3 = ob[1];
+                            swap2(s0, s2); swap2(s1, s3);
+                            buf_store(u32x4{s0, s1, s2, s3}, rC, vC[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES);
+                            if constexpr (ACT == ACT_GELU) {
+                                if (p.aux_out) {
+                                    uint32_t t0 = pa[0], t1 = pa[1], t2 = pb[0], t3 = pb[1];
+                                    swap2(t0, t2); swap2(t1, t3);
+                                    buf_store(u32x4{t0, t1, t2, t3}, rX, vX[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldaux) * ES);
+                                }
+                            }
+                            acc[QM * hm + ii][2 * pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            acc[QM * hm + ii][2 * pp + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        sbase += nk;
+        tile += G;
+        cur = nxt;
+    }
+    if (grp == 0) S2T_BAR();                              // group 0 waits for group 1's last phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail DMAs land in LDS nobody reads; retire them before the wave ends
+#undef S2T_MMA
+#undef S2T_BAR
+#undef S2T_WAIT_TILE
+}
+
+// Shapes this kernel takes: bf16 operands, K a multiple of 64, at least two K-tiles, 16-byte aligned rows, operands below 4 GiB
+// (32-bit byte offsets), no gather maps, no split-K.  Returns 0 when the product is not for this kernel (the caller falls
+// through to gemm.hip), 1 when launched, < 0 on error.
+int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st) {
+    if (a.mapA || a.mapB || a.mapC || a.splitk != 1 || a.rowsum) return 0;
+    if (a.K % BK || a.K < 2 * BK || a.M < 256 || a.N < 256 || (a.N & 7)) return 0;
+    if (((uintptr_t)a.C & 15) || (a.ldc & 7) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
+    if (a.residual && (((uintptr_t)a.residual & 15) || (a.ldr & 7))) return 0;
+    if ((a.aux && ((uintptr_t)a.aux & 15)) || (a.aux_out && ((uintptr_t)a.aux_out & 15)) || ((a.aux || a.aux_out) && (a.ldaux & 7))) return 0;
+    if ((a.lda % 8) || (a.ldb % 8) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15)) return 0;
+    const size_t rowsB = trans_b ? (size_t)a.K : (size_t)a.N;
+    if ((size_t)a.M * a.lda * 2 >= (1ull << 32) || rowsB * a.ldb * 2 >= (1ull << 32)) return 0;
+    const size_t osz = out_dtype == S2T_BF16 ? 2 : 4;
+    if ((size_t)a.M * a.ldc * osz >= (1ull << 31) || (size_t)a.M * a.ldr * osz >= (1ull << 31) || (size_t)a.M * a.ldaux * osz >= (1ull << 31)) return 0;
+    if (trans_b && ((a.N + 7) / 8 * 8 > a.ldb)) return 0;
+    // epilogue variant: the activation and the ONE extra operand stream are compile-time (gemm256_kernel<.., ACT, EXT>)
+    int ext = EXT_NONE;
+    if (a.act == ACT_RELU_BWD || a.act == ACT_GELU_BWD) { if (a.residual || a.accumulate) return 0; ext = EXT_AUX; }
+    else if (a.residual) { if (a.accumulate) return 0; ext = EXT_RES; }
+    else if (a.accumulate) ext = EXT_OLD;
+    if (out_dtype != S2T_BF16) return 0;            // bf16 outputs only (f32 rows -- logits in fp32 mode, split-K partials -- stay in gemm.hip)
+    if (trans_b && (a.bias || a.act == ACT_RELU || a.act == ACT_GELU || ext == EXT_RES)) return 0;   // data gradients: none / act-bwd / accumulate
+    if (!trans_b && (ext == EXT_AUX || ext == EXT_OLD || (a.act != ACT_NONE && ext != EXT_NONE))) return 0;
+    // row-tile height: the one that needs less time on 256 CUs = rounds x rows per tile (ties go to 256: fewer B re-reads)
+    const int tn = (a.N + 255) / 256;
+    const long t256 = (long)((a.M + 255) / 256) * tn, t192 = (long)((a.M + 191) / 192) * tn;
+    if (t192 < 192) return 0;                       // one workgroup per CU: fewer tiles than ~3/4 of the CUs run better as 128 x 128 tiles, 2-3 per CU
+    const bool use192 = ((t192 + 255) / 256) * 192 < ((t256 + 255) / 256) * 256;
+    const int tiles = (int)(use192 ? t192 : t256);
+    const int grid = tiles < 256 ? tiles : 256;
+    const size_t lds = 2 * BUF;
+    bool done = false;
+#define S2T_G256(TO_, TB_, MT_, ACT_, EXT_)                                                                                  \
+    if (!done && (out_dtype == S2T_BF16) == (sizeof(TO_) == 2) && (trans_b != 0) == TB_ && use192 == (MT_ == 6) &&          \
+        a.act == ACT_ && ext == EXT_) {                                                                                      \
+        static bool attr = false;                                                                                            \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO_, TB_, MT_, ACT_, EXT_>),    \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }         \
+        hipLaunchKernelGGL((gemm256_kernel<TO_, TB_, MT_, ACT_, EXT_>), dim3(grid), dim3(512), lds, st, a);                                     \
+        done = true;                                                                                                         \
+    }
+#define S2T_G256_MT(TO_, TB_, ACT_, EXT_) S2T_G256(TO_, TB_, 8, ACT_, EXT_) S2T_G256(TO_, TB_, 6, ACT_, EXT_)
+    S2T_G256_MT(bf16, false, ACT_NONE, EXT_NONE) S2T_G256_MT(bf16, false, ACT_RELU, EXT_NONE) S2T_G256_MT(bf16, false, ACT_GELU, EXT_NONE)
+    S2T_G256_MT(bf16, false, ACT_NONE, EXT_RES)
+    S2T_G256_MT(bf16, true, ACT_NONE, EXT_NONE) S2T_G256_MT(bf16, true, ACT_RELU_BWD, EXT_AUX) S2T_G256_MT(bf16, true, ACT_GELU_BWD, EXT_AUX)
+    S2T_G256_MT(bf16, true, ACT_NONE, EXT_OLD)
+#undef S2T_G256_MT
+#undef S2T_G256
+    if (!done) return 0;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return S2T_EHIP(e);
+    return 1;
+}

@@ -14,7 +14,6 @@ struct GemmArgs {
     //  mapC: output row r is written to C row mapC[r]
     const int* mapA; int periodA; const int* mapB; const int* mapC;
     float p_drop; unsigned long long seed;   // dropout on the activated value, before the residual add
-    int dbg;                                 // benchmarking ablations (S2T_GEMM_DBG): 1 = skip the epilogue, 2 = skip the k-loop
     float* rowsum;                           // optional (TA products): rowsum[m] += sum_k op(A)[m][k]  (bias gradient of a Linear)
 };
 

@@ -8,6 +8,7 @@
 #include <cstring>
 
 int g_s2t_prof_on = 0;
+int g_s2t_opt_gemm256 = 1, g_s2t_opt_attn_v1 = 0, g_s2t_opt_attn_v2_min_tq = 16;
 namespace {
 struct Rec { hipEvent_t a, b; double flops, bytes; };
 struct Fam { std::vector<Rec> recs; double ms = 0, flops = 0, bytes = 0; long long launches = 0; };
@@ -43,6 +44,15 @@ void s2t_prof_push(const char* family, hipStream_t st, double flops, double byte
 
 extern "C" int s2t_abi_version(void) { return 1; }
 extern "C" const char* s2t_build_info(void) { return "libs2t_hip gfx950 (CDNA4, wave64, MFMA) built " __DATE__ " " __TIME__; }
+extern "C" int s2t_set_option(const char* key, int value) {
+    if (!key) return S2T_EINVAL;
+    int* slot = !strcmp(key, "gemm256") ? &g_s2t_opt_gemm256 : !strcmp(key, "attn_v1") ? &g_s2t_opt_attn_v1
+              : !strcmp(key, "attn_v2_min_tq") ? &g_s2t_opt_attn_v2_min_tq : nullptr;
+    if (!slot) return S2T_EINVAL;
+    const int old = *slot;
+    *slot = value;
+    return old;
+}
 extern "C" int s2t_prof_enable(int on) { g_s2t_prof_on = on ? 1 : 0; return S2T_OK; }
 extern "C" int s2t_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);

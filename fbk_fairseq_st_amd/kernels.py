@@ -415,6 +415,14 @@ def host_ctc_uer(pred_cpu, in_len_cpu, targets_cpu, tgt_len_cpu, blank):
     return e.value, n.value
 
 
+def set_option(key, value):
+    """kernel-route option of the library (include/s2t_hip.h, s2t_set_option); returns the previous value"""
+    old = _lib().s2t_set_option(key.encode(), int(value))
+    if old == -22:
+        raise ValueError("unknown libs2t_hip option %r" % key)
+    return old
+
+
 def prof_enable(on):
     _lib().s2t_prof_enable(int(on))
 

@@ -62,6 +62,7 @@ SIGNATURES = {
     "s2t_adam_step": [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, c_int, P],
     "s2t_cast": [c_int, c_int, P, P, c_size_t, P],
     "s2t_scale_by_device_scalar": [c_int, P, c_size_t, P, P],
+    "s2t_set_option": [ctypes.c_char_p, c_int],
     "s2t_prof_enable": [c_int],
     "s2t_prof_reset": [],
     "s2t_prof_read": [ctypes.c_char_p, P, P, P, P],

@@ -264,6 +264,13 @@ int s2t_scale_by_device_scalar(int dtype, void* x, size_t n, const float* scalar
  * While enabled, every launch of the named family on `stream` is bracketed by hipEvents; s2t_prof_read
  * synchronises those events and returns accumulated milliseconds, launches and algorithmic flops/bytes. */
 int s2t_prof_enable(int on);
+/* ---- kernel-route options (tests cover every route; nothing here changes results beyond rounding) --------------------
+ * key = "gemm256": 1 (default) sends the big bf16 NT / NN products to the 256x256x64 LDS-DMA kernel, 0 keeps them on the
+ *                  128x128 register-staged kernels;
+ *       "attn_v1": 1 forces the first-generation attention kernels (f32 / d 32 / short sequences use them anyway), default 0;
+ *       "attn_v2_min_tq": shortest query block taken by the second-generation attention kernels (default 16);
+ * returns the previous value, or S2T_EINVAL (-22) for an unknown key. */
+int s2t_set_option(const char* key, int value);
 int s2t_prof_read(const char* family, double* ms, long long* launches, double* flops, double* bytes);
 int s2t_prof_reset(void);
 

@@ -223,13 +223,18 @@ def encoder_layer(W, cfg, pfx, x, pad_mask):
 
 
 # ------------------------------------------------------------------ CTC compression (a10)
-def ctc_compress(W, cfg, x, lengths):
+def ctc_compress(W, cfg, x, lengths, pred_override=None):
     """average_same_ctc_features, conv_transformer.py:278-291.
-    x (T,B,D) -> x_ctc (T,B,V), compressed (T''max,B,D), new_lengths, pred ids (B,T)."""
+    x (T,B,D) -> x_ctc (T,B,V), compressed (T''max,B,D), new_lengths, pred ids (B,T).
+    pred_override (B,T) int, checker-only: take the arg-max from the caller instead of from this function's own f32 logits.
+    The reduced-precision (bf16) parity tests use it to split the comparison the way the arithmetic splits: the integer
+    path is checked exactly on the product's OWN logits (int_ref), and the float path is checked against this oracle GIVEN
+    the same integer path -- a bf16-rounded logit pair within one ulp of a tie may legitimately pick the other index."""
     x_ctc = F.linear(x, W["encoder.ctc_fc.weight"], W["encoder.ctc_fc.bias"])
     with torch.no_grad():
         prob = F.softmax(x_ctc, dim=-1).transpose(0, 1)                  # (B,T,V)  :282
-        pred = int_ref.argmax_first_np(prob.numpy())                      # (B,T)    :284
+        pred = int_ref.argmax_first_np(prob.numpy()) if pred_override is None else \
+            np.ascontiguousarray(np.asarray(pred_override, dtype=np.int64))         # (B,T)    :284
         runs = int_ref.ctc_rle_np(pred, lengths.numpy())                  # :285
         new_lengths = torch.tensor([len(r) for r in runs], dtype=torch.long)
         Wm = torch.from_numpy(int_ref.compress_weights_np(prob.numpy(), runs, cfg["strategy"]))
@@ -238,7 +243,7 @@ def ctc_compress(W, cfg, x, lengths):
 
 
 # ------------------------------------------------------------------ encoder (a11)
-def encoder_forward(W, cfg, src_tokens, src_lengths, training=False, trace=None):
+def encoder_forward(W, cfg, src_tokens, src_lengths, training=False, trace=None, pred_override=None):
     """ConvolutionalTransformerEncoder.forward, conv_transformer.py:195-276."""
     x, lengths, stats = subsample(W, cfg, src_tokens, src_lengths, training, trace)
     mask = length_mask(lengths, x.shape[0])
@@ -248,7 +253,7 @@ def encoder_forward(W, cfg, src_tokens, src_lengths, training=False, trace=None)
         x = encoder_layer(W, cfg, "encoder.layers.%d." % l, x, mask)
         if cfg["ctc_layer"] and cfg["ctc_layer"] == l + 1:
             ctc_mask = mask
-            x_ctc, x, lengths, pred = ctc_compress(W, cfg, x, lengths)
+            x_ctc, x, lengths, pred = ctc_compress(W, cfg, x, lengths, pred_override)
             new_lengths = lengths
             mask = length_mask(lengths, x.shape[0])
         states.append(x)
@@ -493,12 +498,12 @@ def ctc_branch(cfg, ctc_out, ctc_pad_mask, transcript, transcript_lengths, blank
     return loss, err, tot, in_len
 
 
-def ctc_multi_loss(W, cfg, sample, eps, ctc_weight, blank, training=False):
+def ctc_multi_loss(W, cfg, sample, eps, ctc_weight, blank, training=False, pred_override=None):
     """CTCMultiLoss.forward, ctc_multi_loss.py:140-168, with the encoder-owned ctc_fc
     (--ctc-compress-out) or the criterion-owned fc_out on encoder_states[k-1].
     Returns loss, sample_size (= the CTC branch's, :168), logging dict, EncOut."""
     ni = sample["net_input"]
-    enc, stats = encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training)
+    enc, stats = encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training, pred_override=pred_override)
     logits = decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
     if enc.ctc_out is not None:
         ctc_feat, ctc_mask = enc.ctc_out, enc.ctc_padding_mask

@@ -473,22 +473,59 @@ def test_add_pos_and_permutes():
     assert torch.equal(back.cpu(), w2)
 
 
-@pytest.mark.parametrize("M,N,K_", [(2500, 384, 192), (4096, 128, 64), (3000, 640, 1280), (2048, 200, 128), (24000, 512, 512)])
-def test_gemm_v2_direct_to_lds_kernel(M, N, K_, monkeypatch):
-    """bf16 forward-shaped GEMMs large enough for gemm_v2_kernel (256x128 tiles, global_load_lds ring; opt-in via
-    S2T_GEMM_V2, read once per process: run this file with S2T_GEMM_V2=1 to exercise it, otherwise the same shapes go
-    through the default kernels)."""
+@pytest.mark.parametrize("route", [1, 0], ids=["gemm256", "gemm128"])
+@pytest.mark.parametrize("M,N,K_", [(24000, 384, 192), (12000, 768, 128), (23000, 640, 1280), (36800, 256, 512), (24000, 512, 512), (6211, 1536, 512), (24000, 2048, 128)])
+def test_gemm_big_products_both_routes(M, N, K_, route):
+    """bf16 NT / NN products large enough for the 256 x 256 x 64 LDS-DMA kernel (gemm256.hip: ragged last row / column tiles,
+    2 .. 20 K-tiles, every epilogue) against plain f32 math; route 0 sends the same calls to the 128 x 128 kernels (gemm.hip)."""
     dtype = torch.bfloat16
-    a = rnd(M, K_, dtype=dtype, seed=1); w = rnd(N, K_, dtype=dtype, seed=2, scale=K_ ** -0.5)
-    bias = rnd(N, seed=3); res = rnd(M, N, dtype=dtype, seed=4)
-    ref = a.float() @ w.float().t() + bias
-    assert rel_err(K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV)), ref) < 2e-2
-    out = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), act=K.ACT_RELU, residual=res.to(DEV))
-    assert rel_err(out, F.relu(ref) + res.float()) < 2e-2
-    # dropout in the epilogue: same mask as the standalone kernel on the same index space
-    y = K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), p_drop=0.25, seed=9)
-    y0 = K.dropout(K.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV)), 0.25, 9)
-    assert rel_err(y, y0) < 2e-2
+    old = K.set_option("gemm256", route)
+    try:
+        a = rnd(M, K_, dtype=dtype, seed=1); w = rnd(N, K_, dtype=dtype, seed=2, scale=K_ ** -0.5)
+        bias = rnd(N, seed=3); res = rnd(M, N, dtype=dtype, seed=4)
+        ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
+        ref = a.float() @ w.float().t() + bias
+        assert rel_err(K.gemm(ad, wd, bias=bd), ref) < 2e-2
+        out = K.gemm(ad, wd, bias=bd, act=K.ACT_RELU, residual=rd)
+        assert rel_err(out, F.relu(ref) + res.float()) < 2e-2
+        pre = torch.empty(M, N, dtype=dtype, device=DEV)
+        out = K.gemm(ad, wd, bias=bd, act=K.ACT_GELU, aux_out=pre)
+        assert rel_err(out, F.gelu(ref)) < 2e-2 and rel_err(pre, ref) < 2e-2
+        out32 = K.gemm(ad, wd, out_dtype=torch.float32)                     # f32 output rows stay on the gemm.hip kernels
+        assert rel_err(out32, a.float() @ w.float().t()) < 2e-3
+        # dropout in the epilogue: same mask as the standalone kernel on the same index space
+        y = K.gemm(ad, wd, bias=bd, p_drop=0.25, seed=9)
+        y0 = K.dropout(K.gemm(ad, wd, bias=bd), 0.25, 9)
+        assert rel_err(y, y0) < 2e-2
+        # NN: dX = act_bwd(dY . W) with W stored [K][N] (the weight as it lies in memory), accumulate into an existing buffer
+        dy = rnd(M, N, dtype=dtype, seed=5); dyd = dy.to(DEV)
+        refx = dy.float() @ w.float()
+        assert rel_err(K.gemm(dyd, wd, trans_b=True), refx) < 2e-2
+        aux = rnd(M, K_, dtype=dtype, seed=6)
+        out = K.gemm(dyd, wd, trans_b=True, act=K.ACT_RELU_BWD, aux=aux.to(DEV), alpha=1.25)
+        assert rel_err(out, torch.where(aux.float() > 0, 1.25 * refx, torch.zeros_like(refx))) < 2e-2
+        base = rnd(M, K_, dtype=dtype, seed=7)
+        acc = base.to(DEV).clone()
+        K.gemm(dyd, wd, trans_b=True, out=acc, accumulate=True)
+        assert rel_err(acc, refx + base.float()) < 2e-2
+    finally:
+        K.set_option("gemm256", old)
+
+
+def test_gemm256_is_deterministic_under_load():
+    """the LDS-DMA pipeline orders its reads by counted waits and barriers only: 40 back-to-back launches on fresh random data
+    must reproduce the first result bit for bit (a read that overtakes its DMA shows up as rare wrong tiles)"""
+    dtype = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(1)
+    a = torch.randn(24000, 512, device=DEV, generator=g).to(dtype); w = (torch.randn(2048, 512, device=DEV, generator=g) * 0.05).to(dtype)
+    a2 = torch.randn(24000, 2048, device=DEV, generator=g).to(dtype); w2 = (torch.randn(512, 2048, device=DEV, generator=g) * 0.02).to(dtype)
+    first, first2, firstx = K.gemm(a, w).clone(), K.gemm(a2, w2).clone(), K.gemm(a2, w, trans_b=True).clone()
+    ref = (a[:4096].float() @ w.float().t())
+    assert rel_err(first[:4096], ref) < 2e-2
+    for _ in range(40):
+        assert torch.equal(K.gemm(a, w), first)
+        assert torch.equal(K.gemm(a2, w2), first2)
+        assert torch.equal(K.gemm(a2, w, trans_b=True), firstx)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
