@@ -9,19 +9,27 @@
 //     round 1 put 16 us of a 77 us launch into the register -> LDS writes).  The LDS image is lane-linear per wave-instruction
 //     (1 KiB = 8 rows x 128 B, or 4 k-rows x 256 B for a k-strided operand), so the XOR swizzle that keeps the fragment reads
 //     conflict-free sits on the per-lane SOURCE address (rule 21);
-//   * two K-tile buffers of 64 KiB, each cut into four 16 KiB half-tiles (A-h0, A-h1, B-h0, B-h1) = what ONE of the four compute
-//     phases of a K-tile reads.  A K-tile is four phases, each 16 MFMAs per wave on one 64 x 32 quadrant of the wave's tile:
-//         P1 (A-h0, B-h0)   P2 (A-h0, B-h1)   P3 (A-h1, B-h1)   P4 (A-h1, B-h0)        reads per wave: 12 / 4 / 8 / 4 fragments
-//     and every phase re-stages ONE half-tile that became free two phases earlier:
-//         P1: A-h1(t+1)   P2: B-h0(t+1)   P3: A-h0(t+2)   P4: B-h1(t+2)
-//     One counted s_waitcnt vmcnt(4) per K-tile (in P4: everything but the two youngest half-tiles has landed = all of tile
-//     t+1), never vmcnt(0) in the loop; raw s_barrier (a __syncthreads() would drain the DMA queue);
+//   * two K-tile buffers of 64 KiB, each cut into four 16 KiB half-tiles (A-h0, A-h1, B-h0, B-h1).  A K-tile is two super-phases of
+//     32 MFMAs per wave (two 64 x 32 quadrants of the wave's tile each; the B fragments of both halves stay in registers):
+//         SPa (A-h0 x B-h0, A-h0 x B-h1)      SPb (A-h1 x B-h1, A-h1 x B-h0)            fragment reads per wave: 16 / 8
+//     and every super-phase re-stages two half-tiles (four 1-KiB DMA instructions per wave):
+//         SPa(t): A-h1(t+1), B-h1(t+1)        SPb(t): A-h0(t+2), B-h0(t+2)
+//     ONE counted s_waitcnt vmcnt(4) per K-tile (end of SPb's memory segment: everything but the two half-tiles just issued has
+//     landed = all of K-tile t+1), never vmcnt(0) in the loop; raw s_barrier (a __syncthreads() would drain the DMA queue).
+//     (Round-2 timeline from in-kernel s_memtime stamps, make dbg + tools/gemm_timeline.py: a four-phase version of this loop --
+//     16 MFMAs per barrier pair -- spent 120-250 cycles per barrier hand-off against a 256-cycle MFMA cluster; 32 MFMAs per
+//     hand-off and 4 + 4 DMA instructions per K-tile took the big products from 0.95-1.0x to 1.3x the 128 x 128 kernels.)
 //   * the two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) run one barrier apart: while one group issues its LDS
 //     reads and DMA the other runs its MFMA cluster, so the matrix pipe of a SIMD always has one wave's MFMAs to issue.
-// Hazards, by barrier count (group 0 runs phase p's memory segment in barrier interval 2p and its MFMAs in 2p+1, group 1 one
-// interval later): a half-tile read in phase p is re-staged in phase p+2 -- every wave passed the s_waitcnt lgkmcnt(0) that
-// follows its phase-p reads before barrier 2p+3, the first DMA into it issues in interval 2p+4; a half-tile is read one phase or
-// more after the phase whose vmcnt retired it -- both groups' waits precede barrier 2w+2, the first read is in interval 2w+2.
+//   * persistent: one workgroup per CU walks the output tiles, the operand stream never stops at a tile boundary, the epilogue goes
+//     straight from the accumulators to memory (buffer addressing, 16-byte stores after a v_permlane16_swap of neighbouring quads).
+// Hazards, by barrier count (super-phase p: group 0 runs its memory segment in barrier interval 2p and its MFMAs in 2p+1, group 1
+// one interval later).  Write-after-read: A-h0 / B-h0 (read in SPa's memory segment) and A-h1 (SPb's memory segment) are re-staged in
+// the NEXT super-phase, which is safe because every wave waits for those reads to return (lgkmcnt(0)) BEFORE the barrier that ends
+// its memory segment: group 1's wait precedes barrier 2p+2, group 0's first DMA into the region issues in interval 2p+2.  B-h1 is
+// read at the head of SPa's MFMA cluster (NT form) and re-staged two super-phases later (SPa of the next K-tile: interval 2p+4 >
+// barrier 2p+3 that both groups' clusters precede).  Read-after-write: the wait that retires K-tile t+1 sits in SPb(t)'s memory
+// segment (both groups pass it before barrier 2p+2); its first reader is SPa(t+1)'s memory segment (interval 2p+2 and later).
 #include "common.hpp"
 #include "prof.hpp"
 #include "gemm_epilogue.hpp"
@@ -207,8 +215,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         glds16(Bb + o0 + ko, dst);
         glds16(Bb + o1 + ko, dst + 1024);
     };
-    // the two youngest half-tiles at the P4 wait are A-h0(t+2) and B-h1(t+2): 4 DMA instructions, 3 for a one-piece wave
+    // ONE counted wait per K-tile (never 0 in the loop), at the end of SPb's memory segment: only the half-tiles issued in that
+    // segment (A-h0, B-h0 of K-tile t+2: 4 DMA instructions, 3 for a wave that stages one A piece) may still be in flight, so all of
+    // K-tile t+1 has landed
 #define S2T_WAIT_TILE() do { if (a_two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } while (0)
+    // reads of a half-tile that is re-staged in the very next super-phase must have RETURNED before this wave passes the barrier
+#define S2T_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int a_off = (wr * HR + r16) * 128;                            // + i * 2048
     const int b_off = (wc * 32 + r16) * 128;                            // + j * 2048 (direct image)
 
-    u32x4 fa[QM][2], fb[2][2];
+    u32x4 fa[QM][2], fb[2][2][2];                                        // fb[half][column tile][k-half]: both B halves stay in registers
     // fragment reads of one phase, k-half 0 first: the MFMAs of k-half 0 start when those have landed (counted lgkmcnt, placed by
     // the compiler) while the k-half 1 fragments are still on their way
     auto readAs = [&](const char* buf, int h, int s_) {
@@ -233,25 +245,55 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         const char* base = buf + 2 * HALF + h * HALF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if constexpr (!TB) fb[j][s_] = *reinterpret_cast<const u32x4*>(base + b_off + j * 2048 + (s_ ? swz1 : swz0));
-            else fb[j][s_] = tr_frag(base, wc * 32 + 16 * j, s_, r16, q);
+            if constexpr (!TB) fb[h][j][s_] = *reinterpret_cast<const u32x4*>(base + b_off + j * 2048 + (s_ ? swz1 : swz0));
+            else fb[h][j][s_] = tr_frag(base, wc * 32 + 16 * j, s_, r16, q);
         }
     };
 #define S2T_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define S2T_MMA(MI, NI)                                                                                      \
-    do {                                                                                                     \
-        __builtin_amdgcn_s_setprio(1);                                                       \
+#ifdef S2T_G256_STAMPS
+    // diagnostic build only (make dbg; tools/gemm_timeline.py): s_memtime before and after the MFMA cluster of every phase of
+    // workgroup 0, waves 0 and 4, into the buffer passed as aux_out.  Perturbs the schedule (each stamp waits for its own return).
+    unsigned long long* const DBG = reinterpret_cast<unsigned long long*>(p.aux_out);
+    int dbg_n = 0;
+    const bool dbg_on = DBG && blockIdx.x == 0 && (wave & 3) == 0;
+#define S2T_STAMP(K_)                                                                                        \
+    if (dbg_on && dbg_n < 120) {                                                                             \
+        unsigned long long t_;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                         \
+        if (lane == 0) DBG[(wave >> 2) * 512 + 2 * dbg_n + (K_)] = t_;                                       \
+        dbg_n += (K_);                                                                                       \
+    }
+    unsigned long long tm0_ = 0, tm1_ = 0, tm2_ = 0;
+#define S2T_MT(V_) if (dbg_on) asm volatile("s_memtime %0" : "=s"(V_) :: "memory");
+#define S2T_MEM_END()                                                                                        \
+    if (dbg_on && dbg_n < 120) {                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tm0_), "+s"(tm1_), "+s"(tm2_) :: "memory");               \
+        if (lane == 0) { DBG[1024 + (wave >> 2) * 512 + 3 * dbg_n] = tm0_; DBG[1024 + (wave >> 2) * 512 + 3 * dbg_n + 1] = tm1_;  \
+                         DBG[1024 + (wave >> 2) * 512 + 3 * dbg_n + 2] = tm2_; }                             \
+    }
+#else
+#define S2T_STAMP(K_)
+#define S2T_MT(V_)
+#define S2T_MEM_END()
+#endif
+#define S2T_QUAD(MI, NI)                                                                                     \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                        \
             _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                   \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
-                    acc[QM * (MI) + i][2 * (NI) + j] = mma16<bf16>(fb[j][s], fa[i][s], acc[QM * (MI) + i][2 * (NI) + j]); \
+                    acc[QM * (MI) + i][2 * (NI) + j] = mma16<bf16>(fb[NI][j][s], fa[i][s], acc[QM * (MI) + i][2 * (NI) + j]);
+#define S2T_MMA2(MI, NA, NB)                                                                                 \
+    do {                                                                                                     \
+        S2T_STAMP(0)                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        S2T_QUAD(MI, NA) S2T_QUAD(MI, NB)                                                                    \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
+        S2T_STAMP(1)                                                                                         \
     } while (0)
 
-    // ---- prologue: K-tile 0 completely, then the two half-tiles of K-tile 1 that the steady state stages in P3 / P4 of "tile -1"
+    // ---- prologue: K-tile 0 and what the steady state stages in SPb of "K-tile -1" (A-h0, B-h0 of K-tile 1)
     stageA(0, 0); stageB(0, 0); stageB(1, 0); stageA(1, 0);
-    stageA(0, 1); stageB(1, 1);
+    stageA(0, 1); stageB(0, 1);
     S2T_WAIT_TILE();
     S2T_BAR();
     if (grp == 1) S2T_BAR();                                            // group 1 runs one barrier behind from here on
@@ -271,30 +313,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         if (has_next) offsets(tile + G, nxt);
         for (int t = 0; t < nk; ++t) {
             const char* buf = smem + ((sbase + t) & 1) * BUF;
-            // P1
-            readBs(buf, 0, 0); readAs(buf, 0, 0); readBs(buf, 0, 1); readAs(buf, 0, 1);
-            stageA(1, t + 1);
+            // SPa: quadrants (A-h0 x B-h0), (A-h0 x B-h1).  The B-h1 fragments are read at the head of the MFMA cluster (their latency
+            // hides under the first quadrant's MFMAs).  Re-stage, in the OTHER buffer: A-h1 (last read in SPb of K-tile t-1, reads
+            // returned before that segment's barrier) and B-h1 (last read in the MFMA cluster of SPa of K-tile t-1) with K-tile t+1.
+            S2T_MT(tm0_) readBs(buf, 0, 0); readAs(buf, 0, 0); readBs(buf, 0, 1); readAs(buf, 0, 1);
+            if constexpr (TB) { readBs(buf, 1, 0); readBs(buf, 1, 1); }    // transposed reads: two instructions per fragment, kept out of the MFMA cluster
+            S2T_MT(tm1_) stageA(1, t + 1); stageB(1, t + 1);
+            S2T_MT(tm2_) S2T_MEM_END()
+            S2T_READS_DONE();
             S2T_BAR();
-            S2T_MMA(0, 0);
+            if constexpr (!TB) { readBs(buf, 1, 0); readBs(buf, 1, 1); }
+            S2T_MMA2(0, 0, 1);
             S2T_BAR();
-            // P2
-            readBs(buf, 1, 0); readBs(buf, 1, 1);
-            stageB(0, t + 1);
-            S2T_BAR();
-            S2T_MMA(0, 1);
-            S2T_BAR();
-            // P3
-            readAs(buf, 1, 0); readAs(buf, 1, 1);
-            stageA(0, t + 2);
-            S2T_BAR();
-            S2T_MMA(1, 1);
-            S2T_BAR();
-            // P4
-            readBs(buf, 0, 0); readBs(buf, 0, 1);
-            stageB(1, t + 2);
+            // SPb: quadrants (A-h1 x B-h1), (A-h1 x B-h0) on the B fragments still in registers.  Re-stage, in THIS buffer: A-h0 and B-h0
+            // (read in SPa's memory segment just before: returned before its barrier) with K-tile t+2.
+            S2T_MT(tm0_) readAs(buf, 1, 0); readAs(buf, 1, 1);
+            S2T_MT(tm1_) stageA(0, t + 2); stageB(0, t + 2);
+            S2T_MT(tm2_) S2T_MEM_END()
+            S2T_READS_DONE();
             S2T_WAIT_TILE();
             S2T_BAR();
-            S2T_MMA(1, 0);
+            S2T_MMA2(1, 1, 0);
             S2T_BAR();
         }
         // ---- this tile's epilogue (no barrier inside: the other group is one interval away in its own stream)
@@ -375,9 +414,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     }
     if (grp == 0) S2T_BAR();                              // group 0 waits for group 1's last phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail DMAs land in LDS nobody reads; retire them before the wave ends
-#undef S2T_MMA
+#undef S2T_MMA2
+#undef S2T_QUAD
 #undef S2T_BAR
 #undef S2T_WAIT_TILE
+#undef S2T_READS_DONE
 }
 
 // Shapes this kernel takes: bf16 operands, K a multiple of 64, at least two K-tiles, 16-byte aligned rows, operands below 4 GiB

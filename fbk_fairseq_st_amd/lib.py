@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs2t_hip.so")
+LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")     # S2T_HIP_LIB: diagnostic twin (make dbg)
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
