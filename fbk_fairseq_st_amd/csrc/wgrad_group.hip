@@ -1,0 +1,305 @@
+// Grouped weight-gradient products of the Transformer blocks' Linears, one launch for MANY layers:
+//     dW_p[n_out][n_in] += dY_p[tokens][n_out]^T . X_p[tokens][n_in]        db_p[n_out] += column sums of dY_p
+// (autograd of F.linear at fairseq/modules/multihead_attention.py:190-208, fairseq/modules/transformer_layer.py:132-134; the
+// reference runs one GEMM + one reduction per Linear as backward reaches it).
+//
+// Why grouped and deferred.  A single dW has a small output (512 x 512 ... 2048 x 512) and a huge reduction (every token of the
+// batch), so a launch per Linear must split K over the CUs and meet in f32 atomics: at 64 KB per workgroup the atomic pass alone
+// is ~12 us of a ~50 us launch (the chip adds 1.3 TB/s, MI355X_MICROARCH.md "Global float atomics") and the tiles are too small
+// for an LDS-DMA pipeline to pay (round 1: 470 TFLOP/s, the slowest GEMM family and the largest share of the update).  Nothing
+// consumes a weight gradient before the optimizer (or the gradient all-reduce), so the engine queues (dY, X) pairs during backward
+// and hands a few layers' worth to THIS kernel: a work list of 256 x 256 output tiles, each owned by exactly one workgroup for the
+// WHOLE reduction -- no split-K, no atomics, f32 read-modify-write of the gradient arena by plain 16-byte accesses, operands by
+// LDS-DMA through the pipeline of gemm256.hip (two K-tile buffers in half-tile units, two super-phases of 32 MFMAs per K-tile, one
+// counted vmcnt per K-tile, staggered wave groups).  Both operands have the reduction index as their memory ROW, so both are staged
+// as they lie in memory ([64 tokens][128 columns] images, 256-byte rows, XOR-swizzled chunks) and gathered by ds_read_b64_tr_b16.
+// Token counts that are not a multiple of 64 read zeros for the missing rows (a 1 KiB zero page in device memory).
+// The bias gradient rides on the A operand: one extra MFMA per A fragment against a ones operand, spread over the four wave columns.
+#include "common.hpp"
+#include "prof.hpp"
+#include "../../include/s2t_hip.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+typedef short s16x4_w __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int HALF = 16384, BUF = 65536, BK = 64;
+
+struct Prob {
+    const bf16* dY; const bf16* X; float* dW; float* db;
+    int n_out, n_in, tokens, ldy, ldx, ldw, pad0, pad1;
+};
+// one work item = one 256 x 256 output tile over the K-tiles [kt0, kt1) of its problem.  `atomic`: the tile's token range is
+// shared with other items (only the tail round of a launch is cut like that), so the result is ADDED with f32 atomics.
+struct Item { int prob, tm, tn, kt0, kt1, atomic; };
+
+__device__ uint4 g_zero_page[64];                                  // 1 KiB of zeros (device globals are zero-initialised)
+
+__device__ __forceinline__ int trswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ u32x4 tr_frag(const char* img, int col, int s, int r16, int q) {
+    u32x4 f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 32 * s + 8 * q + 4 * h + (r16 >> 2);
+        const int ch = (col >> 3) + ((r16 & 3) >> 1);
+        const char* a = img + row * 256 + ((ch ^ trswz(row)) << 4) + ((r16 & 1) << 3);
+        const s16x4_w v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_w*)a);
+        const u32x2 w = __builtin_bit_cast(u32x2, v);
+        f[2 * h] = w[0]; f[2 * h + 1] = w[1];
+    }
+    return f;
+}
+}  // namespace
+
+// 8 waves = 2 (M) x 4 (N).  Tile rows [128 h, 128 h + 128) form A half-tile h, wave row wr owns rows 64 wr .. 64 wr + 63 of each;
+// tile columns [128 h, 128 h + 128) form B half-tile h, wave column wc owns columns 32 wc .. 32 wc + 31 of each.
+__global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const Prob* __restrict__ probs, const Item* __restrict__ items, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3, r16 = lane & 15, q = lane >> 4;
+    const int grp = wr;
+    const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+    // items are dealt in rounds of gridDim.x (the host sorts them longest first and cuts the tail round into equal pieces);
+    // inside a round an XCD's workgroups (b, b + 8, ...) take a contiguous run: tiles of one dW sharing operand columns meet in one L2
+    for (int it = xcd_remap(blockIdx.x, gridDim.x); it < n_items; it += gridDim.x) {
+        const Item I = items[it];
+        const Prob P = probs[I.prob];
+        const int tm = I.tm, tn = I.tn;
+        const int row0 = tm * 256, col0 = tn * 256;                      // row = n_out index, col = n_in index
+        const int nk = I.kt1 - I.kt0;
+        const char* Ab = reinterpret_cast<const char*>(P.dY) + (size_t)I.kt0 * BK * P.ldy * 2;
+        const char* Bb = reinterpret_cast<const char*>(P.X) + (size_t)I.kt0 * BK * P.ldx * 2;
+        const int tokens_left = P.tokens - I.kt0 * BK;                   // token rows from this item's first K-tile on
+
+        // ---- staging: this wave fills pieces 2 wave and 2 wave + 1 (4 token rows x 256 B each) of every half-tile
+        // [half][piece]: byte offset (operands are below 4 GiB: checked on the host) of this lane's 16 bytes at token row
+        // krow = 4 piece + lane / 16 of K-tile 0
+        uint32_t ga[2][2], gb[2][2];
+        const int krow0 = 8 * wave + (lane >> 4);                       // piece 2 wave; piece 2 wave + 1 is 4 rows further
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kr = krow0 + 4 * i, pos = lane & 15, cp = (pos ^ trswz(kr)) << 3;
+                const int am = min(row0 + 128 * h + cp, ((P.n_out + 7) & ~7) - 8);
+                const int bn = min(col0 + 128 * h + cp, ((P.n_in + 7) & ~7) - 8);
+                ga[h][i] = (uint32_t)(((size_t)kr * P.ldy + am) * 2);
+                gb[h][i] = (uint32_t)(((size_t)kr * P.ldx + bn) * 2);
+            }
+        const uint32_t kstepA = (uint32_t)BK * (uint32_t)P.ldy * 2u, kstepB = (uint32_t)BK * (uint32_t)P.ldx * 2u;
+        auto stage = [&](const char* base, const uint32_t (&g)[2][2], uint32_t kstep, int region, int h, int t) {
+            char* dst = smem + __builtin_amdgcn_readfirstlane((t & 1) * BUF + region * 2 * HALF + h * HALF + wave * 2048);
+            const int tt = min(t, nk - 1);                               // past the last K-tile: re-read it into a free half-tile (constant DMA count)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool in = tt * BK + krow0 + 4 * i < tokens_left;   // token rows past the end read zeros (select, no branch)
+                const char* src = in ? base + (g[h][i] + (uint32_t)tt * kstep) : zero + 16 * lane;
+                glds16(src, dst + 1024 * i);
+            }
+        };
+        auto stageA = [&](int h, int t) { stage(Ab, ga, kstepA, 0, h, t); };
+        auto stageB = [&](int h, int t) { stage(Bb, gb, kstepB, 1, h, t); };
+#define WG_WAIT_TILE() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+#define WG_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WG_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bool do_rs = P.db != nullptr && tn == 0;                   // bias gradient: the first column tile sums its A operand
+        f32x4 rs[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+        u32x4 fa[4][2], fb[2][2][2];
+        auto readAs = [&](const char* buf, int h, int s_) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i][s_] = tr_frag(buf + h * HALF, wr * 64 + 16 * i, s_, r16, q);
+        };
+        auto readBs = [&](const char* buf, int h, int s_) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[h][j][s_] = tr_frag(buf + 2 * HALF + h * HALF, wc * 32 + 16 * j, s_, r16, q);
+        };
+#define WG_QUAD(MI, NI)                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                        \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                    \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+                    acc[4 * (MI) + i][2 * (NI) + j] = mma16<bf16>(fb[NI][j][s], fa[i][s], acc[4 * (MI) + i][2 * (NI) + j]);
+        // row sums of the A operand: wave column wc takes row tile i == wc of the current A half (both k-halves)
+#define WG_RS(MI)                                                                                            \
+        if (do_rs) {                                                                                         \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                  \
+                const u32x4 f = wc == 0 ? fa[0][s] : wc == 1 ? fa[1][s] : wc == 2 ? fa[2][s] : fa[3][s];     \
+                rs[MI] = mma16<bf16>(ones, f, rs[MI]);                                                       \
+            }                                                                                                \
+        }
+#define WG_MMA2(MI, NA, NB)                                                                                  \
+    do {                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        WG_QUAD(MI, NA) WG_QUAD(MI, NB) WG_RS(MI)                                                            \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    } while (0)
+
+        // ---- prologue: K-tile 0 and what SPb of "K-tile -1" would have staged (A-h0, B-h0 of K-tile 1)
+        stageA(0, 0); stageB(0, 0); stageB(1, 0); stageA(1, 0);
+        stageA(0, 1); stageB(0, 1);
+        WG_WAIT_TILE();
+        WG_BAR();
+        if (grp == 1) WG_BAR();                                          // group 1 runs one barrier behind from here on
+        for (int t = 0; t < nk; ++t) {
+            const char* buf = smem + (t & 1) * BUF;
+            // SPa: (A-h0 x B-h0), (A-h0 x B-h1); re-stage A-h1 and B-h1 of the other buffer with K-tile t+1
+            readBs(buf, 0, 0); readAs(buf, 0, 0); readBs(buf, 0, 1); readAs(buf, 0, 1); readBs(buf, 1, 0); readBs(buf, 1, 1);
+            stageA(1, t + 1); stageB(1, t + 1);
+            WG_READS_DONE();
+            WG_BAR();
+            WG_MMA2(0, 0, 1);
+            WG_BAR();
+            // SPb: (A-h1 x B-h1), (A-h1 x B-h0); re-stage A-h0 and B-h0 of this buffer with K-tile t+2
+            readAs(buf, 1, 0); readAs(buf, 1, 1);
+            stageA(0, t + 2); stageB(0, t + 2);
+            WG_READS_DONE();
+            WG_WAIT_TILE();
+            WG_BAR();
+            WG_MMA2(1, 1, 0);
+            WG_BAR();
+        }
+        if (grp == 0) WG_BAR();                                          // group 0 waits for group 1's last cluster
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the tail DMAs must land before the epilogue reuses the LDS
+        WG_BAR();
+#undef WG_MMA2
+#undef WG_RS
+#undef WG_QUAD
+
+        // ---- epilogue: dW tile += acc, four slabs of 64 rows through LDS (f32, row stride 1040 B), 16-byte read-modify-write
+        if (do_rs && q == 0) {
+#pragma unroll
+            for (int hm = 0; hm < 2; ++hm) {
+                const int row = row0 + 128 * hm + wr * 64 + 16 * wc + r16;
+                if (row < P.n_out) {
+                    if (I.atomic) atomicAdd(P.db + row, rs[hm][0]);
+                    else P.db[row] += rs[hm][0];                         // exactly one lane of one workgroup owns this element
+                }
+            }
+        }
+        constexpr int RS = 256 * 4 + 16;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {                                 // slab sl = rows 64 sl .. 64 sl + 63 = A half sl / 2, wave row sl % 2
+            if (wr == (sl & 1)) {
+                const int hm = sl >> 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int lr = 16 * i + r16, lc = (j >> 1) * 128 + wc * 32 + 16 * (j & 1) + 4 * q;
+                        *reinterpret_cast<f32x4*>(smem + lr * RS + lc * 4) = acc[4 * hm + i][j];
+                    }
+            }
+            __syncthreads();
+            if (I.atomic) {                                              // lanes of a wave on 64 consecutive columns: 256 contiguous bytes per wave-instruction
+                for (int idx = threadIdx.x; idx < 64 * 256; idx += 512) {
+                    const int lr = idx >> 8, lc = idx & 255, row = row0 + 64 * sl + lr, col = col0 + lc;
+                    if (row < P.n_out && col < P.n_in) atomicAdd(P.dW + (size_t)row * P.ldw + col, *reinterpret_cast<const float*>(smem + lr * RS + lc * 4));
+                }
+            } else
+            for (int c = threadIdx.x; c < 64 * 64; c += 512) {           // 64 rows x 64 chunks of 4 floats
+                const int lr = c >> 6, cc = c & 63;
+                const int row = row0 + 64 * sl + lr, col = col0 + 4 * cc;
+                if (row >= P.n_out || col >= P.n_in) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * RS + cc * 16);
+                float* dst = P.dW + (size_t)row * P.ldw + col;
+                if (col + 4 <= P.n_in && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                    f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = o + v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (col + e < P.n_in) dst[e] += v[e];
+                }
+            }
+            __syncthreads();
+        }
+#undef WG_BAR
+#undef WG_WAIT_TILE
+#undef WG_READS_DONE
+    }
+}
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+void* g_dev_table = nullptr;
+size_t g_dev_table_bytes = 0;
+}
+
+extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream) {
+    if (n <= 0) return S2T_OK;
+    if (!probs) return S2T_EINVAL;
+    std::vector<Prob> pv(n);
+    std::vector<Item> iv;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const S2TWgradProblem& s = probs[i];
+        if (!s.dY || !s.X || !s.dW || s.n_out <= 0 || s.n_in <= 0 || s.tokens <= 0) return S2T_EINVAL;
+        if ((size_t)s.tokens * s.ldy * 2 >= (1ull << 32) || (size_t)s.tokens * s.ldx * 2 >= (1ull << 32)) return S2T_EINVAL;   // 32-bit byte offsets
+        // 16-byte column chunks of both operands (the last one may cover row padding, never the next row), 4-byte aligned f32 rows
+        if ((s.ldy & 7) || (s.ldx & 7) || ((uintptr_t)s.dY & 15) || ((uintptr_t)s.X & 15)) return S2T_EINVAL;
+        if (((s.n_out + 7) & ~7) > s.ldy || ((s.n_in + 7) & ~7) > s.ldx || s.n_out < 8 || s.n_in < 8) return S2T_EINVAL;
+        Prob& p = pv[i];
+        p.dY = (const bf16*)s.dY; p.X = (const bf16*)s.X; p.dW = s.dW; p.db = s.db;
+        p.n_out = s.n_out; p.n_in = s.n_in; p.tokens = s.tokens; p.ldy = s.ldy; p.ldx = s.ldx; p.ldw = s.ldw; p.pad0 = p.pad1 = 0;
+        const int nk = (s.tokens + BK - 1) / BK, tn = (s.n_in + 255) / 256, tmn = (s.n_out + 255) / 256;
+        for (int a = 0; a < tmn; ++a)
+            for (int b = 0; b < tn; ++b) iv.push_back(Item{i, a, b, 0, nk, 0});
+        flops += 2.0 * s.n_out * (double)s.n_in * s.tokens;
+        bytes += 2.0 * s.tokens * ((double)s.n_out + s.n_in) + 8.0 * s.n_out * (double)s.n_in;
+    }
+    // Work list: longest reductions first (stable: the tiles of one dW stay neighbours), dealt in rounds of one item per CU.  A
+    // partly filled last round would leave CUs idle for a whole tile's time: its tiles are cut along the token range into as many
+    // equal pieces as fill the round (those pieces meet in f32 atomics: at most 256 x 256 KB, once per launch).
+    const int G = 256;
+    std::stable_sort(iv.begin(), iv.end(), [](const Item& x, const Item& y) { return x.kt1 - x.kt0 > y.kt1 - y.kt0; });
+    const int rem = (int)(iv.size() % G);
+    if (rem) {
+        const int f = G / rem;
+        if (f >= 2) {
+            std::vector<Item> tail(iv.end() - rem, iv.end());
+            iv.resize(iv.size() - rem);
+            for (int piece = 0; piece < f; ++piece)
+                for (const Item& t : tail) {
+                    const int nk = t.kt1, per = (nk + f - 1) / f, k0 = piece * per, k1 = std::min(nk, k0 + per);
+                    if (k0 < k1) iv.push_back(Item{t.prob, t.tm, t.tn, k0, k1, 1});
+                }
+        }
+    }
+    const size_t pb = pv.size() * sizeof(Prob), ib = iv.size() * sizeof(Item), need = pb + ib;
+    hipStream_t st = (hipStream_t)stream;
+    if (need > g_dev_table_bytes) {
+        // grows rarely (the first update); a hipFree of the old table waits for the kernels that may still read it
+        if (g_dev_table) (void)hipFree(g_dev_table);
+        g_dev_table_bytes = std::max(need * 2, (size_t)1 << 16);
+        hipError_t e = hipMalloc(&g_dev_table, g_dev_table_bytes);
+        if (e != hipSuccess) { g_dev_table = nullptr; g_dev_table_bytes = 0; return S2T_EHIP(e); }
+    }
+    // stream-ordered uploads from pageable memory (staged by the runtime before the call returns): the previous launch's kernel,
+    // enqueued earlier on this stream, has finished reading the table when these copies execute
+    hipError_t e = hipMemcpyAsync(g_dev_table, pv.data(), pb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync((char*)g_dev_table + pb, iv.data(), ib, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return S2T_EHIP(e);
+    ProfScope prof("wgrad_group", st, flops, bytes);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr = true; }
+    const int n_items = (int)iv.size();
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3(n_items < G ? n_items : G), dim3(512), 2 * BUF, st,
+                       (const Prob*)g_dev_table, (const Item*)((char*)g_dev_table + pb), n_items);
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

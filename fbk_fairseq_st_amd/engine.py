@@ -181,7 +181,12 @@ class S2TEngine:
         self._maps = {}
         self.bn_buffers = None          # set by the model: dict name -> tensor (running_mean/var, num_batches)
         self.on_grads_ready = None      # callback(prefix): every gradient of parameters named prefix* is final
-        self._wg_side, self._wg_on, self._wg_pending = None, False, False
+        # Weight gradients of the Linears are not needed before the optimizer: in bf16 mode linear_bwd QUEUES (dY, X, dW, db) and the
+        # queue goes out as ONE grouped launch per decoder / encoder backward (K.wgrad_group: every 256 x 256 tile of every dW owned by
+        # one workgroup over all tokens, no split-K atomics; csrc/wgrad_group.hip).  Parameter groups are reported final only after
+        # the launch that holds their products (flush_wgrad).
+        self.defer_wgrad = arena.compute_dtype == torch.bfloat16
+        self._wq, self._wq_ready = [], []
         self._a2d_prescale = None
         self.a2d_time_mfma = os.environ.get("S2T_A2D_TIME_VALU", "0") != "1"     # time attention of ConvAttention2D on the MFMA attention kernels
         # LayerNorm backward also writes dropout(dx) for the block that consumes dx (one pass instead of two; identical bits)
@@ -217,27 +222,21 @@ class S2TEngine:
         return m
 
     def _ready(self, prefix):
-        self.join_wgrad()                                # the weight gradients of this group run on the side stream
-        if self.on_grads_ready is not None:
+        """every gradient of parameters named prefix* has been computed -- or queued: then the report waits for the flush"""
+        if self._wq or self._wq_ready:
+            self._wq_ready.append(prefix)
+        elif self.on_grads_ready is not None:
             self.on_grads_ready(prefix)
 
-    # Weight-gradient products are off the critical path of backward (nothing consumes them before the optimizer / the gradient
-    # all-reduce), so they CAN run on a second stream next to the dX / attention kernels of the same layer.  Measured on the bench
-    # (MI355X, 20 updates): 21.6 / 20.6 ms per update with the side stream against 18.5 / 18.7 ms without -- every big kernel here
-    # already fills the machine and is laid out for XCD-local L2 reuse, two of them at once only thrash it.  Opt-in
-    # (S2T_WGRAD_STREAM=1) for shapes whose kernels leave the GPU mostly empty.
-    def _wgrad_stream(self, tokens=0):
-        if self._wg_side is None:
-            self._wg_all = os.environ.get("S2T_WGRAD_STREAM", "0") == "1"
-            self._wg_maxtok = int(os.environ.get("S2T_WGRAD_STREAM_MAXTOK", "0"))     # side stream only for products over <= this many rows
-            self._wg_on = (self._wg_all or self._wg_maxtok > 0) and torch.device(self.dev).type == "cuda"
-            self._wg_side = torch.cuda.Stream(device=self.dev) if self._wg_on else False
-        return self._wg_side if self._wg_on and (self._wg_all or tokens <= self._wg_maxtok) else None
-
-    def join_wgrad(self):
-        if self._wg_pending:
-            torch.cuda.current_stream(self.dev).wait_stream(self._wg_side)
-            self._wg_pending = False
+    def flush_wgrad(self):
+        """launch the queued weight-gradient products (one grouped kernel) and report the parameter groups that waited for them"""
+        if self._wq:
+            K.wgrad_group(self._wq)
+            self._wq = []
+        ready, self._wq_ready = self._wq_ready, []
+        if self.on_grads_ready is not None:
+            for prefix in ready:
+                self.on_grads_ready(prefix)
 
     def W(self, n):
         return self.A.w(n)
@@ -259,18 +258,11 @@ class S2TEngine:
         """dW += dy^T x ; db += colsum(dy) ; returns dx = epi(dy @ W)."""
         w = self.W(name + ".weight")
         gw = self.G(name + ".weight")
-        side = self._wgrad_stream(dy2d.shape[0])
-        if side is None:
-            K.linear_wgrad(dy2d, x2d, gw, self.G(name + ".bias") if bias else None,
-                           splitk=_splitk(gw.shape[0], gw.shape[1], dy2d.shape[0]))
+        gb = self.G(name + ".bias") if bias else None
+        if self.defer_wgrad and K.wgrad_group_ok(dy2d, x2d):
+            self._wq.append((dy2d, x2d, gw, gb))         # the queue keeps dY and X alive until the grouped launch
         else:
-            main = torch.cuda.current_stream(self.dev)
-            side.wait_stream(main)                       # dy (and x) are ready on the main stream
-            with torch.cuda.stream(side):
-                K.linear_wgrad(dy2d, x2d, gw, self.G(name + ".bias") if bias else None,
-                               splitk=_splitk(gw.shape[0], gw.shape[1], dy2d.shape[0]))
-            dy2d.record_stream(side); x2d.record_stream(side)          # the allocator must not recycle them under the side stream
-            self._wg_pending = True
+            K.linear_wgrad(dy2d, x2d, gw, gb, splitk=_splitk(gw.shape[0], gw.shape[1], dy2d.shape[0]))
         if not need_dx:
             return None
         return K.gemm(dy2d, w, trans_b=True, act=act, aux=aux, alpha=alpha, out=dx_out, accumulate=dx_accumulate)
@@ -679,6 +671,7 @@ class S2TEngine:
         self.subsample_bwd(ctx["sub"], dx)
         for n in ("encoder.fc3.", "encoder.attn_2d.", "encoder.bn.1.", "encoder.convolutions.1.", "encoder.bn.0.", "encoder.convolutions.0."):
             self._ready(n)
+        self.flush_wgrad()
 
     # ------------------------------------------------------------------ decoder
     def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder."):
@@ -798,4 +791,5 @@ class S2TEngine:
             K.dropout(dx, ctx["p"], ctx["seed"] * 1000 + 501, out=dx)
         K.embed_bwd(ctx["tok"], dx.view(L, B, D), self.G(pfx + "embed_tokens.weight"), ctx["scale"], hp.pad)
         self._ready(pfx + "embed_tokens.")
+        self.flush_wgrad()
         return denc

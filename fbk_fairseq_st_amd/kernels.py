@@ -55,6 +55,35 @@ def linear_wgrad(dy, x, dw, db=None, splitk=1):
     return dw
 
 
+WGRAD_GROUP_MAX = 4096
+
+
+def wgrad_group(items):
+    """items: list of (dy [tokens, n_out], x [tokens, n_in], dw [n_out, n_in] f32, db [n_out] f32 or None), bf16 operands:
+    dw += dy^T x and db += column sums of dy for all of them in one launch (s2t_wgrad_group)."""
+    if not items:
+        return
+    for i in range(0, len(items), WGRAD_GROUP_MAX):
+        chunk = items[i:i + WGRAD_GROUP_MAX]
+        arr = (L.WgradProblem * len(chunk))()
+        for k, (dy, x, dw, db) in enumerate(chunk):
+            L.require_cuda(dy, x, dw)
+            assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
+            assert dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0]
+            assert dw.stride(1) == 1 and tuple(dw.shape) == (dy.shape[1], x.shape[1]) and (db is None or db.dtype == torch.float32)
+            arr[k] = L.WgradProblem(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), dy.shape[1], x.shape[1], dy.shape[0],
+                                    dy.stride(0), x.stride(0), dw.stride(0))
+        L.check(_lib().s2t_wgrad_group(len(chunk), ctypes.addressof(arr), L.stream()), "s2t_wgrad_group")
+
+
+def wgrad_group_ok(dy, x):
+    """shapes the grouped kernel takes (otherwise: linear_wgrad)"""
+    return (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
+            and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+            and dy.shape[1] >= 8 and x.shape[1] >= 8
+            and (dy.shape[1] + 7) // 8 * 8 <= dy.stride(0) and (x.shape[1] + 7) // 8 * 8 <= x.stride(0))
+
+
 def colsum(x, out):
     """out[n] += sum_m x[m, n] (f32)."""
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32

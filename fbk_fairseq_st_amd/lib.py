@@ -30,6 +30,7 @@ SIGNATURES = {
     "s2t_gemm_gather": [c_int] * 7 + [P, c_int, P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int,
                                        c_float, P, c_int, P, P, c_float, c_ull, P],
     "s2t_linear_wgrad": [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P],
+    "s2t_wgrad_group": [c_int, P, P],
     "s2t_colsum": [c_int, P, c_int, c_int, c_int, P, P],
     "s2t_attn_fwd": [c_int] * 6 + [P, c_long, c_long] * 4 + [P, P, c_int, c_int, c_float, c_float, c_ull, P],
     "s2t_attn_bwd": [c_int] * 6 + [P, c_long, c_long] * 5 + [P, P] + [P, c_long, c_long] * 3 +
@@ -83,6 +84,12 @@ SIGNATURES = {
     "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],
     "s2t_host_ctc_uer": [P, P, c_int, c_int, P, P, c_int, c_int, P, P],
 }
+
+class WgradProblem(ctypes.Structure):
+    """S2TWgradProblem of include/s2t_hip.h"""
+    _fields_ = [("dY", c_void_p), ("X", c_void_p), ("dW", c_void_p), ("db", c_void_p),
+                ("n_out", c_int), ("n_in", c_int), ("tokens", c_int), ("ldy", c_int), ("ldx", c_int), ("ldw", c_int)]
+
 
 _lib = None
 

@@ -134,6 +134,9 @@ class Trainer:
             self._log_keys = sorted(log)
         if is_dummy:                                                                # trainer.py:412-418
             sample_size, logs = 0, []
+        flush = getattr(self.model.engine, "flush_wgrad", None)
+        if flush is not None:
+            flush()                                                                 # no queued weight gradient may outlive the backward passes
         self.reducer.finish()                                                       # R2
         stats = {"sample_size": float(sample_size)}
         if self.world > 1:

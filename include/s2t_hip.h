@@ -85,6 +85,21 @@ int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
                     const int* mapA, int periodA, const int* mapB, const int* mapC,
                     float p_drop, unsigned long long seed, void* stream);
 
+/* Weight (and bias) gradients of MANY Linears in one launch (bf16 operands, f32 gradients; csrc/wgrad_group.hip):
+ *     dW_p[n_out][n_in] += dY_p[tokens][n_out]^T X_p[tokens][n_in]      db_p[n_out] += column sums of dY_p   (db may be NULL)
+ * Replaces, for the Transformer blocks, the per-Linear autograd products of F.linear (fairseq/modules/multihead_attention.py:190-208,
+ * fairseq/modules/transformer_layer.py:132-134): nothing reads a weight gradient before the optimizer / the gradient all-reduce, so
+ * the caller may queue the (dY, X) pairs of several layers during backward and submit them together.  Every 256 x 256 tile of every
+ * dW is owned by one workgroup for the whole token range: no split-K, no atomics
+ * (when the tile count does not fill the last round of one tile per CU, the tiles of that round are cut along the token range and
+ * meet in f32 atomics).  Requirements: ldy, ldx multiples of 8 elements and >= the column count rounded up to 8, 16-byte aligned
+ * operand bases; a dW must not appear twice in one call.  `probs` is a HOST array (uploaded stream-ordered with the work list). */
+typedef struct S2TWgradProblem {
+    const void* dY; const void* X; float* dW; float* db;
+    int n_out, n_in, tokens, ldy, ldx, ldw;
+} S2TWgradProblem;
+int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream);
+
 /* out[n] += sum_m X[m][n]  (bias gradients of every nn.Linear above; f32 atomics) */
 /* Parameter gradients of a Linear in one pass over dY (autograd of F.linear: fairseq/modules/multihead_attention.py:190-208,
  * fairseq/modules/transformer_layer.py:132-134): dW[n_out][n_in] += dY[tokens][n_out]^T X[tokens][n_in] (f32) and, if db is not

@@ -512,6 +512,41 @@ def test_gemm_big_products_both_routes(M, N, K_, route):
         K.set_option("gemm256", old)
 
 
+@pytest.mark.parametrize("tokens", [24000, 3000, 2560, 777])
+def test_wgrad_group_matches_per_linear_gradients(tokens):
+    """one grouped launch for the parameter gradients of several Linears (csrc/wgrad_group.hip): dW += dY^T X, db += colsum(dY),
+    vs plain f32 math on the same bf16 operands; token counts that are not a multiple of the 64-deep K-tile, output shapes that are
+    not multiples of the 256 x 256 tile, row-padded dY (logit rows), accumulation into existing gradients; the tail round of a
+    launch is cut along the token range and meets in f32 atomics, so reruns agree to f32 rounding, not bit for bit"""
+    shapes = [(512, 512, True), (1536, 512, True), (2048, 512, True), (512, 2048, True), (1001, 512, False), (264, 1280, True)]
+    items, refs = [], []
+    for k, (n_out, n_in, has_b) in enumerate(shapes):
+        dy = rnd(tokens, n_out, dtype=torch.bfloat16, seed=10 + k)
+        x = rnd(tokens, n_in, dtype=torch.bfloat16, seed=20 + k, scale=0.5)
+        dyd = K.alloc_rows((tokens,), n_out, torch.bfloat16, DEV); dyd.copy_(dy)            # row stride padded to 16 bytes
+        dw0 = rnd(n_out, n_in, seed=30 + k); db0 = rnd(n_out, seed=40 + k)
+        items.append((dyd, x.to(DEV), dw0.to(DEV).clone(), db0.to(DEV).clone() if has_b else None))
+        refs.append((dw0.double() + dy.double().t() @ x.double(), db0.double() + dy.double().sum(0)))
+    K.wgrad_group(items)
+    for (dy, x, dw, db), (rw, rb) in zip(items, refs):
+        assert rel_err(dw, rw) < 2e-5 * max(1.0, tokens ** 0.5 / 8), (tuple(dw.shape), rel_err(dw, rw))
+        if db is not None:
+            assert rel_err(db, rb) < 1e-4
+    again = [(dy, x, torch.zeros_like(dw), None) for (dy, x, dw, db) in items]
+    K.wgrad_group(again); first = [a[2].clone() for a in again]
+    for a in again:
+        a[2].zero_()
+    K.wgrad_group(again)
+    assert all(rel_err(a[2], f) < 1e-6 for a, f in zip(again, first))
+    # a list that fills whole rounds of 256 tiles takes no atomics at all: bit-identical reruns
+    big = [(items[2][0], items[2][1], torch.zeros(2048, 512, device=DEV), None) for _ in range(16)]     # 16 x 16 tiles
+    K.wgrad_group(big); ref0 = big[0][2].clone()
+    for b in big:
+        b[2].zero_()
+    K.wgrad_group(big)
+    assert all(torch.equal(b[2], ref0) for b in big)
+
+
 def test_gemm256_is_deterministic_under_load():
     """the LDS-DMA pipeline orders its reads by counted waits and barriers only: 40 back-to-back launches on fresh random data
     must reproduce the first result bit for bit (a read that overtakes its DMA shows up as rare wrong tiles)"""
