@@ -9,7 +9,7 @@ the wall time of full updates (forward + CTC/label-smoothed losses + backward + 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Workload (configs[2] of BASELINE.json): s2t_transformer_m (conv_transformer structure,
+Headline workload (configs[2] of BASELINE.json): s2t_transformer_m (conv_transformer structure,
 D=512, FFN=2048, 8 heads, 12+6 layers) + ctc_multi_loss with --ctc-compress-out after encoder layer 8,
 T=1500 frames x 80 mel, per-GPU batch 64 utterances (96,000 frames: the effective per-GPU batch of the
 reference's paper script, --max-tokens 12000 x --update-freq 8, README.md:144,152, taken in one pass because
@@ -19,13 +19,22 @@ The timed updates run on the random-init model (--lr 1e-9: the optimizer step is
 CTC compression keeps ~98 % of the frames: a model that learns on N(0,1) inputs predicts blank everywhere after ~5 updates and
 encoder layers 9-12 then process ONE frame (--lr 5e-3 shows that state); `config.frames_after_ctc_compression` reports the length.
 
-Rank 0 prints ONE JSON line.  `roofline` times the dominant kernel family (the MFMA GEMMs) with HIP events
-inside the library (s2t_prof_*, on the launch stream) during instrumented steps that directly follow the timed region
-(inside it the events themselves cost 12 % of the step; --no-roofline skips them); `cpu_baseline` times the
-CPU oracle (port of the reference path, verified against it) on the host cores on a bounded sample.
+Secondary entries of the same JSON line (`extra_configs`, single GPU only, fewer timed updates; --no-extra skips them):
+  cfg3_batch8   the per-GPU batch SURVEY.md 8-d writes for Cfg3 (8 x 1500 frames)
+  cfg2_s_fp32   s2t_transformer_s, 32 x 1000 frames, fp32 (configs[1])
+  cfg4_l_bucketed  s2t_transformer_l on MuST-C-shaped lengths (lognormal, clipped to [50, 2000]) fed by the real batch iterator
+                (length-bucketed frame-budget batches, pinned prefetch thread, H2D inside the timed loop)
+--loader runs the HEADLINE workload from that iterator too (collate + pinning + H2D inside the timed loop).
+
+Rank 0 prints ONE JSON line and exits non-zero if the loss or the gradient norm of the timed updates is not finite.
+`roofline` times the dominant kernel family with HIP events inside the library (s2t_prof_*, on the launch stream) during
+instrumented updates that directly follow the timed region (inside it the events themselves cost 12 % of the update;
+--no-roofline skips them); `cpu_baseline` times the CPU oracle (port of the reference path, verified against it) on the
+host cores for full updates (forward, losses, backward, clip, Adam) on a bounded sample of the workload.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -35,54 +44,102 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-# kernel template behind each profiled family (names as they appear in the rocprofv3 kernel trace, profiles/)
-KERNEL_OF = {"gemm_tn": "gemm_tn2_kernel (dW = dY^T X: bf16 -> f32, 128x128 tile, two k-slices per workgroup, split-K atomics)",
-             "gemm_nt": "gemm_fast_kernel<bf16, bf16, false, false, 128, 128, 8 waves> (Y = X W^T)",
-             "gemm_nn": "gemm_fast_kernel<bf16, bf16, false, TB=true, 128, 128, 8 waves> (dX = dY W)",
+# kernel behind each profiled family (names as they appear in the rocprofv3 kernel trace, profiles/)
+KERNEL_OF = {"wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward pass in one launch: 256x256 tiles owned over all tokens, LDS-DMA, no split-K)",
+             "gemm_nt": "gemm256_kernel<bf16, TB=false> (Y = X W^T: 256/192 x 256 x 64, LDS-DMA, persistent) + gemm_fast_kernel 128x128 for the small products",
+             "gemm_nn": "gemm256_kernel<bf16, TB=true> (dX = dY W) + gemm_fast_kernel 128x128 for the small products",
+             "gemm_tn": "gemm_tn2_kernel (dW of the fc3 projection: 128x128 tile, split-K atomics)",
              "gemm_tn_small": "gemm_fast_kernel<.., 64, 64, 4 waves> (small dW)", "gemm_nt_small": "gemm_fast_kernel<.., 64, 64, 4 waves>",
              "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (conv2 as implicit GEMM)"}
+TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
+PEAK_F32_TFLOPS = 157.3
 
 
 def hbm_traffic(family):
-    """HBM bytes per launch of the family's kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_hbm_traffic.json, made by tools/hbm_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes,
-    MI355X_MICROARCH.md section HBM); None when the file is absent."""
+    """HBM bytes per launch of the family's kernels from the committed rocprofv3 PMC passes of this same command
+    (made by tools/hbm_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md section HBM);
+    None when the file is absent.  NOT measured by this run: `traffic_source` in the JSON says so."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_hbm_traffic.json")) as f:
+        with open(os.path.join(REPO, TRAFFIC_FILE)) as f:
             t = json.load(f)
         return t["families"][family]["bytes_per_launch"]
     except Exception:
         return None
 
 
-PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
-PEAK_F32_TFLOPS = 157.3
-
-
-def build_all(args, device, dtype):
+def build_all(arch, batch, frames, tgt_len, ctc_layer, lr, dtype, device, attn_2d=False, want_sd=False):
     from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
     from fbk_fairseq_st_amd.registry import apply_arch, namespace, setup_task
     from fbk_fairseq_st_amd.trainer import Trainer
-    a = namespace(arch=args.arch, task="dummy_s2t", criterion="ctc_multi_loss",
+    a = namespace(arch=arch, task="dummy_s2t", criterion="ctc_multi_loss",
                   underlying_criterion="label_smoothed_cross_entropy", label_smoothing=0.1, sentence_avg=True,
-                  ctc_compress_out=True, ctc_encoder_layer=args.ctc_layer, ctc_weight=1.0, ctc_compress_strategy="avg",
-                  input_feat_per_channel=80, no_attn_2d=not args.attn_2d, dict_size=8000 - 4, src_dict_size=5000 - 4,
-                  batch_size=args.batch, frames=args.frames, tgt_len=args.tgt_len, transcript_len=args.tgt_len,
-                  lr=[args.lr], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=20.0,
-                  warmup_updates=4000, warmup_init_lr=min(args.lr, 3e-4), seed=1, bf16=(dtype == torch.bfloat16), bucket_cap_mb=64)
+                  ctc_compress_out=True, ctc_encoder_layer=ctc_layer, ctc_weight=1.0, ctc_compress_strategy="avg",
+                  input_feat_per_channel=80, no_attn_2d=not attn_2d, dict_size=8000 - 4, src_dict_size=5000 - 4,
+                  batch_size=batch, frames=frames, tgt_len=tgt_len, transcript_len=max(tgt_len, 40),
+                  lr=[lr], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=20.0,
+                  warmup_updates=4000, warmup_init_lr=min(lr, 3e-4), seed=1, bf16=(dtype == torch.bfloat16), bucket_cap_mb=64,
+                  bucket_by_length=True)
     apply_arch(a)
     task = setup_task(a)
     torch.manual_seed(1)
     model = task.build_model(a)
     crit = task.build_criterion(a)
-    ref_sd = model.state_dict() if args.cpu_baseline else None
+    ref_sd = model.state_dict() if want_sd else None
     trainer = Trainer(a, task, model, crit, device=device, compute_dtype=dtype)
     return a, task, model, crit, trainer, ref_sd
 
 
+def timed_updates(trainer, next_batch, steps, warmup, world, device):
+    """W untimed + exactly K timed updates between barrier + synchronize; returns (seconds, frames, mean frames after compression, stats)"""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        trainer.train_step([next_batch()])
+    trainer.reduce_stats()
+    barrier()
+    t0 = time.perf_counter()
+    frames, enc_len = 0, []
+    for _ in range(steps):
+        b = next_batch()
+        frames += int(b["nframes"])
+        trainer.train_step([b])
+        enc_len.append(trainer.model.encoder._last["lengths_host"])       # host list of this update (no extra sync)
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = trainer.reduce_stats()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    enc_mean = sum(sum(l) / len(l) for l in enc_len) / max(len(enc_len), 1)
+    return dt, frames, enc_mean, stats
+
+
+def loader_batches(task, trainer, lengths, max_tokens, max_sentences, seed=1):
+    """endless stream of batches from the product iterator (frame-budget batcher, per-epoch shuffle, pinned prefetch thread)"""
+    task.load_dataset("train", lengths=lengths, seed=seed)
+    itr = task.get_batch_iterator(task.dataset("train"), max_tokens=max_tokens, max_sentences=max_sentences, seed=seed)
+
+    def gen():
+        while True:
+            for b in itr.next_epoch_itr(shuffle=True):
+                if len(b):
+                    yield b
+    g = gen()
+    return lambda: next(g)
+
+
+def finite(stats):
+    return all(math.isfinite(float(stats.get(k, float("nan")))) for k in ("loss", "gnorm"))
+
+
 def cpu_baseline(args, a, ref_sd, task):
-    """The CPU oracle (oracle/s2t_ref.py, a verified port of the reference path) on the host cores: forward +
-    losses + backward of the same model on a bounded sample of the same workload (B_cpu utterances x T frames)."""
+    """The CPU oracle (oracle/s2t_ref.py, a verified port of the reference path) on the host cores: FULL updates (forward +
+    losses + backward + gradient clipping + Adam, fairseq/trainer.py:334-495) of the same model on a bounded sample of the
+    workload (B_cpu utterances x T frames), >= 3 timed updates after one warm-up."""
     from oracle import s2t_ref
     import torch.nn.functional as F
     # torch's intra-op pool does not scale past a few dozen threads on these small GEMMs (256 threads measured
@@ -94,6 +151,9 @@ def cpu_baseline(args, a, ref_sd, task):
     W = {k: v.clone().requires_grad_(v.dtype.is_floating_point and v.dim() > 0 and "running" not in k and "_float_tensor" not in k
                                      and "version" not in k)
          for k, v in ref_sd.items()}
+    train = [k for k, v in W.items() if v.requires_grad]
+    m = {k: torch.zeros_like(W[k]) for k in train}
+    v2 = {k: torch.zeros_like(W[k]) for k in train}
     Bc = args.cpu_batch
     from fbk_fairseq_st_amd.data import synthetic_batch
     s = synthetic_batch(Bc, args.frames, args.tgt_len, args.tgt_len, len(task.tgt_dict), task.src_dict.index("<ctc_blank>"), seed=7)
@@ -103,33 +163,64 @@ def cpu_baseline(args, a, ref_sd, task):
         F.log_softmax(logits.float(), -1), torch.cat([t[i, : tl[i]] for i in range(t.shape[0])]), il, tl,
         blank=b, reduction="sum", zero_infinity=True)
     times = []
-    for it in range(args.cpu_iters + 1):
-        for v in W.values():
-            v.grad = None
+    for it in range(args.cpu_updates + 1):
         t0 = time.perf_counter()
+        for k in train:
+            W[k].grad = None
         loss, ss, log, enc, logits, _ = s2t_ref.ctc_multi_loss(W, cfg, s, 0.1, 1.0, blank, training=True)
         loss.backward()
+        with torch.no_grad():
+            grads = [W[k].grad / float(ss) if W[k].grad is not None else torch.zeros_like(W[k]) for k in train]
+            _, grads = s2t_ref.clip_grad_norm(grads, 20.0)
+            for k, g in zip(train, grads):
+                p, m[k], v2[k] = s2t_ref.adam_step(W[k].data, g, m[k], v2[k], it + 1, 1e-9)
+                W[k].data.copy_(p)
         times.append(time.perf_counter() - t0)
-    t = min(times[1:]) if len(times) > 1 else times[0]
+    t = sum(times[1:]) / len(times[1:])
     return {"value": Bc * args.frames / t, "unit": "audio-frames/s", "cores": ncores, "kind": "port",
-            "sample": "oracle/s2t_ref.py ctc_multi_loss fwd+bwd, fp32, %d x %d frames, best of %d after 1 warm-up" % (Bc, args.frames, args.cpu_iters)}
+            "sample": "oracle/s2t_ref.py full update (ctc_multi_loss fwd+bwd, clip, Adam), fp32, %d x %d frames, mean of %d updates after 1 warm-up"
+                      % (Bc, args.frames, args.cpu_updates)}
+
+
+def extra_config(name, arch, dtype, device, steps, warmup, batch=None, frames=1500, tgt_len=40, ctc_layer=8, lengths=None, max_tokens=None):
+    """one secondary workload; its model is freed before the next one is built"""
+    a, task, model, crit, trainer, _ = build_all(arch, batch or 8, frames, tgt_len, ctc_layer, 1e-9, dtype, device)
+    if lengths is None:
+        sample = trainer.prepare(task.dummy_batch(seed=100))
+        nxt = lambda: sample
+        what = "%d x %d x 80 fbank per update, same batch resident in HBM" % (batch, frames)
+    else:
+        nxt = loader_batches(task, trainer, lengths, max_tokens, None)
+        what = ("%d utterances, T ~ lognormal(ln 600, 0.7) in [50, 2000], length-bucketed batches of <= %d frames from the batch iterator "
+                "(collate + pinned prefetch + H2D inside the timed loop)" % (len(lengths), max_tokens))
+    dt, frames_done, enc_mean, stats = timed_updates(trainer, nxt, steps, warmup, 1, device)
+    out = {"name": name, "value": round(frames_done / dt, 1), "unit": "audio-frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "dtype": "bf16" if dtype == torch.bfloat16 else "fp32",
+           "config": {"workload": "%s + ctc_multi_loss(ctc-compress-out @ layer %d) full update, %s" % (arch, ctc_layer, what),
+                      "frames_per_step": round(frames_done / steps, 1), "frames_after_ctc_compression": round(enc_mean, 1)},
+           "loss_finite": finite(stats)}
+    del trainer, model, crit, task
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arch", default="s2t_transformer_m")
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per update")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per update (SURVEY.md 8-d writes 8 for Cfg3: see extra_configs.cfg3_batch8)")
     ap.add_argument("--frames", type=int, default=1500)
     ap.add_argument("--tgt-len", type=int, default=40)
     ap.add_argument("--ctc-layer", type=int, default=8)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--no-roofline", dest="roofline", action="store_false")
+    ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip the secondary workloads (extra_configs)")
+    ap.add_argument("--loader", action="store_true", help="feed the headline workload from the batch iterator (collate, pinned prefetch, H2D in the timed loop)")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-updates", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--prof-steps", type=int, default=4)
     ap.add_argument("--lr", type=float, default=1e-9,
@@ -156,50 +247,32 @@ def main():
     D.distributed_init("nccl", device)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     args.cpu_baseline = args.cpu_baseline and rank == 0 and world == 1
-    a, task, model, crit, trainer, ref_sd = build_all(args, device, dtype)
-    sample = task.dummy_batch(seed=100 + rank)                       # per-rank data (weak scaling)
-    frames_per_step = int(sample["nframes"])
-    sample = trainer.prepare(sample)                                 # inputs resident in HBM before the timed region
+    args.extra = args.extra and rank == 0 and world == 1
+    a, task, model, crit, trainer, ref_sd = build_all(args.arch, args.batch, args.frames, args.tgt_len, args.ctc_layer, args.lr, dtype,
+                                                      device, attn_2d=args.attn_2d, want_sd=args.cpu_baseline)
+    if args.loader:
+        next_batch = loader_batches(task, trainer, [args.frames] * (4 * args.batch), None, args.batch, seed=100 + rank)
+    else:
+        sample = trainer.prepare(task.dummy_batch(seed=100 + rank))  # per-rank data (weak scaling), resident in HBM before the timed region
+        next_batch = lambda: sample
     torch.cuda.synchronize()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        trainer.train_step([sample])
-    trainer.reduce_stats()
-    barrier()
-    t0 = time.perf_counter()
-    enc_len = []
-    for _ in range(args.steps):
-        trainer.train_step([sample])
-        enc_len.append(model.encoder._last["lengths_host"])           # host list of this update (no extra sync)
-    barrier()
-    dt = time.perf_counter() - t0
-    enc_mean = sum(sum(l) / len(l) for l in enc_len) / max(len(enc_len), 1)
-    stats = trainer.reduce_stats()
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, frames_done, enc_mean, stats = timed_updates(trainer, next_batch, args.steps, args.warmup, world, device)
+    frames_per_step = frames_done // args.steps
 
     roof = None
     if args.roofline and rank == 0:
-        # Instrumented steps run right AFTER the timed region, on the same batch and training state: bracketing every GEMM and
-        # attention launch with two HIP events costs 2.2-2.5 ms per update (measured: 20.2-21.1 vs 18.0-18.6 ms), which would
-        # distort `value` by 12 % if they sat inside the timed region.
+        # Instrumented updates run right AFTER the timed region, on the same batch and training state: bracketing every GEMM and
+        # attention launch with two HIP events costs 2.2-2.5 ms per update, which would distort `value` by 12 % inside the timed region.
         K.prof_reset(); K.prof_enable(True)
         for _ in range(args.prof_steps):
-            trainer.train_step([sample])
+            trainer.train_step([next_batch()])
         torch.cuda.synchronize()
         K.prof_enable(False)
-        names = ("gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small", "gemm_gather", "attn_fwd", "attn_bwd")
+        names = ("wgrad_group", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small", "gemm_gather", "attn_fwd", "attn_bwd")
         fam = {f: K.prof_read(f) for f in names}
-        gemms = {f: v for f, v in fam.items() if f.startswith("gemm") and v["launches"] > 0 and v["ms"] > 0}
+        gemms = {f: v for f, v in fam.items() if (f.startswith("gemm") or f == "wgrad_group") and v["launches"] > 0 and v["ms"] > 0}
         if gemms:
-            # dominant kernel = the GEMM family with the most time per step (one kernel template per family, see KERNEL_OF)
+            # dominant kernel = the MFMA GEMM family with the most time per update (KERNEL_OF names its kernels)
             dom = max(gemms, key=lambda f: gemms[f]["ms"])
             gm = gemms[dom]
             ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
@@ -207,23 +280,28 @@ def main():
             tot_fl = sum(v["flops"] for v in gemms.values()); tot_ms = sum(v["ms"] for v in gemms.values())
             roof = {"bound": "mfma", "kernel": KERNEL_OF[dom], "family": dom,
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": hbm_traffic(dom), "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 2),
+                    "traffic": hbm_traffic(dom), "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured by this run)",
+                    "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 2),
                     "launches_per_step": gm["launches"] // args.prof_steps,
                     "flop_per_launch": round(gm["flops"] / gm["launches"] / 1e9, 3), "flop_unit": "GFLOP",
-                    "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                    "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
+                    "tflops_by_family": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in gemms.items()},
                     "ms_per_step": {k: round(v["ms"] / args.prof_steps, 3) for k, v in fam.items()}}
     if world > 1:
         torch.distributed.barrier()
 
+    ok = finite(stats)
     if rank == 0:
         out = {"metric": "audio-frames/sec (train fwd+bwd) s2t_transformer_m, 80-mel",
-               "value": round(world * frames_per_step * args.steps / dt, 1), "unit": "audio-frames/s",
+               "value": round(world * frames_done / dt, 1), "unit": "audio-frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "%s + ctc_multi_loss(ctc-compress-out @ layer %d) full update, %d x %d x 80 fbank per GPU, "
-                                      "tgt/transcript len %d, V_tgt 8000, V_src 5001, dropout on%s" %
+                                      "tgt/transcript len %d, V_tgt 8000, V_src 5001, dropout on%s%s" %
                                       (args.arch, args.ctc_layer, args.batch, args.frames, args.tgt_len,
-                                       ", WITH ConvAttention2D (diagnostic)" if args.attn_2d else ""),
+                                       ", WITH ConvAttention2D (diagnostic)" if args.attn_2d else "",
+                                       ", fed by the batch iterator (collate + pinned prefetch + H2D in the timed loop)" if args.loader else
+                                       ", batch resident in HBM"),
                           "global_batch": args.batch * world, "frames_per_step": frames_per_step * world, "parallelism": "dp%d" % world,
                           "lr": args.lr, "frames_after_ctc_compression": round(enc_mean, 1), "frames_before": (args.frames + 3) // 4},
                "loss": round(stats.get("loss", float("nan")) / max(stats.get("sample_size", 1), 1), 4),
@@ -232,10 +310,25 @@ def main():
             out["roofline"] = roof
         if args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, a, ref_sd, task)
+    if args.extra:
+        del trainer, model, crit
+        torch.cuda.empty_cache()
+        import numpy as np
+        rs = np.random.RandomState(4)
+        mustc = [int(x) for x in np.clip(rs.lognormal(np.log(600.0), 0.7, 512), 50, 2000)]
+        out["extra_configs"] = [
+            extra_config("cfg3_batch8", "s2t_transformer_m", torch.bfloat16, device, 20, 5, batch=8, frames=1500),
+            extra_config("cfg2_s_fp32", "s2t_transformer_s", torch.float32, device, 10, 3, batch=32, frames=1000, tgt_len=30),
+            extra_config("cfg4_l_bucketed", "s2t_transformer_l", torch.bfloat16, device, 20, 5, tgt_len=0, lengths=mustc, max_tokens=48000),
+        ]
+        ok = ok and all(e["loss_finite"] for e in out["extra_configs"])
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py: loss / gradient norm of the timed updates is not finite")
 
 
 if __name__ == "__main__":

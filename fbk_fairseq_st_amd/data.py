@@ -161,3 +161,57 @@ def synthetic_batch(B, T, L, Lt, V_tgt, V_src_blank, feat=80, seed=0, lengths=No
             "net_input": {"src_tokens": x, "src_lengths": torch.tensor(lengths), "prev_output_tokens": prev},
             "target": tgt, "target_lengths": torch.full((B,), L), "transcript_target": tr,
             "transcript_target_lengths": torch.full((B,), Lt)}
+
+
+class SyntheticS2TDataset:
+    """In-memory MuST-C-shaped utterances behind the dataset interface the batch iterator reads: N(0,1)
+    filterbanks (what per-utterance CMVN yields), uniform target / transcript tokens ending in EOS.  `lengths`: frames per
+    utterance (fixed, or e.g. the lognormal of Cfg4).  Items have the layout of FilterBankToTextDataset wrapped by
+    TranscriptionWrapperDataset (indexed.py), so collation is the product collater (Seq2SeqCollater + transcripts)."""
+
+    def __init__(self, lengths, tgt_len, transcript_len, V_tgt, V_src_blank, feat=80, seed=0, pad=1, eos=2):
+        g = torch.Generator().manual_seed(seed)
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        self.pad, self.eos = pad, eos
+        self.feats = [torch.randn(int(l), feat, generator=g) for l in self.lengths]
+
+        def toks(n, hi):
+            t = torch.randint(4, hi, (len(self.lengths), n), generator=g)
+            t[:, -1] = eos
+            return t
+        # target length follows the utterance (L ~ T / 25, SURVEY 8-d Cfg4) unless a fixed one is asked for
+        self.tgt = toks(tgt_len, V_tgt) if tgt_len > 0 else None
+        self.tr = toks(transcript_len, V_src_blank)
+        if self.tgt is None:
+            self.tgt_list = []
+            for l in self.lengths:
+                n = max(2, int(l) // 25)
+                t = torch.randint(4, V_tgt, (n,), generator=g); t[-1] = eos
+                self.tgt_list.append(t)
+        self.collate = Seq2SeqCollater(0, 1, pad, eos, True)
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def __getitem__(self, i):
+        tgt = self.tgt[i] if self.tgt is not None else self.tgt_list[i]
+        return {"id": i, "data": [self.feats[i], tgt], "transcript_target": self.tr[i]}
+
+    def collater(self, samples):
+        b = collate_with_transcripts(self.collate, samples, self.pad, self.eos)
+        if len(b):
+            b["nframes"] = int(b["net_input"]["src_lengths"].sum())
+        return b
+
+    def num_tokens(self, i):
+        return int(self.lengths[i])
+
+    def size(self, i):
+        return (int(self.lengths[i]), int((self.tgt[i] if self.tgt is not None else self.tgt_list[i]).shape[0]))
+
+    @property
+    def frame_lengths(self):
+        return self.lengths
+
+    def ordered_indices(self):
+        return np.arange(len(self), dtype=np.int64)              # as the reference's fbank datasets (fbank_dataset.py:78-81)

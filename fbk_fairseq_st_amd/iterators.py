@@ -106,11 +106,19 @@ class EpochBatchIterator:
 
 
 def get_batch_iterator(dataset, max_tokens=None, max_sentences=None, max_positions=None, ignore_invalid_inputs=False,
-                       required_batch_size_multiple=1, seed=1, num_shards=1, shard_id=0, epoch=1, prefetch=2, pin_memory=True):
+                       required_batch_size_multiple=1, seed=1, num_shards=1, shard_id=0, epoch=1, prefetch=2, pin_memory=True,
+                       bucket_by_length=False):
+    """bucket_by_length (build-defined, off by default: the reference batches filterbanks in dataset order, fbank_dataset.py:78-81):
+    utterances are ordered by frame count (stable) before the frame-budget batcher runs, so a batch holds utterances of similar
+    length and the zero padding the kernels would chew through shrinks; batches are still shuffled
+    per epoch."""
     indices = dataset.ordered_indices()
     if max_positions is not None:
         indices = filter_by_size(indices, dataset, max_positions, raise_exception=not ignore_invalid_inputs)
     lens = getattr(dataset, "frame_lengths", None)
+    if bucket_by_length:
+        key = np.asarray(lens)[indices] if lens is not None else np.array([dataset.num_tokens(int(i)) for i in indices])
+        indices = indices[np.argsort(key, kind="mergesort")]
     sampler = batch_by_size(indices, lens if lens is not None else dataset.num_tokens, max_tokens=max_tokens,
                             max_sentences=max_sentences, required_batch_size_multiple=required_batch_size_multiple)
     return EpochBatchIterator(dataset, dataset.collater, sampler, seed=seed, num_shards=num_shards, shard_id=shard_id, epoch=epoch,

@@ -22,6 +22,8 @@ class SpeechTranslationCTCTask(FairseqTask):
         a("--max-source-positions", default=1024, type=int, metavar="N")
         a("--max-target-positions", default=1024, type=int, metavar="N")
         a("--skip-normalization", action="store_true")
+        a("--bucket-by-length", action="store_true",
+          help="build-defined: order utterances by frame count before batching (the reference batches in dataset order)")
         a("--legacy-audio-fix-lua-indexing", action="store_true")
         # speech_recognition.py:114-133
         a("--specaugment", action="store_true")
@@ -77,7 +79,7 @@ class SpeechTranslationCTCTask(FairseqTask):
         """fairseq_task.py:107-199 on the native batcher + pinned-memory prefetch thread (iterators.py)"""
         from .iterators import get_batch_iterator
         return get_batch_iterator(dataset, max_tokens, max_sentences, max_positions, ignore_invalid_inputs, required_batch_size_multiple,
-                                  seed, num_shards, shard_id, epoch)
+                                  seed, num_shards, shard_id, epoch, bucket_by_length=getattr(self.args, "bucket_by_length", False))
 
     @property
     def source_dictionary(self):
@@ -127,6 +129,17 @@ class DummyS2TTask(SpeechTranslationCTCTask):
         src = Dictionary.synthetic(getattr(args, "src_dict_size", 4996))
         src.add_symbol("<ctc_blank>")
         return cls(args, tgt, src)
+
+    def load_dataset(self, split, combine=False, n_utterances=256, lengths=None, seed=0, **kwargs):
+        """synthetic utterances behind the real dataset / iterator interface (bench.py --loader: collate, pinning and the H2D
+        copy then sit inside the timed loop)"""
+        from .data import SyntheticS2TDataset
+        a = self.args
+        if lengths is None:
+            lengths = [a.frames] * n_utterances
+        self.datasets[split] = SyntheticS2TDataset(lengths, a.tgt_len, a.transcript_len, len(self.tgt_dict),
+                                                   self.src_dict.index("<ctc_blank>"), feat=getattr(a, "input_feat_per_channel", 80),
+                                                   seed=seed)
 
     def dummy_batch(self, seed=0, lengths=None):
         a = self.args

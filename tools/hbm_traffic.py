@@ -3,7 +3,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d <out>/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d <out>/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
-    python tools/hbm_traffic.py <out>/fetch <out>/write profiles/r01_hbm_traffic.json
+    python tools/hbm_traffic.py <out>/fetch <out>/write profiles/r02_hbm_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes, so reads are
 doubled (the guide's correction for wide coalesced reads); WRITE_SIZE is exact for 16-byte stores and float atomics.
@@ -11,7 +11,9 @@ Kernels are grouped into the families bench.py reports (same template -> same fa
 import collections, csv, glob, json, sys
 
 # (family, kernel-name substrings that must ALL occur): the 128x128 templates bench.py names in KERNEL_OF
-FAMILY = [("gemm_tn", ("gemm_tn2_kernel",)), ("gemm_tn", ("gemm_fast_kernel", "true, true, 128, 128")), ("gemm_tn", ("gemm_fast_kernel", "Lb1ELb1ELi128ELi128")),
+FAMILY = [("wgrad_group", ("wgrad_group_kernel",)), ("gemm_nt", ("gemm256_kernel", "Lb0E")), ("gemm_nn", ("gemm256_kernel", "Lb1E")),
+          ("gemm_nt", ("gemm256_kernel", "false")), ("gemm_nn", ("gemm256_kernel", "true")),
+          ("gemm_tn", ("gemm_tn2_kernel",)), ("gemm_tn", ("gemm_fast_kernel", "true, true, 128, 128")), ("gemm_tn", ("gemm_fast_kernel", "Lb1ELb1ELi128ELi128")),
           ("gemm_nt", ("gemm_fast_kernel", "Lb0ELb0ELi128ELi128")), ("gemm_nn", ("gemm_fast_kernel", "Lb0ELb1ELi128ELi128")),
           ("gemm_gather", ("gemm_kernel",)), ("attn_fwd", ("attn_fwd2",)), ("attn_bwd", ("attn_bwd_d",))]
 

@@ -5,18 +5,18 @@ set -x
 R=$PWD
 mkdir -p $R/gpurun_out/ref
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pf/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pf/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > /dev/null 2>&1
 python3 $R/tools/hbm_traffic.py /tmp/pf/fetch /tmp/pf/write $R/gpurun_out/ref/hbm_traffic.json
-cp $R/gpurun_out/ref/hbm_traffic.json $R/profiles/r01_hbm_traffic.json
+cp $R/gpurun_out/ref/hbm_traffic.json $R/profiles/r02_hbm_traffic.json
 cd $R
 python bench.py > $R/gpurun_out/ref/bench.json 2> $R/gpurun_out/ref/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/ref/bench_under_rocprof.json 2>/tmp/pk.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- python3 $R/bench.py --no-cpu-baseline --no-extra > $R/gpurun_out/ref/bench_under_rocprof.json 2>/tmp/pk.err
 cp $(find /tmp/pk -name "*kernel_stats.csv" | head -1) $R/gpurun_out/ref/kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pa -- python3 $R/bench.py --no-cpu-baseline --no-roofline --attn-2d > $R/gpurun_out/ref/bench_attn2d_under_rocprof.json 2>/tmp/pa.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pa -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-extra --attn-2d > $R/gpurun_out/ref/bench_attn2d_under_rocprof.json 2>/tmp/pa.err
 cp $(find /tmp/pa -name "*kernel_stats.csv" | head -1) $R/gpurun_out/ref/kernel_stats_attn2d.csv
 cd $R
-python bench.py --no-cpu-baseline --no-roofline --attn-2d > $R/gpurun_out/ref/bench_attn2d.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-roofline --no-extra --attn-2d > $R/gpurun_out/ref/bench_attn2d.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $R/gpurun_out/ref/smoke.txt 2>&1
 tail -2 $R/gpurun_out/ref/smoke.txt
