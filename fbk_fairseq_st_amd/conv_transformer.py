@@ -423,6 +423,10 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             for n in ("running_mean", "running_var", "num_batches_tracked"):
                 b = getattr(self, "%s_%s" % (attr, n)).detach().cpu().clone()
                 sd["%s.%s" % (ref, n)] = b.view(()) if n == "num_batches_tracked" else b
+        if self.hp.share_dec_embed:              # the reference's state dict holds the shared tensor under both names (transformer.py:618-624)
+            for dec in ("decoder.", "auxiliary_decoder."):
+                if dec + "embed_tokens.weight" in sd:
+                    sd[dec + "output_projection.weight"] = sd[dec + "embed_tokens.weight"].clone()
         sd["encoder.embed_positions.embeddings._float_tensor"] = torch.FloatTensor(1)
         sd["decoder.embed_positions._float_tensor"] = torch.FloatTensor(1)
         sd["decoder.version"] = torch.Tensor([3])
@@ -502,8 +506,6 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         if getattr(args, "distance_penalty", False) not in (False, None, "log"):
             raise NotImplementedError("--distance-penalty gauss (learnable per-head variance; undefined `num_heads` in the reference, "
                                       "conv_transformer_layer.py:30-38) is not built; `log` is (SURVEY.md 8-f N4)")
-        if getattr(args, "share_decoder_input_output_embed", False):
-            raise NotImplementedError("--share-decoder-input-output-embed")
         src_dict, tgt_dict = task.source_dictionary, task.target_dictionary
         enc_dict = src_dict if src_dict is not None else tgt_dict           # conv_transformer.py:100-101
         convs = eval(args.encoder_convolutions) if isinstance(args.encoder_convolutions, str) else args.encoder_convolutions
@@ -519,7 +521,8 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                      attention_dropout=args.attention_dropout, activation_dropout=args.activation_dropout,
                      pad=tgt_dict.pad(), no_scale_embedding=getattr(args, "no_scale_embedding", False),
                      V_src=len(enc_dict), V_tgt=len(tgt_dict), distance_penalty=getattr(args, "distance_penalty", False) or False,
-                     attn_2d=bool(getattr(args, "attn_2d", False)))
+                     attn_2d=bool(getattr(args, "attn_2d", False)),
+                     share_dec_embed=bool(getattr(args, "share_decoder_input_output_embed", False)))
         assert args.decoder_ffn_embed_dim == args.encoder_ffn_embed_dim
         encoder = ConvolutionalTransformerEncoder(args, enc_dict, audio_features=args.input_feat_per_channel)
         decoder = TransformerDecoder(args, tgt_dict)

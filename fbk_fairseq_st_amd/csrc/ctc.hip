@@ -237,8 +237,9 @@ __device__ __forceinline__ float lae3(float a, float b, float c, bool use_c) {
 // needed from the previous lane travel by shuffle.  Emissions lp[t][ext[s]] = logit - lse are
 // gathered CH time steps at a time into LDS by the whole workgroup.
 // Outputs: la/lb [B][T][Smax] (f32 log alpha/beta), nll[b] (0 if infeasible: zero_infinity).
-#define CTC_CH 16
-template <typename T, int CTC_SPL>
+// CTC_SPL extended-target positions per lane (1 .. 16: transcripts of up to 511 units), CTC_CH time steps of emissions per LDS chunk
+// (the chunk buffer is 2 x CTC_CH x 64 x CTC_SPL floats: CTC_CH shrinks as CTC_SPL grows to stay inside 64 KB of static LDS)
+template <typename T, int CTC_SPL, int CTC_CH = (CTC_SPL <= 4 ? 16 : (CTC_SPL == 8 ? 8 : 4))>
 __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict__ logits, const float* __restrict__ lse,
                                                             const long long* __restrict__ targets, const long long* __restrict__ tgt_len,
                                                             const int* __restrict__ in_len, float* __restrict__ la,
@@ -471,9 +472,9 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
     const bool fwd = phase != 2, bwd = phase != 1;
     float* const lsum_grad = phase == 0 ? loss_sum : nullptr;      // the gradient pass adds up the loss only when it is the same call
     const int Smax = 2 * Lmax + 1;
-    if (Smax > 64 * 4) return S2T_ENOTSUP;                // transcripts longer than 127 tokens
-    const int spl = Smax <= 64 ? 1 : (Smax <= 128 ? 2 : 4);   // extended-target positions per lane
-    if ((size_t)V * 4 > 160 * 1024 - 1024) return S2T_ENOTSUP;
+    if (Smax > 64 * 16) return S2T_ENOTSUP;               // transcripts longer than 511 units (S2T_CTC_MAX_TARGET in the header)
+    const int spl = Smax <= 64 ? 1 : (Smax <= 128 ? 2 : (Smax <= 256 ? 4 : (Smax <= 512 ? 8 : 16)));   // extended-target positions per lane
+    if ((size_t)V * 4 > 160 * 1024 - 1024) return S2T_ENOTSUP;   // the gradient kernel keeps one f32 row of the vocabulary in LDS (V <= 40,704)
     hipStream_t st = (hipStream_t)stream;
     const long rows = (long)T * B;
     dim3 g1((unsigned)((rows + 3) / 4)), g3(T, B);
@@ -483,7 +484,9 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
         if (!lse_given) hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V, ld);
         if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 1>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 2>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 4>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else if (spl == 4) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 4>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else if (spl == 8) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 8>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 16>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         if (phase == 1) hipLaunchKernelGGL(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, st, nll, B, loss_sum);
         }
         static bool attr = false;
@@ -494,7 +497,9 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
         if (!lse_given) hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V, ld);
         if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 1>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 2>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 4>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else if (spl == 4) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 4>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else if (spl == 8) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 8>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        else hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 16>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
         if (phase == 1) hipLaunchKernelGGL(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, st, nll, B, loss_sum);
         }
         static bool attr = false;

@@ -17,7 +17,6 @@ struct GemmArgs {
     float* rowsum;                           // optional (TA products): rowsum[m] += sum_k op(A)[m][k]  (bias gradient of a Linear)
 };
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_GELU_BWD = 4 };
 
 // Finishing loop of the epilogue, specialised on the activation: every thread completes CW consecutive columns
 // of one row per iteration (16 bytes of output) from the f32 tile parked in LDS.

@@ -90,10 +90,11 @@ __device__ __forceinline__ void conv1_window_finish(Conv1Win& w, float (&xv)[9])
 }
 
 // ------------------------------------------------------------------ conv1 forward (+ BN statistics)
-// x [B][T][F] f32 -> y [B][T2][F2][C] T, y = relu(conv(x)+bias); sums[c] += y, sums[C+c] += y^2 (double)
-template <typename T>
+// x [B][T][F] f32 -> y [B][T2][F2][C] T, y = act(conv(x)+bias); sums[c] += y, sums[C+c] += y^2 (double)
+// GELU (--activation-fn gelu): the pre-activation is stored next to y (`pre`), the backward needs it
+template <typename T, bool GELU>
 __global__ __launch_bounds__(256, 4) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, T* __restrict__ y,
+                                                        const float* __restrict__ bias, T* __restrict__ y, T* __restrict__ pre,
                                                         double* __restrict__ sums, int B, int Tin, int F, int T2,
                                                         int F2, int C, int pos_per_block) {
     __shared__ float red[4][16][16];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 4) void conv1_fwd_kernel(const float* __restri
     Conv1Win wn;
     if (p0 + slot < pend) conv1_window_issue(x, p0 + slot, Tin, F, T2, F2, wn);
     for (unsigned p = p0 + slot; p < pend; p += nslot) {
-        float xv[9], o[8];
+        float xv[9], o[8], q[8];
         conv1_window_finish(wn, xv);
         conv1_window_issue(x, min(p + nslot, P - 1), Tin, F, T2, F2, wn);
 #pragma unroll
@@ -123,10 +124,13 @@ __global__ __launch_bounds__(256, 4) void conv1_fwd_kernel(const float* __restri
             float acc = bc[e];
 #pragma unroll
             for (int i = 0; i < 9; ++i) acc += xv[i] * wr[e][i];
-            o[e] = to_f32(from_f32<T>(fmaxf(acc, 0.f)));           // statistics of the value that is stored
+            if constexpr (GELU) { q[e] = acc; acc = gelu_f(to_f32(from_f32<T>(acc))); }   // gelu of the stored pre-activation
+            else acc = fmaxf(acc, 0.f);
+            o[e] = to_f32(from_f32<T>(acc));                       // statistics of the value that is stored
             s1[e] += o[e]; s2[e] += o[e] * o[e];
         }
         store8<T>(y + (size_t)p * C + 8 * g, o);
+        if constexpr (GELU) store8<T>(pre + (size_t)p * C + 8 * g, q);
     }
     chan_pair_reduce(s1, s2, LP, g, sums, C, red);
 }
@@ -272,11 +276,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
-// BatchNorm backward (training statistics) fused with the ReLU mask of the preceding activation:
-//   dy = gamma*rstd*(dyn - dbeta/N - xhat*dgamma/N);  dpre = dy * (y > 0)
+// BatchNorm backward (training statistics) fused with the derivative of the preceding activation:
+//   dy = gamma*rstd*(dyn - dbeta/N - xhat*dgamma/N);  dpre = dy * (y > 0)   (ReLU)   |   dy * gelu'(pre)   (GELU, pre != null)
 // also accumulates dgamma/dbeta into the f32 parameter gradients (block 0).
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dyn, const T* __restrict__ y,
+template <typename T, bool GELU>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dyn, const T* __restrict__ y, const T* __restrict__ pre,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const double* __restrict__ sums,
                                                            T* __restrict__ dpre, float* dgamma, float* dbeta, long n,
@@ -298,14 +302,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     const long nv = n >> 3;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-        float v[8], d[8];
+        float v[8], d[8], q[8];
         load8<T>(y + i * 8, v);
         load8<T>(dyn + i * 8, d);
+        if constexpr (GELU) load8<T>(pre + i * 8, q);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float xh = (v[e] - mu[e]) * rs[e];
             const float r = k1[e] * (d[e] - m1[e] - xh * m2[e]);
-            d[e] = v[e] > 0.f ? r : 0.f;
+            if constexpr (GELU) d[e] = r * gelu_grad_f(q[e]);
+            else d[e] = v[e] > 0.f ? r : 0.f;
         }
         store8<T>(dpre + i * 8, d);
     }
@@ -366,18 +372,25 @@ static inline int nblocks(long n, int cap = 4096) { long b = (n + 255) / 256; re
 #define DISPATCH_T(dtype, EXPR_BF16, EXPR_F32) \
     if ((dtype) == S2T_BF16) { EXPR_BF16; } else if ((dtype) == S2T_F32) { EXPR_F32; } else return S2T_ENOTSUP;
 
-extern "C" int s2t_conv1_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, double* sums,
-                             int B, int T, int F, int C, void* stream) {
+extern "C" int s2t_conv1_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, void* pre, double* sums,
+                             int B, int T, int F, int C, int act, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
     if (!x || !w || !bias || !y || !sums || (C != 64 && C != 128 && C != 32) || F <= 0) return S2T_EINVAL;
+    if ((act != ACT_RELU && act != ACT_GELU) || (act == ACT_GELU && !pre)) return S2T_EINVAL;
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
     const int ppb = (int)((P + 1023) / 1024 < 64 ? 64 : (P + 1023) / 1024);   // <= ~1024 workgroups: every one ends in 2C same-address atomics
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(conv1_fwd_kernel<bf16>, grid, dim3(256), 0, st, x, w, bias, (bf16*)y, sums, B, T, F, T2, F2, C, ppb),
-        hipLaunchKernelGGL(conv1_fwd_kernel<float>, grid, dim3(256), 0, st, x, w, bias, (float*)y, sums, B, T, F, T2, F2, C, ppb));
+    if (act == ACT_GELU) {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((conv1_fwd_kernel<bf16, true>), grid, dim3(256), 0, st, x, w, bias, (bf16*)y, (bf16*)pre, sums, B, T, F, T2, F2, C, ppb),
+            hipLaunchKernelGGL((conv1_fwd_kernel<float, true>), grid, dim3(256), 0, st, x, w, bias, (float*)y, (float*)pre, sums, B, T, F, T2, F2, C, ppb));
+    } else {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((conv1_fwd_kernel<bf16, false>), grid, dim3(256), 0, st, x, w, bias, (bf16*)y, (bf16*)nullptr, sums, B, T, F, T2, F2, C, ppb),
+            hipLaunchKernelGGL((conv1_fwd_kernel<float, false>), grid, dim3(256), 0, st, x, w, bias, (float*)y, (float*)nullptr, sums, B, T, F, T2, F2, C, ppb));
+    }
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
@@ -434,15 +447,21 @@ extern "C" int s2t_bn_apply(int dtype, const void* y, const float* scale, const 
     return S2T_OK;
 }
 
-extern "C" int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const float* mean, const float* rstd,
+extern "C" int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const void* pre, const float* mean, const float* rstd,
                                 const float* gamma, const double* sums, void* dpre, float* dgamma, float* dbeta, long n,
                                 int C, double count, int training, void* stream) {
     if (n <= 0) return S2T_OK;
     if (!dyn || !y || !mean || !rstd || !gamma || !sums || !dpre || !dgamma || !dbeta || C > 256 || (C % 8) || (256 % (C / 8)) || (n % C)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(nblocks(n)), dim3(256), 0, st, (const bf16*)dyn, (const bf16*)y, mean, rstd, gamma, sums, (bf16*)dpre, dgamma, dbeta, n, C, count, training),
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, (const float*)dyn, (const float*)y, mean, rstd, gamma, sums, (float*)dpre, dgamma, dbeta, n, C, count, training));
+    if (pre) {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), dim3(nblocks(n)), dim3(256), 0, st, (const bf16*)dyn, (const bf16*)y, (const bf16*)pre, mean, rstd, gamma, sums, (bf16*)dpre, dgamma, dbeta, n, C, count, training),
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(nblocks(n)), dim3(256), 0, st, (const float*)dyn, (const float*)y, (const float*)pre, mean, rstd, gamma, sums, (float*)dpre, dgamma, dbeta, n, C, count, training));
+    } else {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, false>), dim3(nblocks(n)), dim3(256), 0, st, (const bf16*)dyn, (const bf16*)y, (const bf16*)nullptr, mean, rstd, gamma, sums, (bf16*)dpre, dgamma, dbeta, n, C, count, training),
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(nblocks(n)), dim3(256), 0, st, (const float*)dyn, (const float*)y, (const float*)nullptr, mean, rstd, gamma, sums, (float*)dpre, dgamma, dbeta, n, C, count, training));
+    }
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

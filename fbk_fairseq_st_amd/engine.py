@@ -35,6 +35,7 @@ class HParams:
         self.distance_penalty = False            # 'log': encoder self-attention scores -= max(0, ln|i-j|) (local_attention.py:131-133)
         self.attn_2d = False                     # two residual ConvAttention2D blocks after the convolutions (conv_transformer.py:155-157,216-222)
         self.V_aux = 0                           # > 0: second decoder `auxiliary_decoder.*` over this vocabulary (dual-decoder model)
+        self.share_dec_embed = False             # --share-decoder-input-output-embed: output_projection.weight IS embed_tokens.weight (transformer.py:618-624)
         self.ln_eps = 1e-5; self.bn_eps = 1e-5; self.bn_momentum = 0.1
         for k, v in kw.items():
             if not hasattr(self, k):
@@ -90,7 +91,8 @@ class HParams:
                 lin(p + "encoder_attn.out_proj", D, D)
                 ln(p + "final_layer_norm"); lin(p + "fc1", Ff, D); lin(p + "fc2", D, Ff)
             ln(dec + "layer_norm")
-            lin(dec + "output_projection", V, D, bias=False)
+            if not self.share_dec_embed:
+                lin(dec + "output_projection", V, D, bias=False)
         return s
 
 
@@ -238,6 +240,11 @@ class S2TEngine:
             for prefix in ready:
                 self.on_grads_ready(prefix)
 
+    def out_proj(self, pfx):
+        """parameter-name stem of a decoder's output projection: the embedding itself when input and output embeddings are shared
+        (its gradient then collects the projection's dW and the embedding scatter in one buffer)"""
+        return pfx + ("embed_tokens" if self.hp.share_dec_embed else "output_projection")
+
     def W(self, n):
         return self.A.w(n)
 
@@ -270,8 +277,8 @@ class S2TEngine:
     # ------------------------------------------------------------------ subsampler
     def subsample_fwd(self, src_tokens, len_dev64, training, seed):
         hp, C = self.hp, self.hp.conv_ch
-        if hp.act != "relu":
-            raise NotImplementedError("the convolutional subsampler kernels implement ReLU (reference default) only")
+        gelu = hp.act == "gelu"          # --activation-fn also drives the subsampler (conv_transformer.py:140-142,212,227)
+        act = K.ACT_GELU if gelu else K.ACT_RELU
         B, T, F = src_tokens.shape
         x = src_tokens if src_tokens.dtype == torch.float32 else src_tokens.float()
         x = x.contiguous()
@@ -282,7 +289,7 @@ class S2TEngine:
         p_sub = (max(hp.dropout, 0.1) if hp.sub_dropout is None else hp.sub_dropout) if training else 0.0
         c = dict(x=x, B=B, T=T, F=F, T2=T2, F2=F2, T4=T4, F4=F4, training=training, p_sub=p_sub, seed=seed)
         # conv1 + BN1
-        y1, sums1 = K.conv1_fwd(x, self.P("encoder.convolutions.0.weight"), self.P("encoder.convolutions.0.bias"), C, self.dtype)
+        y1, sums1, pre1 = K.conv1_fwd(x, self.P("encoder.convolutions.0.weight"), self.P("encoder.convolutions.0.bias"), C, self.dtype, act)
         cnt1 = B * T2 * F2
         mean1, rstd1, sc1, sh1 = K.bn_finalize(sums1, self.P("encoder.bn.0.weight"), self.P("encoder.bn.0.bias"),
                                                bufs["encoder.bn.0.running_mean"], bufs["encoder.bn.0.running_var"],
@@ -291,8 +298,9 @@ class S2TEngine:
         # conv2 as implicit GEMM + BN2
         w2p = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 0)
         P2 = T4 * B * F4
+        pre2 = torch.empty((P2, C), dtype=self.dtype, device=self.dev) if gelu else None     # GELU's backward needs the pre-activation
         z2 = K.gemm(y1n.view(-1, C), w2p, M=P2, K=9 * C, map_a=mp["fwd"], period_a=C,
-                    bias=self.P("encoder.convolutions.1.bias"), act=K.ACT_RELU)
+                    bias=self.P("encoder.convolutions.1.bias"), act=act, aux_out=pre2)
         sums2 = K.chan_sums(z2, C)
         mean2, rstd2, sc2, sh2 = K.bn_finalize(sums2, self.P("encoder.bn.1.weight"), self.P("encoder.bn.1.bias"),
                                                bufs["encoder.bn.1.running_mean"], bufs["encoder.bn.1.running_var"],
@@ -306,7 +314,8 @@ class S2TEngine:
         c["a2d"] = a2d
         # fc3 on channels-last rows: weight columns re-ordered k = c*F4+f -> k' = f*C+c
         w3p = K.permute_cf(self.P("encoder.fc3.weight"), torch.empty((hp.D, F4 * C), dtype=self.dtype, device=self.dev), hp.D, C, F4, 0)
-        h3 = K.gemm(z2n.view(T4 * B, F4 * C), w3p, bias=self.P("encoder.fc3.bias"), act=K.ACT_RELU)
+        pre3 = torch.empty((T4 * B, hp.D), dtype=self.dtype, device=self.dev) if gelu else None
+        h3 = K.gemm(z2n.view(T4 * B, F4 * C), w3p, bias=self.P("encoder.fc3.bias"), act=act, aux_out=pre3)
         # lengths: ceil(len/2) twice (conv_transformer.py:213) -- integer bookkeeping on device
         len4 = (((len_dev64 + 1) // 2) + 1) // 2
         len4_32 = len4.to(torch.int32)
@@ -316,7 +325,7 @@ class S2TEngine:
         if p > 0:
             K.dropout(xe, p, seed + 3, out=xe)
         c.update(y1=y1, y1n=y1n, z2=z2, z2n=z2n, h3=h3, w2p=w2p, w3p=w3p, mean1=mean1, rstd1=rstd1, mean2=mean2,
-                 rstd2=rstd2, cnt1=cnt1, P2=P2, p=p)
+                 rstd2=rstd2, cnt1=cnt1, P2=P2, p=p, pre1=pre1, pre2=pre2, pre3=pre3)
         return xe, len4, len4_32, c
 
     def subsample_bwd(self, c, dx):
@@ -326,7 +335,7 @@ class S2TEngine:
         mp = self.maps(B, c["T2"], c["F2"])
         if c["p"] > 0:
             dx = K.dropout(dx, c["p"], c["seed"] + 3)
-        dh3 = K.act_bwd(dx, c["h3"], 1)
+        dh3 = K.act_bwd(dx, c["h3"], 1) if c["pre3"] is None else K.act_bwd(dx, c["pre3"], 2)
         # fc3: weight gradient in the re-ordered layout, then scattered back (+=) to the master layout
         z2n2d = c["z2n"].view(T4 * B, F4 * C)
         gw3p = K.gemm(dh3, z2n2d, trans_a=True, trans_b=True, out_dtype=torch.float32, accumulate=True,
@@ -344,7 +353,7 @@ class S2TEngine:
         # BN2 backward (+ ReLU mask) -> gradient w.r.t. conv2 + bias
         s2 = K.chan_sums(c["z2"], C, dyn=dz2n, mean=c["mean2"], rstd=c["rstd2"])
         dpre2 = K.bn_bwd_apply(dz2n, c["z2"], c["mean2"], c["rstd2"], self.P("encoder.bn.1.weight"), s2,
-                               self.G("encoder.bn.1.weight"), self.G("encoder.bn.1.bias"), c["P2"], c["training"])
+                               self.G("encoder.bn.1.weight"), self.G("encoder.bn.1.bias"), c["P2"], c["training"], pre=c["pre2"])
         K.colsum(dpre2, self.G("encoder.convolutions.1.bias"))
         # conv2 weight gradient: 9 gathered TN GEMMs (one per tap) into [Co][tap*Ci+ci], then back to [Co][Ci][3][3]
         y1n2d = c["y1n"].view(-1, C)
@@ -370,7 +379,8 @@ class S2TEngine:
                    p_drop=c["p_sub"], seed=c["seed"] + 1)
         s1 = K.chan_sums(c["y1"], C, dyn=dy1n, mean=c["mean1"], rstd=c["rstd1"])
         dpre1 = K.bn_bwd_apply(dy1n, c["y1"].view(-1, C), c["mean1"], c["rstd1"], self.P("encoder.bn.0.weight"), s1,
-                               self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"])
+                               self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"],
+                               pre=None if c["pre1"] is None else c["pre1"].view(-1, C))
         K.conv1_bwd(c["x"], dpre1.view(B, c["T2"], c["F2"], C), self.G("encoder.convolutions.0.weight").view(C, 9),
                     self.G("encoder.convolutions.0.bias"))
 
@@ -697,7 +707,7 @@ class S2TEngine:
             ctx["layers"].append((c1, c2, c3))
         xn, mean, rstd = K.layernorm_fwd(x.view(L * B, D), self.P(pfx + "layer_norm.weight"), self.P(pfx + "layer_norm.bias"), hp.ln_eps)
         ctx["final"] = dict(x=x.view(L * B, D), xn=xn, mean=mean, rstd=rstd)
-        logits = self.linear(xn, pfx + "output_projection", bias=False, pad_rows=True)   # [L*B, V] time-major rows
+        logits = self.linear(xn, self.out_proj(pfx), bias=False, pad_rows=True)          # [L*B, V] time-major rows
         return logits, ctx
 
     # ------------------------------------------------------------------ incremental decoding (generation)
@@ -753,7 +763,7 @@ class S2TEngine:
             x = self.linear(a, lp + "fc2", residual=x)
         xn, _, _ = K.layernorm_fwd(x, self.P(pfx + "layer_norm.weight"), self.P(pfx + "layer_norm.bias"), hp.ln_eps)
         st["steps"] = step + 1
-        return self.linear(xn, pfx + "output_projection", bias=False, pad_rows=True)
+        return self.linear(xn, self.out_proj(pfx), bias=False, pad_rows=True)
 
     def decoder_backward(self, ctx, dlogits, denc=None):
         """dlogits [L*B, V] (time-major).  Returns the gradient w.r.t. the encoder output [Ts*B, D]
@@ -761,7 +771,7 @@ class S2TEngine:
         hp = self.hp
         pfx, B, L, D = ctx["pfx"], ctx["B"], ctx["L"], hp.D
         f = ctx["final"]
-        dxn = self.linear_bwd(dlogits, f["xn"], pfx + "output_projection", bias=False)
+        dxn = self.linear_bwd(dlogits, f["xn"], self.out_proj(pfx), bias=False)
         def drop_of(c, off):
             return (c["p"], c["seed"] + off) if self.fuse_bwd_dropout and c["p"] > 0 else None
 

@@ -154,14 +154,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, drop=None)
     return dx if drop is None else (dx, dxd)
 
 
-def conv1_fwd(x, w, bias, C, dtype):
+def conv1_fwd(x, w, bias, C, dtype, act=ACT_RELU):
+    """-> (y, sums, pre): pre = the pre-activation for GELU (None for ReLU, whose backward reads the mask off y)"""
     B, T, F = x.shape
     T2, F2 = (T + 1) // 2, (F + 1) // 2
     y = torch.empty((B, T2, F2, C), dtype=dtype, device=x.device)
+    pre = torch.empty_like(y) if act == ACT_GELU else None
     sums = torch.zeros((2 * C,), dtype=torch.float64, device=x.device)
-    L.check(_lib().s2t_conv1_fwd(L.dt(y), L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(sums), B, T, F, C, L.stream()),
-            "s2t_conv1_fwd")
-    return y, sums
+    L.check(_lib().s2t_conv1_fwd(L.dt(y), L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(pre), L.ptr(sums), B, T, F, C, act,
+                                 L.stream()), "s2t_conv1_fwd")
+    return y, sums, pre
 
 
 def conv1_bwd(x, dpre, dw, db):
@@ -196,9 +198,9 @@ def bn_apply(y, scale, shift, p_drop=0.0, seed=0):
     return yn
 
 
-def bn_bwd_apply(dyn, y, mean, rstd, gamma, sums, dgamma, dbeta, count, training=True):
+def bn_bwd_apply(dyn, y, mean, rstd, gamma, sums, dgamma, dbeta, count, training=True, pre=None):
     dpre = torch.empty_like(y)
-    L.check(_lib().s2t_bn_bwd_apply(L.dt(y), L.ptr(dyn), L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(sums),
+    L.check(_lib().s2t_bn_bwd_apply(L.dt(y), L.ptr(dyn), L.ptr(y), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(sums),
                                     L.ptr(dpre), L.ptr(dgamma), L.ptr(dbeta), y.numel(), gamma.numel(), float(count),
                                     int(training), L.stream()), "s2t_bn_bwd_apply")
     return dpre
@@ -284,11 +286,18 @@ def ctc_compress_bwd(dout, w, seg, dx, accumulate=False):
     return dx
 
 
+CTC_MAX_TARGET, CTC_MAX_VOCAB = 511, 40704        # S2T_CTC_MAX_TARGET / S2T_CTC_MAX_VOCAB of include/s2t_hip.h
+
+
 def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0, defer_grad=False, lse=None):
     """Returns (loss_sum f32[1], grad like logits, nll).  defer_grad: the forward pass only; the second result is then the workspace
     tuple for ctc_loss_grad (called from backward with the upstream gradient as a device scalar: no separate scaling pass)."""
     T, B, V = logits.shape
     Lmax = targets.shape[1]
+    if Lmax > CTC_MAX_TARGET or V > CTC_MAX_VOCAB:
+        raise L.S2THipError("CTC loss kernels take transcripts of at most %d units and vocabularies of at most %d entries "
+                            "(S2T_CTC_MAX_TARGET / S2T_CTC_MAX_VOCAB, include/s2t_hip.h); this batch has %d / %d: filter the data "
+                            "with --max-target-positions or shorten the transcripts" % (CTC_MAX_TARGET, CTC_MAX_VOCAB, Lmax, V))
     dev = logits.device
     S = 2 * Lmax + 1
     lse_given = lse is not None                     # row log-sum-exps of THESE logits from ctc_argmax(want_lse=True)

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
+ABI_VERSION = 2              # s2t_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD = 0, 1, 2, 3, 4
 
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
@@ -37,12 +38,12 @@ SIGNATURES = {
                     [P, c_int, c_int, c_float, c_float, c_ull, P],
     "s2t_layernorm_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_float, P],
     "s2t_layernorm_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_float, c_ull, P],
-    "s2t_conv1_fwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_conv1_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "s2t_conv1_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_chan_sums": [c_int, P, P, P, P, P, c_long, c_int, c_int, P],
     "s2t_bn_finalize": [P] * 10 + [c_double, c_int, c_int, c_float, c_float, P],
     "s2t_bn_apply": [c_int, P, P, P, P, c_long, c_int, c_float, c_ull, P],
-    "s2t_bn_bwd_apply": [c_int, P, P, P, P, P, P, P, P, P, c_long, c_int, c_double, c_int, P],
+    "s2t_bn_bwd_apply": [c_int, P, P, P, P, P, P, P, P, P, P, c_long, c_int, c_double, c_int, P],
     "s2t_permute_cf": [c_int, P, P, c_int, c_int, c_int, c_int, P],
     "s2t_permute_conv_w": [c_int, P, P, c_int, c_int, c_int, P],
     "s2t_add_pos": [c_int, P, P, P, c_int, c_int, c_int, P],
@@ -120,6 +121,9 @@ def load():
         fn.restype = c_int
     lib.s2t_build_info.restype = ctypes.c_char_p
     lib.s2t_build_info.argtypes = []
+    if lib.s2t_abi_version() != ABI_VERSION:
+        raise ImportError("libs2t_hip.so at %s has ABI version %d, this package binds version %d -- rebuild it (make -C %s)"
+                          % (LIB_PATH, lib.s2t_abi_version(), ABI_VERSION, CSRC))
     _lib = lib
     return lib
 

@@ -79,6 +79,12 @@ class InverseSquareRootSchedule:
         self.decay_factor = lr * max(warmup_updates, 1) ** 0.5
         self.step_update(0)
 
+    def state_dict(self):                                  # fairseq_lr_scheduler.py:28-34: only the best validation loss is state
+        return {"best": getattr(self, "best", None)}
+
+    def load_state_dict(self, sd):
+        self.best = sd.get("best")
+
     def step_update(self, num_updates):
         if num_updates < self.warmup_updates:
             lr = self.warmup_init_lr + num_updates * self.lr_step

@@ -7,6 +7,7 @@ What differs is where the work runs: the gradient all-reduce is launched bucket 
 backward (distributed.BucketedGradReducer), scaling + clipping are folded into the norm / Adam kernels,
 and nothing but the CTC-compression lengths synchronises the host with the GPU before the final stats.
 """
+import os
 import time
 
 import torch
@@ -50,6 +51,7 @@ class Trainer:
         self._sync_grads = True         # False while a non-final micro-batch accumulates locally (the reference's no_sync)
         self._dummy_batch = None
         self.last_stats = {}
+        self._optim_history = []
 
     def build_optimizer(self, lr):
         args = self.args
@@ -149,6 +151,52 @@ class Trainer:
         self.lr_scheduler.step_update(self.num_updates)
         self._pending = (logs, gnorm, total_ss)
         return self._pending
+
+    # ---- checkpoints (fairseq/trainer.py:173-266, fairseq/checkpoint_utils.py:245-285): the reference's file layout -- "args",
+    # "model" (reference parameter names, f32 masters), "criterion", "optimizer_history", "extra_state", "last_optimizer_state".
+    # The optimizer state is this build's own (Adam moments as two flat arena-ordered vectors), so a reference checkpoint
+    # restores model + criterion + schedule position and restarts the moments (the reference's --reset-optimizer behaviour).
+    def save_checkpoint(self, filename, extra_state=None):
+        if D.get_rank() != 0:                                       # only the data-parallel master writes (trainer.py:175)
+            return
+        state = {"args": self.args, "model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                 "optimizer_history": self._optim_history + [{"criterion_name": self.criterion.__class__.__name__,
+                                                              "optimizer_name": self.optimizer.__class__.__name__,
+                                                              "lr_scheduler_state": self.lr_scheduler.state_dict(),
+                                                              "num_updates": self.num_updates}],
+                 "extra_state": dict(extra_state or {})}
+        if any(True for _ in self.criterion.parameters()):
+            state["criterion"] = {k: v.detach().cpu() for k, v in self.criterion.state_dict().items()}
+        if not getattr(self.args, "no_save_optimizer_state", False):
+            state["last_optimizer_state"] = self.optimizer.state_dict()
+        tmp = filename + ".tmp"
+        torch.save(state, tmp)
+        os.replace(tmp, filename)                                   # a reader never sees a half-written file
+
+    def load_checkpoint(self, filename, reset_optimizer=False, reset_lr_scheduler=False, allow_non_strict_loading=False):
+        """-> extra_state of the file, or None when it does not exist (trainer.py:189-266)."""
+        if not os.path.isfile(filename):
+            return None
+        state = torch.load(filename, map_location="cpu", weights_only=False)
+        state = self.model.raw_state_dict_upgrade(state)
+        self.model.load_state_dict(state["model"], strict=not allow_non_strict_loading, args=self.args)
+        if any(True for _ in self.criterion.parameters()) and "criterion" in state:
+            self.criterion.load_state_dict(state["criterion"], strict=True)      # its parameters alias arena slices
+        self.arena.refresh_shadow()
+        self._optim_history = state.get("optimizer_history", [])
+        last = state.get("last_optimizer_state")
+        if last is not None and not reset_optimizer:
+            h = self._optim_history[-1]
+            assert h["criterion_name"] == self.criterion.__class__.__name__, \
+                "Criterion does not match; please reset the optimizer (--reset-optimizer)."
+            assert h["optimizer_name"] == self.optimizer.__class__.__name__ and "exp_avg" in last \
+                and last["exp_avg"].numel() == self.arena.numel, "Optimizer does not match; please reset the optimizer (--reset-optimizer)."
+            self.optimizer.load_state_dict(last)
+            self.num_updates = int(h["num_updates"])
+            if not reset_lr_scheduler:
+                self.lr_scheduler.load_state_dict(h.get("lr_scheduler_state") or {})
+            self.lr_scheduler.step_update(self.num_updates)
+        return state.get("extra_state")
 
     def reduce_stats(self):
         """Materialise (one sync) and sum the logging outputs of the last update."""

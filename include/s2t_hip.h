@@ -139,10 +139,11 @@ int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mea
                       int M, int D, void* dx_drop, float p_drop, unsigned long long seed, void* stream);
 
 /* ---- convolutional subsampler (conv_transformer.py:202-232) ----------------------------------------
- * conv1: x [B][T][F] f32 -> y [B][T2][F2][C] (channels-last) = relu(conv3x3 s2 p1 + bias); also the
- * BatchNorm sums: sums[c] += y, sums[C+c] += y^2 (double, caller zeroes).  C in {32, 64, 128}. */
-int s2t_conv1_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, double* sums,
-                  int B, int T, int F, int C, void* stream);
+ * conv1: x [B][T][F] f32 -> y [B][T2][F2][C] (channels-last) = act(conv3x3 s2 p1 + bias), act = S2T_ACT_RELU | S2T_ACT_GELU
+ * (--activation-fn, conv_transformer.py:140-142,212); with GELU the pre-activation goes to `pre` (same shape, needed by the
+ * backward; NULL for ReLU).  Also the BatchNorm sums: sums[c] += y, sums[C+c] += y^2 (double, caller zeroes).  C in {32, 64, 128}. */
+int s2t_conv1_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, void* pre, double* sums,
+                  int B, int T, int F, int C, int act, void* stream);
 /* dw[c][3][3] += , db[c] += from dpre [B][T2][F2][C] (gradient after the ReLU mask) */
 int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float* dw, float* db, int B, int T, int F, int C, void* stream);
 /* per-channel double sums over a channels-last [P][C] tensor: mode 0 (y, y^2); mode 1 (dyn, dyn*xhat) */
@@ -157,8 +158,9 @@ int s2t_bn_finalize(const double* sums, const float* gamma, const float* beta, f
  * in one pass; the mask / rounding are those of s2t_dropout on the normalised tensor */
 int s2t_bn_apply(int dtype, const void* y, const float* scale, const float* shift, void* yn, long n, int C,
                  float p_drop, unsigned long long seed, void* stream);
-/* BatchNorm backward fused with the ReLU mask; sums from s2t_chan_sums(mode 1); dgamma/dbeta += */
-int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const float* mean, const float* rstd,
+/* BatchNorm backward fused with the derivative of the activation in front of it: the ReLU mask (y > 0) when pre == NULL, else
+ * gelu'(pre); sums from s2t_chan_sums(mode 1); dgamma/dbeta += */
+int s2t_bn_bwd_apply(int dtype, const void* dyn, const void* y, const void* pre, const float* mean, const float* rstd,
                      const float* gamma, const double* sums, void* dpre, float* dgamma, float* dbeta,
                      long n, int C, double count, int training, void* stream);
 /* fc3 weight [N][C*F] (k = c*F+f, conv_transformer.py:225-226) <-> channels-last k' = f*C+c */
@@ -191,7 +193,12 @@ int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int*
  * loss_sum[0] += sum_b nll_b (caller zeroes). grad is multiplied by grad_scale and, if given, by the device scalar
  * grad_scale_dev[0] (the upstream gradient autograd hands to backward).  phase 0: loss and gradient in one call;
  * phase 1: loss only (workspaces kept by the caller); phase 2: the gradient from the workspaces of a phase-1 call;
- * phase | 4: `lse` already holds the row log-sum-exps of these logits (written by s2t_ctc_argmax), skip that pass. */
+ * phase | 4: `lse` already holds the row log-sum-exps of these logits (written by s2t_ctc_argmax), skip that pass.
+ * Limits (the reference's F.ctc_loss has none): transcripts of at most S2T_CTC_MAX_TARGET units (Lmax, the padded width of
+ * `targets`) and vocabularies of at most S2T_CTC_MAX_VOCAB entries; beyond them the call returns -95 (ENOTSUP) and the host side
+ * (criterions.py) refuses the batch with the limit in the message. */
+#define S2T_CTC_MAX_TARGET 511
+#define S2T_CTC_MAX_VOCAB 40704
 int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len, const int* in_len,
                  float* lse, float* la, float* lb, float* nll, void* grad, float* loss_sum,
                  int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, int phase, const float* grad_scale_dev,

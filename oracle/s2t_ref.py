@@ -301,7 +301,10 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
     if pre:
         x = layer_norm(W, pfx + "layer_norm.", x)
     x = x.transpose(0, 1)
-    return F.linear(x, W[pfx + "output_projection.weight"])                  # :784-788
+    # :784-788; --share-decoder-input-output-embed: the projection's weight is the embedding table itself
+    # (fairseq/models/transformer.py:618-624), so its state dict need not carry a second copy
+    w_out = W.get(pfx + "output_projection.weight")
+    return F.linear(x, w_out if w_out is not None else W[pfx + "embed_tokens.weight"])
 
 
 # ------------------------------------------------------------------ generation (a22)
@@ -635,7 +638,8 @@ def param_shapes(cfg, V_src, V_tgt, criterion_fc=False, V_aux=0):
             ff(p); ln(p + "final_layer_norm.")
         if cfg["dec_pre_ln"]:
             ln(dec + "layer_norm.")
-        s[dec + "output_projection.weight"] = (V, D)
+        if not cfg.get("share_dec_embed", False):
+            s[dec + "output_projection.weight"] = (V, D)
     if criterion_fc:
         s["criterion.ctc_aware_model.fc_out.weight"] = (V_src, D)
         s["criterion.ctc_aware_model.fc_out.bias"] = (V_src,)

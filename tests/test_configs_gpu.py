@@ -57,14 +57,16 @@ def build(arch, dtype, criterion="ctc_multi_loss", seed=11, dual=False, ctc_laye
     conv = eval(a.encoder_convolutions)[0][0]
     cfg = s2t_ref.default_cfg(D=a.encoder_embed_dim, heads=a.encoder_attention_heads, ffn=a.encoder_ffn_embed_dim,
                               enc_layers=a.encoder_layers, dec_layers=a.decoder_layers, ctc_layer=ctc_layer if is_ctc else 0,
-                              conv_ch=conv, act=a.activation_fn)
+                              conv_ch=conv, act=a.activation_fn,
+                              share_dec_embed=bool(over.get("share_decoder_input_output_embed", False)))
     W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, len(src), len(tgt), criterion_fc=is_ctc, V_aux=len(src) if dual else 0), seed)
     if is_ctc:
         # a CTC head whose arg-max wanders over a handful of units (and the blank): runs of equal predictions occur, the
         # compression really shortens the sequences (random-init logits over 5001 units would almost never repeat)
         blank = src.index("<ctc_blank>")
         W["encoder.ctc_fc.bias"][[7, 19, 123, 2048, 4999, blank]] += 6.0
-    W["decoder.output_projection.weight"][2] *= 4.0           # EOS reachable for the generation tests (as tests/golden/make_golden.py)
+    if "decoder.output_projection.weight" in W:
+        W["decoder.output_projection.weight"][2] *= 4.0       # EOS reachable for the generation tests (as tests/golden/make_golden.py)
     model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
     if is_ctc:
         with torch.no_grad():
@@ -232,6 +234,34 @@ def test_cfg5_m_knowledge_distillation(dtype):
     assert ss == sample["ntokens"]
     assert rel(loss, oloss) <= t["loss"], (float(loss), float(oloss))
     compare_grads(engine_grads(model), ograds, t["grad"], t["cos"], what="kd %s" % dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_shared_decoder_input_output_embedding(dtype):
+    """--share-decoder-input-output-embed (fairseq/models/transformer.py:538,618-624): one [V, D] table serves the token look-up and
+    the output projection; its gradient is the sum of the embedding scatter and the projection's dW"""
+    a, task, model, crit, cfg, W = build("s2t_transformer_s", dtype, criterion="label_smoothed_cross_entropy",
+                                         share_decoder_input_output_embed=True)
+    assert "decoder.output_projection.weight" not in W and "decoder.output_projection.weight" not in model.arena.slices
+    sd = model.state_dict()                                         # the reference's checkpoints carry the tensor under both names
+    assert torch.equal(sd["decoder.output_projection.weight"].float(), sd["decoder.embed_tokens.weight"].float())
+    sample = batch(task, 4, 600, 24, 20, 9, lengths=[600, 600, 531, 322])
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    loss, ss, log = crit(model, to_dev(sample))
+    loss.backward()
+
+    def run(Wg):
+        ni = sample["net_input"]
+        enc, _ = s2t_ref.encoder_forward(Wg, cfg, ni["src_tokens"], ni["src_lengths"], training=True)
+        logits = s2t_ref.decoder_forward(Wg, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+        return s2t_ref.label_smoothed_nll(logits, sample["target"], 0.1, cfg["pad"])
+    out, ograds = oracle_grads(W, run)
+    t = TOL[dtype]
+    assert rel(loss, out[0]) <= t["loss"], (float(loss), float(out[0]))
+    compare_grads(engine_grads(model), ograds, t["grad"], t["cos"], what="shared embed %s" % dtype)
+    # the embedding gradient is NOT the scatter alone: the projection's share dominates it
+    assert float(ograds["decoder.embed_tokens.weight"].norm()) > 0
 
 
 def test_cfg5_m_dual_decoder_loss():

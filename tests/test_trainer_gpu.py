@@ -120,3 +120,66 @@ def test_train_step_applies_time_stretch_and_specaugment():
     assert np.isfinite(st["loss"]) and np.isfinite(st["gnorm"])
     assert st["nframes"] != 650                           # stretched lengths are what the step saw
     assert sample["net_input"]["src_tokens"].shape[1] == 200   # the staged batch itself is untouched
+
+
+def test_freeze_pretrained_leaves_loaded_parameters_untouched():
+    """--freeze-pretrained (conv_transformer.py:114-121): every parameter found in the loaded state dict leaves the optimizer --
+    bit-identical after updates, no share of the gradient norm -- while the rest keeps training"""
+    a, task, model, crit, tr = _setup(torch.bfloat16, dropout=0.0)
+    sd = {k: v.clone() for k, v in model.state_dict().items() if k.startswith("encoder.") and "_float_tensor" not in k}
+    a.freeze_pretrained = True
+    model.load_state_dict(sd, strict=False, args=a)
+    frozen = [n for n in model.arena.slices if n.startswith("encoder.")]
+    assert frozen and model.arena.frozen
+    before = {n: model.arena.p(n).clone() for n in model.arena.slices}
+    m_before = model.arena.exp_avg.clone()
+    sample = tr.prepare(task.dummy_batch(seed=1, lengths=[200, 180, 150, 120]))
+    for _ in range(2):
+        tr.train_step([sample])
+    st = tr.reduce_stats()
+    moved = 0
+    for n in model.arena.slices:
+        same = torch.equal(before[n], model.arena.p(n))
+        if n.startswith("encoder."):
+            assert same, n
+            assert float(model.arena.g(n).abs().max()) == 0.0, n           # zeroed before the norm
+        elif not same:
+            moved += 1
+    assert moved > 10
+    for s, e in model.arena.frozen:
+        assert torch.equal(model.arena.exp_avg[s:e], m_before[s:e])       # no moments either
+    # the reported norm is the norm of the trainable gradients only
+    g = model.arena.grad.double()
+    assert abs(float(g.norm()) - st["gnorm"]) <= 1e-3 * st["gnorm"] or st["gnorm"] >= a.clip_norm
+
+
+def test_checkpoint_round_trip_resumes_training(tmp_path):
+    """save after 2 updates, train 2 more; a fresh trainer that loads the file and trains the same 2 updates ends on the same
+    parameters, moments and schedule position (fairseq/trainer.py:173-266)"""
+    a, task, model, crit, tr = _setup(torch.bfloat16)                      # dropout on: the per-update seed must resume too
+    sample = task.dummy_batch(seed=1, lengths=[200, 180, 150, 120])
+    for _ in range(2):
+        tr.train_step([tr.prepare(sample)])
+    path = str(tmp_path / "checkpoint_last.pt")
+    tr.save_checkpoint(path, {"train_iterator": {"epoch": 1}})
+    for _ in range(2):
+        tr.train_step([tr.prepare(sample)])
+    want = tr.reduce_stats()
+    want_p, want_m = model.arena.master.clone(), model.arena.exp_avg.clone()
+
+    a2, task2, model2, crit2, tr2 = _setup(torch.bfloat16)
+    assert tr2.load_checkpoint(str(tmp_path / "missing.pt")) is None
+    extra = tr2.load_checkpoint(path)
+    assert extra == {"train_iterator": {"epoch": 1}} and tr2.num_updates == 2
+    assert tr2.optimizer.get_lr() == pytest.approx(tr.lr_scheduler.step_update(2)); tr.lr_scheduler.step_update(tr.num_updates)
+    for _ in range(2):
+        tr2.train_step([tr2.prepare(sample)])
+    got = tr2.reduce_stats()
+    # float atomics (embedding scatter, split weight-gradient tails) make two runs differ in the last bits, and Adam turns the
+    # sign of a noise-level gradient (an attention key bias: exactly zero in exact arithmetic) into a full +-lr step
+    close = lambda x, y: float(((x - y).abs() <= 1e-5 + 1e-3 * y.abs()).float().mean())
+    assert close(model2.arena.master, want_p) > 0.99 and close(model2.arena.exp_avg, want_m) > 0.99
+    assert abs(got["loss"] - want["loss"]) <= 1e-3 * abs(want["loss"]) and tr2.num_updates == 4
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) >= {"args", "model", "criterion", "optimizer_history", "extra_state", "last_optimizer_state"}
+    assert "encoder.layers.0.self_attn.q_proj.weight" in ck["model"] and "ctc_aware_model.fc_out.weight" in ck["criterion"]
