@@ -31,7 +31,7 @@ struct Prob {
     int n_out, n_in, tokens, ldy, ldx, ldw, pad0, pad1;
 };
 // one work item = one 256 x 256 output tile over the K-tiles [kt0, kt1) of its problem.  `atomic`: the tile's token range is
-// shared with other items (only the tail round of a launch is cut like that), so the result is ADDED with f32 atomics.
+// shared with other items (a tile that straddles two workgroups' shares), so the result is ADDED with f32 atomics.
 struct Item { int prob, tm, tn, kt0, kt1, atomic; };
 
 __device__ uint4 g_zero_page[64];                                  // 1 KiB of zeros (device globals are zero-initialised)
@@ -65,10 +65,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const Prob* __restr
     const int grp = wr;
     const char* zero = reinterpret_cast<const char*>(g_zero_page);
 
-    // items are dealt in rounds of gridDim.x (the host sorts them longest first and cuts the tail round into equal pieces);
-    // inside a round an XCD's workgroups (b, b + 8, ...) take a contiguous run: tiles of one dW sharing operand columns meet in one L2
+    // the table is [round][workgroup slot] (the host balances the slots' token counts); an XCD's workgroups (b, b + 8, ...) take a
+    // contiguous run of slots: neighbouring tiles of one dW, which share operand columns, meet in one L2
     for (int it = xcd_remap(blockIdx.x, gridDim.x); it < n_items; it += gridDim.x) {
         const Item I = items[it];
+        if (I.kt0 >= I.kt1) break;                                       // this slot's list is shorter than the longest one
         const Prob P = probs[I.prob];
         const int tm = I.tm, tn = I.tn;
         const int row0 = tm * 256, col0 = tn * 256;                      // row = n_out index, col = n_in index
@@ -262,10 +263,41 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
         flops += 2.0 * s.n_out * (double)s.n_in * s.tokens;
         bytes += 2.0 * s.tokens * ((double)s.n_out + s.n_in) + 8.0 * s.n_out * (double)s.n_in;
     }
-    // Work list: longest reductions first (stable: the tiles of one dW stay neighbours), dealt in rounds of one item per CU.  A
-    // partly filled last round would leave CUs idle for a whole tile's time: its tiles are cut along the token range into as many
-    // equal pieces as fill the round (those pieces meet in f32 atomics: at most 256 x 256 KB, once per launch).
-    const int G = 256;
+    // Work list: longest reductions first (stable: the tiles of one dW stay neighbours), dealt in rounds of one item per CU; the
+    // workgroups of a round sweep the token range of neighbouring tiles in step, which is what lets the L2s / the MALL serve the
+    // operand columns those tiles share (a schedule that balanced the CUs perfectly by handing each an arbitrary stretch of a line
+    // of tiles ran 1.6x SLOWER: every tile then streams its 24 MB of operands from HBM alone).  Two cuts along the token range, whose
+    // pieces meet in f32 atomics:
+    //  * a tile whose reduction is much longer than a CU's fair share of the launch (the decoder's group holds 374-K-tile products
+    //    of the encoder output next to 40-K-tile products of its own tokens: 48 long tiles kept 208 CUs waiting) is cut into equal
+    //    pieces of about that share, the same token ranges for all tiles of its dW;
+    //  * a partly filled last round would leave CUs idle for a whole item's time: its items are cut into as many equal pieces as
+    //    fill the round.
+    constexpr int G = 256, C0 = 6, MINP = 8;
+    long units = 0;
+    for (const Item& t : iv) units += t.kt1 + C0;
+    const int share = (int)((units + G - 1) / G);
+    {
+        std::vector<Item> cutv;
+        cutv.reserve(iv.size());
+        for (size_t i = 0; i < iv.size();) {
+            size_t j = i;
+            while (j < iv.size() && iv[j].prob == iv[i].prob) ++j;           // the tiles of one dW: same reduction length
+            const int nk = iv[i].kt1;
+            const int f = nk > share + share / 4 ? std::min((nk + share - 1) / share, nk / MINP) : 1;
+            if (f <= 1) cutv.insert(cutv.end(), iv.begin() + i, iv.begin() + j);
+            else {
+                const int per = (nk + f - 1) / f;
+                for (int piece = 0; piece < f; ++piece)                      // piece-major: equal token ranges sit next to each other
+                    for (size_t k = i; k < j; ++k) {
+                        const int k0 = piece * per, k1 = std::min(nk, k0 + per);
+                        if (k0 < k1) cutv.push_back(Item{iv[k].prob, iv[k].tm, iv[k].tn, k0, k1, 1});
+                    }
+            }
+            i = j;
+        }
+        iv.swap(cutv);
+    }
     std::stable_sort(iv.begin(), iv.end(), [](const Item& x, const Item& y) { return x.kt1 - x.kt0 > y.kt1 - y.kt0; });
     const int rem = (int)(iv.size() % G);
     if (rem) {
@@ -275,11 +307,13 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
             iv.resize(iv.size() - rem);
             for (int piece = 0; piece < f; ++piece)
                 for (const Item& t : tail) {
-                    const int nk = t.kt1, per = (nk + f - 1) / f, k0 = piece * per, k1 = std::min(nk, k0 + per);
-                    if (k0 < k1) iv.push_back(Item{t.prob, t.tm, t.tn, k0, k1, 1});
+                    const int nk = t.kt1 - t.kt0, ff = std::max(1, std::min(f, nk / MINP)), per = (nk + ff - 1) / ff;
+                    const int k0 = t.kt0 + piece * per, k1 = std::min(t.kt1, k0 + per);
+                    if (piece < ff && k0 < k1) iv.push_back(Item{t.prob, t.tm, t.tn, k0, k1, ff > 1 ? 1 : t.atomic});
                 }
         }
     }
+    const int used = (int)std::min<size_t>(iv.size(), G);
     const size_t pb = pv.size() * sizeof(Prob), ib = iv.size() * sizeof(Item), need = pb + ib;
     hipStream_t st = (hipStream_t)stream;
     if (need > g_dev_table_bytes) {
@@ -298,7 +332,7 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr = true; }
     const int n_items = (int)iv.size();
-    hipLaunchKernelGGL(wgrad_group_kernel, dim3(n_items < G ? n_items : G), dim3(512), 2 * BUF, st,
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3(used), dim3(512), 2 * BUF, st,
                        (const Prob*)g_dev_table, (const Item*)((char*)g_dev_table + pb), n_items);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
