@@ -265,11 +265,23 @@ __device__ __forceinline__ int head_xcd_remap(int& head, int nheads, int ntile) 
     return slot % ntile;
 }
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    const bf16 a = (bf16)lo, b = (bf16)hi;
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {          // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
 }
-__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
+// max over the four 16-lane rows of a wave (lanes r, r + 16, r + 32, r + 48): two VALU lane swaps instead of two LDS round trips.
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second, v_permlane32_swap the upper
+// half of the first with the lower half of the second: with both operands = x, (a, b) = (x0 x0 x2 x2, x1 x1 x3 x3), then halves.
+__device__ __forceinline__ float max_over_rows(float v) {
+    uint32_t x = __builtin_bit_cast(uint32_t, v);
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+    x = __builtin_bit_cast(uint32_t, v);
+    r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
+}
+__global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
@@ -302,37 +314,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
     const int ntile = (kv_end + 63) / 64;
 
     // staging: thread -> (row, chunk) of the K and of the V tile, two 16-byte pieces each
-    u32x4 kr[2], vr[2];
-    auto gload = [&](int kv0) {
+    // Staging by LDS-DMA (global_load_lds, 16 bytes per lane, 1 KiB = 8 tile rows per wave-instruction, lane-linear in LDS): no
+    // staging registers (the kernel then fits three workgroups per CU) and no ds_write pass.  The XOR swizzle of the 16-byte
+    // chunks is applied on the SOURCE side: the lane that fills position (row, pos) fetches chunk pos ^ swz(row), so chunk c sits
+    // at position c ^ swz(row): K rows are read back as b128 rows (swz = row & 7), V by transposing reads (swz = row & 6).
+    // Rows past klen are NOT zeroed: the address is clamped to the last row of the tensor (finite data), their scores are masked
+    // to -inf and their probabilities are exact zeros.
+    auto stage = [&](int kv0, char* st) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
-            const bool ok = kv0 + row < klen;
+            const int r8 = 8 * (wave + 4 * i), row = r8 + (lane >> 3), pos = lane & 7;
             const long r = min(kv0 + row, p.Tk - 1);
-            kr[i] = *reinterpret_cast<const u32x4*>(Kg + r * p.k_st + c * 8);
-            vr[i] = *reinterpret_cast<const u32x4*>(Vg + r * p.v_st + c * 8);
-            if (!ok) { kr[i] = (u32x4){0, 0, 0, 0}; vr[i] = (u32x4){0, 0, 0, 0}; }
-        }
-    };
-    auto lstore = [&](char* st) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
-            *reinterpret_cast<u32x4*>(st + row * 128 + ((c ^ (row & 7)) << 4)) = kr[i];                 // K: row reads (b128)
-            *reinterpret_cast<u32x4*>(st + 8192 + row * 128 + ((c ^ (row & 6)) << 4)) = vr[i];          // V: transposed reads
+            char* dst = st + __builtin_amdgcn_readfirstlane(r8 * 128);
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(Kg + r * p.k_st + ((pos ^ (row & 7)) << 3)),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(Vg + r * p.v_st + ((pos ^ (row & 6)) << 3)),
+                                             (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
         }
     };
     const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
     const float drop_inv = 1.f / (1.f - p.p_drop);
+    const uint32_t drop_ks = drop_seed_key(p.seed);
     const float sc2 = p.scale * 1.44269504088896f;
+    // the whole dropout index space of this call in one 32-bit quad word (always, short of 17 G attention probabilities)
+    const bool plain = !p.causal && !p.dist_pen && (uint64_t)p.B * p.H * p.Tq * (uint64_t)((p.Tk + 3) & ~3) < (1ull << 34);
 
-    if (ntile > 0) { gload(0); lstore(smem); }
+    // the Q fragments must have landed before the loop: left pending, the compiler's wait for them sits behind the loop's own
+    // prefetch in the in-order counter and becomes a vmcnt(0) -- the full latency of the K/V prefetch, exposed, every iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0), the other counters untouched
+    if (ntile > 0) stage(0, smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                  // the DMA is not a register write: the compiler inserts no wait for it
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
         const char* sK = smem + (t & 1) * 16384;
         const char* sV = sK + 8192;
-        if (t + 1 < ntile) gload(kv0 + 64);
+        if (t + 1 < ntile) stage(kv0 + 64, smem + ((t + 1) & 1) * 16384);   // its readers of two tiles ago passed the last barrier
         // ---- S^T = K Q^T
         f32x4 s[2][4];
 #pragma unroll
@@ -350,53 +367,70 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
                 for (int g = 0; g < 2; ++g) s[qb][j] = mma16<bf16>(kf[g], qf[qb][g], s[qb][j]);
             }
         }
-        // ---- online softmax, per lane = per query (base-2 domain: s2 = s * scale * log2 e); interior tiles carry no masks
+        // ---- online softmax, per lane = per query (base-2 domain: p = exp2(s * scale * log2 e - max)); interior tiles carry no
+        // masks.  VALU is what bounds this kernel (32 MFMAs against ~700 VALU slots per 64 keys), so the per-element work is
+        // kept to: a share of a max3 on the RAW score (the scale is positive), one fma, the exp2, a share of a packed add for the
+        // row sum, a share of the bf16 pair convert, and for dropout a 16-bit compare + select on the value.  The 1/(1-p) of the
+        // dropout is a constant factor of O: it is applied once, with the 1/l normalisation, at the end.
         u32x4 pf[2][2];                                // [query block][32-key block]
-        auto softmax_tile = [&](auto masked) {
-            constexpr bool MASK = decltype(masked)::value;
+        // Two instantiations: FAST = interior tile of a plain softmax with an index space below 2^34 elements (no masks, no
+        // distance penalty, the dropout quad index stays in its low word); the other handles everything dynamically.
+        auto softmax_tile = [&](auto fast_tag, auto drop_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value, DROP = decltype(drop_tag)::value;      // DROP only narrows FAST
+            const bool pen = !FAST && p.dist_pen;
+            const float k2 = pen ? 1.f : sc2;          // pen: the scores are moved to the log2 domain first (scale, then - log2 distance)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const int qrow = qw + 16 * qb + r16;
                 float mx = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (!FAST) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = s[qb][j][r] * sc2;
-                        if (p.dist_pen) v -= dist_pen_log2(qrow, kv0 + 16 * j + 4 * q + r);
-                        if constexpr (MASK) {
+                        for (int r = 0; r < 4; ++r) {
+                            float v = s[qb][j][r];
                             const int key = kv0 + 16 * j + 4 * q + r;
-                            const bool ok = key < klen && (!p.causal || key <= qrow);
-                            v = ok ? v : -INFINITY;
+                            if (pen) v = v * sc2 - dist_pen_log2(qrow, key);
+                            v = (key < klen && (!p.causal || key <= qrow)) ? v : -INFINITY;
+                            s[qb][j][r] = v;
                         }
-                        s[qb][j][r] = v;
-                        mx = fmaxf(mx, v);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float mn = fmaxf(m[qb], mx);
+                    mx = fmaxf(fmaxf(mx, s[qb][j][0]), s[qb][j][1]);
+                    mx = fmaxf(fmaxf(mx, s[qb][j][2]), s[qb][j][3]);
+                }
+                mx = max_over_rows(mx);
+                const float mn = fmaxf(m[qb], mx * k2);                    // -inf * k2 = -inf (k2 > 0)
                 const float mu = (mn == -INFINITY) ? 0.f : mn;
                 const float alpha = __builtin_amdgcn_exp2f(m[qb] - mu);    // m = -inf -> 0
                 m[qb] = mn;
-                float rs = 0.f;
+                f32x2_t rs2 = {0.f, 0.f};
+                // dropout: the quad of keys 4q .. 4q+3 of 16-key tile j has index quad0 + 4 j (rows are a multiple of 4 keys long)
+                const bool drop = FAST ? DROP : p.p_drop > 0.f;
+                const uint64_t quad0 = drop ? drop_index(p, b, h, qrow, kv0 + 4 * q) >> 2 : 0;
+                const uint32_t qlo = (uint32_t)quad0, hwm0 = drop_high_mix(p.seed, quad0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float pv[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(s[qb][j][r] - mu); rs += pv[r]; }
-                    if (p.p_drop > 0.f) {
-                        const u32x2 hq = drop_hash4(p.seed, drop_index(p, b, h, qrow, kv0 + 16 * j + 4 * q) >> 2);   // keys 4q .. 4q+3 = one quad
+                    for (int r = 0; r < 4; ++r) pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][j][r], k2, -mu));
+                    rs2 += (f32x2_t){pv[0], pv[1]};
+                    rs2 += (f32x2_t){pv[2], pv[3]};
+                    if (drop) {
+                        const u32x2 hq = FAST ? drop_hash4_lo(drop_ks, hwm0, qlo + 4u * j) : drop_hash4(p.seed, quad0 + 4 * j);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) pv[r] = drop_field(hq, r) >= drop_th16 ? pv[r] * drop_inv : 0.f;
+                        for (int r = 0; r < 4; ++r) pv[r] = drop_field(hq, r) >= drop_th16 ? pv[r] : 0.f;
                     }
                     pf[qb][j >> 1][2 * (j & 1)] = pack_bf16(pv[0], pv[1]);
                     pf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(pv[2], pv[3]);
                 }
-                l[qb] = l[qb] * alpha + rs;
+                l[qb] = l[qb] * alpha + (rs2[0] + rs2[1]);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) o[qb][n] *= alpha;
             }
         };
-        if (p.causal || kv0 + 64 > klen) softmax_tile(std::true_type{}); else softmax_tile(std::false_type{});
+        if (!(plain && kv0 + 64 <= klen)) softmax_tile(std::false_type{}, std::false_type{});
+        else if (p.p_drop > 0.f) softmax_tile(std::true_type{}, std::true_type{});
+        else softmax_tile(std::true_type{}, std::false_type{});
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -415,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) o[qb][n] = mma16<bf16>(vf, pf[qb][kb], o[qb][n]);
             }
-        if (t + 1 < ntile) lstore(smem + ((t + 1) & 1) * 16384);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                              // tile t + 1 has landed (this wave's share; the barrier covers the rest)
         __syncthreads();
     }
     bf16* Og = reinterpret_cast<bf16*>(p.O) + (long)b * p.o_sb + (long)h * DH;
@@ -425,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnArgs p) {
         float lt = l[qb];
         lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
         if (qrow >= p.Tq) continue;
-        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        const float inv = lt > 0.f ? drop_inv / lt : 0.f;                 // the dropout's 1/(1-p) rides on the normalisation
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             u32x2 w;
@@ -685,28 +719,24 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v, int r) {
         default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, true);
     }
 }
-struct Stage2 {                       // two [64][64] bf16 tiles per stage, register-prefetched
-    u32x4 ra[2], rb[2];
-    __device__ __forceinline__ void gload(const bf16* A, long a_st, const bf16* B, long b_st, int r0, int nvalid, int nrows) {
+// Two [64 rows][64 d] bf16 tiles (A at st, B at st + 8 KiB) staged by LDS-DMA: 16 bytes per lane, 8 tile rows per wave-instruction,
+// lane-linear in LDS, so the XOR swizzle (chunk c of row r at position c ^ (r & 7)) is applied on the source side.  Rows past the
+// tensor are clamped to its last row (finite data): whoever consumes the tile masks their contribution, nothing is zeroed here.
+// No staging registers, no ds_write pass; the caller waits (vmcnt) before the barrier that publishes the tile.
+__device__ __forceinline__ void stage2_dma(const bf16* A, long a_st, const bf16* B, long b_st, int r0, int nrows, char* st, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
-            const bool ok = r0 + row < nvalid;
-            const long r = min(r0 + row, nrows - 1);
-            ra[i] = *reinterpret_cast<const u32x4*>(A + r * a_st + c * 8);
-            rb[i] = *reinterpret_cast<const u32x4*>(B + r * b_st + c * 8);
-            if (!ok) { ra[i] = (u32x4){0, 0, 0, 0}; rb[i] = (u32x4){0, 0, 0, 0}; }
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int r8 = 8 * (wave + 4 * i), row = r8 + (lane >> 3), pos = lane & 7;
+        const long r = min(r0 + row, nrows - 1);
+        const int ch = (pos ^ (row & 7)) << 3;
+        char* dst = st + __builtin_amdgcn_readfirstlane(r8 * 128);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(A + r * a_st + ch),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(B + r * b_st + ch),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
     }
-    __device__ __forceinline__ void lstore(char* st) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
-            *reinterpret_cast<u32x4*>(st + row * 128 + ((c ^ (row & 7)) << 4)) = ra[i];
-            *reinterpret_cast<u32x4*>(st + 8192 + row * 128 + ((c ^ (row & 7)) << 4)) = rb[i];
-        }
-    }
-};
+}
+#define S2T_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)               /* vmcnt(0); lgkmcnt / expcnt untouched */
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     constexpr int DH = 64;
@@ -744,40 +774,50 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
         for (int n = 0; n < 4; ++n) { dkT[kb][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvT[kb][n] = dkT[kb][n]; }
     const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
     const float drop_inv = 1.f / (1.f - p.p_drop);
+    const uint32_t drop_ks = drop_seed_key(p.seed), drop_hwm = drop_high_mix(p.seed, 0);   // < 2^34 elements (launcher): quad index in one word
+    const uint32_t tkq = (uint32_t)((p.Tk + 3) >> 2);                                        // quads per (padded) row of the index space
 
     const int qstart = p.causal ? bx * 128 : 0;                 // queries before the first key of the workgroup see nothing
     const int ntile = qstart < p.Tq ? (p.Tq - qstart + 63) / 64 : 0;
-    Stage2 sg;
-    // per-query statistics of the tile (LSE pre-multiplied by log2 e, Delta) travel with it: threads 0..63 / 64..127
+    // per-query statistics of the tile (LSE, Delta) travel with it: 4-byte LDS-DMA by waves 0 / 1
     float* sStat = reinterpret_cast<float*>(smem + 32768);          // [2 stages][2][64]
-    float stat = 0.f;
-    auto stat_load = [&](int qt) {
-        if (threadIdx.x < 128) {
-            const int row = qt + (threadIdx.x & 63);
-            stat = 0.f;
-            if (row < p.Tq) stat = threadIdx.x < 64 ? lse[row] * 1.44269504088896f : dlt[row];
+    auto stage = [&](int qt, int stg) {
+        stage2_dma(Qg, p.q_st, dOg, p.do_st, qt, p.Tq, smem + stg * 16384, wave, lane);
+        if (wave < 2) {
+            const float* src = (wave == 0 ? lse : dlt) + min(qt + lane, p.Tq - 1);
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
+                                             (__attribute__((address_space(3))) void*)(sStat + stg * 128 + wave * 64), 4, 0, 0);
         }
     };
-    auto stat_store = [&](int stage) { if (threadIdx.x < 128) sStat[stage * 128 + threadIdx.x] = stat; };
-    if (ntile > 0) { sg.gload(Qg, p.q_st, dOg, p.do_st, qstart, p.Tq, p.Tq); stat_load(qstart); sg.lstore(smem); stat_store(0); }
+    if (ntile > 0) stage(qstart, 0);
+    S2T_WAIT_VM0();
     __syncthreads();
     const float sc2 = p.scale * 1.44269504088896f;
+    const bool generic = p.causal || p.dist_pen;
     for (int t = 0; t < ntile; ++t) {
         const int qt = qstart + t * 64;
         const char* sQ = smem + (t & 1) * 16384;
         const char* sDO = sQ + 8192;
         const float* sL = sStat + (t & 1) * 128;
-        if (t + 1 < ntile) { sg.gload(Qg, p.q_st, dOg, p.do_st, qt + 64, p.Tq, p.Tq); stat_load(qt + 64); }
-#pragma unroll
+        if (t + 1 < ntile) stage(qt + 64, (t + 1) & 1);
+        // EDGE: masks evaluated per element (query rows past Tq -- their tile rows repeat the last query --, the causal triangle,
+        // the distance penalty); DROP: dropout on.  Common factors leave the inner loop: dS carries neither the softmax scale (dK is
+        // scaled once at the end) nor, like P, the dropout's 1/(1-p) (it multiplies dP inside one fma, and dV at the end).
+        auto tile = [&](auto edge_tag, auto drop_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value, DROP = decltype(drop_tag)::value;
+#pragma unroll 1
         for (int ib = 0; ib < 2; ++ib) {                  // 32 queries at a time: their P / dS operands are consumed at once
         u32x4 pf[2], sf[2];                             // [key block]: D*P and dS as B operands
 #pragma unroll
-        for (int i = 2 * ib; i < 2 * ib + 2; ++i) {
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * ib + ii;
             u32x4 qa[2], da[2];
 #pragma unroll
             for (int g = 0; g < 2; ++g) { qa[g] = row_frag128(sQ, 16 * i + r16, 4 * g + q); da[g] = row_frag128(sDO, 16 * i + r16, 4 * g + q); }
-            const f32x4 L = *reinterpret_cast<const f32x4*>(sL + 16 * i + 4 * q);
+            const f32x4 L = *reinterpret_cast<const f32x4*>(sL + 16 * i + 4 * q) * 1.44269504088896f;
             const f32x4 Dl = *reinterpret_cast<const f32x4*>(sL + 64 + 16 * i + 4 * q);
+            // dropout: lane r16 hashes (query 4q + (r16 & 3), key quad r16 >> 2) of both key blocks
+            const uint32_t qrow_quads = DROP ? (uint32_t)(((b * p.H + h) * p.Tq + qt + 16 * i + 4 * q + (r16 & 3))) * tkq : 0u;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
@@ -789,25 +829,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
                 }
                 const int key = kw + 16 * kb + r16;
                 u32x2 hq = {0u, 0u};
-                if (p.p_drop > 0.f) hq = drop_hash4(p.seed, drop_index(p, b, h, qt + 16 * i + 4 * q + (r16 & 3), key) >> 2);
+                if constexpr (DROP) hq = drop_hash4_lo(drop_ks, drop_hwm, qrow_quads + ((uint32_t)key >> 2));
                 float pv[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // rows past Tq are zero in Q / dO / statistics and so contribute exactly 0; columns past klen are
-                    // discarded at the store: only the causal triangle needs a per-element mask
-                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - (p.dist_pen ? dist_pen_log2(qt + 16 * i + 4 * q + r, key) : 0.f) - L[r]);
-                    if (p.causal) e = (key <= qt + 16 * i + 4 * q + r) ? e : 0.f;
-                    float dsc = 1.f;
-                    if (p.p_drop > 0.f) {
-                        // lane r16 hashed (query 4q + (r16 & 3), key quad r16 >> 2): the quad of (query 4q + r, own key) sits in
-                        // lane (r16 & ~3) | r of the same 4-lane group -> DPP quad broadcast, then take the own key's field
-                        dsc = drop_field((u32x2){quad_bcast(hq[0], r), quad_bcast(hq[1], r)}, r16 & 3) >= drop_th16 ? drop_inv : 0.f;
+                    const int qrow = qt + 16 * i + 4 * q + r;
+                    float arg = __builtin_fmaf(st[r], sc2, -L[r]);
+                    if constexpr (EDGE) { if (p.dist_pen) arg -= dist_pen_log2(qrow, key); }
+                    float e = __builtin_amdgcn_exp2f(arg);
+                    if constexpr (EDGE) e = (qrow < p.Tq && (!p.causal || key <= qrow)) ? e : 0.f;     // keys past klen: discarded at the store
+                    if constexpr (DROP) {
+                        // the quad of (query 4q + r, own key) sits in lane (r16 & ~3) | r of the same 4-lane group -> DPP quad
+                        // broadcast, then take the own key's field
+                        const bool keep = drop_field((u32x2){quad_bcast(hq[0], r), quad_bcast(hq[1], r)}, r16 & 3) >= drop_th16;
+                        pv[r] = keep ? e : 0.f;
+                        ds[r] = e * __builtin_fmaf(keep ? dp[r] : 0.f, drop_inv, -Dl[r]);
+                    } else {
+                        pv[r] = e;
+                        ds[r] = e * (dp[r] - Dl[r]);
                     }
-                    pv[r] = e * dsc;
-                    ds[r] = e * (dsc * dp[r] - Dl[r]) * p.scale;
                 }
-                pf[kb][2 * (i & 1)] = pack_bf16(pv[0], pv[1]); pf[kb][2 * (i & 1) + 1] = pack_bf16(pv[2], pv[3]);
-                sf[kb][2 * (i & 1)] = pack_bf16(ds[0], ds[1]); sf[kb][2 * (i & 1) + 1] = pack_bf16(ds[2], ds[3]);
+                pf[kb][2 * ii] = pack_bf16(pv[0], pv[1]); pf[kb][2 * ii + 1] = pack_bf16(pv[2], pv[3]);
+                sf[kb][2 * ii] = pack_bf16(ds[0], ds[1]); sf[kb][2 * ii + 1] = pack_bf16(ds[2], ds[3]);
             }
         }
 #pragma unroll
@@ -820,9 +863,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
                 }
             }
         }
-        if (t + 1 < ntile) { sg.lstore(smem + ((t + 1) & 1) * 16384); stat_store((t + 1) & 1); }
+        };
+        const bool edge = generic || qt + 64 > p.Tq;
+        if (p.p_drop > 0.f) { if (edge) tile(std::true_type{}, std::true_type{}); else tile(std::false_type{}, std::true_type{}); }
+        else if (edge) tile(std::true_type{}, std::false_type{});
+        else tile(std::false_type{}, std::false_type{});
+        S2T_WAIT_VM0();                                   // tile t + 1 has landed (this wave's share; the barrier covers the rest)
         __syncthreads();
     }
+    const float dv_scale = p.p_drop > 0.f ? drop_inv : 1.f;
     bf16* dKg = reinterpret_cast<bf16*>(p.dK) + (long)b * p.dk_sb + (long)h * DH;
     bf16* dVg = reinterpret_cast<bf16*>(p.dV) + (long)b * p.dv_sb + (long)h * DH;
 #pragma unroll
@@ -831,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
         if (key >= p.Tk) continue;
         const float kz = key < klen ? 1.f : 0.f;          // padded keys get exact zeros
 #pragma unroll
-        for (int n = 0; n < 4; ++n) { dkT[kb][n] *= kz; dvT[kb][n] *= kz; }
+        for (int n = 0; n < 4; ++n) { dkT[kb][n] *= kz * p.scale; dvT[kb][n] *= kz * dv_scale; }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             u32x2 w;
@@ -890,22 +939,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
         for (int n = 0; n < 4; ++n) dqT[qb][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
     const float drop_inv = 1.f / (1.f - p.p_drop);
+    const uint32_t drop_ks = drop_seed_key(p.seed), drop_hwm = drop_high_mix(p.seed, 0);   // < 2^34 elements (launcher): quad index in one word
+    const uint32_t tkq = (uint32_t)((p.Tk + 3) >> 2);
 
     int kv_end = klen;
     if (p.causal) kv_end = min(kv_end, bx * 128 + 128);
     const int ntile = (kv_end + 63) / 64;
     const float sc2 = p.scale * 1.44269504088896f;
-    Stage2 sg;
-    if (ntile > 0) { sg.gload(Kg, p.k_st, Vg, p.v_st, 0, klen, p.Tk); sg.lstore(smem); }
+    const bool generic = p.causal || p.dist_pen;
+    // Q / dO fragments must have landed before the loop: left pending, the compiler's wait for them sits behind the loop's own
+    // prefetch in the in-order counter and becomes a vmcnt(0), i.e. the whole K/V prefetch latency, exposed, every iteration
+    S2T_WAIT_VM0();
+    if (ntile > 0) stage2_dma(Kg, p.k_st, Vg, p.v_st, 0, p.Tk, smem, wave, lane);
+    S2T_WAIT_VM0();
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
         const char* sK = smem + (t & 1) * 16384;
         const char* sV = sK + 8192;
-        if (t + 1 < ntile) sg.gload(Kg, p.k_st, Vg, p.v_st, kv0 + 64, klen, p.Tk);
+        if (t + 1 < ntile) stage2_dma(Kg, p.k_st, Vg, p.v_st, kv0 + 64, p.Tk, smem + ((t + 1) & 1) * 16384, wave, lane);
         u32x4 sf[2][2];                                 // [query block][32-key block]: dS^T as B operand
-        auto ds_tile = [&](auto masked) {
-        constexpr bool MASK = decltype(masked)::value;
+        // EDGE: masks per element (keys past klen -- their tile rows hold whatever lies there --, the causal triangle, the distance
+        // penalty).  dS carries neither the softmax scale (dQ is scaled once at the end) nor a separate 1/(1-p) multiply.
+        auto ds_tile = [&](auto edge_tag, auto drop_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value, DROP = decltype(drop_tag)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32x4 ka[2], va[2];
@@ -919,25 +976,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
                 const int qrow = qw + 16 * qb + r16;
                 const int key0 = kv0 + 16 * j + 4 * q;
                 u32x2 hq = {0u, 0u};
-                if (p.p_drop > 0.f) hq = drop_hash4(p.seed, drop_index(p, b, h, qrow, key0) >> 2);     // keys 4q .. 4q+3 = one quad
+                if constexpr (DROP) hq = drop_hash4_lo(drop_ks, drop_hwm, (uint32_t)((b * p.H + h) * p.Tq + qrow) * tkq + ((uint32_t)key0 >> 2));   // keys 4q .. 4q+3 = one quad
                 float ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // query rows past Tq are never stored; padded / future keys must not reach dQ
-                    float e = __builtin_amdgcn_exp2f(st[r] * sc2 - (p.dist_pen ? dist_pen_log2(qrow, key0 + r) : 0.f) - L[qb]);
-                    if constexpr (MASK) {
+                    float arg = __builtin_fmaf(st[r], sc2, -L[qb]);
+                    if constexpr (EDGE) { if (p.dist_pen) arg -= dist_pen_log2(qrow, key0 + r); }
+                    float e = __builtin_amdgcn_exp2f(arg);
+                    if constexpr (EDGE) {
                         const int key = key0 + r;
                         e = (key < klen && (!p.causal || key <= qrow)) ? e : 0.f;
                     }
-                    float dsc = 1.f;
-                    if (p.p_drop > 0.f) dsc = drop_field(hq, r) >= drop_th16 ? drop_inv : 0.f;
-                    ds[r] = e * (dsc * dp[r] - Dl[qb]) * p.scale;
+                    if constexpr (DROP) ds[r] = e * __builtin_fmaf(drop_field(hq, r) >= drop_th16 ? dp[r] : 0.f, drop_inv, -Dl[qb]);
+                    else ds[r] = e * (dp[r] - Dl[qb]);
                 }
                 sf[qb][j >> 1][2 * (j & 1)] = pack_bf16(ds[0], ds[1]); sf[qb][j >> 1][2 * (j & 1) + 1] = pack_bf16(ds[2], ds[3]);
             }
         }
         };
-        if (p.causal || kv0 + 64 > klen) ds_tile(std::true_type{}); else ds_tile(std::false_type{});
+        const bool edge = generic || kv0 + 64 > klen;
+        if (p.p_drop > 0.f) { if (edge) ds_tile(std::true_type{}, std::true_type{}); else ds_tile(std::false_type{}, std::true_type{}); }
+        else if (edge) ds_tile(std::true_type{}, std::false_type{});
+        else ds_tile(std::false_type{}, std::false_type{});
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -946,7 +1007,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) dqT[qb][n] = mma16<bf16>(kt, sf[qb][jb], dqT[qb][n]);
             }
-        if (t + 1 < ntile) sg.lstore(smem + ((t + 1) & 1) * 16384);
+        S2T_WAIT_VM0();                                   // tile t + 1 has landed (this wave's share; the barrier covers the rest)
         __syncthreads();
     }
     bf16* dQg = reinterpret_cast<bf16*>(p.dQ) + (long)b * p.dq_sb + (long)h * DH;
@@ -957,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             u32x2 w;
-            w[0] = pack_bf16(dqT[qb][n][0], dqT[qb][n][1]); w[1] = pack_bf16(dqT[qb][n][2], dqT[qb][n][3]);
+            w[0] = pack_bf16(dqT[qb][n][0] * p.scale, dqT[qb][n][1] * p.scale); w[1] = pack_bf16(dqT[qb][n][2] * p.scale, dqT[qb][n][3] * p.scale);
             *reinterpret_cast<u32x2*>(dQg + (long)qrow * p.dq_st + 16 * n + 4 * q) = w;
         }
     }
@@ -986,8 +1047,10 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
         const bool v1 = g_s2t_opt_attn_v1 != 0;                            // s2t_set_option("attn_v1")
         const bool al = !(a.dk_st % 4) && !(a.dk_sb % 4) && !(a.dv_st % 4) && !(a.dv_sb % 4) && !(a.dq_st % 4) && !(a.dq_sb % 4) &&
                         !((uintptr_t)a.dK & 7) && !((uintptr_t)a.dV & 7) && !((uintptr_t)a.dQ & 7);
-        dkv2 = !v1 && al && a.Tk >= 128;
-        dq2 = !v1 && al && (a.Tq >= 128 || (a.Tq >= S2T_ATTN_V2_MIN_TQ && a.Tk >= 128)) && !(a.o_st % 8) && !(a.o_sb % 8) && !((uintptr_t)a.O & 15);
+        // the second-generation kernels keep the dropout quad index in one 32-bit word
+        const bool idx32 = (unsigned long long)a.B * a.H * a.Tq * (unsigned long long)((a.Tk + 3) & ~3) < (1ull << 34);
+        dkv2 = !v1 && al && idx32 && a.Tk >= 128;
+        dq2 = !v1 && al && idx32 && (a.Tq >= 128 || (a.Tq >= S2T_ATTN_V2_MIN_TQ && a.Tk >= 128)) && !(a.o_st % 8) && !(a.o_sb % 8) && !((uintptr_t)a.O & 15);
         if (dq2) {                                       // first: it also writes Delta for the dK/dV kernel
             hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((a.Tq + 127) / 128, a.H, a.B), dim3(256), 32768, st, a);
             S2T_LAUNCH_CHECK();

@@ -113,16 +113,24 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ u32x2 drop_hash4(uint64_t seed, uint64_t quad) {
-    // the seed is scrambled first (wave-uniform: scalar ALU) so that call sites whose seeds differ by small offsets do not
-    // reuse one mask at xor-neighbouring positions
-    const uint32_t ks = mix32((uint32_t)seed * 0x9E3779B9u + 0x7F4A7C15u);
-    uint32_t x = mix32((uint32_t)quad ^ ks);
-    const uint32_t hw = (uint32_t)(quad >> 32) + (uint32_t)(seed >> 32);     // almost always zero: no multiply spent on it
-    x ^= hw ^ (hw << 13) ^ (hw >> 7) ^ (hw << 27);
+// The hash in two steps, for kernels whose VALU time is the bound (attention): the seed scramble `ks` is wave-uniform, and the
+// contribution `hwm` of the index's high word (almost always zero) is the same for every quad that shares that word, so both are
+// taken once per tile / row and each quad then costs three multiplies and six other operations on its LOW index word.
+__device__ __forceinline__ uint32_t drop_seed_key(uint64_t seed) { return mix32((uint32_t)seed * 0x9E3779B9u + 0x7F4A7C15u); }
+__device__ __forceinline__ uint32_t drop_high_mix(uint64_t seed, uint64_t quad) {
+    const uint32_t hw = (uint32_t)(quad >> 32) + (uint32_t)(seed >> 32);
+    return hw ^ (hw << 13) ^ (hw >> 7) ^ (hw << 27);
+}
+__device__ __forceinline__ u32x2 drop_hash4_lo(uint32_t ks, uint32_t hwm, uint32_t quad_lo) {
+    const uint32_t x = mix32(quad_lo ^ ks) ^ hwm;
     uint32_t y = (x ^ 0x68E31DA4u) * 0xB5297A4Du;
     y ^= y >> 15;
     return (u32x2){x, y};
+}
+__device__ __forceinline__ u32x2 drop_hash4(uint64_t seed, uint64_t quad) {
+    // the seed is scrambled first (wave-uniform: scalar ALU) so that call sites whose seeds differ by small offsets do not
+    // reuse one mask at xor-neighbouring positions
+    return drop_hash4_lo(drop_seed_key(seed), drop_high_mix(seed, quad), (uint32_t)quad);
 }
 // 16-bit uniform of element f (0..3) of the quad: f0 = y.lo, f1 = y.hi, f2 = x.lo, f3 = x.hi
 __device__ __forceinline__ uint32_t drop_field(u32x2 h, int f) {
