@@ -20,7 +20,43 @@ from .registry import CRITERION_REGISTRY, FairseqCriterion, register_criterion
 
 
 def _item(v):
-    return v.item() if torch.is_tensor(v) else v
+    return v.item() if torch.is_tensor(v) else (float(v) if isinstance(v, _Deferred) else v)
+
+
+class _Deferred:
+    """One component of a host-side statistic that is still being computed on the logging thread: a number to whoever sums or
+    prints it (float(), +), resolved on first use."""
+
+    def __init__(self, future, index):
+        self.future, self.index = future, index
+
+    def __float__(self):
+        return float(self.future.result()[self.index])
+
+    def __int__(self):
+        return int(float(self))
+
+    def __add__(self, other):
+        return float(self) + float(other)
+
+    __radd__ = __add__
+
+    def __repr__(self):
+        return repr(float(self))
+
+
+_LOGGING_THREAD = None
+
+
+def _in_background(fn, *args):
+    """Run fn(*args) on the logging thread.  The unit error rate of the CTC head is a logging number only, but its native
+    edit-distance pass takes ~1.3 ms of host time for 64 utterances, right where the launch stream has no lead over the GPU (after
+    the host sync of the CTC compression): on the main thread the GPU sat idle through it.  ctypes releases the GIL during the call."""
+    global _LOGGING_THREAD
+    if _LOGGING_THREAD is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _LOGGING_THREAD = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2t-logging")
+    return _LOGGING_THREAD.submit(fn, *args)
 
 
 class _LSCEFn(torch.autograd.Function):
@@ -220,7 +256,8 @@ class CTCMultiLoss(FairseqCriterion):
         tr_host = tr.cpu() if tr_host is None else tr_host
         trl_host = sample.get("transcript_target_lengths_host")
         trl_host = tr_len.cpu() if trl_host is None else trl_host
-        errors, total = K.host_ctc_uer(pred, torch.tensor(in_len_host, dtype=torch.int64), tr_host, trl_host, self.blank_idx)
+        uer = _in_background(K.host_ctc_uer, pred, torch.tensor(in_len_host, dtype=torch.int64), tr_host, trl_host, self.blank_idx)
+        errors, total = _Deferred(uer, 0), _Deferred(uer, 1)
         ctc_ntokens = int(trl_host.sum())
         if self.sentence_avg:
             ctc_sample_size = sample["target"].size(0)
