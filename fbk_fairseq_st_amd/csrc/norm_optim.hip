@@ -91,16 +91,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 
 // dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) [+ dres],  g = dy*gamma;
 // dgamma += sum_rows dy*xhat, dbeta += sum_rows dy  (per-lane partials over a grid-stride row loop,
-// combined across the 4 waves in LDS, then one f32 atomic per column per workgroup).
-template <typename T, int EPL>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// combined across the workgroup's waves in LDS, then one f32 atomic per column per workgroup).
+// NW waves per workgroup, one row per wave per step.  The kernel is a chain load -> two wave reductions -> store per row, so what
+// it needs is rows in flight: the NEXT row's vectors are requested before the current row is reduced, and the launch puts 16
+// waves on every CU (one 1024-thread workgroup: the same wave count as four 256-thread ones at a quarter of the same-address
+// atomics that end each workgroup).  [24000, 512] bf16 with residual and dropout outputs: 27 us, 4.5 TB/s.
+template <typename T, int EPL, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D,
                                                      T* __restrict__ dx_drop, float p_drop, unsigned long long seed) {
     typedef RowIO<T, EPL> IO;
-    __shared__ float sh[2][4][1024];
+    extern __shared__ float sh_ln[];                       // [2][NW][D]
     const uint32_t th16 = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) >> 16;
     const float inv_keep = 1.f / (1.f - p_drop);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -109,12 +113,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int i = 0; i < 16; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < IO::N; ++i) { const int j = IO::col(lane, i); if (j < D) gm[i] = gamma[j]; }
-    for (int row = blockIdx.x * 4 + w; row < M; row += gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
+    const int stride = gridDim.x * NW;
+    int row = blockIdx.x * NW + w;
+    float xn[16], dn[16], rn[16], mun = 0.f, rsn = 0.f;
+    if (row < M) {
+        IO::load(x + (size_t)row * D, lane, D, xn);
+        IO::load(dy + (size_t)row * D, lane, D, dn);
+        if (dres) IO::load(dres + (size_t)row * D, lane, D, rn);
+        mun = mean[row]; rsn = rstd[row];
+    }
+    for (; row < M; row += stride) {
         float xv[16], dv[16], rv[16];
-        IO::load(x + (size_t)row * D, lane, D, xv);
-        IO::load(dy + (size_t)row * D, lane, D, dv);
-        if (dres) IO::load(dres + (size_t)row * D, lane, D, rv);
+        const float mu = mun, rs = rsn;
+#pragma unroll
+        for (int i = 0; i < IO::N; ++i) { xv[i] = xn[i]; dv[i] = dn[i]; rv[i] = rn[i]; }
+        const int nrow = row + stride;
+        if (nrow < M) {                                         // wave-uniform
+            IO::load(x + (size_t)nrow * D, lane, D, xn);
+            IO::load(dy + (size_t)nrow * D, lane, D, dn);
+            if (dres) IO::load(dres + (size_t)nrow * D, lane, D, rn);
+            mun = mean[nrow]; rsn = rstd[nrow];
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < IO::N; ++i) {
@@ -157,15 +176,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
             IO::store(dx_drop + (size_t)row * D, lane, D, dv);
         }
     }
+    float* sg = sh_ln;
+    float* sb = sh_ln + NW * D;
 #pragma unroll
     for (int i = 0; i < IO::N; ++i) {
         const int j = IO::col(lane, i);
-        if (j < 1024) { sh[0][w][j] = ag[i]; sh[1][w][j] = ab[i]; }
+        if (j < D) { sg[w * D + j] = ag[i]; sb[w * D + j] = ab[i]; }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < D; j += 256) {
-        atomicAdd(dgamma + j, sh[0][0][j] + sh[0][1][j] + sh[0][2][j] + sh[0][3][j]);
-        atomicAdd(dbeta + j, sh[1][0][j] + sh[1][1][j] + sh[1][2][j] + sh[1][3][j]);
+    for (int j = threadIdx.x; j < 2 * D; j += NW * 64) {      // first D threads' worth: dgamma columns, then dbeta
+        const float* src = j < D ? sg + j : sb + (j - D);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) t += src[k * D];
+        // f32 atomics on one address are served one after the other at the memory side (~40 ns each).  For the big activations
+        // the 256 workgroups do not finish together and the chain hides behind the stragglers' rows (writing partials + a finishing
+        // kernel measured the same 27 us); for small M the launch is capped at 64 workgroups (512 of them spent 19 us on 2560 rows).
+        atomicAdd((j < D ? dgamma + j : dbeta + (j - D)), t);
     }
 }
 
@@ -208,14 +235,35 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
     if (D <= 0 || D > 1024) return S2T_ENOTSUP;
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return S2T_EINVAL;
     if (dx_drop && (p_drop < 0.f || p_drop >= 1.f)) return S2T_EINVAL;
-    int blocks = (M + 3) / 4;
-    if (blocks > 512) blocks = 512;            // 2 workgroups per CU; each ends in 2*D same-address atomics
-    dim3 grid(blocks);
     hipStream_t st = (hipStream_t)stream;
     const int epl = ln_epl(D, dy, x, dres, dx, dx_drop);
-    if (dtype == S2T_BF16) LN_DISPATCH(ln_bwd_kernel, bf16, epl, grid, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D, (bf16*)dx_drop, p_drop, seed);
-    else if (dtype == S2T_F32) LN_DISPATCH(ln_bwd_kernel, float, epl, grid, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dres, (float*)dx, dgamma, dbeta, M, D, (float*)dx_drop, p_drop, seed);
+    // NW = 16 waves per workgroup, one workgroup per CU, for the big activations; 4 waves and up to 512 workgroups for small M
+    // (a 1024-thread workgroup with one row per wave would leave most of the chip idle below ~4096 rows)
+    const bool big = M >= 8192;
+    const int nw = big ? 16 : 4;
+    int blocks = (M + nw - 1) / nw;
+    const int cap = big ? 256 : 64;            // small M: a few rows per wave, and at most 64 same-address atomics per column
+    if (blocks > cap) blocks = cap;
+    dim3 grid(blocks);
+    const size_t lds = (size_t)2 * nw * D * sizeof(float);
+#define LN_BWD_LAUNCH(T, EPL_, NW_)                                                                                         \
+    do {                                                                                                                    \
+        static bool attr = false;                                                                                           \
+        if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_kernel<T, EPL_, NW_>),  \
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NW_ * 1024 * 4); attr = true; } \
+        hipLaunchKernelGGL((ln_bwd_kernel<T, EPL_, NW_>), grid, dim3(NW_ * 64), lds, st, (const T*)dy, (const T*)x, mean, rstd, gamma, \
+                           (const T*)dres, (T*)dx, dgamma, dbeta, M, D, (T*)dx_drop, p_drop, seed);                         \
+    } while (0)
+#define LN_BWD_EPL(T, NW_)                                                                                                  \
+    do {                                                                                                                    \
+        if (epl == 4) LN_BWD_LAUNCH(T, 4, NW_); else if (epl == 8) LN_BWD_LAUNCH(T, 8, NW_);                                \
+        else if (epl == 16) LN_BWD_LAUNCH(T, 16, NW_); else LN_BWD_LAUNCH(T, 0, NW_);                                       \
+    } while (0)
+    if (dtype == S2T_BF16) { if (big) LN_BWD_EPL(bf16, 16); else LN_BWD_EPL(bf16, 4); }
+    else if (dtype == S2T_F32) { if (big) LN_BWD_EPL(float, 16); else LN_BWD_EPL(float, 4); }
     else return S2T_ENOTSUP;
+#undef LN_BWD_EPL
+#undef LN_BWD_LAUNCH
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
