@@ -577,7 +577,7 @@ __global__ __launch_bounds__(512) void a2d_freq_bwd_kernel(const T* __restrict__
 // master layout [CO][CI][3][3].
 template <typename T, int CO, int CI>
 __global__ __launch_bounds__(256) void a2d_conv_wgrad_kernel(const T* __restrict__ dY, int ld_dy, const T* __restrict__ X, int ld_x,
-                                                             float* __restrict__ ws, int B, int Tn, int F, int TT, int units, int dbg) {
+                                                             float* __restrict__ ws, int B, int Tn, int F, int TT, int units) {
     extern __shared__ float a2d_lds[];
     constexpr int NCI4 = CI / 4, NCO4 = CO / 4, NCOMBO = NCI4 * NCO4, PS = 256 / (NCOMBO * 3) > 0 ? 256 / (NCOMBO * 3) : 1;
     static_assert(NCOMBO * 3 <= 256, "one thread per (4x4 block, kernel row)");
@@ -602,7 +602,6 @@ __global__ __launch_bounds__(256) void a2d_conv_wgrad_kernel(const T* __restrict
         const int b = u / nchunk, t0 = (u % nchunk) * TT;
         __syncthreads();
         // X rows t0-1 .. t0+TT of batch b (zeros outside the plane), channels in 16-byte chunks
-        if (!(dbg & 1))
         for (int e = tid; e < (TT + 2) * F * (CI / E); e += 256) {
             const int ch = e % (CI / E), f = (e / (CI / E)) % F, tr = e / ((CI / E) * F);
             const int t = t0 - 1 + tr;
@@ -622,7 +621,7 @@ __global__ __launch_bounds__(256) void a2d_conv_wgrad_kernel(const T* __restrict
             for (int k = 0; k < E; ++k) dst[k] = t < Tn ? to_f32(tmp[k]) : 0.f;
         }
         __syncthreads();
-        if (active && !(dbg & 2)) {
+        if (active) {
             for (int tt = ps; tt < TT; tt += PS) {                       // pixel subsets split the frames; f runs with a sliding window
                 const float* dyr = sdy + (size_t)tt * F * CO + co4 * 4;
                 const float* xr = sx + (size_t)(tt + kh) * FW * CI + ci4 * 4;
@@ -865,7 +864,6 @@ extern "C" int s2t_a2d_conv_wgrad(int dtype, const void* dY, int ld_dy, const vo
     if (!dY || !X || !dW || !ws || F <= 0 || ld_dy < CO || ld_x < CI) return S2T_EINVAL;
     const int E = dtype == S2T_BF16 ? 8 : 4;
     if ((ld_dy % E) || (ld_x % E) || (((uintptr_t)dY | (uintptr_t)X) & 15)) return S2T_ENOTSUP;
-    static const int dbg = getenv("S2T_A2D_DBG") ? atoi(getenv("S2T_A2D_DBG")) : 0;
     const int TT = 6;
     const int units = B * ((T + TT - 1) / TT);
     const int grid = units < S2T_A2D_WGRAD_GROUPS ? units : S2T_A2D_WGRAD_GROUPS;
@@ -876,7 +874,7 @@ extern "C" int s2t_a2d_conv_wgrad(int dtype, const void* dY, int ld_dy, const vo
         const size_t lds = ((size_t)(TT + 2) * (F + 2) * CIp + (size_t)TT * F * COp) * 4;                                              \
         if (lds > 150 * 1024) return S2T_ENOTSUP;                                                                                      \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&a2d_conv_wgrad_kernel<TT_, COp, CIp>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((a2d_conv_wgrad_kernel<TT_, COp, CIp>), dim3(grid), dim3(256), lds, st, (const TT_*)dY, ld_dy, (const TT_*)X, ld_x, ws, B, T, F, TT, units, dbg); \
+        hipLaunchKernelGGL((a2d_conv_wgrad_kernel<TT_, COp, CIp>), dim3(grid), dim3(256), lds, st, (const TT_*)dY, ld_dy, (const TT_*)X, ld_x, ws, B, T, F, TT, units); \
         hipLaunchKernelGGL(a2d_wgrad_reduce_kernel, dim3((co_real * CIp * 9 + 255) / 256, (grid + 31) / 32), dim3(256), 0, st, ws, dW, COp * CIp * 9, co_real * CIp * 9, grid); \
     } while (0)
     if (CO <= 16 && CI == 64 && ld_dy >= 16) { A2D_DISPATCH_T(dtype, A2D_WGRAD(bf16, 16, 64, CO), A2D_WGRAD(float, 16, 64, CO)); }

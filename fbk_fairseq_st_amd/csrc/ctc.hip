@@ -38,6 +38,65 @@ __device__ __forceinline__ void row_max_sumexp(const T* __restrict__ x, int V, i
     m_out = m; s_out = wave_sum(s);
 }
 
+// Single-pass form for bf16 rows of up to 64 * 8 * NC units whose rows start 16-byte aligned: the whole row is fetched ONCE into
+// registers (NC 16-byte vectors per lane, all requested before the first is used) and the three sweeps -- max, sum of exp, arg-max
+// of the softmax values -- run on the registers.  (The three-pass kernel below re-read the 10 KB rows from L2 / HBM: 102 us for
+// 24,000 x 5,001, 2.4 TB/s of useful traffic.)  Same arithmetic, same results as the three-pass kernel.
+template <int NC>
+__global__ __launch_bounds__(256) void ctc_argmax_row_kernel(const bf16* __restrict__ logits, int* __restrict__ pred, float* __restrict__ pmax,
+                                                             float* __restrict__ lse_out, int Tn, int B, int V, int ld) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)Tn * B) return;
+    const int t = (int)(row / B), b = (int)(row % B);
+    const bf16* x = logits + row * ld;
+    const int nv = (V + 7) / 8;                                    // the last vector may reach into the row padding (ld >= 8 nv)
+    u32x4 raw[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int c = lane + 64 * k;
+        raw[k] = c < nv ? *reinterpret_cast<const u32x4*>(x + c * 8) : (u32x4){0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u};   // -inf
+    }
+    auto elem = [&](int k, int e) -> float {                       // bf16 -> f32 is a shift / mask of the packed word
+        const uint32_t w = raw[k][e >> 1];
+        const float v = __builtin_bit_cast(float, (e & 1) ? (w & 0xFFFF0000u) : (w << 16));
+        return (lane + 64 * k) * 8 + e < V ? v : -INFINITY;        // padding columns of the last vector
+    };
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, elem(k, e));
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += expf(elem(k, e) - m);     // exp(-inf) = 0 for the padding
+    s = wave_sum(s);
+    float best = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xv = elem(k, e);
+            if (xv >= m - 1e-3f) {                                   // only these can round to the top probability
+                const float pr = expf(xv - m) / s;
+                const int j = (lane + 64 * k) * 8 + e;
+                if (pr > best || (pr == best && j < bi)) { best = pr; bi = j; }
+            }
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+        pred[(long)b * Tn + t] = bi; pmax[(long)b * Tn + t] = best;
+        if (lse_out) lse_out[row] = m + logf(s);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_argmax_kernel(const T* __restrict__ logits, int* __restrict__ pred,
                                                          float* __restrict__ pmax, float* __restrict__ lse_out, int Tn, int B, int V, int ld) {
@@ -405,7 +464,14 @@ extern "C" int s2t_ctc_argmax(int dtype, const void* logits, int* pred, float* p
     if (!logits || !pred || !pmax || V <= 0 || ld < V) return S2T_EINVAL;
     dim3 grid((unsigned)((rows + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, lse, T, B, V, ld);
+    const int nv8 = (V + 7) / 8;
+    if (dtype == S2T_BF16 && !((uintptr_t)logits & 15) && !(ld & 7) && ld >= nv8 * 8 && nv8 <= 64 * 16) {
+        // the row fits the registers of one wave: single pass (NC = vectors per lane)
+        if (nv8 <= 64 * 4) hipLaunchKernelGGL(ctc_argmax_row_kernel<4>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, lse, T, B, V, ld);
+        else if (nv8 <= 64 * 10) hipLaunchKernelGGL(ctc_argmax_row_kernel<10>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, lse, T, B, V, ld);
+        else hipLaunchKernelGGL(ctc_argmax_row_kernel<16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, lse, T, B, V, ld);
+    }
+    else if (dtype == S2T_BF16) hipLaunchKernelGGL(ctc_argmax_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, pred, pmax, lse, T, B, V, ld);
     else if (dtype == S2T_F32) hipLaunchKernelGGL(ctc_argmax_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, pred, pmax, lse, T, B, V, ld);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();

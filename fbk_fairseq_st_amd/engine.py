@@ -190,9 +190,9 @@ class S2TEngine:
         self.defer_wgrad = arena.compute_dtype == torch.bfloat16
         self._wq, self._wq_ready = [], []
         self._a2d_prescale = None
-        self.a2d_time_mfma = os.environ.get("S2T_A2D_TIME_VALU", "0") != "1"     # time attention of ConvAttention2D on the MFMA attention kernels
+        self.a2d_time_mfma = True        # time attention of ConvAttention2D on the MFMA attention kernels (False: the VALU kernels; tests compare the two)
         # LayerNorm backward also writes dropout(dx) for the block that consumes dx (one pass instead of two; identical bits)
-        self.fuse_bwd_dropout = os.environ.get("S2T_FUSE_BWD_DROPOUT", "1") != "0"
+        self.fuse_bwd_dropout = True
         if hp.act not in ("relu", "gelu"):
             raise NotImplementedError("activation_fn %s" % hp.act)
         self.act_fwd = K.ACT_RELU if hp.act == "relu" else K.ACT_GELU

@@ -344,6 +344,26 @@ def test_ctc_argmax_random_matches_oracle(dtype):
     assert [len(r) for r in runs] == new_len.cpu().tolist()
 
 
+@pytest.mark.parametrize("V", [37, 2048, 5001, 5120, 8000, 9001])
+def test_ctc_argmax_padded_rows_single_pass_and_three_pass(V):
+    """rows with a padded stride (what the CTC head writes) take the single-pass kernel up to 8192 units, the three-pass kernel
+    above; both must give the first arg-max of the f32 softmax, its value and the row log-sum-exp, ties included"""
+    T, B = 33, 3
+    x = rnd(T, B, V, dtype=torch.bfloat16, seed=V, scale=3.0)
+    x[5, 1, V - 1] = x[5, 1].max() + 1.0                              # the maximum in the last column (next to the row padding)
+    x[6, 2, 3] = x[6, 2, V // 2] = x[6, 2].max() + 0.5                # a tie: the first index wins
+    xd = K.alloc_rows((T, B), V, torch.bfloat16, DEV)
+    xd.copy_(x.to(DEV))
+    pred, pmax, lse = K.ctc_argmax(xd, want_lse=True)
+    prob = torch.softmax(x.float(), -1).transpose(0, 1)
+    ref = int_ref.argmax_first_np(prob.numpy())
+    assert np.array_equal(pred.cpu().numpy(), ref)
+    assert int(pred[1, 5]) == V - 1 and int(pred[2, 6]) == 3
+    want_p = torch.gather(prob, 2, torch.from_numpy(ref).long().unsqueeze(-1)).squeeze(-1)
+    assert float(((pmax.cpu() - want_p).abs() / want_p).max()) <= 1e-5
+    assert float((lse.cpu().view(T, B) - torch.logsumexp(x.float(), -1)).abs().max()) <= 1e-4
+
+
 def test_ctc_rle_long_runs():
     # runs crossing the 64-frame chunks of the wave-parallel scan
     B, T = 4, 300

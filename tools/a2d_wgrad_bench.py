@@ -1,4 +1,4 @@
-"""Times s2t_a2d_conv_wgrad at the bench shape (diagnostic; S2T_A2D_DBG bits: 1 no X staging, 2 no FMA loop, 4 no atomics)."""
+"""Times s2t_a2d_conv_wgrad at the bench shape."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,5 +17,5 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-print("dbg=%s in_proj %.1f us  out_proj %.1f us" % (os.environ.get("S2T_A2D_DBG", "0"), timeit(lambda: K.a2d_conv_wgrad(dz, x, gi, B, T, F)),
+print("in_proj %.1f us  out_proj %.1f us" % (timeit(lambda: K.a2d_conv_wgrad(dz, x, gi, B, T, F)),
                                                      timeit(lambda: K.a2d_conv_wgrad(dy, cat, go, B, T, F))))

@@ -20,4 +20,4 @@ for p in (0.0, 0.1):
     do = torch.randn_like(o); dq = torch.empty_like(q); dkv = torch.empty_like(kv)
     tf = timeit(lambda: K.attn_fwd(q, k, v, H, klen=klen, p_drop=p, seed=1))
     tb = timeit(lambda: K.attn_bwd(q, k, v, o, do, lse, H, dq, dkv[:, :, :D], dkv[:, :, D:], klen=klen, p_drop=p, seed=1))
-    print("MIN_TQ=%s p_drop=%.1f  fwd %.1f us  bwd %.1f us" % (os.environ.get("S2T_ATTN_V2_MIN_TQ", "16"), p, tf, tb))
+    print("p_drop=%.1f  fwd %.1f us  bwd %.1f us" % (p, tf, tb))
