@@ -189,6 +189,11 @@ class S2TEngine:
         # the launch that holds their products (flush_wgrad).
         self.defer_wgrad = arena.compute_dtype == torch.bfloat16
         self._wq, self._wq_ready = [], []
+        # None: the encoder's queued weight gradients are computed in ONE launch after its backward pass (best packing of the CUs).
+        # k: also after every k-th layer from the top.  The Trainer sets k = enc_layers / 2 when gradients are all-reduced: two
+        # launches of six layers pack as well as one of twelve (576 / 2 tiles each over 256 CUs, tail cut), and half of the encoder's
+        # gradient bytes then travel over xGMI underneath the lower layers' backward instead of after it.
+        self.wgrad_flush_layers = None
         self._a2d_prescale = None
         self.a2d_time_mfma = True        # time attention of ConvAttention2D on the MFMA attention kernels (False: the VALU kernels; tests compare the two)
         # LayerNorm backward also writes dropout(dx) for the block that consumes dx (one pass instead of two; identical bits)
@@ -678,6 +683,8 @@ class S2TEngine:
             if hp.ctc_layer == l + 1:
                 self._ready("encoder.ctc_fc.")
             self._ready(pfx)
+            if self.wgrad_flush_layers and l > 0 and l % self.wgrad_flush_layers == 0:
+                self.flush_wgrad()          # data-parallel runs: the upper layers' gradients go to the reducer while the lower ones run
         self.subsample_bwd(ctx["sub"], dx)
         for n in ("encoder.fc3.", "encoder.attn_2d.", "encoder.bn.1.", "encoder.convolutions.1.", "encoder.bn.0.", "encoder.convolutions.0."):
             self._ready(n)

@@ -47,6 +47,8 @@ class Trainer:
         cap = getattr(args, "bucket_cap_bytes", None)                     # tests: buckets of a few KB
         self.reducer = D.BucketedGradReducer(self.arena.grad, int(cap) if cap else getattr(args, "bucket_cap_mb", 64) << 20)
         model.engine.on_grads_ready = self._grads_ready
+        if self.world > 1 and getattr(model.engine, "defer_wgrad", False):
+            model.engine.wgrad_flush_layers = max(1, model.hp.enc_layers // 2)     # see S2TEngine.wgrad_flush_layers
         self._ranges = {}
         self._sync_grads = True         # False while a non-final micro-batch accumulates locally (the reference's no_sync)
         self._dummy_batch = None

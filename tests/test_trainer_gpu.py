@@ -184,3 +184,30 @@ def test_checkpoint_round_trip_resumes_training(tmp_path):
     ck = torch.load(path, map_location="cpu", weights_only=False)
     assert set(ck) >= {"args", "model", "criterion", "optimizer_history", "extra_state", "last_optimizer_state"}
     assert "encoder.layers.0.self_attn.q_proj.weight" in ck["model"] and "ctc_aware_model.fc_out.weight" in ck["criterion"]
+
+
+def test_mid_backward_weight_gradient_flush_gives_the_same_gradients():
+    """data-parallel runs compute the queued encoder weight gradients in two launches (engine.wgrad_flush_layers) so that the
+    upper layers' slices reach the reducer early: same gradients as the single launch, and the slices are reported ready in
+    arena order from the tail (what the static bucket plan relies on)"""
+    a, task, model, crit, tr = _setup(torch.bfloat16, dropout=0.0)
+    sample = tr.prepare(task.dummy_batch(seed=1, lengths=[200, 180, 150, 120]))
+    model.train(); crit.train()
+
+    def grads(k):
+        model.engine.wgrad_flush_layers = k
+        seen = []
+        model.engine.on_grads_ready = seen.append
+        tr.optimizer.zero_grad()
+        model.set_seed(7)
+        loss, _, _ = crit(model, sample)
+        loss.backward()
+        model.engine.flush_wgrad()
+        torch.cuda.synchronize()
+        return model.arena.grad.clone(), seen
+    g1, seen1 = grads(None)
+    g2, seen2 = grads(2)
+    assert float((g1 - g2).abs().max()) <= 1e-3 * float(g1.abs().max())
+    assert sorted(seen1) == sorted(seen2) and "encoder.layers.0." in seen2
+    # with the early flush the top layers are reported before the bottom ones are even computed
+    assert seen2.index("encoder.layers.3.") < seen2.index("encoder.layers.0.")
