@@ -11,7 +11,10 @@ Kernels are grouped into the families bench.py reports (same template -> same fa
 import collections, csv, glob, json, sys
 
 # (family, kernel-name substrings that must ALL occur): the 128x128 templates bench.py names in KERNEL_OF
-FAMILY = [("wgrad_group", ("wgrad_group_kernel",)), ("gemm_nt", ("gemm256_kernel", "Lb0E")), ("gemm_nn", ("gemm256_kernel", "Lb1E")),
+# (rocprofv3's demangler garbles the TB = true instantiations of gemm256_kernel into "gemm256_kernel<bool _Accum, bool, E, ...>":
+# that spelling therefore identifies the NN products)
+FAMILY = [("wgrad_group", ("wgrad_group_kernel",)), ("gemm_nn", ("gemm256_kernel", "_Accum")),
+          ("gemm_nt", ("gemm256_kernel", "Lb0E")), ("gemm_nn", ("gemm256_kernel", "Lb1E")),
           ("gemm_nt", ("gemm256_kernel", "false")), ("gemm_nn", ("gemm256_kernel", "true")),
           ("gemm_tn", ("gemm_tn2_kernel",)), ("gemm_tn", ("gemm_fast_kernel", "true, true, 128, 128")), ("gemm_tn", ("gemm_fast_kernel", "Lb1ELb1ELi128ELi128")),
           ("gemm_nt", ("gemm_fast_kernel", "Lb0ELb0ELi128ELi128")), ("gemm_nn", ("gemm_fast_kernel", "Lb0ELb1ELi128ELi128")),
