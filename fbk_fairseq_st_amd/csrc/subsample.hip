@@ -45,6 +45,7 @@ __device__ __forceinline__ float group_sum(float v, int LP) {          // over t
     return v;
 }
 // per-channel pair of sums (s1, s2) of a workgroup of 256 threads -> sums[c] += s1, sums[C+c] += s2 (double atomics)
+template <int NW = 4>
 __device__ __forceinline__ void chan_pair_reduce(float (&s1)[8], float (&s2)[8], int LP, int g, double* sums, int C,
                                                  float (*red)[16][16]) {
 #pragma unroll
@@ -55,18 +56,23 @@ __device__ __forceinline__ void chan_pair_reduce(float (&s1)[8], float (&s2)[8],
         for (int e = 0; e < 8; ++e) { red[wave][g][e] = s1[e]; red[wave][g][8 + e] = s2[e]; }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+    for (int t = threadIdx.x; t < 2 * C; t += NW * 64) {
         const int which = t / C, c = t % C;
         double a = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) a += (double)red[w][c >> 3][which * 8 + (c & 7)];
+        for (int w = 0; w < NW; ++w) a += (double)red[w][c >> 3][which * 8 + (c & 7)];
         atomicAdd(sums + which * C + c, a);
     }
 }
 // the 3x3 stride-2 window of output pixel (b, t2, f2) over x[b][Tin][F] (zero padding 1).  All nine loads are issued
 // from clamped (always valid) addresses before any is used: left to itself the compiler sinks each load under its
 // bounds test and waits for it there, i.e. nine serial memory latencies per pixel (seen in the ISA).
-struct Conv1Win { float v[9]; float mt0, mt2, mf0, mf2; };
+// Three 12-byte loads per pixel, one per window row (global_load_dwordx3 needs 4-byte alignment only) instead of nine 4-byte ones
+// (forward 152 -> 134 us; the kernel's bound is its VALU work -- 72 FMAs + statistics per 8 channels of a pixel at ~40 % issue
+// utilisation --, not bytes: 2.0 TB/s of useful traffic).  The three columns start at `fs` = fc - 1 clamped into the row; at the
+// row's borders the wanted columns sit shifted inside the triple.
+typedef float f32x3_t __attribute__((ext_vector_type(3)));
+struct Conv1Win { f32x3_t r[3]; float mt0, mt2, mf0, mf2; int shift; };
 __device__ __forceinline__ void conv1_window_issue(const float* __restrict__ x, unsigned p, int Tin, int F, int T2, int F2, Conv1Win& w) {
     const unsigned r = p / (unsigned)F2;
     const int f2 = (int)(p - r * F2), t2 = (int)(r % (unsigned)T2), b = (int)(r / (unsigned)T2);
@@ -74,19 +80,28 @@ __device__ __forceinline__ void conv1_window_issue(const float* __restrict__ x, 
     const float* r1 = x + ((long)b * Tin + tc) * F;
     const float* r0 = r1 - (tc > 0 ? F : 0);
     const float* r2 = r1 + (tc + 1 < Tin ? F : 0);
-    const int f0 = max(fc - 1, 0), f2c = min(fc + 1, F - 1);
-    w.v[0] = r0[f0]; w.v[1] = r0[fc]; w.v[2] = r0[f2c];
-    w.v[3] = r1[f0]; w.v[4] = r1[fc]; w.v[5] = r1[f2c];
-    w.v[6] = r2[f0]; w.v[7] = r2[fc]; w.v[8] = r2[f2c];
+    const int fs = min(max(fc - 1, 0), max(F - 3, 0));        // first column of the triple (F >= 3: checked on the host)
+    w.shift = fc - 1 - fs;                                    // -1 at the left border, +1 at the right border of an odd row, else 0
+    w.r[0] = *reinterpret_cast<const f32x3_t*>(r0 + fs);
+    w.r[1] = *reinterpret_cast<const f32x3_t*>(r1 + fs);
+    w.r[2] = *reinterpret_cast<const f32x3_t*>(r2 + fs);
     w.mt0 = tc > 0 ? 1.f : 0.f; w.mt2 = tc + 1 < Tin ? 1.f : 0.f;
     w.mf0 = fc > 0 ? 1.f : 0.f; w.mf2 = fc + 1 < F ? 1.f : 0.f;
 }
 __device__ __forceinline__ void conv1_window_finish(Conv1Win& w, float (&xv)[9]) {
+    float v[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(w.v[i]));
-    xv[0] = w.v[0] * (w.mt0 * w.mf0); xv[1] = w.v[1] * w.mt0; xv[2] = w.v[2] * (w.mt0 * w.mf2);
-    xv[3] = w.v[3] * w.mf0;           xv[4] = w.v[4];         xv[5] = w.v[5] * w.mf2;
-    xv[6] = w.v[6] * (w.mt2 * w.mf0); xv[7] = w.v[7] * w.mt2; xv[8] = w.v[8] * (w.mt2 * w.mf2);
+    for (int k = 0; k < 3; ++k) {
+        f32x3_t t = w.r[k];
+        asm volatile("" : "+v"(t));
+        // wanted columns fc-1, fc, fc+1 = triple index (0,1,2) + shift; out-of-row ones are masked to zero below, any value will do
+        v[3 * k + 0] = w.shift > 0 ? t[1] : t[0];
+        v[3 * k + 1] = w.shift < 0 ? t[0] : (w.shift > 0 ? t[2] : t[1]);
+        v[3 * k + 2] = w.shift < 0 ? t[1] : t[2];
+    }
+    xv[0] = v[0] * (w.mt0 * w.mf0); xv[1] = v[1] * w.mt0; xv[2] = v[2] * (w.mt0 * w.mf2);
+    xv[3] = v[3] * w.mf0;           xv[4] = v[4];         xv[5] = v[5] * w.mf2;
+    xv[6] = v[6] * (w.mt2 * w.mf0); xv[7] = v[7] * w.mt2; xv[8] = v[8] * (w.mt2 * w.mf2);
 }
 
 // ------------------------------------------------------------------ conv1 forward (+ BN statistics)
@@ -192,13 +207,16 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 // ------------------------------------------------------------------ per-channel sums over [P][C]
 // mode 0: sums[c] += y, sums[C+c] += y^2            (BatchNorm statistics)
 // mode 1: sums[c] += dyn, sums[C+c] += dyn*xhat     (BatchNorm backward: dbeta, dgamma)
-template <typename T>
-__global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ y, const T* __restrict__ dyn,
+// NW waves per workgroup: every workgroup ends in 2 C double atomics on the same 2 C addresses, served one after the other at the
+// memory side (~40 ns each) -- with 1024 four-wave workgroups that tail was 18 us of a 59 us pass; the big tensors run 256
+// sixteen-wave workgroups (the same number of waves in flight, a quarter of the chain).
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void chan_sums_kernel(const T* __restrict__ y, const T* __restrict__ dyn,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         double* __restrict__ sums, long P, int C, int mode,
                                                         int pos_per_block) {
-    __shared__ float red[4][16][16];
-    const int LP = C >> 3, g = threadIdx.x % LP, slot = threadIdx.x / LP, nslot = 256 / LP;
+    __shared__ float red[NW][16][16];
+    const int LP = C >> 3, g = threadIdx.x % LP, slot = threadIdx.x / LP, nslot = NW * 64 / LP;
     const long p0 = (long)blockIdx.x * pos_per_block;
     const long pend = min(P, p0 + (long)pos_per_block);
     float s1[8], s2[8], mu[8], rs[8];
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ y,
             for (int e = 0; e < 8; ++e) { s1[e] += d[e]; s2[e] += d[e] * (v[e] - mu[e]) * rs[e]; }
         }
     }
-    chan_pair_reduce(s1, s2, LP, g, sums, C, red);
+    chan_pair_reduce<NW>(s1, s2, LP, g, sums, C, red);
 }
 
 // ------------------------------------------------------------------ BatchNorm finalize
@@ -375,7 +393,7 @@ static inline int nblocks(long n, int cap = 4096) { long b = (n + 255) / 256; re
 extern "C" int s2t_conv1_fwd(int dtype, const float* x, const float* w, const float* bias, void* y, void* pre, double* sums,
                              int B, int T, int F, int C, int act, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
-    if (!x || !w || !bias || !y || !sums || (C != 64 && C != 128 && C != 32) || F <= 0) return S2T_EINVAL;
+    if (!x || !w || !bias || !y || !sums || (C != 64 && C != 128 && C != 32) || F < 3) return S2T_EINVAL;
     if ((act != ACT_RELU && act != ACT_GELU) || (act == ACT_GELU && !pre)) return S2T_EINVAL;
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
@@ -398,7 +416,7 @@ extern "C" int s2t_conv1_fwd(int dtype, const float* x, const float* w, const fl
 extern "C" int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float* dw, float* db, int B, int T, int F,
                              int C, void* stream) {
     if (B <= 0 || T <= 0) return S2T_OK;
-    if (!x || !dpre || !dw || !db || (C != 64 && C != 128 && C != 32)) return S2T_EINVAL;
+    if (!x || !dpre || !dw || !db || (C != 64 && C != 128 && C != 32) || F < 3) return S2T_EINVAL;
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
     const int ppb = (int)((P + 767) / 768 < 256 ? 256 : (P + 767) / 768);       // <= 768 workgroups = 3 per CU at 148 VGPRs, all resident (10C atomics each)
@@ -415,12 +433,20 @@ extern "C" int s2t_chan_sums(int dtype, const void* y, const void* dyn, const fl
                              double* sums, long P, int C, int mode, void* stream) {
     if (P <= 0) return S2T_OK;
     if (!y || !sums || (C != 64 && C != 128 && C != 32) || (mode && (!dyn || !mean || !rstd))) return S2T_EINVAL;
-    const int ppb = (int)((P + 1023) / 1024 < 256 ? 256 : (P + 1023) / 1024);
-    dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(chan_sums_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)y, (const bf16*)dyn, mean, rstd, sums, P, C, mode, ppb),
-        hipLaunchKernelGGL(chan_sums_kernel<float>, grid, dim3(256), 0, st, (const float*)y, (const float*)dyn, mean, rstd, sums, P, C, mode, ppb));
+    if (P >= 256L * 1024) {                                    // big tensors: 256 workgroups of 16 waves
+        const int ppb = (int)((P + 255) / 256);
+        dim3 grid((unsigned)((P + ppb - 1) / ppb));
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((chan_sums_kernel<bf16, 16>), grid, dim3(1024), 0, st, (const bf16*)y, (const bf16*)dyn, mean, rstd, sums, P, C, mode, ppb),
+            hipLaunchKernelGGL((chan_sums_kernel<float, 16>), grid, dim3(1024), 0, st, (const float*)y, (const float*)dyn, mean, rstd, sums, P, C, mode, ppb));
+    } else {
+        const int ppb = (int)((P + 255) / 256 < 256 ? 256 : (P + 255) / 256);
+        dim3 grid((unsigned)((P + ppb - 1) / ppb));
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((chan_sums_kernel<bf16, 4>), grid, dim3(256), 0, st, (const bf16*)y, (const bf16*)dyn, mean, rstd, sums, P, C, mode, ppb),
+            hipLaunchKernelGGL((chan_sums_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)y, (const float*)dyn, mean, rstd, sums, P, C, mode, ppb));
+    }
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
