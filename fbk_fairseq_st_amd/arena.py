@@ -63,13 +63,23 @@ class ParamArena:
         off, n, shape = self.slices[name]
         return buf[off:off + n].view(shape)
 
+    # the views are cached: the engine asks for ~500 of them per update, and building one (slice + view) costs ~2 us of host
+    # time on a path where the launch stream is what limits small batches
     def p(self, name):
         """f32 master view."""
-        return self._view(self.master, name)
+        key = ("p", name)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = self._view(self.master, name)
+        return v
 
     def g(self, name):
         """f32 gradient view (kernels accumulate into it)."""
-        return self._view(self.grad, name)
+        key = ("g", name)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = self._view(self.grad, name)
+        return v
 
     def w(self, name):
         """compute-dtype view handed to the GEMM kernels (bf16 shadow or the master itself)."""

@@ -15,33 +15,50 @@ def _lib():
     return L.load()
 
 
+_GEMM = None
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_RAW_STREAM = torch._C._cuda_getCurrentRawStream
+
+
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_NONE, aux=None, aux_out=None,
          out=None, out_dtype=None, accumulate=False, splitk=1, alpha=1.0, M=None, N=None, K=None,
          map_a=None, period_a=0, map_b=None, map_c=None, out_rows=None, p_drop=0.0, seed=0):
-    """C = epi(op(a) @ op(b)); a is [M,K] (or [K,M] if trans_a), b is [N,K] (or [K,N] if trans_b)."""
-    L.require_cuda(a, b)
-    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    """C = epi(op(a) @ op(b)); a is [M,K] (or [K,M] if trans_a), b is [N,K] (or [K,N] if trans_b).
+
+    The most frequent call of an update (~200 per step), written for host time: the bound C function and the dtype codes are
+    looked up once, pointers are taken inline (a host tensor would be a GPU fault, so the operands are still checked)."""
+    global _GEMM
+    if _GEMM is None:
+        _GEMM = _lib().s2t_gemm_gather
+    if not (a.is_cuda and b.is_cuda):
+        raise L.S2THipError("S2T kernels need device tensors: the hot path has no CPU fallback")
+    sa0, sb0 = a.stride(0), b.stride(0)
+    assert a.stride(1) == 1 and b.stride(1) == 1
     if M is None:
         M = a.shape[1] if trans_a else a.shape[0]
     if K is None:
         K = a.shape[0] if trans_a else a.shape[1]
     if N is None:
         N = b.shape[1] if trans_b else b.shape[0]
-    odt = out_dtype or (out.dtype if out is not None else a.dtype)
     if out is None:
+        odt = out_dtype or a.dtype
         rows = out_rows if out_rows is not None else M
         out = (torch.zeros if (accumulate or splitk > 1 or map_c is not None) else torch.empty)(
             (rows, N), dtype=odt, device=a.device)
-    assert out.stride(1) == 1
-    for t in (residual, aux, aux_out):
-        assert t is None or (t.dtype == out.dtype and t.stride(-1) == 1)
-    ldaux = aux.stride(0) if aux is not None else (aux_out.stride(0) if aux_out is not None else 0)
-    rc = _lib().s2t_gemm_gather(
-        L.dt(a), L.dt(out), int(trans_a), int(trans_b), M, N, K, L.ptr(a), a.stride(0), L.ptr(b), b.stride(0),
-        L.ptr(out), out.stride(0), L.ptr(bias), L.ptr(residual), residual.stride(0) if residual is not None else 0,
-        L.ptr(aux), L.ptr(aux_out), ldaux, act, int(accumulate), splitk, float(alpha),
-        L.ptr(map_a), period_a, L.ptr(map_b), L.ptr(map_c), float(p_drop), int(seed), L.stream())
-    L.check(rc, "s2t_gemm")
+    ldaux = 0
+    if residual is not None or aux is not None or aux_out is not None:
+        for t in (residual, aux, aux_out):
+            assert t is None or (t.dtype == out.dtype and t.stride(-1) == 1 and t.is_cuda)
+        ldaux = aux.stride(0) if aux is not None else (aux_out.stride(0) if aux_out is not None else 0)
+    rc = _GEMM(
+        _DT[a.dtype], _DT[out.dtype], int(trans_a), int(trans_b), M, N, K, a.data_ptr(), sa0, b.data_ptr(), sb0,
+        out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else 0,
+        residual.data_ptr() if residual is not None else 0, residual.stride(0) if residual is not None else 0,
+        aux.data_ptr() if aux is not None else 0, aux_out.data_ptr() if aux_out is not None else 0, ldaux, act,
+        int(accumulate), splitk, alpha,
+        L.ptr(map_a), period_a, L.ptr(map_b), L.ptr(map_c), p_drop, seed, _RAW_STREAM(L.device_index()))
+    if rc:
+        L.check(rc, "s2t_gemm")
     return out
 
 

@@ -161,6 +161,14 @@ def ptr(t):
 _DEV_INDEX = None
 
 
+def device_index():
+    """index of the GPU this process drives (looked up once: one process, one GPU)"""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()
+    return _DEV_INDEX
+
+
 def stream():
     """raw hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~4 us of Python per call (device-index and
     availability lookups); with ~1100 launches per update that is host time the small decoder-side kernels cannot hide, so the raw

@@ -9,6 +9,7 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--single-thread-autograd", action="store_true", help="run backward on the calling thread so that cProfile sees it")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
@@ -22,6 +23,8 @@ for _ in range(args.steps):
     trainer.train_step([sample])
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / args.steps * 1e3
+if args.single_thread_autograd:
+    torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(args.steps):
@@ -30,4 +33,4 @@ pr.disable()
 torch.cuda.synchronize()
 print("wall per update without the profiler: %.2f ms" % wall)
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(34)
