@@ -211,3 +211,45 @@ def test_mid_backward_weight_gradient_flush_gives_the_same_gradients():
     assert sorted(seen1) == sorted(seen2) and "encoder.layers.0." in seen2
     # with the early flush the top layers are reported before the bottom ones are even computed
     assert seen2.index("encoder.layers.3.") < seen2.index("encoder.layers.0.")
+
+
+def test_overlapped_all_reduce_path_on_the_gpu(monkeypatch):
+    """The data-parallel machinery with the REAL engine on one GPU: a one-rank RCCL group stands in for the node (all-reduce =
+    identity) while the package is told the world has two ranks, so the Trainer takes every world > 1 branch -- buckets launched
+    asynchronously from inside backward (from the autograd thread) on slices of the gradient arena, the mid-backward
+    weight-gradient flush, the f64 statistics all-reduce.  The update must equal the single-process update."""
+    import torch.distributed as dist
+    from fbk_fairseq_st_amd import distributed as D
+    a, task, model, crit, tr = _setup(torch.bfloat16, dropout=0.0)
+    sample = tr.prepare(task.dummy_batch(seed=1, lengths=[200, 180, 150, 120]))
+    for _ in range(2):
+        tr.train_step([sample])
+    want = tr.reduce_stats()
+    want_p = model.arena.master.clone()
+
+    if not dist.is_initialized():
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", world_size=1, rank=0)
+        except Exception as e:                                   # pragma: no cover
+            pytest.skip("no one-rank RCCL group on this box: %r" % (e,))
+    try:
+        monkeypatch.setattr(D, "get_world_size", lambda: 2)
+        a2, task2, model2, crit2, tr2 = _setup(torch.bfloat16, dropout=0.0)
+        a2.bucket_cap_bytes = 4 << 20                             # several buckets for this small model
+        tr2.reducer = D.BucketedGradReducer(tr2.arena.grad, 4 << 20)
+        assert tr2.world == 2 and model2.engine.wgrad_flush_layers == 2 and len(tr2.reducer.plan) >= 2
+        launched_during_backward = []
+        orig = tr2.reducer.finish
+        tr2.reducer.finish = lambda: (launched_during_backward.append(tr2.reducer.next), orig())[1]
+        sample2 = tr2.prepare(task2.dummy_batch(seed=1, lengths=[200, 180, 150, 120]))
+        for _ in range(2):
+            tr2.train_step([sample2])
+        got = tr2.reduce_stats()
+        torch.cuda.synchronize()
+        assert launched_during_backward[-1] >= 1                  # at least one bucket went out before finish()
+        close = lambda x, y: float(((x - y).abs() <= 1e-5 + 1e-3 * y.abs()).float().mean())
+        assert close(model2.arena.master, want_p) > 0.99
+        assert abs(got["loss"] - want["loss"]) <= 1e-3 * abs(want["loss"])
+    finally:
+        monkeypatch.undo()
+        dist.destroy_process_group()
