@@ -237,12 +237,13 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
     if (dx_drop && (p_drop < 0.f || p_drop >= 1.f)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int epl = ln_epl(D, dy, x, dres, dx, dx_drop);
-    // NW = 16 waves per workgroup, one workgroup per CU, for the big activations; 4 waves and up to 512 workgroups for small M
-    // (a 1024-thread workgroup with one row per wave would leave most of the chip idle below ~4096 rows)
+    // 16 waves per workgroup: one workgroup per CU for the big activations; for small M at most 64 workgroups (each ends in 2 D
+    // same-address atomics, ~40 ns apiece in a chain) of 16 waves, i.e. 2-3 rows per wave at the decoder's 2,560 rows -- with 4 waves
+    // per workgroup every wave walked 10 rows one memory latency after the other (17 us per launch)
     const bool big = M >= 8192;
-    const int nw = big ? 16 : 4;
+    const int nw = 16;
     int blocks = (M + nw - 1) / nw;
-    const int cap = big ? 256 : 64;            // small M: a few rows per wave, and at most 64 same-address atomics per column
+    const int cap = big ? 256 : 64;
     if (blocks > cap) blocks = cap;
     dim3 grid(blocks);
     const size_t lds = (size_t)2 * nw * D * sizeof(float);
@@ -259,8 +260,8 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
         if (epl == 4) LN_BWD_LAUNCH(T, 4, NW_); else if (epl == 8) LN_BWD_LAUNCH(T, 8, NW_);                                \
         else if (epl == 16) LN_BWD_LAUNCH(T, 16, NW_); else LN_BWD_LAUNCH(T, 0, NW_);                                       \
     } while (0)
-    if (dtype == S2T_BF16) { if (big) LN_BWD_EPL(bf16, 16); else LN_BWD_EPL(bf16, 4); }
-    else if (dtype == S2T_F32) { if (big) LN_BWD_EPL(float, 16); else LN_BWD_EPL(float, 4); }
+    if (dtype == S2T_BF16) LN_BWD_EPL(bf16, 16);
+    else if (dtype == S2T_F32) LN_BWD_EPL(float, 16);
     else return S2T_ENOTSUP;
 #undef LN_BWD_EPL
 #undef LN_BWD_LAUNCH

@@ -303,9 +303,13 @@ class S2TEngine:
         # conv2 as implicit GEMM + BN2
         w2p = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 0)
         P2 = T4 * B * F4
-        pre2 = torch.empty((P2, C), dtype=self.dtype, device=self.dev) if gelu else None     # GELU's backward needs the pre-activation
-        z2 = K.gemm(y1n.view(-1, C), w2p, M=P2, K=9 * C, map_a=mp["fwd"], period_a=C,
-                    bias=self.P("encoder.convolutions.1.bias"), act=act, aux_out=pre2)
+        direct = K.conv2_fwd(y1n, w2p, self.P("encoder.convolutions.1.bias"), B, T2, F2, C, act) if y1n.dtype == torch.bfloat16 else None
+        if direct is not None:                   # bf16, 64 channels: input rows staged once in LDS (csrc/conv2.hip)
+            z2, pre2 = direct
+        else:                                    # other shapes / f32: implicit GEMM over per-tap row maps
+            pre2 = torch.empty((P2, C), dtype=self.dtype, device=self.dev) if gelu else None     # GELU's backward needs the pre-activation
+            z2 = K.gemm(y1n.view(-1, C), w2p, M=P2, K=9 * C, map_a=mp["fwd"], period_a=C,
+                        bias=self.P("encoder.convolutions.1.bias"), act=act, aux_out=pre2)
         sums2 = K.chan_sums(z2, C)
         mean2, rstd2, sc2, sh2 = K.bn_finalize(sums2, self.P("encoder.bn.1.weight"), self.P("encoder.bn.1.bias"),
                                                bufs["encoder.bn.1.running_mean"], bufs["encoder.bn.1.running_var"],
@@ -375,13 +379,15 @@ class S2TEngine:
         # blocks, N = 2C, was measured too: 282 us against 261 us for the four class products -- 44 % of its MFMA work is zeros.)
         dy1n = torch.empty_like(c["y1n"]).view(-1, C)
         w2q = K.permute_conv_w(self.P("encoder.convolutions.1.weight"), torch.empty((C, 9 * C), dtype=self.dtype, device=self.dev), C, C, 1)
-        for ci, (pt, pf, taps) in enumerate(_TAPS_BY_CLASS):
-            if mp["bwd"][ci] is None:
-                continue
-            rows, maps = mp["bwd"][ci]
-            s0, nt = _CLASS_SLOT0[ci], len(taps)
-            K.gemm(dpre2, w2q[:, s0 * C:(s0 + nt) * C], M=rows.numel(), K=nt * C, map_a=maps, period_a=C, map_c=rows, out=dy1n,
-                   p_drop=c["p_sub"], seed=c["seed"] + 1)
+        # bf16, 64 channels: one direct kernel for all four classes (csrc/conv2.hip); otherwise the gathered products
+        if not (dpre2.dtype == torch.bfloat16 and K.conv2_dgrad(dpre2, w2q, dy1n, B, c["T2"], c["F2"], C, c["p_sub"], c["seed"] + 1)):
+            for ci, (pt, pf, taps) in enumerate(_TAPS_BY_CLASS):
+                if mp["bwd"][ci] is None:
+                    continue
+                rows, maps = mp["bwd"][ci]
+                s0, nt = _CLASS_SLOT0[ci], len(taps)
+                K.gemm(dpre2, w2q[:, s0 * C:(s0 + nt) * C], M=rows.numel(), K=nt * C, map_a=maps, period_a=C, map_c=rows, out=dy1n,
+                       p_drop=c["p_sub"], seed=c["seed"] + 1)
         s1 = K.chan_sums(c["y1"], C, dyn=dy1n, mean=c["mean1"], rstd=c["rstd1"])
         dpre1 = K.bn_bwd_apply(dy1n, c["y1"].view(-1, C), c["mean1"], c["rstd1"], self.P("encoder.bn.0.weight"), s1,
                                self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"],

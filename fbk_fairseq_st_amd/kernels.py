@@ -390,6 +390,29 @@ def conv2_wgrad(dpre, y1n, gw, B, T2, F2, C):
     return True
 
 
+def conv2_fwd(y1n, w2p, bias, B, T2, F2, C, act=ACT_RELU):
+    """direct stride-2 3x3 convolution of the subsampler on channels-last rows: -> (z2 [T4*B*F4, C], pre or None), or None when the
+    shape / dtype is not covered (caller uses the gathered GEMM)"""
+    T4, F4 = (T2 + 1) // 2, (F2 + 1) // 2
+    z2 = torch.empty((T4 * B * F4, C), dtype=y1n.dtype, device=y1n.device)
+    pre = torch.empty_like(z2) if act == ACT_GELU else None
+    rc = _lib().s2t_conv2_fwd(L.dt(y1n), L.ptr(y1n), L.ptr(w2p), L.ptr(bias), L.ptr(z2), L.ptr(pre), B, T2, F2, C, act, L.stream())
+    if rc == -95:
+        return None
+    L.check(rc, "s2t_conv2_fwd")
+    return z2, pre
+
+
+def conv2_dgrad(dpre, w2q, dy1n, B, T2, F2, C, p_drop=0.0, seed=0):
+    """data gradient of the stride-2 3x3 convolution into dy1n [B*T2*F2, C] (every element written), dropout mask of y1n applied;
+    False when the shape / dtype is not covered (caller uses the four gathered products)"""
+    rc = _lib().s2t_conv2_dgrad(L.dt(dpre), L.ptr(dpre), L.ptr(w2q), L.ptr(dy1n), B, T2, F2, C, float(p_drop), int(seed), L.stream())
+    if rc == -95:
+        return False
+    L.check(rc, "s2t_conv2_dgrad")
+    return True
+
+
 def topk(logits, k):
     """[rows,V] (row stride may be padded) -> (f32 [rows,k] values descending, int32 [rows,k] columns)"""
     rows, V = logits.shape

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2              # s2t_abi_version() of the library this binding was written against
+ABI_VERSION = 3              # s2t_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD = 0, 1, 2, 3, 4
 
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
@@ -69,6 +69,8 @@ SIGNATURES = {
     "s2t_prof_reset": [],
     "s2t_prof_read": [ctypes.c_char_p, P, P, P, P],
     "s2t_conv2_wgrad": [c_int, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_conv2_fwd": [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_conv2_dgrad": [c_int, P, P, P, c_int, c_int, c_int, c_int, c_float, c_ull, P],
     "s2t_topk": [c_int, P, P, P, c_long, c_int, c_int, c_int, P],
     "s2t_augment": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "s2t_a2d_chan_stats": [c_int, P, P, P, P, P, P, P, P, c_long, c_int, c_int, c_int, c_int, c_int, P],

@@ -40,6 +40,16 @@ extern "C" {
  * nine taps in one pass: gw[co][tap*C + ci] += sum_{t4,b,f4} dpre[t4][b][f4][co] * y1n[b][2 t4+kh-1][2 f4+kw-1][ci].
  * bf16, C = 64 (S2T_ENOTSUP otherwise: use the gathered s2t_gemm_gather products). */
 int s2t_conv2_wgrad(int dtype, const void* dpre, const void* y1n, float* gw, int B, int T2, int F2, int C, void* stream);
+/* Forward of the same convolution as a direct kernel (input rows staged once in LDS, no row maps):
+ * z2[t4][b][f4][co] = act(bias[co] + sum y1n[b][2 t4+kh-1][2 f4+kw-1][ci] * w2p[co][(kh*3+kw)*C + ci]), act = S2T_ACT_RELU | S2T_ACT_GELU (GELU also
+ * writes the pre-activation to `pre`).  w2p = s2t_permute_conv_w(mode 0).  bf16, C = 64, F2 <= 48 (S2T_ENOTSUP otherwise: s2t_gemm_gather). */
+int s2t_conv2_fwd(int dtype, const void* y1n, const void* w2p, const float* bias, void* z2, void* pre, int B, int T2, int F2, int C,
+                  int act, void* stream);
+/* Data gradient of the same convolution, all four pixel-parity classes in one launch, with the dropout mask of y1n on the way out:
+ * dy1n[b][t2][f2][ci] = dropout(sum_{taps reaching (t2, f2)} sum_co dpre[t4][b][f4][co] * w[co][ci][kh][kw], p_drop, seed) (mask indexed by the
+ * element's position in dy1n).  w2q = s2t_permute_conv_w(mode 1).  bf16, C = 64, F2 <= 47 (S2T_ENOTSUP otherwise). */
+int s2t_conv2_dgrad(int dtype, const void* dpre, const void* w2q, void* dy1n, int B, int T2, int F2, int C, float p_drop,
+                    unsigned long long seed, void* stream);
 /* The K largest logits of every row, descending, with their columns (scripts/generate_topk.py:64-66: the teacher dump of word-level
  * knowledge distillation).  x [rows][V] with row stride ld; vals f32 [rows][K], idx i32 [rows][K]. */
 int s2t_topk(int dtype, const void* x, float* vals, int* idx, long rows, int V, int ld, int K, void* stream);

@@ -695,6 +695,64 @@ def test_conv2_wgrad_all_taps_kernel(B, T2, F2):
     assert not K.conv2_wgrad(dpre.float().to(DEV), y1n.float().to(DEV).view(-1, C), gw, B, T2, F2, C)      # fp32: not covered
 
 
+@pytest.mark.parametrize("B,T2,F2", [(3, 37, 40), (2, 10, 20), (5, 64, 40), (1, 1, 40), (2, 23, 33), (64, 50, 40)])
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+def test_conv2_forward_direct_kernel(B, T2, F2, act):
+    """s2t_conv2_fwd (bf16, 64 channels: input rows staged once in LDS) against torch's conv2d in fp32 on the same bf16 operands:
+    odd T2 / F2 (zero padding on every side), a single input row, the 40-mel geometry, more units than workgroups."""
+    C = 64
+    T4, F4 = (T2 + 1) // 2, (F2 + 1) // 2
+    bf = torch.bfloat16
+    y1n = rnd(B, T2, F2, C, dtype=bf, seed=1)
+    w = rnd(C, C, 3, 3, seed=2, scale=0.06)
+    bias = rnd(C, seed=3, scale=0.2)
+    w2p = K.permute_conv_w(w.to(DEV), torch.empty((C, 9 * C), dtype=bf, device=DEV), C, C, 0)
+    A = K.ACT_GELU if act == "gelu" else K.ACT_RELU
+    out = K.conv2_fwd(y1n.to(DEV), w2p, bias.to(DEV), B, T2, F2, C, A)
+    assert out is not None
+    z2, pre = out
+    wq = w2p.float().cpu().view(C, 9, C).permute(0, 2, 1).reshape(C, C, 3, 3)     # the bf16-rounded weights the kernel multiplies
+    ref_pre = torch.nn.functional.conv2d(y1n.float().permute(0, 3, 1, 2), wq, bias, stride=2, padding=1)       # [B, C, T4, F4]
+    ref_pre = ref_pre.permute(2, 0, 3, 1).reshape(T4 * B * F4, C)                   # rows (t4, b, f4)
+    if act == "gelu":
+        assert float((pre.float().cpu() - ref_pre).abs().max()) <= 2e-2 * float(ref_pre.abs().max())
+        ref = torch.nn.functional.gelu(pre.float().cpu())                          # gelu of the STORED pre-activation
+    else:
+        assert pre is None
+        ref = torch.relu(ref_pre)
+    err = float((z2.float().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err
+    assert K.conv2_fwd(y1n.float().to(DEV), w2p.float(), bias.to(DEV), B, T2, F2, C, A) is None      # fp32: not covered
+
+
+@pytest.mark.parametrize("B,T2,F2", [(3, 37, 40), (2, 10, 20), (5, 64, 40), (1, 1, 40), (2, 23, 33), (64, 50, 40)])
+def test_conv2_data_gradient_direct_kernel(B, T2, F2):
+    """s2t_conv2_dgrad against torch's conv2d input gradient in fp32 on the same bf16 operands (all four pixel-parity classes in one
+    launch, odd sizes, a single row), and with dropout against s2t_dropout of the unmasked result: the same mask (the kernel scales
+    the f32 sums before its one rounding, s2t_dropout the already rounded values: one bf16 ulp apart)"""
+    C = 64
+    T4, F4 = (T2 + 1) // 2, (F2 + 1) // 2
+    bf = torch.bfloat16
+    dpre = rnd(T4, B, F4, C, dtype=bf, seed=2, scale=0.3)
+    w = rnd(C, C, 3, 3, seed=2, scale=0.06)
+    w2q = K.permute_conv_w(w.to(DEV), torch.empty((C, 9 * C), dtype=bf, device=DEV), C, C, 1)
+    dy = torch.full((B * T2 * F2, C), float("nan"), dtype=bf, device=DEV)               # every element must be written
+    assert K.conv2_dgrad(dpre.to(DEV).view(-1, C), w2q, dy, B, T2, F2, C)
+    wq = w.to(bf).float()                                                              # the bf16-rounded weights the kernel multiplies
+    ref = torch.nn.grad.conv2d_input((B, C, T2, F2), wq, dpre.float().permute(1, 3, 0, 2), stride=2, padding=1)    # [B, C, T2, F2]
+    ref = ref.permute(0, 2, 3, 1).reshape(B * T2 * F2, C)
+    assert not torch.isnan(dy.float()).any()
+    err = float((dy.float().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err
+    dyd = torch.empty_like(dy)
+    assert K.conv2_dgrad(dpre.to(DEV).view(-1, C), w2q, dyd, B, T2, F2, C, 0.1, 77)
+    want = K.dropout(dy, 0.1, 77)
+    keep = K.dropout(torch.ones_like(dy), 0.1, 77) != 0
+    assert torch.equal(dyd != 0, keep & (dy != 0)) or float(((dyd != 0) != (keep & (dy != 0))).float().mean()) < 1e-4     # (tiny values may round to 0)
+    assert float((dyd.float() - want.float()).abs().max()) <= 2 ** -7 * float(want.float().abs().max())
+    assert not K.conv2_dgrad(dpre.float().to(DEV).view(-1, C), w2q.float(), dy.float(), B, T2, F2, C)     # fp32: not covered
+
+
 # ------------------------------------------------------------------ ConvAttention2D pieces (csrc/attn2d.hip)
 def _planes(t, B, T, Fq, C, ch):
     """[M, C] channels-last rows (t, b, f) -> [B, T, Fq] plane of channel ch"""

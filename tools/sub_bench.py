@@ -42,3 +42,17 @@ print("bn_bwd_apply   %8.1f us  %5.2f TB/s" % (t * 1e6, 3 * ybytes / t / 1e12))
 dw = torch.zeros(C, 9, device=dev); dbias = torch.zeros(C, device=dev)
 t = timeit(lambda: K.conv1_bwd(x, dyn, dw, dbias))
 print("conv1_bwd      %8.1f us  %5.2f TB/s" % (t * 1e6, (ybytes + x.numel() * 4) / t / 1e12))
+# conv2 forward: direct kernel vs the gathered GEMM (needs the engine's row maps: timed through the engine below)
+w2 = torch.randn(C, C, 3, 3, device=dev) * 0.05
+w2p = K.permute_conv_w(w2, torch.empty((C, 9 * C), dtype=dt, device=dev), C, C, 0)
+y1n = torch.randn(B, T2, F2, C, device=dev).to(dt)
+t = timeit(lambda: K.conv2_fwd(y1n, w2p, bias, B, T2, F2, C))
+T4, F4 = (T2 + 1) // 2, (F2 + 1) // 2
+print("conv2_fwd      %8.1f us  %5.2f TB/s (read y1n + write z2), %.0f TFLOP/s" % (t * 1e6, (y1n.numel() + B * T4 * F4 * C) * 2 / t / 1e12,
+                                                                                   2.0 * B * T4 * F4 * C * 9 * C / t / 1e12))
+w2q = K.permute_conv_w(w2, torch.empty((C, 9 * C), dtype=dt, device=dev), C, C, 1)
+dpre2 = torch.randn(T4 * B * F4, C, device=dev).to(dt)
+dy1n = torch.empty(B * T2 * F2, C, device=dev, dtype=dt)
+t = timeit(lambda: K.conv2_dgrad(dpre2, w2q, dy1n, B, T2, F2, C, 0.1, 5))
+print("conv2_dgrad    %8.1f us  %5.2f TB/s (read dpre + write dy1n), %.0f TFLOP/s" % (t * 1e6, (dy1n.numel() + dpre2.numel()) * 2 / t / 1e12,
+                                                                                     2.0 * B * T4 * F4 * C * 9 * C / t / 1e12))
