@@ -50,7 +50,9 @@ KERNEL_OF = {"wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward p
              "gemm_nn": "gemm256_kernel<bf16, TB=true> (dX = dY W) + gemm_fast_kernel 128x128 for the small products",
              "gemm_tn": "gemm_tn2_kernel (dW of the fc3 projection: 128x128 tile, split-K atomics)",
              "gemm_tn_small": "gemm_fast_kernel<.., 64, 64, 4 waves> (small dW)", "gemm_nt_small": "gemm_fast_kernel<.., 64, 64, 4 waves>",
-             "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (conv2 as implicit GEMM)"}
+             "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (implicit-GEMM convolutions)",
+             "conv2_fwd": "conv2_fwd_kernel (3x3 stride-2 convolution, input rows staged once in LDS, weights in registers)",
+             "conv2_dgrad": "conv2_dgrad_kernel (its data gradient, four pixel-parity classes in one launch)"}
 TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_F32_TFLOPS = 157.3
@@ -268,9 +270,10 @@ def main():
             trainer.train_step([next_batch()])
         torch.cuda.synchronize()
         K.prof_enable(False)
-        names = ("wgrad_group", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small", "gemm_gather", "attn_fwd", "attn_bwd")
+        names = ("wgrad_group", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small", "gemm_gather", "conv2_fwd",
+                 "conv2_dgrad", "attn_fwd", "attn_bwd")
         fam = {f: K.prof_read(f) for f in names}
-        gemms = {f: v for f, v in fam.items() if (f.startswith("gemm") or f == "wgrad_group") and v["launches"] > 0 and v["ms"] > 0}
+        gemms = {f: v for f, v in fam.items() if not f.startswith("attn") and v["launches"] > 0 and v["ms"] > 0}     # every MFMA product family
         if gemms:
             # dominant kernel = the MFMA GEMM family with the most time per update (KERNEL_OF names its kernels)
             dom = max(gemms, key=lambda f: gemms[f]["ms"])

@@ -18,7 +18,7 @@ FAMILY = [("wgrad_group", ("wgrad_group_kernel",)), ("gemm_nn", ("gemm256_kernel
           ("gemm_nt", ("gemm256_kernel", "false")), ("gemm_nn", ("gemm256_kernel", "true")),
           ("gemm_tn", ("gemm_tn2_kernel",)), ("gemm_tn", ("gemm_fast_kernel", "true, true, 128, 128")), ("gemm_tn", ("gemm_fast_kernel", "Lb1ELb1ELi128ELi128")),
           ("gemm_nt", ("gemm_fast_kernel", "Lb0ELb0ELi128ELi128")), ("gemm_nn", ("gemm_fast_kernel", "Lb0ELb1ELi128ELi128")),
-          ("gemm_gather", ("gemm_kernel",)), ("attn_fwd", ("attn_fwd2",)), ("attn_bwd", ("attn_bwd_d",))]
+          ("gemm_gather", ("gemm_kernel",)), ("conv2_fwd", ("conv2_fwd_kernel",)), ("conv2_dgrad", ("conv2_dgrad_kernel",)), ("attn_fwd", ("attn_fwd2",)), ("attn_bwd", ("attn_bwd_d",))]
 
 
 def family_of(name):

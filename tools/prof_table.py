@@ -9,7 +9,8 @@ GROUPS = [("`gemm256_kernel` NT (Y = XWᵀ + epilogue)", lambda n: "gemm256" in 
           ("`attn_bwd_dkv2`", lambda n: "attn_bwd_dkv2" in n),
           ("decoder self-attention (first-generation kernels, T = 40)", lambda n: "attn_" in n),
           ("`gemm_fast_kernel` 128x128 / 64x64, `gemm_tn2_kernel` (decoder-side, logits, fc3 dW)", lambda n: "gemm_fast" in n or "gemm_tn2" in n),
-          ("`gemm_kernel` with row gather (conv2 fwd + data gradient)", lambda n: "gemm_kernel" in n),
+          ("`conv2_fwd_kernel` / `conv2_dgrad_kernel` (direct 3x3 stride-2 convolution)", lambda n: "conv2_fwd" in n or "conv2_dgrad" in n),
+          ("`gemm_kernel` with row gather (implicit-GEMM convolutions)", lambda n: "gemm_kernel" in n),
           ("`ln_bwd`", lambda n: "ln_bwd" in n), ("`ln_fwd`", lambda n: "ln_fwd" in n),
           ("`conv1_fwd` / `conv1_bwd` / `conv2_wgrad`", lambda n: "conv1_" in n or "conv2_wgrad" in n),
           ("`chan_sums` / `bn_apply` / `bn_bwd_apply` / `bn_finalize`", lambda n: "chan_sums" in n or "bn_" in n),
