@@ -52,15 +52,22 @@ __global__ __launch_bounds__(256) void ctc_argmax_row_kernel(const bf16* __restr
     const bf16* x = logits + row * ld;
     const int nv = (V + 7) / 8;                                    // the last vector may reach into the row padding (ld >= 8 nv)
     u32x4 raw[NC];
+    const int tail = V & 7;                                            // real elements of the last vector (0: all eight)
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         const int c = lane + 64 * k;
         raw[k] = c < nv ? *reinterpret_cast<const u32x4*>(x + c * 8) : (u32x4){0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u};   // -inf
+        if (tail && c == nv - 1) {                                     // padding columns of the last vector -> -inf, once
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (2 * w >= tail) raw[k][w] = 0xFF80FF80u;
+                else if (2 * w + 1 >= tail) raw[k][w] = (raw[k][w] & 0x0000FFFFu) | 0xFF800000u;
+            }
+        }
     }
     auto elem = [&](int k, int e) -> float {                       // bf16 -> f32 is a shift / mask of the packed word
         const uint32_t w = raw[k][e >> 1];
-        const float v = __builtin_bit_cast(float, (e & 1) ? (w & 0xFFFF0000u) : (w << 16));
-        return (lane + 64 * k) * 8 + e < V ? v : -INFINITY;        // padding columns of the last vector
+        return __builtin_bit_cast(float, (e & 1) ? (w & 0xFFFF0000u) : (w << 16));
     };
     float m = -INFINITY;
 #pragma unroll
@@ -68,11 +75,15 @@ __global__ __launch_bounds__(256) void ctc_argmax_row_kernel(const bf16* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) m = fmaxf(m, elem(k, e));
     m = wave_max(m);
+    // sum of exp(x - m) with the hardware exp2 (two instructions per element; the libm-accurate expf made this sweep 3/4 of the
+    // kernel's time).  Only the common denominator comes from here: which index wins is decided below on accurately evaluated
+    // numerators, and the reported probability / log-sum-exp move by ~1e-7 relative.
+    const float ml2 = m * 1.44269504088896f;
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += expf(elem(k, e) - m);     // exp(-inf) = 0 for the padding
+        for (int e = 0; e < 8; ++e) s += __builtin_amdgcn_exp2f(__builtin_fmaf(elem(k, e), 1.44269504088896f, -ml2));     // exp2(-inf) = 0 for the padding
     s = wave_sum(s);
     float best = -1.f; int bi = 0x7fffffff;
 #pragma unroll
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(256) void ctc_argmax_row_kernel(const bf16* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float xv = elem(k, e);
-            if (xv >= m - 1e-3f) {                                   // only these can round to the top probability
+            if (xv >= m - 1e-3f) {                                   // only these can round to the top probability (padding is -inf)
                 const float pr = expf(xv - m) / s;
                 const int j = (lane + 64 * k) * 8 + e;
                 if (pr > best || (pr == best && j < bi)) { best = pr; bi = j; }
