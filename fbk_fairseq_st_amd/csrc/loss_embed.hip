@@ -10,16 +10,21 @@
 //   dlogits[v] = gscale * (softmax[v] - (1-eps)*[v==y] - eps/V)   (0 on pad rows)
 template <typename T>
 __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits, const long long* __restrict__ target,
-                                                   T* __restrict__ dlogits, float* __restrict__ sums, int V, int ld,
+                                                   T* __restrict__ dlogits, float* __restrict__ sums, long rows, int V, int ld,
                                                    float eps, int pad, float gscale) {
     __shared__ float sh[16];
-    const long row = blockIdx.x;
+    // A workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ... and adds its loss sums ONCE: one workgroup per row ended in two
+    // same-address f32 atomics each, a 2,560-deep chain served serially at the memory side (~40 ns apiece) -- 80 us for a pass over
+    // 41 MB of logits.  exp through the hardware exp2 (the gradient and the loss move by ~1e-7 relative).
+    float acc_loss = 0.f, acc_nll = 0.f;
+    constexpr float L2E = 1.44269504088896f;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
     const T* x = logits + row * ld;
     T* g = dlogits ? dlogits + row * ld : nullptr;
     const long long y = target[row];
     if (y == pad) {
         if (g) for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
-        return;
+        continue;
     }
     // 16-byte row accesses when the row is aligned (ld multiple of 8 bf16 / 4 f32: kernels.py alloc_rows), scalar tail otherwise
     constexpr int E = 16 / (int)sizeof(T);
@@ -35,50 +40,55 @@ __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits,
     for (int v = nv * E + threadIdx.x; v < V; v += 256) { const float f = to_f32(x[v]); m = fmaxf(m, f); sx += f; }
     m = block_max(m, sh);
     sx = block_sum(sx, sh);
+    const float ml2 = m * L2E;
     float se = 0.f;
     for (int c = threadIdx.x; c < nv; c += 256) {
         T t[E];
         *reinterpret_cast<u32x4*>(t) = *reinterpret_cast<const u32x4*>(x + c * E);
 #pragma unroll
-        for (int e = 0; e < E; ++e) se += expf(to_f32(t[e]) - m);
+        for (int e = 0; e < E; ++e) se += __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(t[e]), L2E, -ml2));
     }
-    for (int v = nv * E + threadIdx.x; v < V; v += 256) se += expf(to_f32(x[v]) - m);
+    for (int v = nv * E + threadIdx.x; v < V; v += 256) se += __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(x[v]), L2E, -ml2));
     se = block_sum(se, sh);
     const float lse = m + logf(se);
     if (threadIdx.x == 0) {
         const float nll = lse - to_f32(x[y]);
         const float smooth = (float)V * lse - sx;
-        atomicAdd(sums + 0, (1.f - eps) * nll + (eps / (float)V) * smooth);
-        atomicAdd(sums + 1, nll);
+        acc_loss += (1.f - eps) * nll + (eps / (float)V) * smooth;
+        acc_nll += nll;
     }
     if (g) {
-        const float ev = eps / (float)V;
+        const float ev = eps / (float)V, lsel2 = lse * L2E;
         for (int c = threadIdx.x; c < nv; c += 256) {
             T t[E], o[E];
             *reinterpret_cast<u32x4*>(t) = *reinterpret_cast<const u32x4*>(x + c * E);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                float d = expf(to_f32(t[e]) - lse) - ev;
+                float d = __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(t[e]), L2E, -lsel2)) - ev;
                 if (c * E + e == y) d -= (1.f - eps);
                 o[e] = from_f32<T>(d * gscale);
             }
             *reinterpret_cast<u32x4*>(g + c * E) = *reinterpret_cast<const u32x4*>(o);
         }
         for (int v = nv * E + threadIdx.x; v < V; v += 256) {
-            float d = expf(to_f32(x[v]) - lse) - ev;
+            float d = __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(x[v]), L2E, -lsel2)) - ev;
             if (v == y) d -= (1.f - eps);
             g[v] = from_f32<T>(d * gscale);
         }
     }
+    __syncthreads();                                 // `sh` is reused by the next row's reductions
+    }
+    if (threadIdx.x == 0 && (acc_loss != 0.f || acc_nll != 0.f)) { atomicAdd(sums + 0, acc_loss); atomicAdd(sums + 1, acc_nll); }
 }
 
-extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2,
-                        long rows, int V, int ld, float eps, int pad, float grad_scale, void* stream) {
+extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2, long rows, int V, int ld,
+                        float eps, int pad, float grad_scale, void* stream) {
     if (rows <= 0) return S2T_OK;
     if (!logits || !target || !sums2 || V <= 0 || ld < V) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(lsce_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, target, (bf16*)dlogits, sums2, V, ld, eps, pad, grad_scale);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(lsce_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, (float*)dlogits, sums2, V, ld, eps, pad, grad_scale);
+    const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);       // four workgroups per CU; each ends in two atomics
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(lsce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)logits, target, (bf16*)dlogits, sums2, rows, V, ld, eps, pad, grad_scale);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(lsce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)logits, target, (float*)dlogits, sums2, rows, V, ld, eps, pad, grad_scale);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
