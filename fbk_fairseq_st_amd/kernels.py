@@ -77,20 +77,24 @@ WGRAD_GROUP_MAX = 4096
 
 def wgrad_group(items):
     """items: list of (dy [tokens, n_out], x [tokens, n_in], dw [n_out, n_in] f32, db [n_out] f32 or None), bf16 operands:
-    dw += dy^T x and db += column sums of dy for all of them in one launch (s2t_wgrad_group)."""
+    dw += dy^T x and db += column sums of dy for all of them in one launch (s2t_wgrad_group).  The operands were checked by
+    wgrad_group_ok when they were queued; here only what the C side cannot see is re-checked (host time: this runs at the end of
+    the decoder's backward, where the launch stream is what the GPU waits for)."""
     if not items:
         return
+    fn = _lib().s2t_wgrad_group
     for i in range(0, len(items), WGRAD_GROUP_MAX):
         chunk = items[i:i + WGRAD_GROUP_MAX]
         arr = (L.WgradProblem * len(chunk))()
         for k, (dy, x, dw, db) in enumerate(chunk):
-            L.require_cuda(dy, x, dw)
-            assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32
-            assert dy.dim() == 2 and x.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0]
-            assert dw.stride(1) == 1 and tuple(dw.shape) == (dy.shape[1], x.shape[1]) and (db is None or db.dtype == torch.float32)
-            arr[k] = L.WgradProblem(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(db), dy.shape[1], x.shape[1], dy.shape[0],
-                                    dy.stride(0), x.stride(0), dw.stride(0))
-        L.check(_lib().s2t_wgrad_group(len(chunk), ctypes.addressof(arr), L.stream()), "s2t_wgrad_group")
+            if not (dy.is_cuda and x.is_cuda and dw.is_cuda and dw.dtype == torch.float32 and dy.shape[0] == x.shape[0]
+                    and dw.shape[0] == dy.shape[1] and dw.shape[1] == x.shape[1]):
+                raise L.S2THipError("wgrad_group: item %d is not a (dy [tokens, n_out], x [tokens, n_in], f32 dw [n_out, n_in]) device triple" % k)
+            p = arr[k]
+            p.dY = dy.data_ptr(); p.X = x.data_ptr(); p.dW = dw.data_ptr(); p.db = db.data_ptr() if db is not None else None
+            p.n_out = dy.shape[1]; p.n_in = x.shape[1]; p.tokens = dy.shape[0]
+            p.ldy = dy.stride(0); p.ldx = x.stride(0); p.ldw = dw.stride(0)
+        L.check(fn(len(chunk), ctypes.addressof(arr), L.stream()), "s2t_wgrad_group")
 
 
 def wgrad_group_ok(dy, x):
