@@ -204,6 +204,88 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     }
 }
 
+
+// BatchNorm backward + activation derivative + conv1 backward in ONE pass over (dyn, y): the gradient w.r.t. the convolution's
+// output, dpre = act'(.) * gamma*rstd*(dyn - dbeta/N - xhat*dgamma/N), is formed in registers (two fmas per element from three
+// per-channel constants) and consumed by the weight / bias sums at once -- it was a 245 MB tensor written by s2t_bn_bwd_apply and
+// read back by s2t_conv1_bwd (153 + 148 us).  Also adds the BatchNorm parameter gradients (block 0), as s2t_bn_bwd_apply does.
+template <typename T, bool GELU>
+__global__ __launch_bounds__(256) void conv1_bwd_bn_kernel(const float* __restrict__ x, const T* __restrict__ dyn, const T* __restrict__ y,
+                                                           const T* __restrict__ pre, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* __restrict__ sums, float* __restrict__ dw,
+                                                           float* __restrict__ db, float* dgamma, float* dbeta, int B, int Tin, int F, int T2, int F2,
+                                                           int C, int pos_per_block, double count, int training) {
+    __shared__ float red[4][16][80];
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            atomicAdd(dbeta + c, (float)sums[c]);
+            atomicAdd(dgamma + c, (float)sums[C + c]);
+        }
+    }
+    const int LP = C >> 3, g = threadIdx.x % LP, slot = threadIdx.x / LP, nslot = 256 / LP;
+    // dpre = act' * (ka * dyn + kb * y + kc):  ka = gamma*rstd, kb = -ka*m2*rstd, kc = ka*(m2*rstd*mean - m1)   (m1, m2 = dbeta/N, dgamma/N)
+    float ka[8], kb[8], kc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 8 * g + e;
+        const float rs = rstd[c], mu = mean[c];
+        const float m1 = training ? (float)(sums[c] / count) : 0.f, m2 = training ? (float)(sums[C + c] / count) : 0.f;
+        ka[e] = gamma[c] * rs; kb[e] = -ka[e] * m2 * rs; kc[e] = ka[e] * (m2 * rs * mu - m1);
+    }
+    float a[8][10];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) a[e][i] = 0.f;
+    const unsigned P = (unsigned)B * T2 * F2;
+    const unsigned p0 = blockIdx.x * (unsigned)pos_per_block, pend = min(P, p0 + (unsigned)pos_per_block);
+    Conv1Win wn;
+    float dn[8], yn[8], qn[8];
+    if (p0 + slot < pend) {
+        conv1_window_issue(x, p0 + slot, Tin, F, T2, F2, wn);
+        load8<T>(dyn + (size_t)(p0 + slot) * C + 8 * g, dn);
+        load8<T>(y + (size_t)(p0 + slot) * C + 8 * g, yn);
+        if constexpr (GELU) load8<T>(pre + (size_t)(p0 + slot) * C + 8 * g, qn);
+    }
+    for (unsigned p = p0 + slot; p < pend; p += nslot) {
+        float xv[9], gq[8];
+        conv1_window_finish(wn, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float r = __builtin_fmaf(ka[e], dn[e], __builtin_fmaf(kb[e], yn[e], kc[e]));
+            if constexpr (GELU) gq[e] = r * gelu_grad_f(qn[e]);
+            else gq[e] = yn[e] > 0.f ? r : 0.f;
+        }
+        const unsigned pn = min(p + nslot, P - 1);
+        conv1_window_issue(x, pn, Tin, F, T2, F2, wn);
+        load8<T>(dyn + (size_t)pn * C + 8 * g, dn);
+        load8<T>(y + (size_t)pn * C + 8 * g, yn);
+        if constexpr (GELU) load8<T>(pre + (size_t)pn * C + 8 * g, qn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[e][i] += gq[e] * xv[i];
+            a[e][9] += gq[e];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const float v = group_sum(a[e][i], LP);
+            if (lane < LP) red[wave][g][e * 10 + i] = v;
+        }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 10 * C; t += 256) {
+        const int c = t / 10, i = t % 10;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) v += red[wv][c >> 3][(c & 7) * 10 + i];
+        if (i < 9) atomicAdd(dw + c * 9 + i, v); else atomicAdd(db + c, v);
+    }
+}
+
 // ------------------------------------------------------------------ per-channel sums over [P][C]
 // mode 0: sums[c] += y, sums[C+c] += y^2            (BatchNorm statistics)
 // mode 1: sums[c] += dyn, sums[C+c] += dyn*xhat     (BatchNorm backward: dbeta, dgamma)
@@ -425,6 +507,29 @@ extern "C" int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float*
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(conv1_bwd_kernel<bf16>, grid, dim3(256), 0, st, x, (const bf16*)dpre, dw, db, B, T, F, T2, F2, C, ppb),
         hipLaunchKernelGGL(conv1_bwd_kernel<float>, grid, dim3(256), 0, st, x, (const float*)dpre, dw, db, B, T, F, T2, F2, C, ppb));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_conv1_bwd_bn(int dtype, const float* x, const void* dyn, const void* y, const void* pre, const float* mean, const float* rstd,
+                                const float* gamma, const double* sums, float* dw, float* db, float* dgamma, float* dbeta, int B, int T, int F,
+                                int C, double count, int training, void* stream) {
+    if (B <= 0 || T <= 0) return S2T_OK;
+    if (!x || !dyn || !y || !mean || !rstd || !gamma || !sums || !dw || !db || !dgamma || !dbeta || (C != 64 && C != 128 && C != 32) || F < 3) return S2T_EINVAL;
+    const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
+    const long P = (long)B * T2 * F2;
+    const int ppb = (int)((P + 511) / 512 < 256 ? 256 : (P + 511) / 512);     // <= 512 workgroups = 2 per CU at ~172 VGPRs, all resident
+    dim3 grid((unsigned)((P + ppb - 1) / ppb));
+    hipStream_t st = (hipStream_t)stream;
+    if (pre) {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((conv1_bwd_bn_kernel<bf16, true>), grid, dim3(256), 0, st, x, (const bf16*)dyn, (const bf16*)y, (const bf16*)pre, mean, rstd, gamma, sums, dw, db, dgamma, dbeta, B, T, F, T2, F2, C, ppb, count, training),
+            hipLaunchKernelGGL((conv1_bwd_bn_kernel<float, true>), grid, dim3(256), 0, st, x, (const float*)dyn, (const float*)y, (const float*)pre, mean, rstd, gamma, sums, dw, db, dgamma, dbeta, B, T, F, T2, F2, C, ppb, count, training));
+    } else {
+        DISPATCH_T(dtype,
+            hipLaunchKernelGGL((conv1_bwd_bn_kernel<bf16, false>), grid, dim3(256), 0, st, x, (const bf16*)dyn, (const bf16*)y, (const bf16*)nullptr, mean, rstd, gamma, sums, dw, db, dgamma, dbeta, B, T, F, T2, F2, C, ppb, count, training),
+            hipLaunchKernelGGL((conv1_bwd_bn_kernel<float, false>), grid, dim3(256), 0, st, x, (const float*)dyn, (const float*)y, (const float*)nullptr, mean, rstd, gamma, sums, dw, db, dgamma, dbeta, B, T, F, T2, F2, C, ppb, count, training));
+    }
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

@@ -389,11 +389,11 @@ class S2TEngine:
                 K.gemm(dpre2, w2q[:, s0 * C:(s0 + nt) * C], M=rows.numel(), K=nt * C, map_a=maps, period_a=C, map_c=rows, out=dy1n,
                        p_drop=c["p_sub"], seed=c["seed"] + 1)
         s1 = K.chan_sums(c["y1"], C, dyn=dy1n, mean=c["mean1"], rstd=c["rstd1"])
-        dpre1 = K.bn_bwd_apply(dy1n, c["y1"].view(-1, C), c["mean1"], c["rstd1"], self.P("encoder.bn.0.weight"), s1,
-                               self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"],
-                               pre=None if c["pre1"] is None else c["pre1"].view(-1, C))
-        K.conv1_bwd(c["x"], dpre1.view(B, c["T2"], c["F2"], C), self.G("encoder.convolutions.0.weight").view(C, 9),
-                    self.G("encoder.convolutions.0.bias"))
+        # BatchNorm backward, activation derivative and the conv1 weight / bias sums in one pass (dpre1 is never materialised)
+        K.conv1_bwd_bn(c["x"], dy1n, c["y1"].view(-1, C), c["mean1"], c["rstd1"], self.P("encoder.bn.0.weight"), s1,
+                       self.G("encoder.convolutions.0.weight").view(C, 9), self.G("encoder.convolutions.0.bias"),
+                       self.G("encoder.bn.0.weight"), self.G("encoder.bn.0.bias"), c["cnt1"], c["training"],
+                       pre=None if c["pre1"] is None else c["pre1"].view(-1, C))
 
     # ------------------------------------------------------------------ ConvAttention2D
     def _a2d_bn(self, p, names, sums, count, training):

@@ -202,6 +202,15 @@ def chan_sums(y, C, dyn=None, mean=None, rstd=None):
     return sums
 
 
+def conv1_bwd_bn(x, dyn, y, mean, rstd, gamma, sums, dw, db, dgamma, dbeta, count, training=True, pre=None):
+    """bn_bwd_apply + conv1_bwd in one pass: the gradient w.r.t. conv1's output stays in registers"""
+    B, T, F = x.shape
+    C = y.shape[-1]
+    L.check(_lib().s2t_conv1_bwd_bn(L.dt(y), L.ptr(x), L.ptr(dyn), L.ptr(y), L.ptr(pre), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(sums),
+                                    L.ptr(dw), L.ptr(db), L.ptr(dgamma), L.ptr(dbeta), B, T, F, C, float(count), int(training), L.stream()),
+            "s2t_conv1_bwd_bn")
+
+
 def bn_finalize(sums, gamma, beta, run_mean, run_var, num_batches, count, training, momentum=0.1, eps=1e-5):
     C = gamma.numel()
     o = torch.empty((4, C), dtype=torch.float32, device=gamma.device)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "s2t_layernorm_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_float, c_ull, P],
     "s2t_conv1_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
     "s2t_conv1_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "s2t_conv1_bwd_bn": [c_int] + [P] * 12 + [c_int, c_int, c_int, c_int, c_double, c_int, P],
     "s2t_chan_sums": [c_int, P, P, P, P, P, c_long, c_int, c_int, P],
     "s2t_bn_finalize": [P] * 10 + [c_double, c_int, c_int, c_float, c_float, P],
     "s2t_bn_apply": [c_int, P, P, P, P, c_long, c_int, c_float, c_ull, P],

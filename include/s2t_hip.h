@@ -156,6 +156,12 @@ int s2t_conv1_fwd(int dtype, const float* x, const float* w, const float* bias, 
                   int B, int T, int F, int C, int act, void* stream);
 /* dw[c][3][3] += , db[c] += from dpre [B][T2][F2][C] (gradient after the ReLU mask) */
 int s2t_conv1_bwd(int dtype, const float* x, const void* dpre, float* dw, float* db, int B, int T, int F, int C, void* stream);
+/* s2t_bn_bwd_apply + s2t_conv1_bwd in one pass (the gradient w.r.t. the convolution's output is never written): dw / db += as
+ * s2t_conv1_bwd would from dpre = act'(.) * BatchNorm'(dyn) (arguments as s2t_bn_bwd_apply: y = BatchNorm input, pre = pre-activation
+ * for GELU or NULL, sums from s2t_chan_sums(mode 1)); dgamma / dbeta += */
+int s2t_conv1_bwd_bn(int dtype, const float* x, const void* dyn, const void* y, const void* pre, const float* mean, const float* rstd,
+                     const float* gamma, const double* sums, float* dw, float* db, float* dgamma, float* dbeta, int B, int T, int F,
+                     int C, double count, int training, void* stream);
 /* per-channel double sums over a channels-last [P][C] tensor: mode 0 (y, y^2); mode 1 (dyn, dyn*xhat) */
 int s2t_chan_sums(int dtype, const void* y, const void* dyn, const float* mean, const float* rstd,
                   double* sums, long P, int C, int mode, void* stream);

@@ -300,6 +300,12 @@ def test_conv1_bn(dtype, B, T):
     K.conv1_bwd(x.to(DEV), dpre, dw, dbias)
     assert rel_err(dw.view(C, 1, 3, 3), wf.grad) < t
     assert rel_err(dbias, bf.grad) < t
+    # the one-pass form (dpre never written): same four gradients
+    dg2 = torch.zeros(C, device=DEV); db2 = torch.zeros(C, device=DEV)
+    dw2 = torch.zeros(C, 9, device=DEV); dbias2 = torch.zeros(C, device=DEV)
+    K.conv1_bwd_bn(x.to(DEV), dynd, yd, mean, rstd, gamma.to(DEV), s2, dw2, dbias2, dg2, db2, cnt)
+    assert rel_err(dw2.view(C, 1, 3, 3), wf.grad) < t and rel_err(dbias2, bf.grad) < t
+    assert rel_err(dg2, gf.grad) < t and rel_err(db2, btf.grad) < t
 
 
 # ------------------------------------------------------------------ CTC compression (integers bit-exact)

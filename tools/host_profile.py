@@ -9,11 +9,12 @@ import bench
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--attn-2d", action="store_true")
 ap.add_argument("--single-thread-autograd", action="store_true", help="run backward on the calling thread so that cProfile sees it")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
-a, task, model, crit, trainer, _ = bench.build_all("s2t_transformer_m", args.batch, 1500, 40, 8, 1e-9, torch.bfloat16, dev)
+a, task, model, crit, trainer, _ = bench.build_all("s2t_transformer_m", args.batch, 1500, 40, 8, 1e-9, torch.bfloat16, dev, attn_2d=args.attn_2d)
 sample = trainer.prepare(task.dummy_batch(seed=1))
 for _ in range(5):
     trainer.train_step([sample])
