@@ -81,7 +81,7 @@ template <> struct Pack4<float> { typedef u32x4 type; };
 // arithmetic of one output quad (row, col .. col + 3); `pre` receives the GELU pre-activation (aux_out)
 template <typename TO, int ACT, int EXT>
 __device__ __forceinline__ typename Pack4<TO>::type epi_quad(const GemmArgs& p, f32x4 v, f32x4 b4, typename Pack4<TO>::type ext,
-                                                             uint64_t quad, uint32_t drop_th, float drop_inv,
+                                                             uint32_t quad, uint32_t drop_ks, uint32_t drop_hwm, uint32_t drop_th, float drop_inv,
                                                              typename Pack4<TO>::type& pre_out) {
     typedef typename Pack4<TO>::type PK;
     float x[4];
@@ -99,7 +99,9 @@ __device__ __forceinline__ typename Pack4<TO>::type epi_quad(const GemmArgs& p, 
     }
     if constexpr (ACT == ACT_GELU) pre_out = *reinterpret_cast<const PK*>(pre);
     if (p.p_drop > 0.f) {
-        const u32x2 dh = drop_hash4(p.seed, quad);
+        // the output has fewer than 2^34 elements (host check): the quad index is one 32-bit word, the seed scramble and the
+        // high-word term are per-launch constants (common.hpp drop_hash4_lo: the same mask as every other kernel)
+        const u32x2 dh = drop_hash4_lo(drop_ks, drop_hwm, quad);
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = (drop_field(dh, e) >= (drop_th >> 16)) ? x[e] * drop_inv : 0.f;
     }
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
     const uint32_t drop_th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
     const float drop_inv = 1.f / (1.f - p.p_drop);
+    const uint32_t drop_ks = drop_seed_key(p.seed), drop_hwm = drop_high_mix(p.seed, 0);
     // buffer descriptors of the output, the extra operand stream and aux_out: M rows each (rows >= M fall outside)
     const void* Eptr = EXT == EXT_RES ? p.residual : EXT == EXT_OLD ? (const void*)p.C : p.aux;
     const int lde = EXT == EXT_RES ? p.ldr : EXT == EXT_OLD ? p.ldc : p.ldaux;
@@ -386,10 +389,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             const int row = roww + hm * HR + 16 * ii;
                             uint32_t e0 = e16[ii][pp][0], e1 = e16[ii][pp][1], e2 = e16[ii][pp][2], e3 = e16[ii][pp][3];
                             if constexpr (EXT != EXT_NONE) { swap2(e0, e2); swap2(e1, e3); }
-                            const uint64_t qa = ((uint64_t)row * p.N + (colw + pp * 128)) >> 2;
+                            const uint32_t qa = (uint32_t)(((uint64_t)row * p.N + (colw + pp * 128)) >> 2);
                             PK pa, pb;
-                            const PK oa = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp], b4[2 * pp], PK{e0, e1}, qa, drop_th, drop_inv, pa);
-                            const PK ob = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp + 1], b4[2 * pp + 1], PK{e2, e3}, qa + 4, drop_th, drop_inv, pb);
+                            const PK oa = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp], b4[2 * pp], PK{e0, e1}, qa, drop_ks, drop_hwm, drop_th, drop_inv, pa);
+                            const PK ob = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp + 1], b4[2 * pp + 1], PK{e2, e3}, qa + 4, drop_ks, drop_hwm, drop_th, drop_inv, pb);
                             uint32_t s0 = oa[0], s1 = oa[1], s2 = ob[0], s3 = ob[1];
                             swap2(s0, s2); swap2(s1, s3);
                             buf_store(u32x4{s0, s1, s2, s3}, rC, vC[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES);
@@ -436,6 +439,7 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     const size_t osz = out_dtype == S2T_BF16 ? 2 : 4;
     if ((size_t)a.M * a.ldc * osz >= (1ull << 31) || (size_t)a.M * a.ldr * osz >= (1ull << 31) || (size_t)a.M * a.ldaux * osz >= (1ull << 31)) return 0;
     if (trans_b && ((a.N + 7) / 8 * 8 > a.ldb)) return 0;
+    if (a.p_drop > 0.f && (unsigned long long)a.M * (unsigned long long)a.N >= (1ull << 34)) return 0;   // the epilogue keeps the mask's quad index in 32 bits
     // epilogue variant: the activation and the ONE extra operand stream are compile-time (gemm256_kernel<.., ACT, EXT>)
     int ext = EXT_NONE;
     if (a.act == ACT_RELU_BWD || a.act == ACT_GELU_BWD) { if (a.residual || a.accumulate) return 0; ext = EXT_AUX; }
