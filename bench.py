@@ -262,14 +262,18 @@ def main():
     frames_per_step = frames_done // args.steps
 
     roof = None
-    if args.roofline and rank == 0:
+    if args.roofline:
         # Instrumented updates run right AFTER the timed region, on the same batch and training state: bracketing every GEMM and
         # attention launch with two HIP events costs 2.2-2.5 ms per update, which would distort `value` by 12 % inside the timed region.
-        K.prof_reset(); K.prof_enable(True)
+        # EVERY rank runs them (an update contains the gradient all-reduce: rank 0 alone would wait for the others forever); only
+        # rank 0 instruments and reports.
+        if rank == 0:
+            K.prof_reset(); K.prof_enable(True)
         for _ in range(args.prof_steps):
             trainer.train_step([next_batch()])
         torch.cuda.synchronize()
         K.prof_enable(False)
+    if args.roofline and rank == 0:
         names = ("wgrad_group", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small", "gemm_gather", "conv2_fwd",
                  "conv2_dgrad", "attn_fwd", "attn_bwd")
         fam = {f: K.prof_read(f) for f in names}
