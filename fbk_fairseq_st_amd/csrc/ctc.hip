@@ -334,6 +334,12 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
         else skip2[i] = (s + 2 < S && ext_s[s + 2] != blank && ext_s[s + 2] != es[i]);
     }
     float* out = (dir == 0 ? la : lb) + (long)b * Tn * Smax;
+    // Every step's vector is stored RELATIVE to its own maximum (one wave reduction per step, ~5 % of the step's latency) and the
+    // maxima are summed in double.  In plain log space alpha and beta reach -3,000 over 375 frames x 5,001 units, where one f32 ulp
+    // is 2.4e-4: alpha + beta - log P then carries ~1e-3 of relative error into every posterior (measured against float64: 8e-4 in
+    // |dg|/|g|, torch's own f32 ctc_loss 6e-4).  Relative vectors stay within a few tens of their maximum, and the gradient kernel
+    // normalises alpha + beta - emission per frame, so the offsets never enter the posteriors; only the loss needs their sum.
+    double offsum = 0.0;
     const int nch = (Tb + CTC_CH - 1) / CTC_CH;
     for (int ch = 0; ch < nch; ++ch) {
         // chunk of time steps handled in this iteration: alpha walks forward, beta backward
@@ -399,9 +405,15 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
                     n[i] = (s < S) ? v + em[1][k][s] : -INFINITY;
                 }
             }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < CTC_SPL; ++i) mx = fmaxf(mx, n[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (mx > -INFINITY) offsum += (double)mx; else mx = 0.f;      // (all -inf: an infeasible alignment, nothing to shift)
 #pragma unroll
             for (int i = 0; i < CTC_SPL; ++i) {
-                a[i] = n[i];
+                a[i] = n[i] - mx;                                         // -inf stays -inf
                 const int s = lane * CTC_SPL + i;
                 if (s < S) out[(long)t * Smax + s] = a[i];
             }
@@ -417,13 +429,15 @@ __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict_
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = lae(v, __shfl_xor(v, o));
-        if (lane == 0) nll[b] = (Tb > 0 && v > -INFINITY) ? -v : INFINITY;
+        if (lane == 0) nll[b] = (Tb > 0 && v > -INFINITY) ? (float)-((double)v + offsum) : INFINITY;
     }
 }
 
 // Pass 3: gradient w.r.t. the logits, one workgroup per (t,b) row:
-//   g[c] = softmax[c] - sum_{s: ext[s]=c} exp(la+lb - lp[c] + nll)   for t < in_len[b] and finite nll, else 0
-// and the summed loss (atomic add of the finite nll's, done by the t = 0 rows).
+//   g[c] = softmax[c] - sum_{s: ext[s]=c} post[s],   post[s] = exp(la + lb - lp[ext s]) / sum_s' exp(la + lb - lp[ext s'])
+// for t < in_len[b] and finite nll, else 0.  (sum_s alpha_t(s) beta_t(s) / y_t(ext s) = P for every t: normalising per frame is
+// the same posterior as exp(la + lb - lp + nll) and is indifferent to the per-step offsets the recursion subtracts.)
+// Also the summed loss (atomic add of the finite nll's, done by the t = 0 rows).
 template <typename T>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ logits, const float* __restrict__ lse,
                                                        const long long* __restrict__ targets, const long long* __restrict__ tgt_len,
@@ -446,14 +460,36 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     for (int c = threadIdx.x; c < V; c += 256) occ[c] = 0.f;
     __syncthreads();
     const int S = 2 * (int)tgt_len[b] + 1;
-    for (int s = threadIdx.x; s < S; s += 256) {
-        const int c = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : blank;
-        const float lab = la[((long)b * Tn + t) * Smax + s] + lb[((long)b * Tn + t) * Smax + s];
-        if (lab > -INFINITY) {
-            const float lp = to_f32(x[c]) - ls;
-            atomicAdd(&occ[c], expf(lab - lp + nl));
+    __shared__ float redm[4], reds[4];
+    // w[s] = la + lb - lp: up to four states per thread (S <= 1023); frame maximum, then frame sum
+    float wv[4]; int wc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int s = threadIdx.x + 256 * k;
+        wv[k] = -INFINITY; wc[k] = 0;
+        if (s < S) {
+            wc[k] = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : blank;
+            const float lab = la[((long)b * Tn + t) * Smax + s] + lb[((long)b * Tn + t) * Smax + s];
+            if (lab > -INFINITY) wv[k] = lab - (to_f32(x[wc[k]]) - ls);
         }
+        mx = fmaxf(mx, wv[k]);
     }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+    float ev[4], sm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ev[k] = wv[k] > -INFINITY ? expf(wv[k] - mx) : 0.f; sm += ev[k]; }
+    sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) reds[threadIdx.x >> 6] = sm;
+    __syncthreads();
+    sm = (reds[0] + reds[1]) + (reds[2] + reds[3]);
+    const float inv = sm > 0.f ? 1.f / sm : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (ev[k] > 0.f) atomicAdd(&occ[wc[k]], ev[k] * inv);
     __syncthreads();
     constexpr int E = 16 / (int)sizeof(T);
     const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;

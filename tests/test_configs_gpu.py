@@ -129,11 +129,11 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-12)
 
 
-# fp32 gradient tolerance 2e-3: everything below the CTC tap (encoder layers 1-8, the subsampler) inherits the noise of a float32
-# log-space CTC recursion over 375 frames x 5,001 units -- alpha + beta - log P subtracts numbers near -3,000 (ulp 2.4e-4) before the
-# exp.  Against float64: torch's own f32 ctc_loss (what the oracle calls, as the reference does) is off by 6.4e-4 in |dg|/|g|, the HIP
-# kernel by 8.2e-4, independently -- they differ by ~1.0e-3 from each other (tensors above the tap agree to 1e-5..3e-4).
-TOL = {torch.float32: dict(loss=1e-4, grad=2e-3, cos=0.9999), torch.bfloat16: dict(loss=2e-2, grad=1e-1, cos=0.99)}
+# fp32: the gradient norms agree to ~2e-5 (worst: encoder.bn.0.weight 1.7e-5 on the ragged Cfg3 case); 2e-4 leaves an order of magnitude.
+# (With a plain float32 log-space CTC recursion in the product this was 1e-3 for everything below the CTC tap: alpha + beta - log P
+# cancels numbers near -3,000.  The oracle runs its recursion in float64; the kernels now keep every step's vector relative to its
+# maximum and normalise the posteriors per frame: 4e-6 from float64 where torch's own f32 ctc_loss is 6e-4, tools/ctc_accuracy.py.)
+TOL = {torch.float32: dict(loss=1e-4, grad=2e-4, cos=0.9999), torch.bfloat16: dict(loss=2e-2, grad=1e-1, cos=0.99)}
 
 
 def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
