@@ -243,17 +243,18 @@ extern "C" int s2t_add_inplace(int dtype, const void* x, void* y, size_t n, void
 template <typename T>
 __global__ __launch_bounds__(256) void kd_kernel(const T* __restrict__ logits, const long long* __restrict__ target,
                                                  const long long* __restrict__ tidx, const float* __restrict__ tlog,
-                                                 T* __restrict__ dlogits, float* __restrict__ sums, int V, int ld, int Kt,
+                                                 T* __restrict__ dlogits, float* __restrict__ sums, long rows, int V, int ld, int Kt,
                                                  float lambda, float tau, int pad, float gscale) {
     __shared__ float sh[16];
     __shared__ float wk[64];
-    const long row = blockIdx.x;
+    float acc_loss = 0.f;                            // rows per workgroup, one atomic at the end (as lsce_kernel)
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
     const T* x = logits + row * ld;
     T* g = dlogits ? dlogits + row * ld : nullptr;
     const long long y = target[row];
     if (y == pad) {
         if (g) for (int v = threadIdx.x; v < V; v += 256) g[v] = from_f32<T>(0.f);
-        return;
+        continue;
     }
     const float it = 1.f / tau;
     float m = -INFINITY;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void kd_kernel(const T* __restrict__ logits, c
         float kd = 0.f;
         if (lambda > 0.f) for (int k = 0; k < Kt; ++k) kd -= wk[k] * (to_f32(x[tidx[row * Kt + k]]) * it - lset);
         const float truth = lambda < 1.f ? lse1 - to_f32(x[y]) : 0.f;
-        atomicAdd(sums, (1.f - lambda) * truth + lambda * kd);
+        acc_loss += (1.f - lambda) * truth + lambda * kd;
     }
     if (g) {
         for (int v = threadIdx.x; v < V; v += 256) {
@@ -294,6 +295,9 @@ __global__ __launch_bounds__(256) void kd_kernel(const T* __restrict__ logits, c
                 g[c] = from_f32<T>(to_f32(g[c]) - lambda * it * wk[k] * gscale);
             }
     }
+    __syncthreads();                                 // `sh` / `wk` are reused by the next row
+    }
+    if (threadIdx.x == 0 && acc_loss != 0.f) atomicAdd(sums, acc_loss);
 }
 
 extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* target, const long long* teacher_idx,
@@ -303,8 +307,9 @@ extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* targe
     if (!logits || !target || !sum1 || V <= 0 || ld < V || tau <= 0.f || lambda < 0.f || lambda > 1.f) return S2T_EINVAL;
     if (lambda > 0.f && (!teacher_idx || !teacher_logits || Kt < 1 || Kt > 64)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(kd_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, target, teacher_idx, teacher_logits, (bf16*)dlogits, sum1, V, ld, Kt, lambda, tau, pad, grad_scale);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(kd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, target, teacher_idx, teacher_logits, (float*)dlogits, sum1, V, ld, Kt, lambda, tau, pad, grad_scale);
+    const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(kd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)logits, target, teacher_idx, teacher_logits, (bf16*)dlogits, sum1, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(kd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)logits, target, teacher_idx, teacher_logits, (float*)dlogits, sum1, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;
