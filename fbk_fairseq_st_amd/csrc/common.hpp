@@ -96,7 +96,7 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
 }
 
 // S2T_ACT_* of include/s2t_hip.h
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_GELU_BWD = 4 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_RELU_BWD = 3, ACT_GELU_BWD = 4, ACT_RELU_MASK = 5, ACT_RELU_BWD_MASK = 6 };
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));

@@ -775,7 +775,9 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     if (!A || !B || !C) return S2T_EINVAL;
     if (splitk < 1) splitk = 1;
     if (splitk > 1 && (out_dtype != S2T_F32 || bias || residual || act != ACT_NONE)) return S2T_EINVAL;
-    if ((act == ACT_RELU_BWD || act == ACT_GELU_BWD) && !aux) return S2T_EINVAL;
+    if ((act == ACT_RELU_BWD || act == ACT_GELU_BWD || act == ACT_RELU_BWD_MASK) && !aux) return S2T_EINVAL;
+    if (act == ACT_RELU_MASK && !aux_out) return S2T_EINVAL;
+    if (act < ACT_NONE || act > ACT_RELU_BWD_MASK) return S2T_EINVAL;
     if (mapA && (trans_a || periodA <= 0 || periodA % 8)) return S2T_EINVAL;
     if (mapB && !trans_b) return S2T_EINVAL;
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && splitk > 1)) return S2T_EINVAL;
@@ -818,6 +820,7 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
             if (r != 0) return r < 0 ? r : S2T_OK;
         }
     }
+    if (act == ACT_RELU_MASK || act == ACT_RELU_BWD_MASK) return S2T_ENOTSUP;   // the 1-bit record exists only in the 256-wide kernel's tile order
 #define S2T_PICK(TI_, TO_)                                                                   \
     return small ? launch_t<TI_, TO_, 64, 64>(a, trans_a, trans_b, st)                       \
                  : (narrow ? launch_t<TI_, TO_, 128, 64>(a, trans_a, trans_b, st)            \

@@ -92,7 +92,7 @@ __device__ __forceinline__ typename Pack4<TO>::type epi_quad(const GemmArgs& p, 
     TO pre[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if constexpr (ACT == ACT_RELU) x[e] = fmaxf(x[e], 0.f);
+        if constexpr (ACT == ACT_RELU || ACT == ACT_RELU_MASK) x[e] = fmaxf(x[e], 0.f);
         else if constexpr (ACT == ACT_GELU) { pre[e] = from_f32<TO>(x[e]); x[e] = gelu_f(x[e]); }
         else if constexpr (ACT == ACT_RELU_BWD) x[e] = (to_f32(xe[e]) > 0.f) ? x[e] : 0.f;
         else if constexpr (ACT == ACT_GELU_BWD) x[e] *= gelu_grad_f(to_f32(xe[e]));
@@ -372,6 +372,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                     const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
                     x = r[0]; y = r[1];
                 };
+                // 1-bit ReLU record (ACT_RELU_MASK writes it, ACT_RELU_BWD_MASK reads it): one bit per output element in the order
+                // THIS lane meets them: 16 bytes per lane and tile, lane-linear in memory.  Both products have the same M and N, hence
+                // the same tiling and the same lane -> element map: no exchange, one 16-byte access.  Register k of the record covers
+                // the steps 4k .. 4k+3 = 16 packed bf16 pairs; pair i of them owns bit 15 - i (low element) and bit 31 - i (high
+                // element): written as rec = rec << 1 | min(pair & 0x7FFF7FFF, 0x00010001) (3 VALU per pair), applied as
+                // pair &= ((rec >> (15 - i)) & 0x00010001) * 0xFFFF (4 VALU per pair; the stored activation is never negative).
+                constexpr bool MOUT = ACT == ACT_RELU_MASK, MIN = ACT == ACT_RELU_BWD_MASK;
+                u32x4 mk = {0u, 0u, 0u, 0u};
+                const size_t moff = ((size_t)tile * 512 + threadIdx.x) * 16;
+                if constexpr (MIN) mk = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux) + moff);
+                auto pos_pair = [](uint32_t w) -> uint32_t {   // (hipcc scalarises __builtin_elementwise_min on u16x2 into compares and selects)
+                    uint32_t r;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w & 0x7FFF7FFFu), "v"(0x00010001u));
+                    return r;
+                };
 #pragma unroll
                 for (int hm = 0; hm < 2; ++hm) {
                     u32x4 e16[QM][2];
@@ -391,9 +406,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             if constexpr (EXT != EXT_NONE) { swap2(e0, e2); swap2(e1, e3); }
                             const uint32_t qa = (uint32_t)(((uint64_t)row * p.N + (colw + pp * 128)) >> 2);
                             PK pa, pb;
+                            const int ms = (QM * hm + ii) * 2 + pp;              // step: pairs 4 (ms & 3) .. + 3 of record register ms >> 2
                             const PK oa = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp], b4[2 * pp], PK{e0, e1}, qa, drop_ks, drop_hwm, drop_th, drop_inv, pa);
                             const PK ob = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp + 1], b4[2 * pp + 1], PK{e2, e3}, qa + 4, drop_ks, drop_hwm, drop_th, drop_inv, pb);
                             uint32_t s0 = oa[0], s1 = oa[1], s2 = ob[0], s3 = ob[1];
+                            if constexpr (MOUT) {
+                                uint32_t r = mk[ms >> 2];
+                                r = (r << 1) | pos_pair(s0); r = (r << 1) | pos_pair(s1); r = (r << 1) | pos_pair(s2); r = (r << 1) | pos_pair(s3);
+                                mk[ms >> 2] = r;
+                            }
+                            if constexpr (MIN) {
+                                const uint32_t r = mk[ms >> 2];
+                                constexpr uint32_t LOHI = 0x00010001u;
+                                const int i0 = 4 * (ms & 3);
+                                s0 &= ((r >> (15 - i0)) & LOHI) * 0xFFFFu; s1 &= ((r >> (14 - i0)) & LOHI) * 0xFFFFu;
+                                s2 &= ((r >> (13 - i0)) & LOHI) * 0xFFFFu; s3 &= ((r >> (12 - i0)) & LOHI) * 0xFFFFu;
+                            }
                             swap2(s0, s2); swap2(s1, s3);
                             buf_store(u32x4{s0, s1, s2, s3}, rC, vC[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES);
                             if constexpr (ACT == ACT_GELU) {
@@ -407,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             acc[QM * hm + ii][2 * pp + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                 }
+                if constexpr (MOUT) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.aux_out) + moff) = mk;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -427,6 +456,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 // Shapes this kernel takes: bf16 operands, K a multiple of 64, at least two K-tiles, 16-byte aligned rows, operands below 4 GiB
 // (32-bit byte offsets), no gather maps, no split-K.  Returns 0 when the product is not for this kernel (the caller falls
 // through to gemm.hip), 1 when launched, < 0 on error.
+// row-tile height: the one that needs less time on 256 CUs = rounds x rows per tile (ties go to 256: fewer B re-reads).  Returns the
+// number of tiles, 0 when the product has too few of them for this kernel.
+static long g256_tiles(int M, int N, bool& use192) {
+    const int tn = (N + 255) / 256;
+    const long t256 = (long)((M + 255) / 256) * tn, t192 = (long)((M + 191) / 192) * tn;
+    if (t192 < 192) return 0;                       // one workgroup per CU: fewer tiles than ~3/4 of the CUs run better as 128 x 128 tiles, 2-3 per CU
+    use192 = ((t192 + 255) / 256) * 192 < ((t256 + 255) / 256) * 256;
+    return use192 ? t192 : t256;
+}
+
+// include/s2t_hip.h: 8 KiB per tile (512 lanes x 16 bytes), 0 when an [M][N] product over K does not come here (the shape part of the
+// gates of s2t_gemm256_try and of gemm_run's "small" rule for NT products)
+extern "C" size_t s2t_gemm_relu_mask_bytes(int M, int N, int K) {
+    if (!g_s2t_opt_gemm256 || K % BK || K < 2 * BK || M < 256 || N < 256 || (N & 7)) return 0;
+    if ((unsigned long long)M * (unsigned long long)N >= (1ull << 30)) return 0;        // bf16 output below 2 GiB
+    if ((long)((M + 127) / 128) * ((N + 127) / 128) < 192) return 0;
+    bool use192 = false;
+    return (size_t)g256_tiles(M, N, use192) * 8192;
+}
+
 int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st) {
     if (a.mapA || a.mapB || a.mapC || a.splitk != 1 || a.rowsum) return 0;
     if (a.K % BK || a.K < 2 * BK || a.M < 256 || a.N < 256 || (a.N & 7)) return 0;
@@ -442,18 +491,17 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     if (a.p_drop > 0.f && (unsigned long long)a.M * (unsigned long long)a.N >= (1ull << 34)) return 0;   // the epilogue keeps the mask's quad index in 32 bits
     // epilogue variant: the activation and the ONE extra operand stream are compile-time (gemm256_kernel<.., ACT, EXT>)
     int ext = EXT_NONE;
-    if (a.act == ACT_RELU_BWD || a.act == ACT_GELU_BWD) { if (a.residual || a.accumulate) return 0; ext = EXT_AUX; }
+    if (a.act == ACT_RELU_MASK) { if (trans_b || !a.aux_out || a.residual || a.accumulate) return 0; }
+    else if (a.act == ACT_RELU_BWD_MASK) { if (!trans_b || !a.aux || a.residual || a.accumulate || a.bias || a.p_drop > 0.f) return 0; }
+    else if (a.act == ACT_RELU_BWD || a.act == ACT_GELU_BWD) { if (a.residual || a.accumulate) return 0; ext = EXT_AUX; }
     else if (a.residual) { if (a.accumulate) return 0; ext = EXT_RES; }
     else if (a.accumulate) ext = EXT_OLD;
     if (out_dtype != S2T_BF16) return 0;            // bf16 outputs only (f32 rows -- logits in fp32 mode, split-K partials -- stay in gemm.hip)
-    if (trans_b && (a.bias || a.act == ACT_RELU || a.act == ACT_GELU || ext == EXT_RES)) return 0;   // data gradients: none / act-bwd / accumulate
+    if (trans_b && (a.bias || a.act == ACT_RELU || a.act == ACT_GELU || a.act == ACT_RELU_MASK || ext == EXT_RES)) return 0;   // data gradients: none / act-bwd / accumulate
     if (!trans_b && (ext == EXT_AUX || ext == EXT_OLD || (a.act != ACT_NONE && ext != EXT_NONE))) return 0;
-    // row-tile height: the one that needs less time on 256 CUs = rounds x rows per tile (ties go to 256: fewer B re-reads)
-    const int tn = (a.N + 255) / 256;
-    const long t256 = (long)((a.M + 255) / 256) * tn, t192 = (long)((a.M + 191) / 192) * tn;
-    if (t192 < 192) return 0;                       // one workgroup per CU: fewer tiles than ~3/4 of the CUs run better as 128 x 128 tiles, 2-3 per CU
-    const bool use192 = ((t192 + 255) / 256) * 192 < ((t256 + 255) / 256) * 256;
-    const int tiles = (int)(use192 ? t192 : t256);
+    bool use192 = false;
+    const int tiles = (int)g256_tiles(a.M, a.N, use192);
+    if (!tiles) return 0;
     const int grid = tiles < 256 ? tiles : 256;
     const size_t lds = 2 * BUF;
     bool done = false;
@@ -468,8 +516,9 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     }
 #define S2T_G256_MT(TO_, TB_, ACT_, EXT_) S2T_G256(TO_, TB_, 8, ACT_, EXT_) S2T_G256(TO_, TB_, 6, ACT_, EXT_)
     S2T_G256_MT(bf16, false, ACT_NONE, EXT_NONE) S2T_G256_MT(bf16, false, ACT_RELU, EXT_NONE) S2T_G256_MT(bf16, false, ACT_GELU, EXT_NONE)
-    S2T_G256_MT(bf16, false, ACT_NONE, EXT_RES)
+    S2T_G256_MT(bf16, false, ACT_NONE, EXT_RES) S2T_G256_MT(bf16, false, ACT_RELU_MASK, EXT_NONE)
     S2T_G256_MT(bf16, true, ACT_NONE, EXT_NONE) S2T_G256_MT(bf16, true, ACT_RELU_BWD, EXT_AUX) S2T_G256_MT(bf16, true, ACT_GELU_BWD, EXT_AUX)
+    S2T_G256_MT(bf16, true, ACT_RELU_BWD_MASK, EXT_NONE)
     S2T_G256_MT(bf16, true, ACT_NONE, EXT_OLD)
 #undef S2T_G256_MT
 #undef S2T_G256

@@ -574,10 +574,15 @@ class S2TEngine:
         h, mean, rstd = K.layernorm_fwd(x2, self.P(pfx + "final_layer_norm.weight"), self.P(pfx + "final_layer_norm.bias"), hp.ln_eps)
         pact = hp.activation_dropout if training else 0.0
         pre = torch.empty((T * B, hp.ffn), dtype=self.dtype, device=self.dev) if hp.act == "gelu" else None
-        a = self.linear(h, pfx + "fc1", act=self.act_fwd, aux_out=pre, p_drop=pact, seed=seed + 3)
+        # ReLU in training: the backward needs one bit per activation ("stored value > 0" = active and kept), written by fc1's epilogue
+        # in its own tile order when the product runs on the 256-wide kernel (K.relu_mask_bytes > 0), instead of a re-read of `a`
+        nmask = K.relu_mask_bytes(T * B, hp.ffn, D) if (training and hp.act == "relu" and self.dtype == torch.bfloat16) else 0
+        amask = torch.empty((nmask,), dtype=torch.uint8, device=self.dev) if nmask else None
+        a = self.linear(h, pfx + "fc1", act=K.ACT_RELU_MASK if nmask else self.act_fwd, aux_out=amask if nmask else pre,
+                        p_drop=pact, seed=seed + 3)
         p = hp.dropout if training else 0.0
         y = self.linear(a, pfx + "fc2", residual=x2, p_drop=p, seed=seed + 4)
-        c = dict(x=x2, h=h, mean=mean, rstd=rstd, a=a, pre=pre, pact=pact, p=p, seed=seed)
+        c = dict(x=x2, h=h, mean=mean, rstd=rstd, a=a, pre=pre, pact=pact, p=p, seed=seed, amask=amask)
         return y.view(T, B, D), c
 
     def ffn_block_bwd(self, pfx, c, dy, d=None, nxt=None):
@@ -585,7 +590,10 @@ class S2TEngine:
             d = K.dropout(dy, c["p"], c["seed"] + 4) if c["p"] > 0 else dy
         if self.hp.act == "relu":
             # a = relu(z) * keep/(1-p): a > 0 <=> active and kept; the 1/(1-p) factor goes in alpha
-            da = self.linear_bwd(d, c["a"], pfx + "fc2", act=K.ACT_RELU_BWD, aux=c["a"], alpha=1.0 / (1.0 - c["pact"]))
+            if c.get("amask") is not None:
+                da = self.linear_bwd(d, c["a"], pfx + "fc2", act=K.ACT_RELU_BWD_MASK, aux=c["amask"], alpha=1.0 / (1.0 - c["pact"]))
+            else:
+                da = self.linear_bwd(d, c["a"], pfx + "fc2", act=K.ACT_RELU_BWD, aux=c["a"], alpha=1.0 / (1.0 - c["pact"]))
         else:
             da = self.linear_bwd(d, c["a"], pfx + "fc2", act=K.ACT_GELU_BWD, aux=c["pre"])
             if c["pact"] > 0:

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import lib as L
-from .lib import ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD  # noqa: F401
+from .lib import ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD, ACT_RELU_MASK, ACT_RELU_BWD_MASK  # noqa: F401
 
 
 def _lib():
@@ -46,7 +46,10 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_N
         out = (torch.zeros if (accumulate or splitk > 1 or map_c is not None) else torch.empty)(
             (rows, N), dtype=odt, device=a.device)
     ldaux = 0
-    if residual is not None or aux is not None or aux_out is not None:
+    if act >= ACT_RELU_MASK:                 # aux / aux_out is the 1-bit record (relu_mask_bytes), not a tensor of the output's shape
+        t = aux_out if act == ACT_RELU_MASK else aux
+        assert t is not None and t.is_cuda and t.dtype == torch.uint8 and t.numel() == relu_mask_bytes(M, N, K) > 0
+    elif residual is not None or aux is not None or aux_out is not None:
         for t in (residual, aux, aux_out):
             assert t is None or (t.dtype == out.dtype and t.stride(-1) == 1 and t.is_cuda)
         ldaux = aux.stride(0) if aux is not None else (aux_out.stride(0) if aux_out is not None else 0)
@@ -60,6 +63,19 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, residual=None, act=ACT_N
     if rc:
         L.check(rc, "s2t_gemm")
     return out
+
+
+_MASK_BYTES = {}
+
+
+def relu_mask_bytes(M, N, K):
+    """Bytes of the 1-bit ReLU record of an [M, N] bf16 product over K (ACT_RELU_MASK / ACT_RELU_BWD_MASK); 0 = products of this
+    shape keep the activations as the backward operand (ACT_RELU / ACT_RELU_BWD)."""
+    key = (M, N, K)
+    n = _MASK_BYTES.get(key)
+    if n is None:
+        n = _MASK_BYTES[key] = int(_lib().s2t_gemm_relu_mask_bytes(M, N, K))
+    return n
 
 
 def linear_wgrad(dy, x, dw, db=None, splitk=1):

@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 3              # s2t_abi_version() of the library this binding was written against
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD = 0, 1, 2, 3, 4
+ABI_VERSION = 4              # s2t_abi_version() of the library this binding was written against
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD, ACT_RELU_MASK, ACT_RELU_BWD_MASK = 0, 1, 2, 3, 4, 5, 6
 
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
                                                         ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t)
@@ -30,6 +30,7 @@ SIGNATURES = {
     "s2t_gemm": [c_int] * 7 + [P, c_int, P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, P],
     "s2t_gemm_gather": [c_int] * 7 + [P, c_int, P, c_int, P, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int,
                                        c_float, P, c_int, P, P, c_float, c_ull, P],
+    "s2t_gemm_relu_mask_bytes": [c_int, c_int, c_int],          # returns size_t
     "s2t_linear_wgrad": [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P],
     "s2t_wgrad_group": [c_int, P, P],
     "s2t_colsum": [c_int, P, c_int, c_int, c_int, P, P],
@@ -123,6 +124,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_int
     lib.s2t_build_info.restype = ctypes.c_char_p
+    lib.s2t_gemm_relu_mask_bytes.restype = c_size_t
     lib.s2t_build_info.argtypes = []
     if lib.s2t_abi_version() != ABI_VERSION:
         raise ImportError("libs2t_hip.so at %s has ABI version %d, this package binds version %d -- rebuild it (make -C %s)"

@@ -34,6 +34,13 @@ extern "C" {
 #define S2T_ACT_GELU 2      /* fairseq/modules/gelu.py:24-25 (erf form, computed in f32); pre-activation -> aux_out */
 #define S2T_ACT_RELU_BWD 3  /* out = acc * (aux > 0)            (aux = forward post-activation) */
 #define S2T_ACT_GELU_BWD 4  /* out = acc * gelu'(aux)           (aux = forward pre-activation)  */
+/* ReLU with a 1-bit record instead of a re-read of the activations in the backward pass (the FFN of transformer_layer.py:171-176: the data
+ * gradient of fc2 needs only "was the stored, post-dropout activation > 0").  S2T_ACT_RELU_MASK = S2T_ACT_RELU that also writes the
+ * record to aux_out; S2T_ACT_RELU_BWD_MASK = S2T_ACT_RELU_BWD with aux = that record.  The record is s2t_gemm_relu_mask_bytes(M, N, K)
+ * bytes in the tile / lane order of the 256-wide kernel (opaque: valid only between two products of the same M, N); products that kernel
+ * does not take get S2T_ENOTSUP with these codes -- ask s2t_gemm_relu_mask_bytes first (0 = use S2T_ACT_RELU / S2T_ACT_RELU_BWD). */
+#define S2T_ACT_RELU_MASK 5
+#define S2T_ACT_RELU_BWD_MASK 6
 
 /* ---- library info ------------------------------------------------------------------------- */
 /* Weight gradient of the second subsampling convolution (nn.Conv2d(C, C, 3, stride 2, padding 1), conv_transformer.py:348-354), all
@@ -94,6 +101,9 @@ int s2t_gemm_gather(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
                     int act, int accumulate, int splitk, float alpha,
                     const int* mapA, int periodA, const int* mapB, const int* mapC,
                     float p_drop, unsigned long long seed, void* stream);
+/* Size in bytes of the 1-bit ReLU record of an [M][N] bf16 product with reduction length K (S2T_ACT_RELU_MASK / S2T_ACT_RELU_BWD_MASK
+ * above), or 0 when products of that shape do not run on the kernel that keeps such records. */
+size_t s2t_gemm_relu_mask_bytes(int M, int N, int K);
 
 /* Weight (and bias) gradients of MANY Linears in one launch (bf16 operands, f32 gradients; csrc/wgrad_group.hip):
  *     dW_p[n_out][n_in] += dY_p[tokens][n_out]^T X_p[tokens][n_in]      db_p[n_out] += column sums of dY_p   (db may be NULL)

@@ -589,6 +589,43 @@ def test_gemm256_is_deterministic_under_load():
         assert torch.equal(K.gemm(a2, w, trans_b=True), firstx)
 
 
+@pytest.mark.parametrize("M,N,K_", [(24000, 2048, 512), (23936, 2048, 512), (6211, 1536, 512), (24000, 1000, 128), (50000, 256, 192)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_gemm_relu_one_bit_record(M, N, K_, p_drop):
+    """fc1 / fc2 of the FFN (transformer_layer.py:128-136) with the ReLU decision kept as one bit per activation: the forward product
+    equals the ACT_RELU one bit for bit, and the data gradient through the record equals the one that re-reads the activations"""
+    dtype = torch.bfloat16
+    nb = K.relu_mask_bytes(M, N, K_)
+    assert nb > 0 and nb % 8192 == 0 and nb * 8 >= M * N
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K_, device=DEV, generator=g).to(dtype); w = (torch.randn(N, K_, device=DEV, generator=g) * K_ ** -0.5).to(dtype)
+    b = torch.randn(N, device=DEV, generator=g) * 0.1
+    dy = torch.randn(M, K_, device=DEV, generator=g).to(dtype); w2 = (torch.randn(K_, N, device=DEV, generator=g) * 0.05).to(dtype)
+    a_ref = K.gemm(x, w, bias=b, act=K.ACT_RELU, p_drop=p_drop, seed=77)
+    rec = torch.full((nb,), 0xA5, dtype=torch.uint8, device=DEV)
+    a = K.gemm(x, w, bias=b, act=K.ACT_RELU_MASK, aux_out=rec, p_drop=p_drop, seed=77)
+    assert torch.equal(a, a_ref)
+    frac = float((a > 0).float().mean())
+    assert (0.4 if p_drop == 0 else 0.35) < frac < 0.55
+    alpha = 1.0 / (1.0 - p_drop)
+    da_ref = K.gemm(dy, w2, trans_b=True, act=K.ACT_RELU_BWD, aux=a, alpha=alpha)
+    da = K.gemm(dy, w2, trans_b=True, act=K.ACT_RELU_BWD_MASK, aux=rec, alpha=alpha)
+    assert torch.equal(da, da_ref)
+    assert torch.equal(da != 0, (a > 0) & (K.gemm(dy, w2, trans_b=True, alpha=alpha) != 0))
+
+
+def test_gemm_relu_one_bit_record_refused_where_the_kernel_does_not_run():
+    """decoder-side products (M = 2,560) are not on the 256-wide kernel: no record, and the codes are refused loudly"""
+    assert K.relu_mask_bytes(2560, 2048, 512) == 0 and K.relu_mask_bytes(24000, 2048, 100) == 0
+    x = torch.randn(2560, 512, device=DEV).to(torch.bfloat16); w = torch.randn(2048, 512, device=DEV).to(torch.bfloat16)
+    from fbk_fairseq_st_amd import lib as L
+    lib = L.load()
+    rec = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV); out = torch.empty(2560, 2048, device=DEV, dtype=torch.bfloat16)
+    rc = lib.s2t_gemm_gather(1, 1, 0, 0, 2560, 2048, 512, x.data_ptr(), 512, w.data_ptr(), 512, out.data_ptr(), 2048, None, None, 0,
+                             None, rec.data_ptr(), 0, K.ACT_RELU_MASK, 0, 1, 1.0, None, 0, None, None, 0.0, 0, L.stream())
+    assert rc == -95                       # S2T_ENOTSUP
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("V", [1001, 523])
 def test_gemm_ctc_head_shapes_odd_vocabulary(dtype, V):
