@@ -351,7 +351,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = colw + (j >> 1) * 128 + 16 * (j & 1);
-                b4[j] = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.bias && col + 4 <= p.N) b4[j] = *reinterpret_cast<const f32x4*>(p.bias + col);
+                else if (p.bias && col < p.N) {                            // N not a multiple of 4 (a vocabulary of 5,001): the last quad, element by element
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b4[j][e] = col + e < p.N ? p.bias[col + e] : 0.f;
+                }
             }
             static_assert(sizeof(TO) == 2, "bf16 outputs");
             {
@@ -478,7 +483,13 @@ extern "C" size_t s2t_gemm_relu_mask_bytes(int M, int N, int K) {
 
 int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st) {
     if (a.mapA || a.mapB || a.mapC || a.splitk != 1 || a.rowsum) return 0;
-    if (a.K % BK || a.K < 2 * BK || a.M < 256 || a.N < 256 || (a.N & 7)) return 0;
+    if (a.K % BK || a.K < 2 * BK || a.M < 256 || a.N < 256) return 0;
+    if (a.N & 7) {
+        // N not a multiple of 8 (the CTC head's 5,001 logits per row): the last 16-byte store of a row covers columns up to the next
+        // multiple of 8, i.e. the row padding of the caller's buffer (K.alloc_rows), which must exist; plain bias epilogue only (the
+        // dropout mask and the operand streams are addressed by aligned element quads)
+        if (trans_b || a.ldc < ((a.N + 7) & ~7) || a.residual || a.accumulate || a.aux || a.aux_out || a.p_drop > 0.f || a.act != ACT_NONE) return 0;
+    }
     if (((uintptr_t)a.C & 15) || (a.ldc & 7) || (a.bias && ((uintptr_t)a.bias & 15))) return 0;
     if (a.residual && (((uintptr_t)a.residual & 15) || (a.ldr & 7))) return 0;
     if ((a.aux && ((uintptr_t)a.aux & 15)) || (a.aux_out && ((uintptr_t)a.aux_out & 15)) || ((a.aux || a.aux_out) && (a.ldaux & 7))) return 0;

@@ -238,42 +238,40 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const Prob* __restr
 #include <mutex>
 #include <vector>
 
+namespace {
+// ---- work lists.  A list is a table [round][slot]: workgroup slot s runs items s, s + G, s + 2G, ... until an empty one.
+// Cost model for comparing lists: an item costs its K-tiles plus C0 (pipeline fill from cold operands + the epilogue's 256 KB
+// read-modify-write, measured ~8 K-tile times at 40-K-tile items); a launch takes as long as its most loaded slot.
+constexpr int G = 256, C0 = 8, MINP = 8;
+struct Layout { std::vector<Item> table; int used = 0; long makespan = 0; };
 
-extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream) {
-    if (n <= 0) return S2T_OK;
-    if (!probs) return S2T_EINVAL;
-    std::vector<Prob> pv(n);
-    std::vector<Item> iv;
-    double flops = 0.0, bytes = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const S2TWgradProblem& s = probs[i];
-        if (!s.dY || !s.X || !s.dW || s.n_out <= 0 || s.n_in <= 0 || s.tokens <= 0) return S2T_EINVAL;
-        if ((size_t)s.tokens * s.ldy * 2 >= (1ull << 32) || (size_t)s.tokens * s.ldx * 2 >= (1ull << 32)) return S2T_EINVAL;   // 32-bit byte offsets
-        // 16-byte column chunks of both operands (the last one may cover row padding, never the next row), 4-byte aligned f32 rows
-        if ((s.ldy & 7) || (s.ldx & 7) || ((uintptr_t)s.dY & 15) || ((uintptr_t)s.X & 15)) return S2T_EINVAL;
-        if (((s.n_out + 7) & ~7) > s.ldy || ((s.n_in + 7) & ~7) > s.ldx || s.n_out < 8 || s.n_in < 8) return S2T_EINVAL;
-        Prob& p = pv[i];
-        p.dY = (const bf16*)s.dY; p.X = (const bf16*)s.X; p.dW = s.dW; p.db = s.db;
-        p.n_out = s.n_out; p.n_in = s.n_in; p.tokens = s.tokens; p.ldy = s.ldy; p.ldx = s.ldx; p.ldw = s.ldw; p.pad0 = p.pad1 = 0;
-        const int nk = (s.tokens + BK - 1) / BK, tn = (s.n_in + 255) / 256, tmn = (s.n_out + 255) / 256;
-        for (int a = 0; a < tmn; ++a)
-            for (int b = 0; b < tn; ++b) iv.push_back(Item{i, a, b, 0, nk, 0});
-        flops += 2.0 * s.n_out * (double)s.n_in * s.tokens;
-        bytes += 2.0 * s.tokens * ((double)s.n_out + s.n_in) + 8.0 * s.n_out * (double)s.n_in;
+long load_of(const Layout& L) {
+    long worst = 0;
+    for (int sl = 0; sl < L.used; ++sl) {
+        long u = 0;
+        for (size_t it = sl; it < L.table.size(); it += L.used) {
+            const Item& t = L.table[it];
+            if (t.kt0 >= t.kt1) break;
+            u += t.kt1 - t.kt0 + C0;
+        }
+        worst = std::max(worst, u);
     }
-    // Work list: longest reductions first (stable: the tiles of one dW stay neighbours), dealt in rounds of one item per CU; the
-    // workgroups of a round sweep the token range of neighbouring tiles in step, which is what lets the L2s / the MALL serve the
-    // operand columns those tiles share (a schedule that balanced the CUs perfectly by handing each an arbitrary stretch of a line
-    // of tiles ran 1.6x SLOWER: every tile then streams its 24 MB of operands from HBM alone).  Two cuts along the token range, whose
-    // pieces meet in f32 atomics:
-    //  * a tile whose reduction is much longer than a CU's fair share of the launch (the decoder's group holds 374-K-tile products
-    //    of the encoder output next to 40-K-tile products of its own tokens: 48 long tiles kept 208 CUs waiting) is cut into equal
-    //    pieces of about that share, the same token ranges for all tiles of its dW;
-    //  * a partly filled last round would leave CUs idle for a whole item's time: its items are cut into as many equal pieces as
-    //    fill the round.
-    constexpr int G = 256, C0 = 6, MINP = 8;
+    return worst;
+}
+
+// Layout 1 -- rounds.  Longest reductions first (stable: the tiles of one dW stay neighbours), dealt in rounds of one item per CU; the
+// workgroups of a round sweep the token range of neighbouring tiles in step, which is what lets the L2s / the MALL serve the
+// operand columns those tiles share (a schedule that balanced the CUs perfectly by handing each an arbitrary stretch of a line
+// of tiles ran 1.6x SLOWER: every tile then streams its 24 MB of operands from HBM alone).  Two cuts along the token range, whose
+// pieces meet in f32 atomics:
+//  * a tile whose reduction is much longer than a CU's fair share of the launch is cut into equal pieces of about that share, the
+//    same token ranges for all tiles of its dW;
+//  * a partly filled last round would leave CUs idle for a whole item's time: its items are cut into as many equal pieces as
+//    fill the round.
+// The right list for uniform groups (the encoder's 616 tiles of 375 K-tiles).
+void layout_rounds(std::vector<Item> iv, Layout& out) {
     long units = 0;
-    for (const Item& t : iv) units += t.kt1 + C0;
+    for (const Item& t : iv) units += t.kt1 + 6;
     const int share = (int)((units + G - 1) / G);
     {
         std::vector<Item> cutv;
@@ -311,54 +309,157 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
                 }
         }
     }
-    const int used = (int)std::min<size_t>(iv.size(), G);
-    // Device-side tables (problems, then items) in one buffer.  A training loop hands over the same list update after update (same
-    // shapes, and the caching allocator returns the same activation addresses), so the last few tables are kept on the device with a
-    // host copy: an identical list is launched without any upload (the two pageable-memory copies cost ~35 us of GPU timeline per
-    // launch, as much as the 40 K-tiles of a decoder-sized product).
-    const size_t pb = pv.size() * sizeof(Prob), ib = iv.size() * sizeof(Item), need = pb + ib;
-    std::vector<char> host(need);
-    memcpy(host.data(), pv.data(), pb);
-    memcpy(host.data() + pb, iv.data(), ib);
+    out.used = (int)std::min<size_t>(iv.size(), G);
+    out.table.swap(iv);
+    out.makespan = load_of(out);
+}
+
+// Layout 2 -- fill to a level.  For groups that mix a few very long reductions with many short ones (the decoder's: six K/V
+// projections over the ~24,000 source tokens = 48 tiles of 374 K-tiles next to 400 tiles of 40 K-tiles over its own 2,560 tokens):
+// the short tiles are dealt over the slots whole (1 or 2 each), then the long dWs are poured into what is left of every slot up to
+// a common level T: the tiles of one dW always as a gang on neighbouring slots with the SAME token range (they sweep it in step, first
+// thing in their slots), the range cut wherever a gang's slots are full.  Every slot ends within a few K-tiles of T.
+bool layout_fill(const std::vector<Item>& tiles, Layout& out) {
+    struct Line { size_t first, count; int nk; };
+    std::vector<Line> lines;
+    long units = 0;
+    for (size_t i = 0; i < tiles.size();) {
+        size_t j = i;
+        while (j < tiles.size() && tiles[j].prob == tiles[i].prob) ++j;
+        lines.push_back(Line{i, j - i, tiles[i].kt1});
+        units += (long)(j - i) * (tiles[i].kt1 + C0);
+        i = j;
+    }
+    const long fair = units / G;
+    std::vector<Line> longs;
+    std::vector<Item> shorts;
+    long long_k = 0;
+    for (const Line& l : lines) {
+        if (l.nk + C0 > fair && l.count <= (size_t)G / 2 && l.nk >= 4 * MINP) { longs.push_back(l); long_k += (long)l.count * l.nk; }
+        else shorts.insert(shorts.end(), tiles.begin() + l.first, tiles.begin() + l.first + l.count);
+    }
+    if (longs.empty()) return false;
+    std::stable_sort(shorts.begin(), shorts.end(), [](const Item& x, const Item& y) { return x.kt1 > y.kt1; });
+    std::vector<std::vector<Item>> tail(G), head(G);
+    std::vector<long> base(G, 0);
+    for (size_t i = 0; i < shorts.size(); ++i) { tail[i % G].push_back(shorts[i]); base[i % G] += shorts[i].kt1 + C0; }
+    long sum_base = 0;
+    for (long b : base) sum_base += b;
+    std::vector<long> ld;
+    long T = (sum_base + long_k + (long)G * C0 + G - 1) / G;
+    for (int attempt = 0; attempt < 64; ++attempt, T += std::max(1L, T / 64)) {
+        for (auto& h : head) h.clear();
+        ld = base;
+        size_t sl = 0;
+        bool ok = true;
+        for (const Line& l : longs) {
+            int k0 = 0;
+            while (k0 < l.nk && ok) {
+                if (sl + l.count > (size_t)G) { ok = false; break; }
+                long cap = T;
+                for (size_t j = 0; j < l.count; ++j) cap = std::min(cap, T - ld[sl + j] - C0);
+                int len = (int)std::min<long>(cap, l.nk - k0);
+                if (l.nk - k0 - len > 0 && l.nk - k0 - len < MINP) len = l.nk - k0 - MINP;     // never leave a remainder shorter than MINP
+                if (len < MINP) { sl += l.count; continue; }                                    // this gang is full
+                for (size_t j = 0; j < l.count; ++j) {
+                    const Item& t = tiles[l.first + j];
+                    head[sl + j].push_back(Item{t.prob, t.tm, t.tn, k0, k0 + len, len == l.nk ? 0 : 1});
+                    ld[sl + j] += len + C0;
+                }
+                k0 += len;
+            }
+            if (!ok) break;
+        }
+        if (!ok) continue;
+        size_t rounds = 0;
+        for (int i = 0; i < G; ++i) rounds = std::max(rounds, head[i].size() + tail[i].size());
+        out.table.assign(rounds * G, Item{0, 0, 0, 0, 0, 0});
+        for (int i = 0; i < G; ++i) {
+            size_t r = 0;
+            for (const Item& t : head[i]) out.table[(r++) * G + i] = t;
+            for (const Item& t : tail[i]) out.table[(r++) * G + i] = t;
+        }
+        out.used = G;
+        out.makespan = load_of(out);
+        return true;
+    }
+    return false;
+}
+}  // namespace
+
+extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream) {
+    if (n <= 0) return S2T_OK;
+    if (!probs) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    struct Cached { std::vector<char> host; void* dev = nullptr; size_t cap = 0; unsigned long long used = 0; };
+    // A training loop hands over the same list update after update (same shapes, and the caching allocator returns the same activation
+    // addresses), so the last few lists are kept: their work tables stay on the device (the two pageable-memory copies of an upload
+    // cost ~35 us of GPU timeline per launch, as much as the 40 K-tiles of a decoder-sized product) and an identical list is launched
+    // without building anything.
+    struct Cached { std::vector<char> key; void* dev = nullptr; size_t cap = 0; unsigned long long used = 0;
+                    size_t pb = 0; int n_items = 0, grid = 0; double flops = 0.0, bytes = 0.0; };
     static Cached cache[4];
     static unsigned long long tick = 0;
     static std::mutex mu;
-    void* table = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        ++tick;
-        Cached* hit = nullptr;
-        Cached* lru = &cache[0];
-        for (Cached& c : cache) {
-            if (c.dev && c.host.size() == need && memcmp(c.host.data(), host.data(), need) == 0) { hit = &c; break; }
-            if (c.used < lru->used) lru = &c;
-        }
-        if (hit) { hit->used = tick; table = hit->dev; }
-        else {
-            if (need > lru->cap) {
-                // grows rarely (the first updates); a hipFree of the old table waits for the kernels that may still read it
-                if (lru->dev) (void)hipFree(lru->dev);
-                lru->cap = std::max(need * 2, (size_t)1 << 16);
-                hipError_t e = hipMalloc(&lru->dev, lru->cap);
-                if (e != hipSuccess) { lru->dev = nullptr; lru->cap = 0; lru->host.clear(); return S2T_EHIP(e); }
-            }
-            // stream-ordered upload from pageable memory (staged by the runtime before the call returns); earlier launches that read
-            // this slot were enqueued before it on the same stream (one training stream per process)
-            hipError_t e = hipMemcpyAsync(lru->dev, host.data(), need, hipMemcpyHostToDevice, st);
-            if (e != hipSuccess) { lru->host.clear(); return S2T_EHIP(e); }
-            lru->host.swap(host);
-            lru->used = tick;
-            table = lru->dev;
-        }
+    const size_t key_bytes = (size_t)n * sizeof(S2TWgradProblem);
+    std::lock_guard<std::mutex> lock(mu);
+    ++tick;
+    Cached* hit = nullptr;
+    Cached* lru = &cache[0];
+    for (Cached& c : cache) {
+        if (c.dev && c.key.size() == key_bytes && memcmp(c.key.data(), probs, key_bytes) == 0) { hit = &c; break; }
+        if (c.used < lru->used) lru = &c;
     }
-    ProfScope prof("wgrad_group", st, flops, bytes);
+    if (!hit) {
+        std::vector<Prob> pv(n);
+        std::vector<Item> iv;
+        double flops = 0.0, bytes = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const S2TWgradProblem& s = probs[i];
+            if (!s.dY || !s.X || !s.dW || s.n_out <= 0 || s.n_in <= 0 || s.tokens <= 0) return S2T_EINVAL;
+            if ((size_t)s.tokens * s.ldy * 2 >= (1ull << 32) || (size_t)s.tokens * s.ldx * 2 >= (1ull << 32)) return S2T_EINVAL;   // 32-bit byte offsets
+            // 16-byte column chunks of both operands (the last one may cover row padding, never the next row), 4-byte aligned f32 rows
+            if ((s.ldy & 7) || (s.ldx & 7) || ((uintptr_t)s.dY & 15) || ((uintptr_t)s.X & 15)) return S2T_EINVAL;
+            if (((s.n_out + 7) & ~7) > s.ldy || ((s.n_in + 7) & ~7) > s.ldx || s.n_out < 8 || s.n_in < 8) return S2T_EINVAL;
+            Prob& p = pv[i];
+            p.dY = (const bf16*)s.dY; p.X = (const bf16*)s.X; p.dW = s.dW; p.db = s.db;
+            p.n_out = s.n_out; p.n_in = s.n_in; p.tokens = s.tokens; p.ldy = s.ldy; p.ldx = s.ldx; p.ldw = s.ldw; p.pad0 = p.pad1 = 0;
+            const int nk = (s.tokens + BK - 1) / BK, tn = (s.n_in + 255) / 256, tmn = (s.n_out + 255) / 256;
+            for (int a = 0; a < tmn; ++a)
+                for (int b = 0; b < tn; ++b) iv.push_back(Item{i, a, b, 0, nk, 0});
+            flops += 2.0 * s.n_out * (double)s.n_in * s.tokens;
+            bytes += 2.0 * s.tokens * ((double)s.n_out + s.n_in) + 8.0 * s.n_out * (double)s.n_in;
+        }
+        Layout lay, alt;
+        const bool have_alt = layout_fill(iv, alt);
+        layout_rounds(std::move(iv), lay);
+        if (have_alt && alt.makespan < lay.makespan) std::swap(lay, alt);
+        // device-side tables (problems, then items) in one buffer
+        const size_t pb = pv.size() * sizeof(Prob), ib = lay.table.size() * sizeof(Item), need = pb + ib;
+        std::vector<char> host(need);
+        memcpy(host.data(), pv.data(), pb);
+        memcpy(host.data() + pb, lay.table.data(), ib);
+        if (need > lru->cap) {
+            // grows rarely (the first updates); a hipFree of the old table waits for the kernels that may still read it
+            if (lru->dev) (void)hipFree(lru->dev);
+            lru->dev = nullptr; lru->key.clear();
+            lru->cap = std::max(need * 2, (size_t)1 << 16);
+            hipError_t e = hipMalloc(&lru->dev, lru->cap);
+            if (e != hipSuccess) { lru->dev = nullptr; lru->cap = 0; return S2T_EHIP(e); }
+        }
+        // stream-ordered upload from pageable memory (staged by the runtime before the call returns); earlier launches that read
+        // this slot were enqueued before it on the same stream (one training stream per process)
+        hipError_t e = hipMemcpyAsync(lru->dev, host.data(), need, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { lru->key.clear(); return S2T_EHIP(e); }
+        lru->key.assign(reinterpret_cast<const char*>(probs), reinterpret_cast<const char*>(probs) + key_bytes);
+        lru->pb = pb; lru->n_items = (int)lay.table.size(); lru->grid = lay.used; lru->flops = flops; lru->bytes = bytes;
+        hit = lru;
+    }
+    hit->used = tick;
+    ProfScope prof("wgrad_group", st, hit->flops, hit->bytes);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF); attr = true; }
-    const int n_items = (int)iv.size();
-    hipLaunchKernelGGL(wgrad_group_kernel, dim3(used), dim3(512), 2 * BUF, st,
-                       (const Prob*)table, (const Item*)((char*)table + pb), n_items);
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3(hit->grid), dim3(512), 2 * BUF, st,
+                       (const Prob*)hit->dev, (const Item*)((char*)hit->dev + hit->pb), hit->n_items);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

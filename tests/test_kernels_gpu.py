@@ -538,6 +538,30 @@ def test_gemm_big_products_both_routes(M, N, K_, route):
         K.set_option("gemm256", old)
 
 
+@pytest.mark.parametrize("M,V", [(24000, 5001), (12345, 1003)])
+def test_gemm_big_logit_rows_odd_vocabulary_both_routes(M, V):
+    """the CTC head at full size (conv_transformer.py:279: ctc_fc over 24,000 frames, V_src = 5,001): logit rows in a padded buffer,
+    the 256-wide kernel's last 16-byte store of a row lands in the row padding; against the 128-wide route and f32 math"""
+    dtype, D = torch.bfloat16, 512
+    g = torch.Generator(device=DEV).manual_seed(V)
+    x = torch.randn(M, D, device=DEV, generator=g).to(dtype); w = (torch.randn(V, D, device=DEV, generator=g) * D ** -0.5).to(dtype)
+    b = torch.randn(V, device=DEV, generator=g)
+    outs = []
+    for route in (1, 0):
+        old = K.set_option("gemm256", route)
+        try:
+            out = K.alloc_rows((M,), V, dtype, DEV, zero=True)
+            K.gemm(x, w, bias=b, out=out)
+            outs.append(out)
+        finally:
+            K.set_option("gemm256", old)
+    assert rel_err(outs[0], outs[1]) < 1e-2
+    ref = x[:2048].float() @ w.float().t() + b
+    assert rel_err(outs[0][:2048], ref) < 2e-2
+    base = outs[0].as_strided((M, K.padded_cols(V, dtype)), (K.padded_cols(V, dtype), 1))
+    assert bool(torch.isfinite(base.float()).all())
+
+
 @pytest.mark.parametrize("tokens", [24000, 3000, 2560, 777])
 def test_wgrad_group_matches_per_linear_gradients(tokens):
     """one grouped launch for the parameter gradients of several Linears (csrc/wgrad_group.hip): dW += dY^T X, db += colsum(dY),
@@ -571,6 +595,30 @@ def test_wgrad_group_matches_per_linear_gradients(tokens):
         b[2].zero_()
     K.wgrad_group(big)
     assert all(torch.equal(b[2], ref0) for b in big)
+
+
+@pytest.mark.parametrize("t_long,t_short,n_long", [(23936, 2560, 6), (6001, 333, 2), (9000, 1000, 1)])
+def test_wgrad_group_mixed_reduction_lengths(t_long, t_short, n_long):
+    """the decoder's launch: K/V projections of the cross-attention over the source tokens (long reductions) next to the products over
+    its own tokens (short ones).  The work list pours the long dWs into what the short tiles leave of every workgroup's share
+    (wgrad_group.hip, layout_fill): token ranges cut at arbitrary K-tiles, pieces meeting in f32 atomics, bias gradients included"""
+    g = torch.Generator(device=DEV).manual_seed(t_long)
+
+    def mk(tokens, n_out, n_in, has_b=True):
+        dy = (torch.randn(tokens, n_out, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+        x = (torch.randn(tokens, n_in, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
+        return (dy, x, torch.randn(n_out, n_in, device=DEV, generator=g), torch.randn(n_out, device=DEV, generator=g) if has_b else None)
+
+    items = [mk(t_long, 1024, 512) for _ in range(n_long)]
+    for _ in range(3):
+        items += [mk(t_short, 1536, 512), mk(t_short, 512, 512), mk(t_short, 2048, 512), mk(t_short, 512, 2048)]
+    items.append(mk(t_short, 1000, 512, has_b=False))
+    refs = [(dw.double() + dy.double().t() @ x.double(), None if db is None else db.double() + dy.double().sum(0)) for dy, x, dw, db in items]
+    K.wgrad_group(items)
+    for (dy, x, dw, db), (rw, rb) in zip(items, refs):
+        assert rel_err(dw, rw) < 2e-5 * max(1.0, dy.shape[0] ** 0.5 / 8), (tuple(dw.shape), dy.shape[0], rel_err(dw, rw))
+        if db is not None:
+            assert rel_err(db, rb) < 1e-4
 
 
 def test_gemm256_is_deterministic_under_load():
