@@ -115,35 +115,14 @@ struct AttnArgs {
 };
 
 // dropout element index of (b, h, query, key): key rows are padded to a multiple of 4 so that 4 consecutive keys from a
-// multiple of 4 form one hash quad (attn_hash4 below) in every kernel's register layout
+// multiple of 4 form one hash quad (common.hpp drop_hash4) in every kernel's register layout
 __device__ __forceinline__ uint64_t drop_index(const AttnArgs& p, int b, int h, int qrow, int key) {
     return (((uint64_t)b * p.H + h) * p.Tq + qrow) * (uint64_t)((p.Tk + 3) & ~3) + key;
-}
-// The attention kernels' own hash for those quads (same interface and field order as common.hpp drop_hash4_lo, which every other
-// dropout site uses): these kernels are VALU-bound and hash 72 M probabilities per encoder layer three times (forward, dK/dV, dQ), and
-// drop_hash4_lo's three 32-bit multiplies run at quarter rate (23 issue slots per quad).  This one is built from full-rate
-// operations only -- v_mad_u32_u24 (x + (x mod 2^24) * C with C even: a bijection that mixes upwards) and v_bfrev_b32 (turns the
-// well-mixed top bits into the next multiply's low bits) -- 12 slots per quad.  Checked offline like the other one: avalanche
-// |P(flip) - 1/2| < 0.01 on all 64 output bits for every input bit, chi-square of the 16-bit fields ~1.0, keep-bit correlations
-// between neighbouring keys / rows < 1e-3, per-row and per-column keep counts binomial.  All attention kernels (both generations,
-// forward and backward) take their mask from here; the mask is not shared with any other kernel.
-__device__ __forceinline__ u32x2 attn_hash4(uint32_t ks, uint32_t hwm, uint32_t quad_lo) {
-    uint32_t a = quad_lo ^ ks;
-    a = __umul24(a, 0x3C6EF2u) + a; a = __builtin_bitreverse32(a);
-    a = __umul24(a, 0x9E3778u) + a; a = __builtin_bitreverse32(a);
-    a = __umul24(a, 0x85EBCAu) + a; a ^= a >> 16;
-    const uint32_t x = a ^ hwm;
-    const uint32_t y = __builtin_bitreverse32(__umul24(x ^ 0x68E31DA4u, 0xC2B2AEu) + x);
-    return (u32x2){x, y};
-}
-__device__ __forceinline__ u32x2 attn_hash4(uint64_t seed, uint64_t quad) {
-    return attn_hash4(drop_seed_key(seed), drop_high_mix(seed, quad), (uint32_t)quad);
 }
 __device__ __forceinline__ float drop_scale(const AttnArgs& p, int b, int h, int qrow, int key) {
     if (p.p_drop <= 0.f) return 1.f;
     const uint32_t th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
-    const uint64_t idx = drop_index(p, b, h, qrow, key);
-    return drop_field(attn_hash4(p.seed, idx >> 2), (int)(idx & 3)) >= (th >> 16) ? 1.f / (1.f - p.p_drop) : 0.f;
+    return dropout_keep(p.seed, drop_index(p, b, h, qrow, key), th) ? 1.f / (1.f - p.p_drop) : 0.f;
 }
 
 // pair of bf16 bit patterns (non-negative values) times the keep decisions of a pair of 16-bit uniforms: field >= th  <=>  the
@@ -454,7 +433,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
                         // y.lo, y.hi; 2, 3 = x.lo, x.hi), so "field >= threshold" is a saturating packed subtract of threshold - 1,
                         // a packed min with 1, and the packed product of the bf16 bit patterns with that 0 / 1: 3 VALU per pair
                         // where extract + compare + select per element took 6
-                        const u32x2 hq = FAST ? attn_hash4(drop_ks, hwm0, qlo + 4u * j) : attn_hash4(p.seed, quad0 + 4 * j);
+                        const u32x2 hq = FAST ? drop_hash4_lo(drop_ks, hwm0, qlo + 4u * j) : drop_hash4(p.seed, quad0 + 4 * j);
                         p01 = drop_pair(p01, hq[1], drop_thm1x2); p23 = drop_pair(p23, hq[0], drop_thm1x2);
                     }
                     pf[qb][j >> 1][2 * (j & 1)] = p01;
@@ -866,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
                 }
                 const int key = kw + 16 * kb + r16;
                 u32x2 hq = {0u, 0u};
-                if constexpr (DROP) hq = attn_hash4(drop_ks, drop_hwm, qrow_quads + ((uint32_t)key >> 2));
+                if constexpr (DROP) hq = drop_hash4_lo(drop_ks, drop_hwm, qrow_quads + ((uint32_t)key >> 2));
                 float pv[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1013,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
                 const int qrow = qw + 16 * qb + r16;
                 const int key0 = kv0 + 16 * j + 4 * q;
                 u32x2 hq = {0u, 0u};
-                if constexpr (DROP) hq = attn_hash4(drop_ks, drop_hwm, (uint32_t)((b * p.H + h) * p.Tq + qrow) * tkq + ((uint32_t)key0 >> 2));   // keys 4q .. 4q+3 = one quad
+                if constexpr (DROP) hq = drop_hash4_lo(drop_ks, drop_hwm, (uint32_t)((b * p.H + h) * p.Tq + qrow) * tkq + ((uint32_t)key0 >> 2));   // keys 4q .. 4q+3 = one quad
                 float ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

@@ -107,24 +107,32 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // Dropout masks are a stateless integer hash of (seed, element index): nothing is stored, the backward pass
 // re-evaluates it, and every element is independent so GEMM / attention epilogues can evaluate it in whatever
 // register layout they hold.  One hash serves the element QUAD (4i .. 4i+3) as four 16-bit uniforms (the rate is
-// quantised to 1/65536): three 32-bit multiplies (quarter-rate on CDNA) per four elements.  Lag / seed correlations
-// and chi-square of the 16-bit fields were checked offline (< 1e-3, ~1.0).
+// quantised to 1/65536).
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-// The hash in two steps, for kernels whose VALU time is the bound (attention): the seed scramble `ks` is wave-uniform, and the
-// contribution `hwm` of the index's high word (almost always zero) is the same for every quad that shares that word, so both are
-// taken once per tile / row and each quad then costs three multiplies and six other operations on its LOW index word.
+// The hash in two steps, for kernels whose VALU time is the bound (attention: 72 M probabilities per encoder layer, hashed in the
+// forward, the dK/dV and the dQ kernels; the GEMM epilogues, which run beside no MFMA): the seed scramble `ks` is wave-uniform
+// (scalar ALU, mix32), and the contribution `hwm` of the index's high word (almost always zero) is the same for every quad that
+// shares that word, so both are taken once per tile / row.  The per-quad part is built from full-rate operations only -- 32-bit
+// multiplies run at quarter rate on CDNA, three of them made 23 issue slots per quad; v_mad_u32_u24 (x + (x mod 2^24) * C with C
+// even: a bijection that mixes upwards) and v_bfrev_b32 (turns the well-mixed top bits into the next multiply's low bits) make 12.
+// Checked offline (tools/drop_hash_check.py, profiles/r02_drop_hash_check.txt): avalanche |P(flip) - 1/2| < 0.01 on all 64 output
+// bits for every input bit, chi-square of the 16-bit fields ~1.0, keep-bit correlations between neighbouring elements / rows < 1e-3,
+// per-row and per-column keep counts binomial.
 __device__ __forceinline__ uint32_t drop_seed_key(uint64_t seed) { return mix32((uint32_t)seed * 0x9E3779B9u + 0x7F4A7C15u); }
 __device__ __forceinline__ uint32_t drop_high_mix(uint64_t seed, uint64_t quad) {
     const uint32_t hw = (uint32_t)(quad >> 32) + (uint32_t)(seed >> 32);
     return hw ^ (hw << 13) ^ (hw >> 7) ^ (hw << 27);
 }
 __device__ __forceinline__ u32x2 drop_hash4_lo(uint32_t ks, uint32_t hwm, uint32_t quad_lo) {
-    const uint32_t x = mix32(quad_lo ^ ks) ^ hwm;
-    uint32_t y = (x ^ 0x68E31DA4u) * 0xB5297A4Du;
-    y ^= y >> 15;
+    uint32_t a = quad_lo ^ ks;
+    a = __umul24(a, 0x3C6EF2u) + a; a = __builtin_bitreverse32(a);
+    a = __umul24(a, 0x9E3778u) + a; a = __builtin_bitreverse32(a);
+    a = __umul24(a, 0x85EBCAu) + a; a ^= a >> 16;
+    const uint32_t x = a ^ hwm;
+    const uint32_t y = __builtin_bitreverse32(__umul24(x ^ 0x68E31DA4u, 0xC2B2AEu) + x);
     return (u32x2){x, y};
 }
 __device__ __forceinline__ u32x2 drop_hash4(uint64_t seed, uint64_t quad) {

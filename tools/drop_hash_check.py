@@ -1,7 +1,7 @@
-"""Offline quality check (CPU, numpy) of the attention kernels' dropout hash (csrc/attention.hip attn_hash4) next to the hash every
-other dropout site uses (csrc/common.hpp drop_hash4_lo): avalanche of all 64 output bits for every input bit, chi-square of the
+"""Offline quality check (CPU, numpy) of the dropout hash (csrc/common.hpp drop_hash4_lo) next to the one it replaced (three 32-bit
+multiplies, quarter rate on CDNA): avalanche of all 64 output bits for every input bit, chi-square of the
 16-bit fields, keep-bit correlations along keys and rows of a real index space (rows of 94 quads), keep counts per row / column
-against the binomial variance.  python tools/attn_hash_check.py"""
+against the binomial variance.  python tools/drop_hash_check.py"""
 import numpy as np
 
 M32 = np.uint64(0xFFFFFFFF)
@@ -20,13 +20,13 @@ def bitrev(a):
     return r
 
 
-def drop_hash4_lo(q, ks):
+def old_hash4(q, ks):
     x = xs(q ^ ks, 16); x = mul32(x, 0x7feb352d); x = xs(x, 15); x = mul32(x, 0x846ca68b); x = xs(x, 16)
     y = xs(mul32(x ^ np.uint64(0x68E31DA4), 0xB5297A4D), 15)
     return x, y
 
 
-def attn_hash4(q, ks):
+def drop_hash4_lo(q, ks):
     a = q ^ ks
     a = mad24(a, 0x3C6EF2, a); a = bitrev(a)
     a = mad24(a, 0x9E3778, a); a = bitrev(a)
@@ -62,5 +62,5 @@ def stats(fn, p=0.1, rows=40000, quads=94):
                 row_count_var=float(cnt.sum(1).var() / (quads * 4 * var)), col_count_var=float(cnt.sum(0).var() / (rows * var)))
 
 
-for name, fn in (("drop_hash4_lo (3 x v_mul_lo_u32)", drop_hash4_lo), ("attn_hash4 (4 x v_mad_u32_u24 + 3 x v_bfrev)", attn_hash4)):
+for name, fn in (("round-1 hash (3 x v_mul_lo_u32)          ", old_hash4), ("drop_hash4_lo now (4 x v_mad_u32_u24 + 3 x v_bfrev)", drop_hash4_lo)):
     print("%-46s avalanche worst |P - 1/2| = %.4f" % (name, avalanche(fn)), " ".join("%s=%.4f" % kv for kv in stats(fn).items()))
