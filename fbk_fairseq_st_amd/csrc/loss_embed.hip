@@ -193,23 +193,53 @@ extern "C" int s2t_dropout(int dtype, const void* x, void* y, size_t n, float p,
     return S2T_OK;
 }
 
-// ------------------------------------------------------------------ activation backward (elementwise)
-// out = dy * act'(.)   act 1: relu with y = post-activation (mask y > 0); act 2: gelu with y = pre-activation
+// ------------------------------------------------------------------ activation backward (elementwise) behind a dropout
+// out = dropout(dy) * act'(.)   act 1: relu with y = post-activation (mask y > 0); act 2: gelu with y = pre-activation.  The dropout
+// (p_drop > 0) is the backward of the one that FOLLOWED the activation in the forward pass (conv_transformer.py:227-232: fc3, act,
+// + positions, dropout): the mask of s2t_dropout on the flat element index, applied to dy first, rounded like the separate pass did.
 template <typename T>
-__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, size_t n, int act) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float d = to_f32(dy[i]), v = to_f32(y[i]);
-        out[i] = from_f32<T>(act == 1 ? (v > 0.f ? d : 0.f) : d * gelu_grad_f(v));
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ out, size_t n, int act,
+                                                      float p, unsigned long long seed, int vec) {
+    const uint32_t th = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
+    const float inv = 1.f / (1.f - p);
+    constexpr int E = 16 / (int)sizeof(T);
+    const size_t nv = vec ? n / E : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+        T d[E], v[E];
+        *reinterpret_cast<u32x4*>(d) = *reinterpret_cast<const u32x4*>(dy + i * E);
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(y + i * E);
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            u32x2 h = {0u, 0u};
+            if (p > 0.f) h = drop_hash4(seed, i * (E / 4) + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float g = to_f32(d[4 * k + e]);
+                if (p > 0.f) g = to_f32(from_f32<T>(drop_field(h, e) >= (th >> 16) ? g * inv : 0.f));
+                const float a = to_f32(v[4 * k + e]);
+                d[4 * k + e] = from_f32<T>(act == 1 ? (a > 0.f ? g : 0.f) : g * gelu_grad_f(a));
+            }
+        }
+        *reinterpret_cast<u32x4*>(out + i * E) = *reinterpret_cast<const u32x4*>(d);
+    }
+    for (size_t i = nv * E + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float g = to_f32(dy[i]);
+        if (p > 0.f) g = to_f32(from_f32<T>(dropout_keep(seed, i, th) ? g * inv : 0.f));
+        const float a = to_f32(y[i]);
+        out[i] = from_f32<T>(act == 1 ? (a > 0.f ? g : 0.f) : g * gelu_grad_f(a));
     }
 }
-extern "C" int s2t_act_bwd(int dtype, const void* dy, const void* y, void* out, size_t n, int act, void* stream) {
+extern "C" int s2t_act_bwd(int dtype, const void* dy, const void* y, void* out, size_t n, int act, float p_drop, unsigned long long seed,
+                           void* stream) {
     if (n == 0) return S2T_OK;
-    if (!dy || !y || !out || (act != 1 && act != 2)) return S2T_EINVAL;
-    int blocks = (int)((n + 255) / 256);
-    blocks = blocks > 4096 ? 4096 : blocks;
+    if (!dy || !y || !out || (act != 1 && act != 2) || p_drop < 0.f || p_drop >= 1.f) return S2T_EINVAL;
+    const int vec = (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15) == 0;
+    const size_t per = dtype == S2T_BF16 ? 8 : 4;
+    int blocks = (int)((n / (vec ? per : 1) + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)out, n, act);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)out, n, act);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)out, n, act, p_drop, seed, vec);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)out, n, act, p_drop, seed, vec);
     else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

@@ -453,17 +453,47 @@ __global__ __launch_bounds__(256) void permute_conv_w_kernel(const float* __rest
     }
 }
 
-// ------------------------------------------------------------------ positional embedding add
-// x[t][b][:] += table[(t < len[b]) ? t+1 : 0][:]   (positional_embedding_audio.py:21-27 +
-// sinusoidal_positional_embedding.py: positions 1..len, padding row 0 = zeros); table is f32 [>=T+1][D]
-template <typename T>
-__global__ __launch_bounds__(256) void add_pos_kernel(T* __restrict__ x, const float* __restrict__ table,
-                                                      const int* __restrict__ len, int Tn, int B, int D) {
+// ------------------------------------------------------------------ positional embedding add (+ dropout)
+// dst[t][b][:] = dropout(src[t][b][:] + table[(t < len[b]) ? t+1 : 0][:])   (positional_embedding_audio.py:21-27 +
+// sinusoidal_positional_embedding.py: positions 1..len, padding row 0 = zeros; conv_transformer.py:229-232: x += positions, then
+// F.dropout); table is f32 [>=T+1][D].  One pass from the activation the backward keeps (src) to the encoder's input (dst); the mask
+// is the one of s2t_dropout on the flat element index.  VEC: 16-byte accesses (D a multiple of the elements per access).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void add_pos_kernel(const T* __restrict__ src, T* __restrict__ dst, const float* __restrict__ table,
+                                                      const int* __restrict__ len, int Tn, int B, int D, float p, unsigned long long seed) {
+    const uint32_t th = (uint32_t)fminf(p * 4294967296.f, 4294967295.f);
+    const float inv = 1.f / (1.f - p);
     const long n = (long)Tn * B * D;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int d = (int)(i % D), b = (int)((i / D) % B), t = (int)(i / ((long)D * B));
-        const int pos = (t < len[b]) ? t + 1 : 0;
-        x[i] = from_f32<T>(to_f32(x[i]) + table[(long)pos * D + d]);
+    if constexpr (VEC) {
+        constexpr int E = 16 / (int)sizeof(T);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n / E; i += (long)gridDim.x * 256) {
+            const long e0 = i * E, row = e0 / D;
+            const int d = (int)(e0 - row * D), b = (int)(row % B), t = (int)(row / B);
+            const float* tab = table + (long)((t < len[b]) ? t + 1 : 0) * D + d;
+            T v[E];
+            *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(src + e0);
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(tab + 4 * k);
+                u32x2 h = {0u, 0u};
+                if (p > 0.f) h = drop_hash4(seed, (uint64_t)i * (E / 4) + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = to_f32(from_f32<T>(to_f32(v[4 * k + e]) + tb[e]));          // rounded like the separate passes did
+                    if (p > 0.f) x = drop_field(h, e) >= (th >> 16) ? x * inv : 0.f;
+                    v[4 * k + e] = from_f32<T>(x);
+                }
+            }
+            *reinterpret_cast<u32x4*>(dst + e0) = *reinterpret_cast<const u32x4*>(v);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const int d = (int)(i % D), b = (int)((i / D) % B), t = (int)(i / ((long)D * B));
+            const int pos = (t < len[b]) ? t + 1 : 0;
+            float x = to_f32(from_f32<T>(to_f32(src[i]) + table[(long)pos * D + d]));
+            if (p > 0.f) x = dropout_keep(seed, (uint64_t)i, th) ? x * inv : 0.f;
+            dst[i] = from_f32<T>(x);
+        }
     }
 }
 
@@ -621,14 +651,19 @@ extern "C" int s2t_permute_conv_w(int dst_dtype, const float* src, void* dst, in
     return S2T_OK;
 }
 
-extern "C" int s2t_add_pos(int dtype, void* x, const float* table, const int* len, int T, int B, int D, void* stream) {
+extern "C" int s2t_add_pos(int dtype, const void* src, void* dst, const float* table, const int* len, int T, int B, int D,
+                           float p_drop, unsigned long long seed, void* stream) {
     const long n = (long)T * B * D;
     if (n <= 0) return S2T_OK;
-    if (!x || !table || !len) return S2T_EINVAL;
+    if (!src || !dst || !table || !len || p_drop < 0.f || p_drop >= 1.f) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(add_pos_kernel<bf16>, dim3(nblocks(n)), dim3(256), 0, st, (bf16*)x, table, len, T, B, D),
-        hipLaunchKernelGGL(add_pos_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, (float*)x, table, len, T, B, D));
+    const int E = dtype == S2T_BF16 ? 8 : 4;
+    const bool vec = D % E == 0 && ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)table) & 15) == 0);
+    const int nb = nblocks(vec ? n / E : n);
+#define S2T_ADD_POS(T_, V_) hipLaunchKernelGGL((add_pos_kernel<T_, V_>), dim3(nb), dim3(256), 0, st, (const T_*)src, (T_*)dst, table, len, T, B, D, p_drop, seed)
+    if (vec) { DISPATCH_T(dtype, S2T_ADD_POS(bf16, true), S2T_ADD_POS(float, true)); }
+    else { DISPATCH_T(dtype, S2T_ADD_POS(bf16, false), S2T_ADD_POS(float, false)); }
+#undef S2T_ADD_POS
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

@@ -188,7 +188,7 @@ class S2TEngine:
         # one workgroup over all tokens, no split-K atomics; csrc/wgrad_group.hip).  Parameter groups are reported final only after
         # the launch that holds their products (flush_wgrad).
         self.defer_wgrad = arena.compute_dtype == torch.bfloat16
-        self._wq, self._wq_ready = [], []
+        self._wq, self._wq_ready, self._wq_post = [], [], []     # _wq_post: what must follow the grouped launch (re-ordering a dW)
         # None: the encoder's queued weight gradients are computed in ONE launch after its backward pass (best packing of the CUs).
         # k: also after every k-th layer from the top.  The Trainer sets k = enc_layers / 2 when gradients are all-reduced: two
         # launches of six layers pack as well as one of twelve (576 / 2 tiles each over 256 CUs, tail cut), and half of the encoder's
@@ -240,6 +240,9 @@ class S2TEngine:
         if self._wq:
             K.wgrad_group(self._wq)
             self._wq = []
+        post, self._wq_post = self._wq_post, []
+        for fn in post:
+            fn()
         ready, self._wq_ready = self._wq_ready, []
         if self.on_grads_ready is not None:
             for prefix in ready:
@@ -280,7 +283,7 @@ class S2TEngine:
         return K.gemm(dy2d, w, trans_b=True, act=act, aux=aux, alpha=alpha, out=dx_out, accumulate=dx_accumulate)
 
     # ------------------------------------------------------------------ subsampler
-    def subsample_fwd(self, src_tokens, len_dev64, training, seed):
+    def subsample_fwd(self, src_tokens, len4_32, training, seed):
         hp, C = self.hp, self.hp.conv_ch
         gelu = hp.act == "gelu"          # --activation-fn also drives the subsampler (conv_transformer.py:140-142,212,227)
         act = K.ACT_GELU if gelu else K.ACT_RELU
@@ -325,32 +328,32 @@ class S2TEngine:
         w3p = K.permute_cf(self.P("encoder.fc3.weight"), torch.empty((hp.D, F4 * C), dtype=self.dtype, device=self.dev), hp.D, C, F4, 0)
         pre3 = torch.empty((T4 * B, hp.D), dtype=self.dtype, device=self.dev) if gelu else None
         h3 = K.gemm(z2n.view(T4 * B, F4 * C), w3p, bias=self.P("encoder.fc3.bias"), act=act, aux_out=pre3)
-        # lengths: ceil(len/2) twice (conv_transformer.py:213) -- integer bookkeeping on device
-        len4 = (((len_dev64 + 1) // 2) + 1) // 2
-        len4_32 = len4.to(torch.int32)
-        xe = h3.clone().view(T4, B, hp.D)
-        K.add_pos(xe, self.table(T4 + 1, 0), len4_32)
         p = hp.dropout if training else 0.0
-        if p > 0:
-            K.dropout(xe, p, seed + 3, out=xe)
+        xe = K.add_pos(h3.view(T4, B, hp.D), self.table(T4 + 1, 0), len4_32, out=torch.empty((T4, B, hp.D), dtype=self.dtype, device=self.dev),
+                       p_drop=p, seed=seed + 3)
         c.update(y1=y1, y1n=y1n, z2=z2, z2n=z2n, h3=h3, w2p=w2p, w3p=w3p, mean1=mean1, rstd1=rstd1, mean2=mean2,
                  rstd2=rstd2, cnt1=cnt1, P2=P2, p=p, pre1=pre1, pre2=pre2, pre3=pre3)
-        return xe, len4, len4_32, c
+        return xe, c
 
     def subsample_bwd(self, c, dx):
         """dx: gradient w.r.t. the subsampler output [T4*B, D]."""
         hp, C = self.hp, self.hp.conv_ch
         B, T4, F4 = c["B"], c["T4"], c["F4"]
         mp = self.maps(B, c["T2"], c["F2"])
-        if c["p"] > 0:
-            dx = K.dropout(dx, c["p"], c["seed"] + 3)
-        dh3 = K.act_bwd(dx, c["h3"], 1) if c["pre3"] is None else K.act_bwd(dx, c["pre3"], 2)
+        dx = dx.contiguous()
+        dh3 = K.act_bwd(dx, c["h3"], 1, c["p"], c["seed"] + 3) if c["pre3"] is None else K.act_bwd(dx, c["pre3"], 2, c["p"], c["seed"] + 3)
         # fc3: weight gradient in the re-ordered layout, then scattered back (+=) to the master layout
         z2n2d = c["z2n"].view(T4 * B, F4 * C)
-        gw3p = K.gemm(dh3, z2n2d, trans_a=True, trans_b=True, out_dtype=torch.float32, accumulate=True,
-                      splitk=_splitk(hp.D, F4 * C, dh3.shape[0]))
-        K.permute_cf(gw3p, self.G("encoder.fc3.weight"), hp.D, C, F4, 1)
-        K.colsum(dh3, self.G("encoder.fc3.bias"))
+        if self.defer_wgrad and K.wgrad_group_ok(dh3, z2n2d):
+            # with the Transformer blocks' products in the grouped launch (10 more tiles of the same reduction length); bias included
+            gw3p = torch.zeros((hp.D, F4 * C), dtype=torch.float32, device=self.dev)
+            self._wq.append((dh3, z2n2d, gw3p, self.G("encoder.fc3.bias")))
+            self._wq_post.append(lambda: K.permute_cf(gw3p, self.G("encoder.fc3.weight"), hp.D, C, F4, 1))
+        else:
+            gw3p = K.gemm(dh3, z2n2d, trans_a=True, trans_b=True, out_dtype=torch.float32, accumulate=True,
+                          splitk=_splitk(hp.D, F4 * C, dh3.shape[0]))
+            K.permute_cf(gw3p, self.G("encoder.fc3.weight"), hp.D, C, F4, 1)
+            K.colsum(dh3, self.G("encoder.fc3.bias"))
         if c["a2d"]:
             dz2n = K.gemm(dh3, c["w3p"], trans_b=True).view(-1, C)
             for ci in reversed(c["a2d"]):
@@ -550,8 +553,9 @@ class S2TEngine:
         c = dict(x=x2, h=h, mean=mean, rstd=rstd, q=q, kv=kv, ctx=ctx, lse=lse, klen=enc_klen32, pa=pa, p=p, seed=seed, T=T, B=B, Ts=Ts, enc2d=enc2d)
         return y.view(T, B, D), c
 
-    def cross_attn_block_bwd(self, pfx, c, dy, denc, d=None, nxt=None):
-        """accumulates the encoder-output gradient into denc [Ts*B, D]; returns dx (d / nxt as in self_attn_block_bwd)."""
+    def cross_attn_block_bwd(self, pfx, c, dy, denc, d=None, nxt=None, accumulate=True):
+        """accumulates (accumulate=False: writes) the encoder-output gradient into denc [Ts*B, D]; returns dx (d / nxt as in
+        self_attn_block_bwd)."""
         hp = self.hp
         T, B, D, Ts = c["T"], c["B"], self.hp.D, c["Ts"]
         if d is None:
@@ -561,7 +565,7 @@ class S2TEngine:
         kv = c["kv"]
         K.attn_bwd(c["q"], kv[:, :, :D], kv[:, :, D:], c["ctx"], dctx.view(T, B, D), c["lse"], hp.heads,
                    dq, dkv[:, :, :D], dkv[:, :, D:], klen=c["klen"], causal=False, p_drop=c["pa"], seed=c["seed"] + 1)
-        self.linear_bwd(dkv.view(Ts * B, 2 * D), c["enc2d"], pfx + "encoder_attn.kv", dx_out=denc, dx_accumulate=True)
+        self.linear_bwd(dkv.view(Ts * B, 2 * D), c["enc2d"], pfx + "encoder_attn.kv", dx_out=denc, dx_accumulate=accumulate)
         dh = self.linear_bwd(dq.view(T * B, D), c["h"], pfx + "encoder_attn.q_proj")
         return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "encoder_attn_layer_norm.weight"),
                                self.G(pfx + "encoder_attn_layer_norm.weight"), self.G(pfx + "encoder_attn_layer_norm.bias"), dres=dy, drop=nxt)
@@ -607,11 +611,13 @@ class S2TEngine:
         """Returns dict(out [T'',B,D], lengths int64 [B] (device), lengths_host list, ctc_out, ctc_lengths, ...), ctx."""
         hp = self.hp
         len_host = [int(v) for v in (src_lengths.tolist() if torch.is_tensor(src_lengths) else src_lengths)]
-        len_dev = torch.tensor(len_host, dtype=torch.int64).to(self.dev, non_blocking=True) if not (
-            torch.is_tensor(src_lengths) and src_lengths.is_cuda) else src_lengths.to(torch.int64)
-        x, len4, len4_32, sub = self.subsample_fwd(src_tokens, len_dev, training, seed * 1000)
-        T4, B, D = x.shape
+        # lengths after the two stride-2 convolutions: ceil(len / 2) twice (conv_transformer.py:213), on the host, one upload each for
+        # the two integer widths the kernels read
         lens_host = [((l + 1) // 2 + 1) // 2 for l in len_host]
+        len4 = torch.tensor(lens_host, dtype=torch.int64).to(self.dev, non_blocking=True)
+        len4_32 = torch.tensor(lens_host, dtype=torch.int32).to(self.dev, non_blocking=True)
+        x, sub = self.subsample_fwd(src_tokens, len4_32, training, seed * 1000)
+        T4, B, D = x.shape
         klen = len4_32 if min(lens_host) < T4 else None             # create_mask -> None when nothing is padded
         ctx = dict(sub=sub, layers=[], ctc=None, T4=T4, B=B)
         out = dict(ctc_out=None, ctc_lengths=None, ctc_lengths_host=None, pred=None, states=[] if return_all_hiddens else None)
@@ -800,8 +806,9 @@ class S2TEngine:
         dx = K.layernorm_bwd(dxn, f["x"], f["mean"], f["rstd"], self.P(pfx + "layer_norm.weight"),
                              self.G(pfx + "layer_norm.weight"), self.G(pfx + "layer_norm.bias"), drop=nxt)
         dx, dxd = dx if nxt is not None else (dx, None)
+        fresh = denc is None and hp.dec_layers > 0      # the top layer's K/V data gradient WRITES the buffer: no fill, no read of zeros
         if denc is None:
-            denc = torch.zeros((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
+            denc = (torch.empty if fresh else torch.zeros)((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
         for l in reversed(range(hp.dec_layers)):
             lp = pfx + "layers.%d." % l
             c1, c2, c3 = ctx["layers"][l]
@@ -809,7 +816,8 @@ class S2TEngine:
             dx = self.ffn_block_bwd(lp, c3, dx, d=dxd, nxt=nxt)
             dx, dxd = dx if nxt is not None else (dx, None)
             nxt = drop_of(c1, 2)
-            dx = self.cross_attn_block_bwd(lp, c2, dx, denc, d=dxd, nxt=nxt)
+            dx = self.cross_attn_block_bwd(lp, c2, dx, denc, d=dxd, nxt=nxt, accumulate=not fresh)
+            fresh = False
             dx, dxd = dx if nxt is not None else (dx, None)
             nxt = drop_of(ctx["layers"][l - 1][2], 4) if l > 0 else None
             dx = self.self_attn_block_bwd(lp, c1, dx, d=dxd, nxt=nxt)

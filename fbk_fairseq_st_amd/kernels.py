@@ -262,11 +262,15 @@ def permute_conv_w(src, dst, Co, Ci, mode):
     return dst
 
 
-def add_pos(x, table, len32):
+def add_pos(x, table, len32, out=None, p_drop=0.0, seed=0):
+    """out = dropout(x + positions) in one pass (out = None: in place)"""
     T, B, D = x.shape
-    assert x.is_contiguous() and table.shape[0] >= T + 1 and table.shape[1] == D
-    L.check(_lib().s2t_add_pos(L.dt(x), L.ptr(x), L.ptr(table), L.ptr(len32), T, B, D, L.stream()), "s2t_add_pos")
-    return x
+    out = x if out is None else out
+    assert x.is_contiguous() and out.is_contiguous() and out.shape == x.shape and out.dtype == x.dtype
+    assert table.shape[0] >= T + 1 and table.shape[1] == D
+    L.check(_lib().s2t_add_pos(L.dt(x), L.ptr(x), L.ptr(out), L.ptr(table), L.ptr(len32), T, B, D, float(p_drop), int(seed), L.stream()),
+            "s2t_add_pos")
+    return out
 
 
 def padded_cols(V, dtype):
@@ -467,9 +471,11 @@ def embed_bwd(tokens, dout, dW, scale, pad):
             "s2t_embed_bwd")
 
 
-def act_bwd(dy, y, act):
+def act_bwd(dy, y, act, p_drop=0.0, seed=0):
+    """dropout(dy) * act'(y): the backward of act followed by a dropout, one pass"""
+    assert dy.is_contiguous() and y.is_contiguous() and dy.dtype == y.dtype and dy.numel() == y.numel()
     out = torch.empty_like(dy)
-    L.check(_lib().s2t_act_bwd(L.dt(dy), L.ptr(dy), L.ptr(y), L.ptr(out), dy.numel(), act, L.stream()), "s2t_act_bwd")
+    L.check(_lib().s2t_act_bwd(L.dt(dy), L.ptr(dy), L.ptr(y), L.ptr(out), dy.numel(), act, float(p_drop), int(seed), L.stream()), "s2t_act_bwd")
     return out
 
 

@@ -194,8 +194,10 @@ int s2t_permute_cf(int dst_dtype, const float* src, void* dst, int N, int C, int
 /* conv2 weight [Co][Ci][3][3] <-> implicit-GEMM operand layouts (see subsample.hip): 0 forward, 1 data gradient by parity
  * class, 2 weight gradient back to the master layout */
 int s2t_permute_conv_w(int dst_dtype, const float* src, void* dst, int Co, int Ci, int mode, void* stream);
-/* x[t][b][:] += sinusoid[(t < len[b]) ? t+1 : 0][:]  (positional_embedding_audio.py:21-27) */
-int s2t_add_pos(int dtype, void* x, const float* table, const int* len, int T, int B, int D, void* stream);
+/* dst[t][b][:] = dropout(src[t][b][:] + sinusoid[(t < len[b]) ? t+1 : 0][:])  (positional_embedding_audio.py:21-27; the add and the
+ * F.dropout of conv_transformer.py:229-232 in one pass; src may equal dst; p_drop = 0: no dropout; mask = s2t_dropout's on the flat index) */
+int s2t_add_pos(int dtype, const void* src, void* dst, const float* table, const int* len, int T, int B, int D,
+                float p_drop, unsigned long long seed, void* stream);
 
 /* ---- CTC compression (conv_transformer.py:278-291, 385-426) -----------------------------------------
  * pred[b][t] = first arg-max of softmax(logits[t][b][:]) (bit-exact integer path), pmax = its probability.
@@ -247,8 +249,10 @@ int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float
 int s2t_log_softmax(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream);
 int s2t_embed_bwd(int dtype, const long long* tokens, const void* dout, float* dW, int B, int L, int D,
                   float scale, int pad, void* stream);
-/* out = dy * act'(y): act 1 = relu (y = post-activation), act 2 = gelu (y = pre-activation) */
-int s2t_act_bwd(int dtype, const void* dy, const void* y, void* out, size_t n, int act, void* stream);
+/* out = dropout(dy) * act'(y): act 1 = relu (y = post-activation), act 2 = gelu (y = pre-activation); the dropout (p_drop > 0, mask
+ * of s2t_dropout on the flat index) is the backward of one that followed the activation in the forward pass */
+int s2t_act_bwd(int dtype, const void* dy, const void* y, void* out, size_t n, int act, float p_drop, unsigned long long seed,
+                void* stream);
 /* y += x (merging the gradients of two consumers of one activation) */
 int s2t_add_inplace(int dtype, const void* x, void* y, size_t n, void* stream);
 /* y = x * keep/(1-p), mask from Philox(seed, index); the backward pass calls it again on the gradient */

@@ -484,6 +484,16 @@ def test_add_pos_and_permutes():
     ref = x + table[s2t_ref.audio_positions(lens, T)].transpose(0, 1)
     out = K.add_pos(x.clone().to(DEV), table.to(DEV), lens.to(torch.int32).to(DEV))
     assert rel_err(out, ref) < 1e-6
+    # positions + dropout in one pass, out of place (both dtypes, a width that takes the element-wise path too): bit for bit
+    # the separate kernels; and the backward twin: dropout + activation gradient in one pass
+    for dtype, Dw in ((torch.bfloat16, 64), (torch.float32, 64), (torch.bfloat16, 20), (torch.float32, 6)):
+        xs = rnd(T, B, Dw, dtype=dtype, seed=4).to(DEV); tb = s2t_ref.sinusoid_table(T + 1, Dw, 0).to(DEV); l32 = lens.to(torch.int32).to(DEV)
+        two = K.dropout(K.add_pos(xs.clone(), tb, l32), 0.3, 99)
+        one = K.add_pos(xs, tb, l32, out=torch.empty_like(xs), p_drop=0.3, seed=99)
+        assert torch.equal(one, two) and 0.5 < float((one != 0).float().mean()) < 0.85
+        dy = rnd(T * B, Dw, dtype=dtype, seed=5).to(DEV); yv = rnd(T * B, Dw, dtype=dtype, seed=6).to(DEV)
+        for act in (1, 2):
+            assert torch.equal(K.act_bwd(dy, yv, act, 0.3, 99), K.act_bwd(K.dropout(dy, 0.3, 99), yv, act))
     N, C, Fq = 5, 64, 20
     w = rnd(N, C * Fq, seed=2)
     wp = K.permute_cf(w.to(DEV), torch.empty(N, C * Fq, device=DEV), N, C, Fq, 0)
