@@ -634,8 +634,12 @@ class S2TEngine:
                 x_ctc = self.linear(x2, "encoder.ctc_fc", pad_rows=True).view(Tn, B, hp.V_src)   # row stride padded to 16 B
                 pred, pmax, ctc_lse = K.ctc_argmax(x_ctc, want_lse=True)     # the CTC loss over x_ctc reuses the row log-sum-exps
                 seg, rs, rl, new_len, w = K.ctc_rle(pred, pmax, cur_len, hp.ctc_strategy)
-                new_len_host = new_len.tolist()                     # the one host sync of the forward pass
-                out["pred_host"] = pred.cpu()                       # greedy path for the host-side UER (logging)
+                # greedy path for the host-side UER (logging): copied to pinned memory on the stream BEFORE the one host sync of the
+                # forward pass (the compressed lengths), which then covers both transfers
+                pred_host = torch.empty(pred.shape, dtype=pred.dtype, pin_memory=True)
+                pred_host.copy_(pred, non_blocking=True)
+                new_len_host = new_len.tolist()
+                out["pred_host"] = pred_host
                 Tout = max(new_len_host)
                 xc = K.ctc_compress_fwd(x, w, rs, rl, new_len, Tout)
                 ctx["ctc"] = dict(layer=l, x=x2, seg=seg, w=w, Tn=Tn, Tout=Tout)
