@@ -299,19 +299,49 @@ __global__ void clip_coef_kernel(const double* acc, float scale, float max_norm,
 
 // Adam over the flat arena (fairseq/optim/adam.py:147-202): g' = g*mult; m,v update; decoupled wd;
 // p -= step_size * m / (sqrt(v)+eps); optionally refresh the bf16 shadow used by the MFMA GEMMs.
+__device__ __forceinline__ float adam_one(float& pi, float gi, float& mi, float& vi, float mult, float lr, float beta1, float beta2,
+                                          float eps, float wd, float step_size) {
+    gi *= mult;
+    mi = beta1 * mi + (1.f - beta1) * gi;
+    vi = beta2 * vi + (1.f - beta2) * gi * gi;
+    if (wd != 0.f) pi -= wd * lr * pi;
+    pi -= step_size * mi / (sqrtf(vi) + eps);
+    return pi;
+}
+// VEC: all five arrays 16-byte aligned (the arena's are): four parameters per lane and access, 30 bytes per parameter in 16-byte
+// (8-byte for the bf16 shadow) accesses; the tail and unaligned sub-ranges (frozen-parameter gaps) take the element-wise form.
+template <bool VEC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16* __restrict__ shadow, size_t n, const float* mult_ptr,
                                                    float lr, float beta1, float beta2, float eps, float wd,
                                                    float step_size) {
     const float mult = mult_ptr ? mult_ptr[1] : 1.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gi = g[i] * mult;
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-        float pi = p[i];
-        if (wd != 0.f) pi -= wd * lr * pi;
-        pi -= step_size * mi / (sqrtf(vi) + eps);
+    size_t done = 0;
+    if constexpr (VEC) {
+        const size_t nv = n / 4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+            f32x4 pi = reinterpret_cast<const f32x4*>(p)[i], mi = reinterpret_cast<const f32x4*>(m)[i], vi = reinterpret_cast<const f32x4*>(v)[i];
+            const f32x4 gi = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pe = pi[e], me = mi[e], ve = vi[e];
+                adam_one(pe, gi[e], me, ve, mult, lr, beta1, beta2, eps, wd, step_size);
+                pi[e] = pe; mi[e] = me; vi[e] = ve;
+            }
+            reinterpret_cast<f32x4*>(m)[i] = mi; reinterpret_cast<f32x4*>(v)[i] = vi; reinterpret_cast<f32x4*>(p)[i] = pi;
+            if (shadow) {
+                bf16 sh[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sh[e] = (bf16)pi[e];
+                reinterpret_cast<u32x2*>(shadow)[i] = *reinterpret_cast<const u32x2*>(sh);
+            }
+        }
+        done = nv * 4;
+    }
+    for (size_t i = done + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_one(pi, g[i], mi, vi, mult, lr, beta1, beta2, eps, wd, step_size);
         m[i] = mi; v[i] = vi; p[i] = pi;
         if (shadow) shadow[i] = (bf16)pi;
     }
@@ -341,10 +371,13 @@ extern "C" int s2t_adam_step(float* p, const float* g, float* m, float* v, void*
     if (!p || !g || !m || !v || step < 1) return S2T_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
-    int blocks = (int)((n + 255) / 256);
-    blocks = blocks > 4096 ? 4096 : blocks;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n,
-                       mult2, lr, beta1, beta2, eps, wd, step_size);
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (((uintptr_t)shadow_bf16 & 7) == 0) && n >= 4;
+    int blocks = (int)(((vec ? n / 4 : n) + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+    if (vec) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n,
+                                mult2, lr, beta1, beta2, eps, wd, step_size);
+    else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n,
+                            mult2, lr, beta1, beta2, eps, wd, step_size);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
