@@ -72,10 +72,10 @@ rows = []
 for key, evs in rec.items():
     us = sorted(s.elapsed_time(e) * 1e3 for s, e, _ in evs)
     med = us[len(us) // 2]
-    rows.append((key, len(evs) // args.reps, med, evs[0][2]))
+    rows.append((key, len(evs) / args.reps, med, evs[0][2]))       # a fraction: the token count after CTC compression varies from update to update
 tot = sum(n * us for _, n, us, _ in rows)
 print("%-4s %7s %6s %6s  %-34s %5s %9s %9s %7s" % ("op", "M", "N", "K", "epilogue", "n", "us", "TF/s", "ms/upd"))
 for key, n, us, fl in sorted(rows, key=lambda r: -r[1] * r[2]):
-    print("%-4s %7d %6d %6d  %-34s %5d %9.1f %9.1f %7.3f" % (key[0], key[1], key[2], key[3], key[4], n, us, fl / us / 1e6, n * us / 1e3))
-print("total %.3f ms per update in %d products; %.1f TF/s overall" % (tot / 1e3, sum(r[1] for r in rows),
+    print("%-4s %7d %6d %6d  %-34s %5.1f %9.1f %9.1f %7.3f" % (key[0], key[1], key[2], key[3], key[4], n, us, fl / us / 1e6, n * us / 1e3))
+print("total %.3f ms per update in %.0f products; %.1f TF/s overall" % (tot / 1e3, sum(r[1] for r in rows),
                                                                       sum(r[1] * r[3] for r in rows) / tot / 1e6))
