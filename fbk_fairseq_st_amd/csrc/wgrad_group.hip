@@ -192,8 +192,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const Prob* __restr
             }
         }
         constexpr int RS = 256 * 4 + 16;
+        // a tile inside the matrix with 16-byte aligned rows (every tile of the Transformer's Linears): the eight 16-byte chunks a lane
+        // adds to per slab are LOADED TOGETHER before the slab goes through LDS -- one memory round trip per slab under the LDS write and
+        // its barrier.  (The element-wise form below waits for every chunk before it touches the next: 32 dependent round trips per tile,
+        // ~20 us per work item with all CUs in their epilogues at once.)
+        const bool interior = !I.atomic && row0 + 256 <= P.n_out && col0 + 256 <= P.n_in && (P.ldw & 3) == 0 &&
+                              (reinterpret_cast<uintptr_t>(P.dW) & 15) == 0;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {                                 // slab sl = rows 64 sl .. 64 sl + 63 = A half sl / 2, wave row sl % 2
+            f32x4 oldv[8];
+            if (interior) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int c = threadIdx.x + 512 * it, lr = c >> 6, cc = c & 63;
+                    oldv[it] = *reinterpret_cast<const f32x4*>(P.dW + (size_t)(row0 + 64 * sl + lr) * P.ldw + col0 + 4 * cc);
+                }
+            }
             if (wr == (sl & 1)) {
                 const int hm = sl >> 1;
 #pragma unroll
@@ -209,6 +223,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_group_kernel(const Prob* __restr
                 for (int idx = threadIdx.x; idx < 64 * 256; idx += 512) {
                     const int lr = idx >> 8, lc = idx & 255, row = row0 + 64 * sl + lr, col = col0 + lc;
                     if (row < P.n_out && col < P.n_in) atomicAdd(P.dW + (size_t)row * P.ldw + col, *reinterpret_cast<const float*>(smem + lr * RS + lc * 4));
+                }
+            } else if (interior) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int c = threadIdx.x + 512 * it, lr = c >> 6, cc = c & 63;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(smem + lr * RS + cc * 16);
+                    *reinterpret_cast<f32x4*>(P.dW + (size_t)(row0 + 64 * sl + lr) * P.ldw + col0 + 4 * cc) = oldv[it] + v;
                 }
             } else
             for (int c = threadIdx.x; c < 64 * 64; c += 512) {           // 64 rows x 64 chunks of 4 floats
