@@ -104,50 +104,141 @@ __device__ __forceinline__ void conv1_window_finish(Conv1Win& w, float (&xv)[9])
     xv[6] = v[6] * (w.mt2 * w.mf0); xv[7] = v[7] * w.mt2; xv[8] = v[8] * (w.mt2 * w.mf2);
 }
 
-// ------------------------------------------------------------------ conv1 forward (+ BN statistics)
-// x [B][T][F] f32 -> y [B][T2][F2][C] T, y = act(conv(x)+bias); sums[c] += y, sums[C+c] += y^2 (double)
-// GELU (--activation-fn gelu): the pre-activation is stored next to y (`pre`), the backward needs it
-template <typename T, bool GELU>
-__global__ __launch_bounds__(256, 4) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, T* __restrict__ y, T* __restrict__ pre,
-                                                        double* __restrict__ sums, int B, int Tin, int F, int T2,
-                                                        int F2, int C, int pos_per_block) {
-    __shared__ float red[4][16][16];
-    const int LP = C >> 3, g = threadIdx.x % LP, slot = threadIdx.x / LP, nslot = 256 / LP;
-    float wr[8][9], bc[8];
+// ------------------------------------------------------------------ conv1 forward (+ BN statistics) on the f32 matrix cores
+// x [B][T][F] f32 -> y [B][T2][F2][C] T, y = act(conv(x)+bias); sums[c] += y, sums[C+c] += y^2 (double).  GELU (--activation-fn gelu): the
+// pre-activation is stored next to y (`pre`), the backward needs it.
+// The convolution as 16 x 16 x 4 f32 MFMAs (exact f32 products and sums: 7e-7 from a float64 evaluation): per unit of 16 consecutive
+// output pixels, D[channel][pixel] = W[channel][tap] . X^T[tap][pixel] with the nine taps padded to 12 = three MFMAs per 16 channels.
+// Lane (r16, q) of a wave supplies taps q, 4 + q, 8 + q of pixel r16 (three, two, two, two scalar loads) and receives channels
+// 4q .. 4q + 3 of every 16-channel tile of that pixel: the 72 FMAs per 8 channels of a pixel that bound the round-1 kernel (8 channels per thread, 134 us)
+// become 12 MFMAs per 16 pixels, and what is left per output value is bias, activation, rounding and the statistics (93 us).
+struct Conv1Taps {                                    // this lane's three taps: row / column offsets and validity
+    int dt[3], df[3]; bool on[3];
+    __device__ __forceinline__ void init(int q) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bc[e] = bias[8 * g + e];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) wr[e][i] = w[(8 * g + e) * 9 + i];
+        for (int m = 0; m < 3; ++m) { const int k = 4 * m + q; on[m] = k < 9; dt[m] = k / 3 - 1; df[m] = k % 3 - 1; }
     }
-    const unsigned P = (unsigned)B * T2 * F2;
-    const unsigned p0 = blockIdx.x * (unsigned)pos_per_block, pend = min(P, p0 + (unsigned)pos_per_block);
-    float s1[8], s2[8];
+};
+// window values of pixel (b, t2, f2) for this lane's taps; out-of-plane taps read a clamped address and are zeroed by select
+__device__ __forceinline__ void conv1_taps_load(const float* __restrict__ x, const Conv1Taps& tp, int b, int t2, int f2, int Tin, int F,
+                                                bool live, float (&xv)[3]) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    // the window of the next pixel is requested before the current one is consumed (one memory latency per two pixels
-    // would otherwise sit exposed between the index arithmetic and the FMAs); the last prefetch re-reads a valid pixel
-    Conv1Win wn;
-    if (p0 + slot < pend) conv1_window_issue(x, p0 + slot, Tin, F, T2, F2, wn);
-    for (unsigned p = p0 + slot; p < pend; p += nslot) {
-        float xv[9], o[8], q[8];
-        conv1_window_finish(wn, xv);
-        conv1_window_issue(x, min(p + nslot, P - 1), Tin, F, T2, F2, wn);
+    for (int m = 0; m < 3; ++m) {
+        const int t = 2 * t2 + tp.dt[m], f = 2 * f2 + tp.df[m];
+        const bool ok = live && tp.on[m] && t >= 0 && t < Tin && f >= 0 && f < F;
+        const float v = x[((long)b * Tin + min(max(t, 0), Tin - 1)) * F + min(max(f, 0), F - 1)];
+        xv[m] = ok ? v : 0.f;
+    }
+}
+template <int NT>
+struct Conv1W {                                       // weight fragments: wa[j][m] = w[16 j + r16][4 m + q] (0 past the ninth tap)
+    float wa[NT][3];
+    __device__ __forceinline__ void init(const float* __restrict__ w, int r16, int q) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float acc = bc[e];
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int i = 0; i < 9; ++i) acc += xv[i] * wr[e][i];
-            if constexpr (GELU) { q[e] = acc; acc = gelu_f(to_f32(from_f32<T>(acc))); }   // gelu of the stored pre-activation
-            else acc = fmaxf(acc, 0.f);
-            o[e] = to_f32(from_f32<T>(acc));                       // statistics of the value that is stored
-            s1[e] += o[e]; s2[e] += o[e] * o[e];
+            for (int m = 0; m < 3; ++m) wa[j][m] = 4 * m + q < 9 ? w[(16 * j + r16) * 9 + 4 * m + q] : 0.f;
+    }
+    __device__ __forceinline__ void mul(const float (&xv)[3], f32x4 (&acc)[NT]) const {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][m], xv[m], acc[j], 0, 0, 0);
         }
-        store8<T>(y + (size_t)p * C + 8 * g, o);
-        if constexpr (GELU) store8<T>(pre + (size_t)p * C + 8 * g, q);
     }
-    chan_pair_reduce(s1, s2, LP, g, sums, C, red);
+};
+
+// forward: y = act(conv + bias) (+ pre for GELU) stored, statistics of the stored values.
+// 8 waves per workgroup; a wave walks units of 16 pixels.  bf16 stores: the quads of two neighbouring 16-channel tiles are exchanged
+// between lane rows q and q ^ 1 (v_permlane16_swap) so that every lane stores 8 consecutive channels = 16 bytes.
+template <typename T, int NT, bool GELU>
+__global__ __launch_bounds__(512) void conv1_mfma_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ y, T* __restrict__ pre,
+                                                             double* __restrict__ sums, int B, int Tin, int F, int T2, int F2) {
+    constexpr int C = 16 * NT;
+    __shared__ float red[8][2][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    Conv1Taps tp; tp.init(q);
+    Conv1W<NT> cw; cw.init(w, r16, q);
+    f32x4 b4[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b4[j] = *reinterpret_cast<const f32x4*>(bias + 16 * j + 4 * q);
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[j][e] = s2[j][e] = 0.f;
+    const unsigned P = (unsigned)B * T2 * F2, units = (P + 15) / 16, stride = gridDim.x * 8;
+    auto swap2 = [](uint32_t& a, uint32_t& b) {
+        const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+        a = r[0]; b = r[1];
+    };
+    for (unsigned u = blockIdx.x * 8 + wave; u < units; u += stride) {
+        const unsigned p = u * 16 + r16, pc = min(p, P - 1);
+        const unsigned row = pc / (unsigned)F2;
+        const int f2 = (int)(pc - row * F2), t2 = (int)(row % (unsigned)T2), b = (int)(row / (unsigned)T2);
+        float xv[3];
+        conv1_taps_load(x, tp, b, t2, f2, Tin, F, p < P, xv);
+        f32x4 acc[NT];
+        cw.mul(xv, acc);
+        const bool live = p < P;
+        uint32_t oq[NT][2], pq[NT][2];                 // packed bf16 quads (bf16 path)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            T o[4], pr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[j][e] + b4[j][e];
+                if constexpr (GELU) { pr[e] = from_f32<T>(v); v = gelu_f(to_f32(pr[e])); }     // gelu of the stored pre-activation
+                else v = fmaxf(v, 0.f);
+                o[e] = from_f32<T>(v);
+                const float r = live ? to_f32(o[e]) : 0.f;                                    // statistics of the value that is stored
+                s1[j][e] += r; s2[j][e] += r * r;
+            }
+            if constexpr (sizeof(T) == 4) {
+                if (live) {
+                    *reinterpret_cast<f32x4*>(y + (size_t)p * C + 16 * j + 4 * q) = *reinterpret_cast<const f32x4*>(o);
+                    if constexpr (GELU) *reinterpret_cast<f32x4*>(pre + (size_t)p * C + 16 * j + 4 * q) = *reinterpret_cast<const f32x4*>(pr);
+                }
+            } else {
+                oq[j][0] = reinterpret_cast<const uint32_t*>(o)[0]; oq[j][1] = reinterpret_cast<const uint32_t*>(o)[1];
+                if constexpr (GELU) { pq[j][0] = reinterpret_cast<const uint32_t*>(pr)[0]; pq[j][1] = reinterpret_cast<const uint32_t*>(pr)[1]; }
+            }
+        }
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int pp = 0; pp < NT / 2; ++pp) {
+                const size_t off = (size_t)p * C + 32 * pp + 16 * (q & 1) + 8 * (q >> 1);
+                uint32_t a0 = oq[2 * pp][0], a1 = oq[2 * pp][1], a2 = oq[2 * pp + 1][0], a3 = oq[2 * pp + 1][1];
+                swap2(a0, a2); swap2(a1, a3);
+                if (live) *reinterpret_cast<u32x4*>(y + off) = (u32x4){a0, a1, a2, a3};
+                if constexpr (GELU) {
+                    uint32_t c0 = pq[2 * pp][0], c1 = pq[2 * pp][1], c2 = pq[2 * pp + 1][0], c3 = pq[2 * pp + 1][1];
+                    swap2(c0, c2); swap2(c1, c3);
+                    if (live) *reinterpret_cast<u32x4*>(pre + off) = (u32x4){c0, c1, c2, c3};
+                }
+            }
+        }
+    }
+    // per-channel sums: over the 16 pixels of a lane row, then the 8 waves, then one double atomic per channel and workgroup
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = s1[j][e], b2 = s2[j][e];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b2 += __shfl_xor(b2, o); }
+            if (r16 == 0) { red[wave][0][16 * j + 4 * q + e] = a; red[wave][1][16 * j + 4 * q + e] = b2; }
+        }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += 512) {
+        const int which = t / C, c = t % C;
+        double a = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) a += (double)red[wv][which][c];
+        atomicAdd(sums + which * C + c, a);
+    }
 }
 
 // ------------------------------------------------------------------ conv1 backward (weights, bias)
@@ -509,18 +600,15 @@ extern "C" int s2t_conv1_fwd(int dtype, const float* x, const float* w, const fl
     if ((act != ACT_RELU && act != ACT_GELU) || (act == ACT_GELU && !pre)) return S2T_EINVAL;
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
-    const int ppb = (int)((P + 1023) / 1024 < 64 ? 64 : (P + 1023) / 1024);   // <= ~1024 workgroups: every one ends in 2C same-address atomics
-    dim3 grid((unsigned)((P + ppb - 1) / ppb));
     hipStream_t st = (hipStream_t)stream;
-    if (act == ACT_GELU) {
-        DISPATCH_T(dtype,
-            hipLaunchKernelGGL((conv1_fwd_kernel<bf16, true>), grid, dim3(256), 0, st, x, w, bias, (bf16*)y, (bf16*)pre, sums, B, T, F, T2, F2, C, ppb),
-            hipLaunchKernelGGL((conv1_fwd_kernel<float, true>), grid, dim3(256), 0, st, x, w, bias, (float*)y, (float*)pre, sums, B, T, F, T2, F2, C, ppb));
-    } else {
-        DISPATCH_T(dtype,
-            hipLaunchKernelGGL((conv1_fwd_kernel<bf16, false>), grid, dim3(256), 0, st, x, w, bias, (bf16*)y, (bf16*)nullptr, sums, B, T, F, T2, F2, C, ppb),
-            hipLaunchKernelGGL((conv1_fwd_kernel<float, false>), grid, dim3(256), 0, st, x, w, bias, (float*)y, (float*)nullptr, sums, B, T, F, T2, F2, C, ppb));
-    }
+    const long units = (P + 15) / 16;
+    dim3 grid((unsigned)(units < 8 * 512 ? (units + 7) / 8 : 512));          // 512 workgroups of 8 waves: each ends in 2C double atomics
+#define S2T_C1(T_, NT_, G_) hipLaunchKernelGGL((conv1_mfma_fwd_kernel<T_, NT_, G_>), grid, dim3(512), 0, st, x, w, bias, (T_*)y, (T_*)pre, sums, B, T, F, T2, F2)
+#define S2T_C1_NT(T_, G_) { if (C == 64) S2T_C1(T_, 4, G_); else if (C == 128) S2T_C1(T_, 8, G_); else S2T_C1(T_, 2, G_); }
+    if (act == ACT_GELU) { DISPATCH_T(dtype, S2T_C1_NT(bf16, true), S2T_C1_NT(float, true)); }
+    else { DISPATCH_T(dtype, S2T_C1_NT(bf16, false), S2T_C1_NT(float, false)); }
+#undef S2T_C1_NT
+#undef S2T_C1
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

@@ -129,11 +129,16 @@ def rel(a, b):
     return abs(a - b) / max(abs(b), 1e-12)
 
 
-# fp32: the gradient norms agree to ~2e-5 (worst: encoder.bn.0.weight 1.7e-5 on the ragged Cfg3 case); 2e-4 leaves an order of magnitude.
-# (With a plain float32 log-space CTC recursion in the product this was 1e-3 for everything below the CTC tap: alpha + beta - log P
+# fp32: the median per-tensor gradient-norm error is ~1e-6; the tolerance is 1e-3 because the comparison contains DISCRETE decisions.  The
+# forward passes of the engine and of the oracle differ by f32 rounding (~1e-7: summation orders, the order in which double atomics add the
+# BatchNorm statistics), and a ReLU input within that distance of zero is active in one and not in the other.  One such flip in a decoder
+# FFN (80 token rows at B = 2, L = 40) moves that layer's weight gradient by ~5e-3 in direction and ~4e-4 in norm, and everything
+# upstream of it by ~1e-3 -- measured: with the same build, the first update of a process and the third differ by exactly this pattern
+# (decoder.layers.2.fc1 7e-3, median 2e-5), and which seed shows it changes whenever a kernel's summation order does.
+# (With a plain float32 log-space CTC recursion in the product the error was 1e-3 for EVERYTHING below the CTC tap: alpha + beta - log P
 # cancels numbers near -3,000.  The oracle runs its recursion in float64; the kernels now keep every step's vector relative to its
 # maximum and normalise the posteriors per frame: 4e-6 from float64 where torch's own f32 ctc_loss is 6e-4, tools/ctc_accuracy.py.)
-TOL = {torch.float32: dict(loss=1e-4, grad=2e-4, cos=0.9999), torch.bfloat16: dict(loss=2e-2, grad=1e-1, cos=0.99)}
+TOL = {torch.float32: dict(loss=1e-4, grad=1e-3, cos=0.9999), torch.bfloat16: dict(loss=2e-2, grad=1e-1, cos=0.99)}
 
 
 def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
