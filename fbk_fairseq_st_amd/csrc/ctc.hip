@@ -494,14 +494,19 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     constexpr int E = 16 / (int)sizeof(T);
     const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
     const int nv = vec ? V / E : 0;
+    // softmax(x)[c] = exp2(x log2 e - lse log2 e) on the hardware exp2 (one quarter-rate instruction; expf costs ~15 VALU per element, and
+    // this loop runs over T x B x V = 120 M of them): relative error ~2e-7, far below what the posteriors carry
+    constexpr float L2E = 1.44269504088896f;
+    const float ls2 = ls * L2E;
     for (int c = threadIdx.x; c < nv; c += 256) {
         T v[E], o[E];
         *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(x + c * E);
 #pragma unroll
-        for (int e = 0; e < E; ++e) o[e] = from_f32<T>((expf(to_f32(v[e]) - ls) - occ[c * E + e]) * gscale);
+        for (int e = 0; e < E; ++e) o[e] = from_f32<T>((__builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(v[e]), L2E, -ls2)) - occ[c * E + e]) * gscale);
         *reinterpret_cast<u32x4*>(g + c * E) = *reinterpret_cast<const u32x4*>(o);
     }
-    for (int c = nv * E + threadIdx.x; c < V; c += 256) g[c] = from_f32<T>((expf(to_f32(x[c]) - ls) - occ[c]) * gscale);
+    for (int c = nv * E + threadIdx.x; c < V; c += 256)
+        g[c] = from_f32<T>((__builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(x[c]), L2E, -ls2)) - occ[c]) * gscale);
 }
 
 // ------------------------------------------------------------------ C ABI
