@@ -8,16 +8,19 @@
 //   lse = logsumexp(row);  nll = lse - x[y];  smooth = V*lse - sum(x)
 //   loss += (1-eps)*nll + eps/V*smooth ; nll_sum += nll     (pad rows contribute nothing)
 //   dlogits[v] = gscale * (softmax[v] - (1-eps)*[v==y] - eps/V)   (0 on pad rows)
-template <typename T>
+// NC > 0: the row's 16-byte vectors (at most 256 NC of them) stay in registers between the three sweeps -- one read of the logits, and the
+// maximum and the plain sum share one pair of barriers; NC = 0: rows of any length, re-read from L2 per sweep.
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits, const long long* __restrict__ target,
-                                                   T* __restrict__ dlogits, float* __restrict__ sums, long rows, int V, int ld,
+                                                   T* __restrict__ dlogits, float* __restrict__ part, long rows, int V, int ld,
                                                    float eps, int pad, float gscale) {
     __shared__ float sh[16];
-    // A workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ... and adds its loss sums ONCE: one workgroup per row ended in two
-    // same-address f32 atomics each, a 2,560-deep chain served serially at the memory side (~40 ns apiece) -- 80 us for a pass over
-    // 41 MB of logits.  exp through the hardware exp2 (the gradient and the loss move by ~1e-7 relative).
+    // A workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ... and hands over its loss sums once, as a partial (below).
+    // exp through the hardware exp2 (the gradient and the loss move by ~1e-7 relative).
     float acc_loss = 0.f, acc_nll = 0.f;
     constexpr float L2E = 1.44269504088896f;
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int NR = NC > 0 ? NC : 1;
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
     const T* x = logits + row * ld;
     T* g = dlogits ? dlogits + row * ld : nullptr;
@@ -27,27 +30,52 @@ __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits,
         continue;
     }
     // 16-byte row accesses when the row is aligned (ld multiple of 8 bf16 / 4 f32: kernels.py alloc_rows), scalar tail otherwise
-    constexpr int E = 16 / (int)sizeof(T);
     const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
     const int nv = vec ? V / E : 0;
+    u32x4 rv[NR];
+    auto vec_at = [&](int k, int c) -> u32x4 {
+        if constexpr (NC > 0) return rv[k];
+        else return *reinterpret_cast<const u32x4*>(x + c * E);
+    };
+    if constexpr (NC > 0) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int c = threadIdx.x + 256 * k;
+            rv[k] = c < nv ? *reinterpret_cast<const u32x4*>(x + c * E) : (u32x4){0u, 0u, 0u, 0u};
+        }
+    }
+    // the sweeps visit vector c = threadIdx.x + 256 k; with NC > 0 the trip count is the compile-time NC (rows of <= 256 NC vectors)
+    auto sweep = [&](auto body) {
+        if constexpr (NC > 0) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int c = threadIdx.x + 256 * k;
+                if (c < nv) { T t[E]; *reinterpret_cast<u32x4*>(t) = vec_at(k, c); body(c, t); }
+            }
+        } else {
+            for (int c = threadIdx.x; c < nv; c += 256) { T t[E]; *reinterpret_cast<u32x4*>(t) = vec_at(0, c); body(c, t); }
+        }
+    };
     float m = -INFINITY, sx = 0.f;
-    for (int c = threadIdx.x; c < nv; c += 256) {
-        T t[E];
-        *reinterpret_cast<u32x4*>(t) = *reinterpret_cast<const u32x4*>(x + c * E);
+    sweep([&](int, const T (&t)[E]) {
 #pragma unroll
         for (int e = 0; e < E; ++e) { const float f = to_f32(t[e]); m = fmaxf(m, f); sx += f; }
-    }
+    });
     for (int v = nv * E + threadIdx.x; v < V; v += 256) { const float f = to_f32(x[v]); m = fmaxf(m, f); sx += f; }
-    m = block_max(m, sh);
-    sx = block_sum(sx, sh);
+    {   // maximum and sum over the workgroup behind one pair of barriers
+        m = wave_max(m); sx = wave_sum(sx);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = m; sh[4 + (threadIdx.x >> 6)] = sx; }
+        __syncthreads();
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        sx = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+    }
     const float ml2 = m * L2E;
     float se = 0.f;
-    for (int c = threadIdx.x; c < nv; c += 256) {
-        T t[E];
-        *reinterpret_cast<u32x4*>(t) = *reinterpret_cast<const u32x4*>(x + c * E);
+    sweep([&](int, const T (&t)[E]) {
 #pragma unroll
         for (int e = 0; e < E; ++e) se += __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(t[e]), L2E, -ml2));
-    }
+    });
     for (int v = nv * E + threadIdx.x; v < V; v += 256) se += __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(x[v]), L2E, -ml2));
     se = block_sum(se, sh);
     const float lse = m + logf(se);
@@ -59,9 +87,8 @@ __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits,
     }
     if (g) {
         const float ev = eps / (float)V, lsel2 = lse * L2E;
-        for (int c = threadIdx.x; c < nv; c += 256) {
-            T t[E], o[E];
-            *reinterpret_cast<u32x4*>(t) = *reinterpret_cast<const u32x4*>(x + c * E);
+        sweep([&](int c, const T (&t)[E]) {
+            T o[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 float d = __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(t[e]), L2E, -lsel2)) - ev;
@@ -69,7 +96,7 @@ __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits,
                 o[e] = from_f32<T>(d * gscale);
             }
             *reinterpret_cast<u32x4*>(g + c * E) = *reinterpret_cast<const u32x4*>(o);
-        }
+        });
         for (int v = nv * E + threadIdx.x; v < V; v += 256) {
             float d = __builtin_amdgcn_exp2f(__builtin_fmaf(to_f32(x[v]), L2E, -lsel2)) - ev;
             if (v == y) d -= (1.f - eps);
@@ -78,7 +105,16 @@ __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits,
     }
     __syncthreads();                                 // `sh` is reused by the next row's reductions
     }
-    if (threadIdx.x == 0 && (acc_loss != 0.f || acc_nll != 0.f)) { atomicAdd(sums + 0, acc_loss); atomicAdd(sums + 1, acc_nll); }
+    // per-workgroup partial sums; lsce_finish_kernel adds them up (1,024 workgroups ending in two same-address atomics each were a
+    // ~40 us chain at the memory side: the whole kernel took 43 us for 82 MB)
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = acc_loss; part[2 * blockIdx.x + 1] = acc_nll; }
+}
+__global__ __launch_bounds__(256) void lsce_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ sums) {
+    __shared__ float sh[16];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    a = block_sum(a, sh); b = block_sum(b, sh);
+    if (threadIdx.x == 0) { sums[0] += a; sums[1] += b; }
 }
 
 extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2, long rows, int V, int ld,
@@ -86,10 +122,15 @@ extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, 
     if (rows <= 0) return S2T_OK;
     if (!logits || !target || !sums2 || V <= 0 || ld < V) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);       // four workgroups per CU; each ends in two atomics
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(lsce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)logits, target, (bf16*)dlogits, sums2, rows, V, ld, eps, pad, grad_scale);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(lsce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)logits, target, (float*)dlogits, sums2, rows, V, ld, eps, pad, grad_scale);
+    const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);       // four workgroups per CU
+    static float* part = nullptr;                                      // 1,024 x 2 partial sums (one training stream per process)
+    if (!part) { hipError_t e = hipMalloc(&part, 2 * 1024 * sizeof(float)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+#define S2T_LSCE(T_, NC_) hipLaunchKernelGGL((lsce_kernel<T_, NC_>), dim3(grid), dim3(256), 0, st, (const T_*)logits, target, (T_*)dlogits, part, rows, V, ld, eps, pad, grad_scale)
+    if (dtype == S2T_BF16) { if (V <= 256 * 4 * 8) S2T_LSCE(bf16, 4); else S2T_LSCE(bf16, 0); }      // vocabularies up to 8,192 units: the row in registers
+    else if (dtype == S2T_F32) { if (V <= 256 * 4 * 4) S2T_LSCE(float, 4); else S2T_LSCE(float, 0); }
     else return S2T_ENOTSUP;
+#undef S2T_LSCE
+    hipLaunchKernelGGL(lsce_finish_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, sums2);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

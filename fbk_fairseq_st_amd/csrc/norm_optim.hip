@@ -270,8 +270,9 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
 }
 
 // ------------------------------------------------------------------ gradient norm, clip, Adam
-// sumsq: acc[0] += sum g^2 (double).  One launch over the flat gradient arena.
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* acc) {
+// sumsq: part[workgroup] = sum g^2 over its share (double), one launch over the flat gradient arena; clip_coef_kernel adds the partials
+// (2,048 workgroups ending in one same-address double atomic each arrive faster than the memory side serves them, ~40 ns apiece).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* __restrict__ part) {
     __shared__ double shd[4];
     double s = 0.0;
     const size_t n4 = n / 4;
@@ -284,13 +285,23 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, shd[0] + shd[1] + shd[2] + shd[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = shd[0] + shd[1] + shd[2] + shd[3];
 }
 
-// out[0] = gnorm = scale*sqrt(acc) ; out[1] = multiplier = scale * min(1, max_norm/(gnorm+1e-6))
+// acc[0] = sum of the partials; out[0] = gnorm = scale*sqrt(acc) ; out[1] = multiplier = scale * min(1, max_norm/(gnorm+1e-6))
 // (fairseq/utils.py:268-276 on gradients already multiplied by `scale`, trainer.py:426-436)
-__global__ void clip_coef_kernel(const double* acc, float scale, float max_norm, float* out) {
-    const float gn = scale * (float)sqrt(acc[0]);
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ part, int nparts, double* __restrict__ acc, float scale,
+                                                        float max_norm, float* __restrict__ out) {
+    __shared__ double shd[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double tot = shd[0] + shd[1] + shd[2] + shd[3];
+    acc[0] = tot;
+    const float gn = scale * (float)sqrt(tot);
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(max_norm / (gn + 1e-6f), 1.f);
     out[0] = gn;
@@ -351,15 +362,16 @@ extern "C" int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, floa
                                   float* out2, void* stream) {
     if (!g || !acc_ws || !out2) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(acc_ws, 0, sizeof(double), st);
-    if (e != hipSuccess) return S2T_EHIP(e);
+    static double* part = nullptr;                                       // 2,048 partial sums (one training stream per process)
+    if (!part) { hipError_t e = hipMalloc(&part, 2048 * sizeof(double)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+    int blocks = 0;
     if (n) {
-        int blocks = (int)((n / 4 + 255) / 256);
+        blocks = (int)((n / 4 + 255) / 256);
         blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, acc_ws);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, part);
         S2T_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, st, acc_ws, scale, max_norm, out2);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, part, blocks, acc_ws, scale, max_norm, out2);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
