@@ -109,12 +109,12 @@ __global__ __launch_bounds__(256) void lsce_kernel(const T* __restrict__ logits,
     // ~40 us chain at the memory side: the whole kernel took 43 us for 82 MB)
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = acc_loss; part[2 * blockIdx.x + 1] = acc_nll; }
 }
-__global__ __launch_bounds__(256) void lsce_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ sums) {
+__global__ __launch_bounds__(256) void lsce_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ sums, int two) {
     __shared__ float sh[16];
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
     a = block_sum(a, sh); b = block_sum(b, sh);
-    if (threadIdx.x == 0) { sums[0] += a; sums[1] += b; }
+    if (threadIdx.x == 0) { sums[0] += a; if (two) sums[1] += b; }
 }
 
 extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, void* dlogits, float* sums2, long rows, int V, int ld,
@@ -130,7 +130,7 @@ extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, 
     else if (dtype == S2T_F32) { if (V <= 256 * 4 * 4) S2T_LSCE(float, 4); else S2T_LSCE(float, 0); }
     else return S2T_ENOTSUP;
 #undef S2T_LSCE
-    hipLaunchKernelGGL(lsce_finish_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, sums2);
+    hipLaunchKernelGGL(lsce_finish_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, sums2, 1);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void kd_kernel(const T* __restrict__ logits, c
     }
     __syncthreads();                                 // `sh` / `wk` are reused by the next row
     }
-    if (threadIdx.x == 0 && acc_loss != 0.f) atomicAdd(sums, acc_loss);
+    if (threadIdx.x == 0) { sums[2 * blockIdx.x] = acc_loss; sums[2 * blockIdx.x + 1] = 0.f; }      // partials, as lsce_kernel: lsce_finish_kernel adds them
 }
 
 extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* target, const long long* teacher_idx,
@@ -379,9 +379,12 @@ extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* targe
     if (lambda > 0.f && (!teacher_idx || !teacher_logits || Kt < 1 || Kt > 64)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(kd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)logits, target, teacher_idx, teacher_logits, (bf16*)dlogits, sum1, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(kd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)logits, target, teacher_idx, teacher_logits, (float*)dlogits, sum1, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
+    static float* part = nullptr;                                      // 1,024 x 2 partial sums (one training stream per process)
+    if (!part) { hipError_t e = hipMalloc(&part, 2 * 1024 * sizeof(float)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(kd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)logits, target, teacher_idx, teacher_logits, (bf16*)dlogits, part, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(kd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)logits, target, teacher_idx, teacher_logits, (float*)dlogits, part, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
     else return S2T_ENOTSUP;
+    hipLaunchKernelGGL(lsce_finish_kernel, dim3(1), dim3(256), 0, st, part, (int)grid, sum1, 0);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }
