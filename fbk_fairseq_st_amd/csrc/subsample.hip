@@ -112,6 +112,14 @@ __device__ __forceinline__ void conv1_window_finish(Conv1Win& w, float (&xv)[9])
 // Lane (r16, q) of a wave supplies taps q, 4 + q, 8 + q of pixel r16 (three, two, two, two scalar loads) and receives channels
 // 4q .. 4q + 3 of every 16-channel tile of that pixel: the 72 FMAs per 8 channels of a pixel that bound the round-1 kernel (8 channels per thread, 134 us)
 // become 12 MFMAs per 16 pixels, and what is left per output value is bias, activation, rounding and the statistics (93 us).
+// quotient and remainder of n < 2^24 by a runtime constant d (rcp = 1.f / d): a float multiply and a correction instead of the ~40
+// instructions of a 32-bit division
+__device__ __forceinline__ void divmod_small(unsigned n, unsigned d, float rcp, unsigned& qo, unsigned& ro) {     // n < 2^24
+    unsigned qv = (unsigned)((float)n * rcp);
+    int rr = (int)(n - qv * d);
+    if (rr < 0) { qv -= 1; rr += (int)d; } else if (rr >= (int)d) { qv += 1; rr -= (int)d; }
+    qo = qv; ro = (unsigned)rr;
+}
 struct Conv1Taps {                                    // this lane's three taps: row / column offsets and validity
     int dt[3], df[3]; bool on[3];
     __device__ __forceinline__ void init(int q) {
@@ -170,16 +178,26 @@ __global__ __launch_bounds__(512) void conv1_mfma_fwd_kernel(const float* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[j][e] = s2[j][e] = 0.f;
     const unsigned P = (unsigned)B * T2 * F2, units = (P + 15) / 16, stride = gridDim.x * 8;
+    const bool small = P < (1u << 24);
+    const float rF2 = 1.f / (float)F2, rT2 = 1.f / (float)T2;
     auto swap2 = [](uint32_t& a, uint32_t& b) {
         const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
         a = r[0]; b = r[1];
     };
-    for (unsigned u = blockIdx.x * 8 + wave; u < units; u += stride) {
+    // the window values of the next unit are requested before this unit is consumed (a wave owns its units alone)
+    float xn[3];
+    auto issue = [&](unsigned u) {
         const unsigned p = u * 16 + r16, pc = min(p, P - 1);
-        const unsigned row = pc / (unsigned)F2;
-        const int f2 = (int)(pc - row * F2), t2 = (int)(row % (unsigned)T2), b = (int)(row / (unsigned)T2);
-        float xv[3];
-        conv1_taps_load(x, tp, b, t2, f2, Tin, F, p < P, xv);
+        unsigned row, f2u, bu, t2u;
+        if (small) { divmod_small(pc, (unsigned)F2, rF2, row, f2u); divmod_small(row, (unsigned)T2, rT2, bu, t2u); }
+        else { row = pc / (unsigned)F2; f2u = pc - row * F2; bu = row / (unsigned)T2; t2u = row - bu * T2; }
+        conv1_taps_load(x, tp, (int)bu, (int)t2u, (int)f2u, Tin, F, p < P, xn);
+    };
+    if (blockIdx.x * 8 + wave < units) issue(blockIdx.x * 8 + wave);
+    for (unsigned u = blockIdx.x * 8 + wave; u < units; u += stride) {
+        const unsigned p = u * 16 + r16;
+        float xv[3] = {xn[0], xn[1], xn[2]};
+        if (u + stride < units) issue(u + stride);
         f32x4 acc[NT];
         cw.mul(xv, acc);
         const bool live = p < P;
@@ -375,6 +393,159 @@ __global__ __launch_bounds__(256) void conv1_bwd_bn_kernel(const float* __restri
         for (int wv = 0; wv < 4; ++wv) v += red[wv][c >> 3][(c & 7) * 10 + i];
         if (i < 9) atomicAdd(dw + c * 9 + i, v); else atomicAdd(db + c, v);
     }
+}
+
+// The same pass on the f32 matrix cores.  Per unit of 16 pixels a wave stages the [16 pixels][C] tiles of dyn and y (and pre) through a
+// private LDS region so that lane (r16, q) holds, for channel 16 j + r16 of every 16-channel tile j, the four pixels 4q .. 4q + 3; dpre is
+// formed there (three per-channel constants per tile) and is at once the B operand of  dW^T[tap][channel] += X^T[tap][pixel] . dpre[pixel]
+// [channel]  as four 16 x 16 x 4 f32 MFMAs per tile (instruction e contracts the pixels 4k + e, k = 0..3; lane (tap r16, q) loads
+// x of pixel 4q + e for tap r16).  16 accumulator registers per lane where the FMA form above keeps 80 (2 waves per SIMD, 188 us for
+// 520 MB): this one runs at the occupancy of a streaming kernel.  Workgroup sums go out as partials (chan_partials_f32_kernel).
+template <typename T, int NT, bool GELU>
+__global__ __launch_bounds__(256) void conv1_bwd_bn_mfma_kernel(const float* __restrict__ x, const T* __restrict__ dyn, const T* __restrict__ y,
+                                                                const T* __restrict__ pre, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                const double* __restrict__ sums, float* __restrict__ part, float* dgamma,
+                                                                float* dbeta, int B, int Tin, int F, int T2, int F2, double count, int training) {
+    constexpr int C = 16 * NT, EPV = 16 / (int)sizeof(T), VPP = C / EPV, RSB = C * (int)sizeof(T) + 16, NTEN = GELU ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) char c1smem[];
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            atomicAdd(dbeta + c, (float)sums[c]);
+            atomicAdd(dgamma + c, (float)sums[C + c]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    char* tile = c1smem + wave * (NTEN * 16 * RSB);
+    // dpre = act' * (ka * dyn + kb * y + kc):  ka = gamma*rstd, kb = -ka*m2*rstd, kc = ka*(m2*rstd*mean - m1)   (m1, m2 = dbeta/N, dgamma/N)
+    float ka[NT], kb[NT], kc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int c = 16 * j + r16;
+        const float rs = rstd[c], mu = mean[c];
+        const float m1 = training ? (float)(sums[c] / count) : 0.f, m2 = training ? (float)(sums[C + c] / count) : 0.f;
+        ka[j] = gamma[c] * rs; kb[j] = -ka[j] * m2 * rs; kc[j] = ka[j] * (m2 * rs * mu - m1);
+    }
+    const bool tap_on = r16 < 9;
+    const int dt = r16 / 3 - 1, df = r16 % 3 - 1;                        // this lane's tap as the A operand
+    f32x4 accT[NT];
+    float dbs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { accT[j] = (f32x4){0.f, 0.f, 0.f, 0.f}; dbs[j] = 0.f; }
+    const unsigned P = (unsigned)B * T2 * F2, units = (P + 15) / 16, stride = gridDim.x * 4;
+    const float rF2 = 1.f / (float)F2, rT2 = 1.f / (float)T2;
+    // One unit ahead: the 16-byte vectors of the next unit's tiles and its x values are requested before this unit is consumed (a wave
+    // owns its units alone, nothing else would cover the memory latency between them).
+    constexpr int NV = 16 * VPP / 64;                                    // vectors per lane and tensor
+    u32x4 nd[NV], ny[NV], np_[GELU ? NV : 1];
+    float nx[4];
+    auto issue = [&](unsigned u) {
+        const unsigned p0 = u * 16;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int v = 64 * k + lane, pix = v / VPP, ch = v % VPP;
+            const bool in = p0 + pix < P;
+            const size_t off = (size_t)(in ? p0 + pix : 0) * C + ch * EPV;
+            nd[k] = *reinterpret_cast<const u32x4*>(dyn + off); ny[k] = *reinterpret_cast<const u32x4*>(y + off);
+            if constexpr (GELU) np_[k] = *reinterpret_cast<const u32x4*>(pre + off);
+        }
+        unsigned row, f2u, bu, t2u;
+        divmod_small(min(p0 + 4 * q, P - 1), (unsigned)F2, rF2, row, f2u);
+        divmod_small(row, (unsigned)T2, rT2, bu, t2u);
+        int f2 = (int)f2u, t2 = (int)t2u, b = (int)bu;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int t = 2 * t2 + dt, f = 2 * f2 + df;
+            const bool ok = tap_on && p0 + 4 * q + e < P && t >= 0 && t < Tin && f >= 0 && f < F;
+            const float v = x[((long)b * Tin + min(max(t, 0), Tin - 1)) * F + min(max(f, 0), F - 1)];
+            nx[e] = ok ? v : 0.f;
+            if (++f2 == F2) { f2 = 0; if (++t2 == T2) { t2 = 0; b = min(b + 1, B - 1); } }
+        }
+    };
+    unsigned u = blockIdx.x * 4 + wave;
+    if (u < units) issue(u);
+    for (; u < units; u += stride) {
+        const unsigned p0 = u * 16;
+        // ---- this unit's tiles -> LDS (rows past P as zeros), its x values -> registers
+        float xt[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xt[e] = nx[e];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int v = 64 * k + lane, pix = v / VPP, ch = v % VPP;
+            const bool in = p0 + pix < P;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(tile + pix * RSB + ch * 16) = in ? nd[k] : z;
+            *reinterpret_cast<u32x4*>(tile + 16 * RSB + pix * RSB + ch * 16) = in ? ny[k] : z;
+            if constexpr (GELU) *reinterpret_cast<u32x4*>(tile + 32 * RSB + pix * RSB + ch * 16) = in ? np_[k] : z;
+        }
+        if (u + stride < units) issue(u + stride);
+        // the staged rows are read by OTHER lanes of this wave: LDS serves a wave's instructions in order; the asm keeps the compiler from
+        // moving the reads above the writes (and, at the end of the body, the next unit's writes above these reads) without making
+        // it wait for the global loads just issued
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- dpre per channel tile from the staged values; weight-gradient products
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int c = 16 * j + r16;
+            // bf16: one transposed LDS read per tensor and tile -- the 16-lane group q addresses the 4 x 16 block (pixels 4q .. 4q + 3,
+            // channels 16 j ..) in 8-byte pieces, lane r16 receives the four pixels of channel 16 j + r16 (ds_read_b64_tr_b16)
+            T dq[4], yq[4], pq[4];
+            if constexpr (sizeof(T) == 2) {
+                typedef short s16x4_c1 __attribute__((ext_vector_type(4)));
+                const char* a0 = tile + (4 * q + (r16 >> 2)) * RSB + (16 * j + 4 * (r16 & 3)) * 2;
+                *reinterpret_cast<s16x4_c1*>(dq) = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_c1*)a0);
+                *reinterpret_cast<s16x4_c1*>(yq) = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_c1*)(a0 + 16 * RSB));
+                if constexpr (GELU) *reinterpret_cast<s16x4_c1*>(pq) = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_c1*)(a0 + 32 * RSB));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dq[e] = *reinterpret_cast<const T*>(tile + (4 * q + e) * RSB + c * (int)sizeof(T));
+                    yq[e] = *reinterpret_cast<const T*>(tile + 16 * RSB + (4 * q + e) * RSB + c * (int)sizeof(T));
+                    if constexpr (GELU) pq[e] = *reinterpret_cast<const T*>(tile + 32 * RSB + (4 * q + e) * RSB + c * (int)sizeof(T));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int pix = 4 * q + e;
+                const float dv = to_f32(dq[e]), yv = to_f32(yq[e]);
+                const float r = __builtin_fmaf(ka[j], dv, __builtin_fmaf(kb[j], yv, kc[j]));
+                float gq;
+                if constexpr (GELU) gq = r * gelu_grad_f(to_f32(pq[e]));
+                else gq = yv > 0.f ? r : 0.f;
+                gq = p0 + pix < P ? gq : 0.f;
+                dbs[j] += gq;
+                accT[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[e], gq, accT[j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- this workgroup's sums -> partials: part[blockIdx.x][c * 10 + tap] (tap 9 = bias gradient)
+    __syncthreads();                                                     // every wave is done with its staging region
+    float* red = reinterpret_cast<float*>(c1smem);                      // [4 waves][C * 10]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int c = 16 * j + r16;
+        float d = dbs[j];
+        d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * q + i < 9) red[wave * (C * 10) + c * 10 + 4 * q + i] = accT[j][i];
+        if (q == 0) red[wave * (C * 10) + c * 10 + 9] = d;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 10 * C; t += 256)
+        part[(size_t)blockIdx.x * (10 * C) + t] = (red[t] + red[C * 10 + t]) + (red[2 * C * 10 + t] + red[3 * C * 10 + t]);
+}
+// out(i) += sum over the workgroups' partials part[w][i], i = c * 10 + tap: taps 0..8 -> dw[c * 9 + tap], 9 -> db[c]; one workgroup per i
+__global__ __launch_bounds__(256) void chan_partials_f32_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+    __shared__ float sh[16];
+    const int i = blockIdx.x;
+    float a = 0.f;
+    for (int w = threadIdx.x; w < nparts; w += 256) a += part[(size_t)w * (10 * C) + i];
+    a = block_sum(a, sh);
+    if (threadIdx.x == 0) { const int c = i / 10, tap = i % 10; if (tap < 9) dw[c * 9 + tap] += a; else db[c] += a; }
 }
 
 // ------------------------------------------------------------------ per-channel sums over [P][C]
@@ -636,9 +807,30 @@ extern "C" int s2t_conv1_bwd_bn(int dtype, const float* x, const void* dyn, cons
     if (!x || !dyn || !y || !mean || !rstd || !gamma || !sums || !dw || !db || !dgamma || !dbeta || (C != 64 && C != 128 && C != 32) || F < 3) return S2T_EINVAL;
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < (1l << 24)) {
+        // matrix-core form: 1,024 workgroups of 4 waves; LDS = 4 waves x (2 or 3 tensors) x 16 pixel rows, at least the 4 x 10 C reduction floats
+        const long units = (P + 15) / 16;
+        const unsigned nwg = (unsigned)(units < 4 * 1024 ? (units + 3) / 4 : 1024);
+        const size_t esz = dtype == S2T_BF16 ? 2 : 4;
+        size_t lds = 4 * (size_t)(pre ? 3 : 2) * 16 * (C * esz + 16);
+        if (lds < (size_t)4 * 10 * C * 4) lds = (size_t)4 * 10 * C * 4;
+        static float* part = nullptr;                                            // 1,024 workgroups x 10 x 128 (one training stream per process)
+        if (!part) { hipError_t e = hipMalloc(&part, (size_t)1024 * 1280 * sizeof(float)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+#define S2T_C1B(T_, NT_, G_) do { static bool attr = false;                                                                                   \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bwd_bn_mfma_kernel<T_, NT_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; } \
+        hipLaunchKernelGGL((conv1_bwd_bn_mfma_kernel<T_, NT_, G_>), dim3(nwg), dim3(256), lds, st, x, (const T_*)dyn, (const T_*)y, (const T_*)pre, mean, rstd, gamma, sums, part, dgamma, dbeta, B, T, F, T2, F2, count, training); } while (0)
+#define S2T_C1B_NT(T_, G_) { if (C == 64) S2T_C1B(T_, 4, G_); else if (C == 128) S2T_C1B(T_, 8, G_); else S2T_C1B(T_, 2, G_); }
+        if (pre) { DISPATCH_T(dtype, S2T_C1B_NT(bf16, true), S2T_C1B_NT(float, true)); }
+        else { DISPATCH_T(dtype, S2T_C1B_NT(bf16, false), S2T_C1B_NT(float, false)); }
+#undef S2T_C1B_NT
+#undef S2T_C1B
+        hipLaunchKernelGGL(chan_partials_f32_kernel, dim3(10 * C), dim3(256), 0, st, part, (int)nwg, C, dw, db);
+        S2T_LAUNCH_CHECK();
+        return S2T_OK;
+    }
     const int ppb = (int)((P + 511) / 512 < 256 ? 256 : (P + 511) / 512);     // <= 512 workgroups = 2 per CU at ~172 VGPRs, all resident
     dim3 grid((unsigned)((P + ppb - 1) / ppb));
-    hipStream_t st = (hipStream_t)stream;
     if (pre) {
         DISPATCH_T(dtype,
             hipLaunchKernelGGL((conv1_bwd_bn_kernel<bf16, true>), grid, dim3(256), 0, st, x, (const bf16*)dyn, (const bf16*)y, (const bf16*)pre, mean, rstd, gamma, sums, dw, db, dgamma, dbeta, B, T, F, T2, F2, C, ppb, count, training),
