@@ -134,7 +134,7 @@ __device__ __forceinline__ void conv1_taps_load(const float* __restrict__ x, con
     for (int m = 0; m < 3; ++m) {
         const int t = 2 * t2 + tp.dt[m], f = 2 * f2 + tp.df[m];
         const bool ok = live && tp.on[m] && t >= 0 && t < Tin && f >= 0 && f < F;
-        const float v = x[((long)b * Tin + min(max(t, 0), Tin - 1)) * F + min(max(f, 0), F - 1)];
+        const float v = x[(unsigned)((b * Tin + min(max(t, 0), Tin - 1)) * F + min(max(f, 0), F - 1))];      // B T F < 2^31: checked on the host
         xv[m] = ok ? v : 0.f;
     }
 }
@@ -147,10 +147,10 @@ struct Conv1W {                                       // weight fragments: wa[j]
 #pragma unroll
             for (int m = 0; m < 3; ++m) wa[j][m] = 4 * m + q < 9 ? w[(16 * j + r16) * 9 + 4 * m + q] : 0.f;
     }
-    __device__ __forceinline__ void mul(const float (&xv)[3], f32x4 (&acc)[NT]) const {
+    __device__ __forceinline__ void mul(const float (&xv)[3], const f32x4 (&init)[NT], f32x4 (&acc)[NT]) const {     // acc = init + W . X^T
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[j] = init[j];
 #pragma unroll
             for (int m = 0; m < 3; ++m) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j][m], xv[m], acc[j], 0, 0, 0);
         }
@@ -199,19 +199,20 @@ __global__ __launch_bounds__(512) void conv1_mfma_fwd_kernel(const float* __rest
         float xv[3] = {xn[0], xn[1], xn[2]};
         if (u + stride < units) issue(u + stride);
         f32x4 acc[NT];
-        cw.mul(xv, acc);
+        cw.mul(xv, b4, acc);                          // the bias is the accumulators' starting value
         const bool live = p < P;
+        const bool full = u * 16 + 16 <= P;            // wave-uniform: every unit but (possibly) the last one
         uint32_t oq[NT][2], pq[NT][2];                 // packed bf16 quads (bf16 path)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             T o[4], pr[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = acc[j][e] + b4[j][e];
+                float v = acc[j][e];
                 if constexpr (GELU) { pr[e] = from_f32<T>(v); v = gelu_f(to_f32(pr[e])); }     // gelu of the stored pre-activation
                 else v = fmaxf(v, 0.f);
                 o[e] = from_f32<T>(v);
-                const float r = live ? to_f32(o[e]) : 0.f;                                    // statistics of the value that is stored
+                const float r = (full || live) ? to_f32(o[e]) : 0.f;                          // statistics of the value that is stored
                 s1[j][e] += r; s2[j][e] += r * r;
             }
             if constexpr (sizeof(T) == 4) {
@@ -769,6 +770,7 @@ extern "C" int s2t_conv1_fwd(int dtype, const float* x, const float* w, const fl
     if (B <= 0 || T <= 0) return S2T_OK;
     if (!x || !w || !bias || !y || !sums || (C != 64 && C != 128 && C != 32) || F < 3) return S2T_EINVAL;
     if ((act != ACT_RELU && act != ACT_GELU) || (act == ACT_GELU && !pre)) return S2T_EINVAL;
+    if ((long)B * T * F >= (1l << 31)) return S2T_ENOTSUP;                   // 32-bit element offsets into x
     const int T2 = (T + 1) / 2, F2 = (F + 1) / 2;
     const long P = (long)B * T2 * F2;
     hipStream_t st = (hipStream_t)stream;
