@@ -240,10 +240,12 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
     // 16 waves per workgroup: one workgroup per CU for the big activations; for small M at most 64 workgroups (each ends in 2 D
     // same-address atomics, ~40 ns apiece in a chain) of 16 waves, i.e. 2-3 rows per wave at the decoder's 2,560 rows -- with 4 waves
     // per workgroup every wave walked 10 rows one memory latency after the other (17 us per launch)
+    // 16 elements per lane (D = 1,024) and the element-wise form keep a row's working set near 250 registers: 8 waves per workgroup
+    // (a 1,024-thread workgroup allows 128, and those variants spilled ~200 registers), twice the workgroups
     const bool big = M >= 8192;
-    const int nw = 16;
+    const int nw = (epl == 16 || epl == 0) ? 8 : 16;
     int blocks = (M + nw - 1) / nw;
-    const int cap = big ? 256 : 64;
+    const int cap = (big ? 256 : 64) * (nw == 8 ? 2 : 1);
     if (blocks > cap) blocks = cap;
     dim3 grid(blocks);
     const size_t lds = (size_t)2 * nw * D * sizeof(float);
@@ -255,13 +257,13 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
         hipLaunchKernelGGL((ln_bwd_kernel<T, EPL_, NW_>), grid, dim3(NW_ * 64), lds, st, (const T*)dy, (const T*)x, mean, rstd, gamma, \
                            (const T*)dres, (T*)dx, dgamma, dbeta, M, D, (T*)dx_drop, p_drop, seed);                         \
     } while (0)
-#define LN_BWD_EPL(T, NW_)                                                                                                  \
+#define LN_BWD_EPL(T)                                                                                                       \
     do {                                                                                                                    \
-        if (epl == 4) LN_BWD_LAUNCH(T, 4, NW_); else if (epl == 8) LN_BWD_LAUNCH(T, 8, NW_);                                \
-        else if (epl == 16) LN_BWD_LAUNCH(T, 16, NW_); else LN_BWD_LAUNCH(T, 0, NW_);                                       \
+        if (epl == 4) LN_BWD_LAUNCH(T, 4, 16); else if (epl == 8) LN_BWD_LAUNCH(T, 8, 16);                                  \
+        else if (epl == 16) LN_BWD_LAUNCH(T, 16, 8); else LN_BWD_LAUNCH(T, 0, 8);                                           \
     } while (0)
-    if (dtype == S2T_BF16) LN_BWD_EPL(bf16, 16);
-    else if (dtype == S2T_F32) LN_BWD_EPL(float, 16);
+    if (dtype == S2T_BF16) LN_BWD_EPL(bf16);
+    else if (dtype == S2T_F32) LN_BWD_EPL(float);
     else return S2T_ENOTSUP;
 #undef LN_BWD_EPL
 #undef LN_BWD_LAUNCH
