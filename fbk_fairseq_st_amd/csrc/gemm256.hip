@@ -466,7 +466,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 static long g256_tiles(int M, int N, bool& use192) {
     const int tn = (N + 255) / 256;
     const long t256 = (long)((M + 255) / 256) * tn, t192 = (long)((M + 191) / 192) * tn;
-    if (t192 < 192) return 0;                       // one workgroup per CU: fewer tiles than ~3/4 of the CUs run better as 128 x 128 tiles, 2-3 per CU
+    // one workgroup per CU: with too few tiles the 128 x 128 kernels (2-3 tiles per CU) win.  tools/gemm_gate_probe.py: at 188 tiles
+    // (the l preset's 9,000 tokens x N = 1,024) this kernel is 1.3-1.45x faster (K = 1,024 .. 4,096), at 126-128 tiles the two tie, at
+    // 96 and below the small tiles win -> 160.  "gemm256_min_tiles" (s2t_set_option) overrides the threshold for such measurements.
+    if (t192 < (g_s2t_opt_gemm256_min_tiles > 0 ? g_s2t_opt_gemm256_min_tiles : 160)) return 0;
     use192 = ((t192 + 255) / 256) * 192 < ((t256 + 255) / 256) * 256;
     return use192 ? t192 : t256;
 }

@@ -321,6 +321,8 @@ int s2t_prof_enable(int on);
  *                  128x128 register-staged kernels;
  *       "attn_v1": 1 forces the first-generation attention kernels (f32 / d 32 / short sequences use them anyway), default 0;
  *       "attn_v2_min_tq": shortest query block taken by the second-generation attention kernels (default 16);
+ *       "gemm256_min_tiles": fewest 192 / 256-row output tiles a product must have for the 256-wide kernel (0 = default = 160;
+ *                  tools/gemm_gate_probe.py measures both sides of it);
  * returns the previous value, or S2T_EINVAL (-22) for an unknown key. */
 int s2t_set_option(const char* key, int value);
 int s2t_prof_read(const char* family, double* ms, long long* launches, double* flops, double* bytes);
