@@ -165,29 +165,49 @@ def attn_bwd(q, k, v, o, do, lse, heads, dq, dk, dv, klen=None, causal=False, sc
     return dq, dk, dv
 
 
+_LN_FWD = _LN_BWD = None
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    """-> (y, mean, rstd).  88 calls per update, written for host time like gemm(): one allocation for both statistics, the bound C
+    function looked up once, pointers taken inline (the operands are still checked: a host pointer would be a GPU fault)."""
+    global _LN_FWD
+    if _LN_FWD is None:
+        _LN_FWD = _lib().s2t_layernorm_fwd
+    if not (x.is_cuda and gamma.is_cuda and beta.is_cuda):
+        raise L.S2THipError("S2T kernels need device tensors: the hot path has no CPU fallback")
     D = x.shape[-1]
     M = x.numel() // D
     assert x.is_contiguous()
     y = torch.empty_like(x)
-    mean = torch.empty((M,), dtype=torch.float32, device=x.device)
-    rstd = torch.empty((M,), dtype=torch.float32, device=x.device)
-    L.check(_lib().s2t_layernorm_fwd(L.dt(x), L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean), L.ptr(rstd),
-                                     M, D, float(eps), L.stream()), "s2t_layernorm_fwd")
+    st = torch.empty((2, M), dtype=torch.float32, device=x.device)
+    mean, rstd = st[0], st[1]
+    rc = _LN_FWD(_DT[x.dtype], x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                 M, D, float(eps), _RAW_STREAM(L.device_index()))
+    if rc:
+        L.check(rc, "s2t_layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dres=None, drop=None):
     """drop = (p, seed) of the dropout that consumes dx next: returns (dx, dropout(dx, p, seed)) from one pass."""
+    global _LN_BWD
+    if _LN_BWD is None:
+        _LN_BWD = _lib().s2t_layernorm_bwd
+    if not (dy.is_cuda and x.is_cuda and mean.is_cuda and rstd.is_cuda and gamma.is_cuda and dgamma.is_cuda and dbeta.is_cuda
+            and (dres is None or dres.is_cuda)):
+        raise L.S2THipError("S2T kernels need device tensors: the hot path has no CPU fallback")
     D = x.shape[-1]
     M = x.numel() // D
     assert dy.is_contiguous() and x.is_contiguous() and (dres is None or dres.is_contiguous())
     dx = torch.empty_like(x)
     dxd = torch.empty_like(x) if drop is not None else None
     p, seed = drop if drop is not None else (0.0, 0)
-    L.check(_lib().s2t_layernorm_bwd(L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres),
-                                     L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), M, D, L.ptr(dxd), float(p), int(seed), L.stream()),
-            "s2t_layernorm_bwd")
+    rc = _LN_BWD(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                 dres.data_ptr() if dres is not None else 0, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), M, D,
+                 dxd.data_ptr() if dxd is not None else 0, float(p), int(seed), _RAW_STREAM(L.device_index()))
+    if rc:
+        L.check(rc, "s2t_layernorm_bwd")
     return dx if drop is None else (dx, dxd)
 
 
