@@ -56,6 +56,10 @@ dy1n = torch.empty(B * T2 * F2, C, device=dev, dtype=dt)
 t = timeit(lambda: K.conv2_dgrad(dpre2, w2q, dy1n, B, T2, F2, C, 0.1, 5))
 print("conv2_dgrad    %8.1f us  %5.2f TB/s (read dpre + write dy1n), %.0f TFLOP/s" % (t * 1e6, (dy1n.numel() + dpre2.numel()) * 2 / t / 1e12,
                                                                                      2.0 * B * T4 * F4 * C * 9 * C / t / 1e12))
+gw2 = torch.zeros(C, 9 * C, device=dev)
+t = timeit(lambda: K.conv2_wgrad(dpre2, y1n.view(-1, C), gw2, B, T2, F2, C))
+print("conv2_wgrad    %8.1f us  %5.2f TB/s (read dpre + y1n), %.0f TFLOP/s" % (t * 1e6, (y1n.numel() + dpre2.numel()) * 2 / t / 1e12,
+      2.0 * T4 * B * F4 * C * 9 * C / t / 1e12))
 gw = torch.zeros(C, 9, device=dev); gb = torch.zeros(C, device=dev)
 t = timeit(lambda: K.conv1_bwd_bn(x, dyn, y, mean, rstd, gamma, s2, gw, gb, dg, db, float(P)))
 print("conv1_bwd_bn   %8.1f us  %5.2f TB/s (read dyn + y + x)" % (t * 1e6, (2 * ybytes + x.numel() * 4) / t / 1e12))
