@@ -112,9 +112,13 @@ def timed_updates(trainer, next_batch, steps, warmup, world, device):
     barrier()
     dt = time.perf_counter() - t0
     stats = trainer.reduce_stats()
+    stats["_rank_ms"] = (dt / steps * 1e3, dt / steps * 1e3)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmin = tmax.clone()
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tmin, op=torch.distributed.ReduceOp.MIN)
+        stats["_rank_ms"] = (float(tmin.item()) / steps * 1e3, float(tmax.item()) / steps * 1e3)
         dt = float(tmax.item())
     enc_mean = sum(sum(l) / len(l) for l in enc_len) / max(len(enc_len), 1)
     return dt, frames, enc_mean, stats
@@ -206,6 +210,38 @@ def extra_config(name, arch, dtype, device, steps, warmup, batch=None, frames=15
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one fresh process per GPU,
+    BEFORE this process has touched the GPU (the reference spawns its own ranks the same way: fairseq/distributed_utils.py:143-173,
+    fairseq_cli/train.py:327-359).  Every child re-runs this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, i.e. exactly
+    what torch.distributed.run would have given it; rank 0 prints the one JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.05)
+            for p in list(live):
+                if p.poll() is not None:
+                    live.remove(p)
+                    rc = max(rc, abs(p.returncode))
+    finally:
+        for p in procs:                              # a rank that died leaves the others in a collective: end exactly the PIDs we started
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,10 +272,13 @@ def main():
     if args.attn_2d:
         args.cpu_baseline = False
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                       # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the S2T hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -313,6 +352,15 @@ def main():
                           "lr": args.lr, "frames_after_ctc_compression": round(enc_mean, 1), "frames_before": (args.frames + 3) // 4},
                "loss": round(stats.get("loss", float("nan")) / max(stats.get("sample_size", 1), 1), 4),
                "gnorm": round(stats.get("gnorm", float("nan")), 4)}
+        red = trainer.reducer
+        out["data_parallel"] = {
+            "rccl_ranks": world if world > 1 else 0, "rank_ms_per_step_min": round(stats["_rank_ms"][0], 3),
+            "rank_ms_per_step_max": round(stats["_rank_ms"][1], 3),
+            # bytes of the flat f32 gradient buffer summed over the ranks per update, and the share of them whose all-reduce was
+            # launched from INSIDE backward (before finish(), i.e. able to travel under the remaining backward kernels)
+            "allreduce_bytes_per_step": red.n * red.flat.element_size() if world > 1 else 0,
+            "allreduce_buckets": len(red.plan), "bucket_bytes": red.bucket_elems * red.flat.element_size(),
+            "allreduce_launched_in_backward_frac": round(red.early_elems / max(red.n, 1), 4) if world > 1 else None}
         if roof is not None:
             out["roofline"] = roof
         if args.cpu_baseline:

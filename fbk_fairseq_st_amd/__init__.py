@@ -9,3 +9,7 @@ standalone ones otherwise -- as `examples/speech_recognition/__init__.py:1` does
 __version__ = "0.2.0"
 
 from . import tasks, criterions, conv_transformer  # noqa: E402,F401  (registration side effects)
+from . import registry as _registry  # noqa: E402
+
+if _registry.inside_fairseq():
+    from . import fairseq_optim  # noqa: E402,F401  (`--optimizer adam` of fairseq's own trainer over the arena)

@@ -6,10 +6,12 @@ encoder/decoder call signatures and output tuples, same state-dict key names (SU
 On top of the reference's presets it registers the build-defined `s2t_transformer{,_xs,_s,_m,_l}`
 presets that BASELINE.json names.
 
-`--distance-penalty log` (LocalAttention) is supported.  Out of scope here: ConvAttention2D
-(`--no-attn-2d` is required), `--distance-penalty gauss`, learned positions, adaptive softmax, LayerDrop.
+`--distance-penalty log` (LocalAttention), the ConvAttention2D front end (N3) and LayerDrop
+(`--encoder-layerdrop` / `--decoder-layerdrop`) are supported.  Out of scope here:
+`--distance-penalty gauss`, learned positions, adaptive softmax.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -65,13 +67,31 @@ def fused_to_reference(sd):
     return out
 
 
+def reference_slot(name):
+    """reference parameter name -> (arena name, block index or None, blocks): where that parameter's rows live in the fused
+    layout (q|k|v of a self-attention, k|v of an encoder attention; LocalAttention's in_proj IS the fused tensor)."""
+    for kind in ("weight", "bias"):
+        for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            if name.endswith(".self_attn.%s.%s" % (n, kind)):
+                return name[: -len("%s.%s" % (n, kind))] + "qkv." + kind, i, 3
+        for i, n in enumerate(("k_proj", "v_proj")):
+            if name.endswith(".encoder_attn.%s.%s" % (n, kind)):
+                return name[: -len("%s.%s" % (n, kind))] + "kv." + kind, i, 2
+        if name.endswith(".self_attn.in_proj_" + kind):
+            return name[: -len("in_proj_" + kind)] + "qkv." + kind, None, 1
+    if name.startswith("ctc_aware_model."):                      # criterion-owned head (ctc_multi_loss.py:14-46)
+        return "criterion." + name, None, 1
+    return name, None, 1
+
+
 # ------------------------------------------------------------------ autograd bridges
 class _EncoderFn(torch.autograd.Function):
     """Connects the engine's encoder to torch autograd: outputs (encoder_out, ctc_out, state_k)."""
 
     @staticmethod
-    def forward(ctx, anchor, enc, src_tokens, src_lengths, training, seed, want_state):
-        out, ectx = enc.engine.encoder_forward(src_tokens, src_lengths, training, seed, return_all_hiddens=want_state is not None)
+    def forward(ctx, anchor, enc, src_tokens, src_lengths, training, seed, want_state, keep=None):
+        out, ectx = enc.engine.encoder_forward(src_tokens, src_lengths, training, seed, return_all_hiddens=want_state is not None,
+                                               keep=keep)
         ctx.enc, ctx.ectx, ctx.want_state = enc, ectx, want_state
         enc._last = out
         eo = out["out"]
@@ -84,16 +104,18 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, d_out, d_ctc, d_state):
         eng = ctx.enc.engine
         has_ctc = ctx.ectx["ctc"] is not None
-        ds = {ctx.want_state: d_state.contiguous()} if (ctx.want_state is not None and d_state is not None) else None
+        # `states` holds one entry per layer that RAN (LayerDrop): entry -> layer index
+        ds = ({ctx.ectx["state_layers"][ctx.want_state]: d_state.contiguous()}
+              if (ctx.want_state is not None and d_state is not None) else None)
         eng.encoder_backward(ctx.ectx, d_out, d_ctc if (has_ctc and d_ctc is not None) else None, ds)
         ctx.enc._after_backward("encoder")
-        return (None,) * 7
+        return (None,) * 8
 
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, dec, prev_tokens, enc_out, enc_klen, training, seed):
-        logits, dctx = dec.engine.decoder_forward(prev_tokens, enc_out.contiguous(), enc_klen, training, seed, pfx=dec.pfx)
+    def forward(ctx, anchor, dec, prev_tokens, enc_out, enc_klen, training, seed, keep=None):
+        logits, dctx = dec.engine.decoder_forward(prev_tokens, enc_out.contiguous(), enc_klen, training, seed, pfx=dec.pfx, keep=keep)
         ctx.dec, ctx.dctx = dec, dctx
         return logits
 
@@ -102,7 +124,7 @@ class _DecoderFn(torch.autograd.Function):
         denc = ctx.dec.engine.decoder_backward(ctx.dctx, dlogits if dlogits.stride(-1) == 1 else dlogits.contiguous())
         ctx.dec._after_backward(ctx.dec.pfx.rstrip("."))
         c = ctx.dctx
-        return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None
+        return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None, None
 
 
 class _DualDecoderFn(torch.autograd.Function):
@@ -167,7 +189,14 @@ class ConvolutionalTransformerEncoder(FairseqEncoder):
         if return_all_hiddens and want_state is None and not self.ctc_compress_out:
             want_state = getattr(m, "_ctc_state_layer", None)
         seed = m._next_seed()
-        eo, co, st = _EncoderFn.apply(m.anchor, self, src_tokens, src_lengths, self.training, seed, want_state)
+        keep = None
+        if m.hp.encoder_layerdrop > 0:
+            # LayerDrop (conv_transformer.py:238-243): one host draw per layer from torch's CPU generator, in both modes, exactly
+            # the reference's `torch.empty(1).uniform_()` sequence -- seeded alike, the same layers drop out
+            draws = [float(torch.empty(1).uniform_()) for _ in range(m.hp.enc_layers)]
+            if self.training:
+                keep = [d > m.hp.encoder_layerdrop for d in draws]
+        eo, co, st = _EncoderFn.apply(m.anchor, self, src_tokens, src_lengths, self.training, seed, want_state, keep)
         o = self._last
         B = eo.shape[1]
         pad_mask = None
@@ -236,7 +265,12 @@ class TransformerDecoder(FairseqIncrementalDecoder):
         klen = None
         if encoder_out.encoder_padding_mask is not None:
             klen = encoder_out.src_lengths.to(torch.int32)
-        logits_tm = _DecoderFn.apply(m.anchor, self, prev_output_tokens, eo, klen, self.training, m._next_seed())
+        keep = None
+        if m.hp.decoder_layerdrop > 0:                  # fairseq/modules/layer_drop.py:39-44: one vector of draws per pass
+            draws = torch.empty(m.hp.dec_layers).uniform_().tolist()
+            if self.training:
+                keep = [d > m.hp.decoder_layerdrop for d in draws]
+        logits_tm = _DecoderFn.apply(m.anchor, self, prev_output_tokens, eo, klen, self.training, m._next_seed(), keep)
         B, L = prev_output_tokens.shape
         logits = logits_tm.view(L, B, -1).transpose(0, 1)         # view, no copy: (B, L, V)
         return logits, {"attn": [None], "inner_states": None}
@@ -270,8 +304,8 @@ class TransformerDecoder(FairseqIncrementalDecoder):
 
     def reorder_incremental_state(self, incremental_state, new_order):       # transformer.py:840-852
         st = incremental_state.get("s2t_hip_state.%s" % self.pfx)
-        if st is not None:
-            self.engine.decoder_reorder(st, new_order)
+        if st is not None:                      # the reference's generator also compacts finished sentences away: encoder side too
+            self.engine.decoder_reorder(st, new_order, encoder_side=True)
 
     def max_positions(self):
         return self.max_target_positions
@@ -304,6 +338,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             self.register_buffer(attr + "_running_var", torch.ones(ch))
             self.register_buffer(attr + "_num_batches_tracked", torch.zeros(1, dtype=torch.int64))
         self.anchor = nn.Parameter(torch.zeros(1), requires_grad=True)      # keeps the autograd bridges alive
+        self.anchor._s2t_anchor = True
         self.engine = None
         self.arena = None
         self.compute_dtype = torch.float32
@@ -314,7 +349,10 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
     # ---- parameter plumbing
     def _register(self, name, tensor):
         key = name.replace(".", "__")
-        self.params[key] = nn.Parameter(tensor)
+        p = nn.Parameter(tensor)
+        # how an optimizer that is handed bare parameters (fairseq/trainer.py:140-146) finds the arena they belong to (fairseq_optim.py)
+        p._s2t_name, p._s2t_owner = name, weakref.ref(self)
+        self.params[key] = p
         self._names[name] = key
 
     def _init_param(self, name, shape):
@@ -355,6 +393,56 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
     def named_arena_params(self):
         return {n: self.params[k] for n, k in self._names.items()}
 
+    def reference_parameter_names(self):
+        """`[n for n, p in model.named_parameters()]` of the REFERENCE's module tree for this configuration -- the order in which
+        fairseq's trainer hands parameters to its optimizer (fairseq/trainer.py:140-146) and therefore the meaning of the integer
+        keys in a reference checkpoint's `last_optimizer_state` (torch.optim state dict).  Registration order of
+        ConvolutionalTransformerEncoder.__init__ (conv_transformer.py:124-194), TransformerEncoderLayer / TransformerDecoderLayer
+        (fairseq/modules/transformer_layer.py:31-70,167-232: self_attn k/v/q/out, its LayerNorm, [encoder_attn ..], fc1, fc2, final
+        LayerNorm), MultiheadAttention (multihead_attention.py:56-75: k_proj, v_proj, q_proj, out_proj), LocalAttention
+        (local_attention.py:34-47: one in_proj), ConvAttention2D (conv_attention_2d.py:24-37), TransformerDecoder
+        (fairseq/models/transformer.py:540-631: embed_tokens, layers, layer_norm, output_projection).  Pinned to the reference by
+        tests/golden/param_order.json."""
+        hp = self.hp
+        wb = lambda stem: [stem + ".weight", stem + ".bias"]
+        names = wb("encoder.convolutions.0") + wb("encoder.convolutions.1")
+        if hp.attn_2d:
+            for i in range(2):
+                a = "encoder.attn_2d.%d." % i
+                names += [a + "in_proj_weight", a + "in_proj_bias"] + wb(a + "out_proj")
+                for n in ("bn_q", "bn_k", "bn_v", "bn_out"):
+                    names += wb(a + n)
+        names += wb("encoder.bn.0") + wb("encoder.bn.1") + wb("encoder.fc3")
+
+        def mha(stem):
+            out = []
+            for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+                out += wb(stem + n)
+            return out
+
+        for l in range(hp.enc_layers):
+            lp = "encoder.layers.%d." % l
+            if hp.distance_penalty:
+                names += [lp + "self_attn.in_proj_weight", lp + "self_attn.in_proj_bias"] + wb(lp + "self_attn.out_proj")
+            else:
+                names += mha(lp + "self_attn.")
+            names += wb(lp + "self_attn_layer_norm") + wb(lp + "fc1") + wb(lp + "fc2") + wb(lp + "final_layer_norm")
+        names += wb("encoder.layer_norm")
+        if hp.ctc_layer:
+            names += wb("encoder.ctc_fc")
+        for dec, V in (("decoder.", hp.V_tgt), ("auxiliary_decoder.", hp.V_aux)):
+            if V <= 0:
+                continue
+            names.append(dec + "embed_tokens.weight")
+            for l in range(hp.dec_layers):
+                lp = dec + "layers.%d." % l
+                names += mha(lp + "self_attn.") + wb(lp + "self_attn_layer_norm") + mha(lp + "encoder_attn.")
+                names += wb(lp + "encoder_attn_layer_norm") + wb(lp + "fc1") + wb(lp + "fc2") + wb(lp + "final_layer_norm")
+            names += wb(dec + "layer_norm")
+            if not hp.share_dec_embed:
+                names.append(dec + "output_projection.weight")
+        return names
+
     def materialize(self, device, compute_dtype=torch.float32, extra=None):
         """Move every parameter into one flat arena on `device` (and build the engine)."""
         # extras (criterion-owned heads) go FIRST: backward finalises the arena tail-first, so whatever is never
@@ -366,6 +454,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             arena.p(n).copy_(p.data.to(device=device, dtype=torch.float32))
             p.data = arena.p(n)
             p.grad = arena.g(n)
+            p._s2t_owner = weakref.ref(self)             # also on the criterion-owned extras: their loader refreshes the bf16 shadow
         self.anchor.data = self.anchor.data.to(device)
         for b in self.buffers():
             b.data = b.data.to(device)
@@ -392,6 +481,15 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
     def set_seed(self, seed):
         """dropout streams are keyed on (seed, call counter): trainer reseeds with seed + num_updates (trainer.py:655-661)"""
         self._seed_base, self._seed_ctr = int(seed) % 1000003, 0
+
+    def set_num_updates(self, num_updates):
+        """FairseqTask.train_step calls this before every forward (fairseq_task.py:370-372).  Under the reference's own trainer it
+        is where the dropout streams get their per-update seed (its `_set_seed` only seeds torch's generators, which the kernels do
+        not read); under this package's Trainer set_seed already ran for this update and the counter must keep running across the
+        micro-batches of --update-freq."""
+        seed = int(getattr(self.args, "seed", 1)) + int(num_updates)
+        if seed % 1000003 != self._seed_base:
+            self.set_seed(seed)
 
     def add_grads_ready_hook(self, fn):
         self._grad_hooks.append(fn)
@@ -456,7 +554,15 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                 mine[n].requires_grad = False
             if self.arena is not None:
                 self.arena.freeze(self._frozen_names)
-        return self
+        # what nn.Module.load_state_dict returns and fairseq's trainer inspects (fairseq/trainer.py:207-214): keys of the file that
+        # nothing here consumed.  Placeholders of the reference's tree (sinusoidal-table dummies, decoder.version, the shared output
+        # projection listed under both names) are known and not "unexpected".
+        known = set(mine) | {"%s.%s" % (ref, n) for ref in self._bn_refs for n in ("running_mean", "running_var", "num_batches_tracked")}
+        unexpected = [k for k in sd if k not in known and not k.endswith(("_float_tensor", ".version")) and not k.startswith("criterion.")
+                      and not (self.hp.share_dec_embed and k.endswith("output_projection.weight"))]
+        if strict and unexpected:
+            raise RuntimeError("Unexpected key(s) in state_dict: " + ", ".join(unexpected))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def raw_state_dict_upgrade(self, state_dict):                   # conv_transformer.py:105-112
         if self.encoder.ctc_compress_out and "encoder.ctc_fc.weight" not in state_dict["model"]:
@@ -481,6 +587,10 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         a("--decoder-layers", type=int, metavar="N"); a("--decoder-attention-heads", type=int, metavar="N")
         a("--encoder-normalize-before", action="store_true"); a("--decoder-normalize-before", action="store_true")
         a("--share-decoder-input-output-embed", action="store_true")
+        a("--encoder-layerdrop", type=float, metavar="D", default=0)      # fairseq/models/transformer.py:160-163
+        a("--decoder-layerdrop", type=float, metavar="D", default=0)
+        a("--compute-dtype", choices=["fp32", "bf16"], default=None,
+          help="build-defined: arithmetic of the HIP engine (bf16 = bf16 storage, f32 accumulation, f32 master weights)")
         a("--no-scale-embedding", action="store_true")
         a("--encoder-convolutions", type=str, metavar="EXPR")
         a("--normalization-constant", type=float, default=1.0)
@@ -522,7 +632,9 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                      pad=tgt_dict.pad(), no_scale_embedding=getattr(args, "no_scale_embedding", False),
                      V_src=len(enc_dict), V_tgt=len(tgt_dict), distance_penalty=getattr(args, "distance_penalty", False) or False,
                      attn_2d=bool(getattr(args, "attn_2d", False)),
-                     share_dec_embed=bool(getattr(args, "share_decoder_input_output_embed", False)))
+                     share_dec_embed=bool(getattr(args, "share_decoder_input_output_embed", False)),
+                     encoder_layerdrop=float(getattr(args, "encoder_layerdrop", 0) or 0),
+                     decoder_layerdrop=float(getattr(args, "decoder_layerdrop", 0) or 0))
         assert args.decoder_ffn_embed_dim == args.encoder_ffn_embed_dim
         encoder = ConvolutionalTransformerEncoder(args, enc_dict, audio_features=args.input_feat_per_channel)
         decoder = TransformerDecoder(args, tgt_dict)

@@ -41,8 +41,41 @@ class _Deferred:
 
     __radd__ = __add__
 
+    def __mul__(self, other):
+        return float(self) * float(other)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return float(self) / float(other)
+
+    def __rtruediv__(self, other):
+        return float(other) / float(self)
+
+    def __lt__(self, other):
+        return float(self) < float(other)
+
+    def __gt__(self, other):
+        return float(self) > float(other)
+
+    def __eq__(self, other):
+        return float(self) == float(other)
+
+    __hash__ = None
+
     def __repr__(self):
         return repr(float(self))
+
+
+def _publish(stats):
+    """inside a fairseq process the reduced statistics also go where its trainer and progress bar read them
+    (fairseq/logging/metrics.py: the reference's criteria call metrics.log_scalar from reduce_metrics)"""
+    from .registry import inside_fairseq
+    if inside_fairseq():
+        from fairseq.logging import metrics
+        for k, v in stats.items():
+            metrics.log_scalar(k, float(v), round=3)
+    return stats
 
 
 _LOGGING_THREAD = None
@@ -55,7 +88,9 @@ def _in_background(fn, *args):
     global _LOGGING_THREAD
     if _LOGGING_THREAD is None:
         from concurrent.futures import ThreadPoolExecutor
+        import atexit
         _LOGGING_THREAD = ThreadPoolExecutor(max_workers=1, thread_name_prefix="s2t-logging")
+        atexit.register(_LOGGING_THREAD.shutdown, wait=False)
     return _LOGGING_THREAD.submit(fn, *args)
 
 
@@ -185,8 +220,8 @@ class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
         ntokens = sum(_item(l.get("ntokens", 0)) for l in logging_outputs)
         sample_size = sum(_item(l.get("sample_size", 0)) for l in logging_outputs)
         nll = nll_sum / ntokens / math.log(2)
-        return {"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
-                "ntokens": ntokens, "sample_size": sample_size}
+        return _publish({"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
+                         "ntokens": ntokens, "sample_size": sample_size})
 
     @staticmethod
     def logging_outputs_can_be_summed():
@@ -209,6 +244,8 @@ class CTCMultiLoss(FairseqCriterion):
         assert task.source_dictionary is not None
         self.args = args
         self.ctc_aware_model = CTCEncoderWrapperModel(args, task.source_dictionary)
+        for n, p in self.arena_params().items():            # see conv_transformer._register: arena name of a criterion-owned parameter
+            p._s2t_extra_name = n
         self.blank_idx = task.source_dictionary.index("<ctc_blank>")          # ctc_multi_loss.py:103
         self.pad_idx = task.source_dictionary.pad()
         saved = args.criterion
@@ -231,6 +268,16 @@ class CTCMultiLoss(FairseqCriterion):
         """criterion-owned parameters that must live in the model's arena (optimised together)."""
         return {"criterion.ctc_aware_model.fc_out.weight": self.ctc_aware_model.fc_out.weight,
                 "criterion.ctc_aware_model.fc_out.bias": self.ctc_aware_model.fc_out.bias}
+
+    def load_state_dict(self, state_dict, strict=True):
+        """fairseq/trainer.py:215-218 loads the criterion's own parameters; once they live in a model's arena the bf16 copy the
+        GEMMs read has to follow"""
+        out = super().load_state_dict(state_dict, strict=strict)
+        owner = getattr(self.ctc_aware_model.fc_out.weight, "_s2t_owner", None)
+        model = owner() if owner is not None else None
+        if model is not None and model.arena is not None:
+            model.arena.refresh_shadow()
+        return out
 
     def forward(self, model, sample, reduce=True, log_probs=True):
         ni = {k: v for k, v in sample["net_input"].items() if k != "transcript_prev_output_tokens"}   # SURVEY.md F6
@@ -288,9 +335,9 @@ class CTCMultiLoss(FairseqCriterion):
         ntokens, sample_size = s("ntokens"), s("sample_size")
         errors, total, nframes = s("ctc_errors"), s("ctc_total"), s("nframes")
         nll = nll_sum / ntokens / math.log(2)
-        return {"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
-                "ctc_loss": ctc_sum / sample_size / math.log(2),
-                "ctc_acc": 100.0 - min(errors * 100.0 / max(total, 1), 100.0), "nframes": nframes}
+        return _publish({"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
+                         "ctc_loss": ctc_sum / sample_size / math.log(2),
+                         "ctc_acc": 100.0 - min(errors * 100.0 / max(total, 1), 100.0), "nframes": nframes})
 
 
 class _KDFn(torch.autograd.Function):
@@ -353,7 +400,7 @@ class CrossEntropyKnowledgeDistillationCriterion(FairseqCriterion):
         out = {"loss": loss_sum / sample_size / math.log(2)}
         nll = loss_sum / ntokens / math.log(2) if sample_size != ntokens else out["loss"]
         out.update(nll_loss=nll, ppl=2 ** nll)
-        return out
+        return _publish(out)
 
 
 @register_criterion("cross_entropy_dualdecoder")
@@ -397,6 +444,6 @@ class CrossEntropyDualDecoder(FairseqCriterion):
         s = lambda k: sum(_item(l.get(k, 0)) for l in logging_outputs)
         ss, nt, ant = s("sample_size"), s("ntokens"), s("auxiliary_ntokens")
         ln2 = math.log(2)
-        return {"loss": s("loss") / ss / ln2, "primary_loss": s("primary_loss") / ss / ln2,
-                "auxiliary_loss": s("auxiliary_loss") / ss / ln2, "primary_nll_loss": s("primary_nll_loss") / nt / ln2,
-                "auxiliary_nll_loss": s("auxiliary_nll_loss") / max(ant, 1) / ln2}
+        return _publish({"loss": s("loss") / ss / ln2, "primary_loss": s("primary_loss") / ss / ln2,
+                         "auxiliary_loss": s("auxiliary_loss") / ss / ln2, "primary_nll_loss": s("primary_nll_loss") / nt / ln2,
+                         "auxiliary_nll_loss": s("auxiliary_nll_loss") / max(ant, 1) / ln2})

@@ -3,6 +3,7 @@
 // (fairseq/models/fairseq_decoder.py:58-79); fairseq/models/transformer.py:720-737 (embed*sqrt(D) + sinusoidal
 // positions from utils.make_positions, fairseq/utils.py:192-202).
 #include "common.hpp"
+#include "prof.hpp"
 
 // One workgroup per target row (B*L rows, V columns).  Never materialises lprobs:
 //   lse = logsumexp(row);  nll = lse - x[y];  smooth = V*lse - sum(x)
@@ -123,8 +124,9 @@ extern "C" int s2t_lsce(int dtype, const void* logits, const long long* target, 
     if (!logits || !target || !sums2 || V <= 0 || ld < V) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);       // four workgroups per CU
-    static float* part = nullptr;                                      // 1,024 x 2 partial sums (one training stream per process)
-    if (!part) { hipError_t e = hipMalloc(&part, 2 * 1024 * sizeof(float)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+    hipError_t se = hipSuccess;                                        // 1,024 x 2 partial sums, per (device, stream)
+    float* part = (float*)s2t_scratch(S2T_SCRATCH_LSCE, st, 2 * 1024 * sizeof(float), &se);
+    if (!part) return S2T_EHIP(se);
 #define S2T_LSCE(T_, NC_) hipLaunchKernelGGL((lsce_kernel<T_, NC_>), dim3(grid), dim3(256), 0, st, (const T_*)logits, target, (T_*)dlogits, part, rows, V, ld, eps, pad, grad_scale)
     if (dtype == S2T_BF16) { if (V <= 256 * 4 * 8) S2T_LSCE(bf16, 4); else S2T_LSCE(bf16, 0); }      // vocabularies up to 8,192 units: the row in registers
     else if (dtype == S2T_F32) { if (V <= 256 * 4 * 4) S2T_LSCE(float, 4); else S2T_LSCE(float, 0); }
@@ -379,8 +381,9 @@ extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* targe
     if (lambda > 0.f && (!teacher_idx || !teacher_logits || Kt < 1 || Kt > 64)) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)(rows < 1024 ? rows : 1024);
-    static float* part = nullptr;                                      // 1,024 x 2 partial sums (one training stream per process)
-    if (!part) { hipError_t e = hipMalloc(&part, 2 * 1024 * sizeof(float)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+    hipError_t se = hipSuccess;                                        // 1,024 x 2 partial sums, per (device, stream)
+    float* part = (float*)s2t_scratch(S2T_SCRATCH_KD, st, 2 * 1024 * sizeof(float), &se);
+    if (!part) return S2T_EHIP(se);
     if (dtype == S2T_BF16) hipLaunchKernelGGL(kd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)logits, target, teacher_idx, teacher_logits, (bf16*)dlogits, part, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
     else if (dtype == S2T_F32) hipLaunchKernelGGL(kd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)logits, target, teacher_idx, teacher_logits, (float*)dlogits, part, rows, V, ld, Kt, lambda, tau, pad, grad_scale);
     else return S2T_ENOTSUP;

@@ -4,6 +4,7 @@
 // fairseq/optim/adam.py:147-202; fairseq/utils.py:253-277 (clip_grad_norm_);
 // fairseq/trainer.py:416-443 (multiply_grads -> clip -> step).
 #include "common.hpp"
+#include "prof.hpp"
 
 // ------------------------------------------------------------------ LayerNorm
 // One wavefront per row.  Lane l owns EPL contiguous elements [l*EPL, l*EPL+EPL) (D = 64*EPL, EPL in {4,8,16}):
@@ -364,8 +365,9 @@ extern "C" int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, floa
                                   float* out2, void* stream) {
     if (!g || !acc_ws || !out2) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    static double* part = nullptr;                                       // 2,048 partial sums (one training stream per process)
-    if (!part) { hipError_t e = hipMalloc(&part, 2048 * sizeof(double)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+    hipError_t se = hipSuccess;                                          // 2,048 partial sums, per (device, stream)
+    double* part = (double*)s2t_scratch(S2T_SCRATCH_GNORM, st, 2048 * sizeof(double), &se);
+    if (!part) return S2T_EHIP(se);
     int blocks = 0;
     if (n) {
         blocks = (int)((n / 4 + 255) / 256);

@@ -10,3 +10,9 @@ struct ProfScope {
     }
     ~ProfScope() { if (g_s2t_prof_on) s2t_prof_push(fam, st, flops, bytes, false); }
 };
+
+// Per-(device, stream) scratch of the entry points that hand workgroup partial sums to a finishing kernel: two calls of one entry
+// point on different streams (or devices) get different buffers; calls on ONE stream are ordered by the stream.  Grows, never
+// shrinks; lives until process exit.  Returns nullptr and sets *err when the allocation fails.
+enum { S2T_SCRATCH_LSCE = 0, S2T_SCRATCH_KD, S2T_SCRATCH_GNORM, S2T_SCRATCH_CONV1_BWD, S2T_SCRATCH_SLOTS };
+void* s2t_scratch(int slot, hipStream_t st, size_t bytes, hipError_t* err);

@@ -4,6 +4,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 #include <cstring>
 
@@ -40,6 +41,24 @@ void s2t_prof_push(const char* family, hipStream_t st, double flops, double byte
     } else if (!f.recs.empty()) {
         (void)hipEventRecord(f.recs.back().b, st);
     }
+}
+
+void* s2t_scratch(int slot, hipStream_t st, size_t bytes, hipError_t* err) {
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    static std::map<std::tuple<int, int, hipStream_t>, Buf> bufs;
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    Buf& b = bufs[std::make_tuple(slot, dev, st)];
+    if (b.cap < bytes) {
+        if (b.p) (void)hipFree(b.p);                   // waits for the kernels that may still read it
+        b.p = nullptr; b.cap = 0;
+        hipError_t e = hipMalloc(&b.p, bytes);
+        if (e != hipSuccess) { b.p = nullptr; if (err) *err = e; return nullptr; }
+        b.cap = bytes;
+    }
+    return b.p;
 }
 
 extern "C" int s2t_abi_version(void) { return 5; }

@@ -11,6 +11,7 @@
 //   * fc3 consumes z2 directly: its weight is re-ordered once per step from the reference's
 //     k = c*F4+f (conv_transformer.py:225-226) to k' = f*C+c (permute kernels below).
 #include "common.hpp"
+#include "prof.hpp"
 
 // ------------------------------------------------------------------ 8-channel vectors
 // Every HBM-bound kernel of this file gives a thread 8 consecutive channels of one pixel (one 16-byte bf16 access),
@@ -817,8 +818,9 @@ extern "C" int s2t_conv1_bwd_bn(int dtype, const float* x, const void* dyn, cons
         const size_t esz = dtype == S2T_BF16 ? 2 : 4;
         size_t lds = 4 * (size_t)(pre ? 3 : 2) * 16 * (C * esz + 16);
         if (lds < (size_t)4 * 10 * C * 4) lds = (size_t)4 * 10 * C * 4;
-        static float* part = nullptr;                                            // 1,024 workgroups x 10 x 128 (one training stream per process)
-        if (!part) { hipError_t e = hipMalloc(&part, (size_t)1024 * 1280 * sizeof(float)); if (e != hipSuccess) { part = nullptr; return S2T_EHIP(e); } }
+        hipError_t se = hipSuccess;                                              // 1,024 workgroups x 10 x 128, per (device, stream)
+        float* part = (float*)s2t_scratch(S2T_SCRATCH_CONV1_BWD, st, (size_t)1024 * 1280 * sizeof(float), &se);
+        if (!part) return S2T_EHIP(se);
 #define S2T_C1B(T_, NT_, G_) do { static bool attr = false;                                                                                   \
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bwd_bn_mfma_kernel<T_, NT_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; } \
         hipLaunchKernelGGL((conv1_bwd_bn_mfma_kernel<T_, NT_, G_>), dim3(nwg), dim3(256), lds, st, x, (const T_*)dyn, (const T_*)y, (const T_*)pre, mean, rstd, gamma, sums, part, dgamma, dbeta, B, T, F, T2, F2, count, training); } while (0)

@@ -416,18 +416,21 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
     // addresses), so the last few lists are kept: their work tables stay on the device (the two pageable-memory copies of an upload
     // cost ~35 us of GPU timeline per launch, as much as the 40 K-tiles of a decoder-sized product) and an identical list is launched
     // without building anything.
-    struct Cached { std::vector<char> key; void* dev = nullptr; size_t cap = 0; unsigned long long used = 0;
+    struct Cached { std::vector<char> key; hipStream_t st = nullptr; int device = -1; void* dev = nullptr; size_t cap = 0; unsigned long long used = 0;
                     size_t pb = 0; int n_items = 0, grid = 0; double flops = 0.0, bytes = 0.0; };
     static Cached cache[4];
     static unsigned long long tick = 0;
     static std::mutex mu;
     const size_t key_bytes = (size_t)n * sizeof(S2TWgradProblem);
+    int device = 0;
+    (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> lock(mu);
     ++tick;
     Cached* hit = nullptr;
     Cached* lru = &cache[0];
     for (Cached& c : cache) {
-        if (c.dev && c.key.size() == key_bytes && memcmp(c.key.data(), probs, key_bytes) == 0) { hit = &c; break; }
+        // a cached table serves only the (device, stream) it was uploaded on: its upload and its readers are ordered by that stream
+        if (c.dev && c.st == st && c.device == device && c.key.size() == key_bytes && memcmp(c.key.data(), probs, key_bytes) == 0) { hit = &c; break; }
         if (c.used < lru->used) lru = &c;
     }
     if (!hit) {
@@ -459,7 +462,7 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
         std::vector<char> host(need);
         memcpy(host.data(), pv.data(), pb);
         memcpy(host.data() + pb, lay.table.data(), ib);
-        if (need > lru->cap) {
+        if (need > lru->cap || lru->device != device) {
             // grows rarely (the first updates); a hipFree of the old table waits for the kernels that may still read it
             if (lru->dev) (void)hipFree(lru->dev);
             lru->dev = nullptr; lru->key.clear();
@@ -467,11 +470,13 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
             hipError_t e = hipMalloc(&lru->dev, lru->cap);
             if (e != hipSuccess) { lru->dev = nullptr; lru->cap = 0; return S2T_EHIP(e); }
         }
-        // stream-ordered upload from pageable memory (staged by the runtime before the call returns); earlier launches that read
-        // this slot were enqueued before it on the same stream (one training stream per process)
+        // stream-ordered upload from pageable memory (staged by the runtime before the call returns).  Earlier launches that read
+        // this slot were enqueued on the stream recorded in it: if that is another stream, wait for it before overwriting the table
+        if (lru->dev && lru->st != st && lru->device == device) (void)hipStreamSynchronize(lru->st);
         hipError_t e = hipMemcpyAsync(lru->dev, host.data(), need, hipMemcpyHostToDevice, st);
         if (e != hipSuccess) { lru->key.clear(); return S2T_EHIP(e); }
         lru->key.assign(reinterpret_cast<const char*>(probs), reinterpret_cast<const char*>(probs) + key_bytes);
+        lru->st = st; lru->device = device;
         lru->pb = pb; lru->n_items = (int)lay.table.size(); lru->grid = lay.used; lru->flops = flops; lru->bytes = bytes;
         hit = lru;
     }

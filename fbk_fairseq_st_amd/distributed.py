@@ -81,11 +81,14 @@ class BucketedGradReducer:
         self.ready_low = self.n    # everything in [ready_low, n) is final
         self.handles = []
         self.launched = []
+        self.early_elems = 0       # elements whose bucket left from inside backward (notify), not from finish()
 
-    def _launch_next(self):
+    def _launch_next(self, early=False):
         start, end = self.plan[self.next]
         self.next += 1
         self.launched.append((start, end))
+        if early:
+            self.early_elems += end - start
         if get_world_size() > 1:
             self.handles.append(dist.all_reduce(self.flat[start:end], group=self.group, async_op=True))
 
@@ -94,7 +97,7 @@ class BucketedGradReducer:
         if end >= self.ready_low and start < self.ready_low:
             self.ready_low = start
         while self.next < len(self.plan) and self.plan[self.next][0] >= self.ready_low:
-            self._launch_next()
+            self._launch_next(early=True)
 
     def finish(self):
         while self.next < len(self.plan):

@@ -37,6 +37,7 @@ class HParams:
         self.V_aux = 0                           # > 0: second decoder `auxiliary_decoder.*` over this vocabulary (dual-decoder model)
         self.share_dec_embed = False             # --share-decoder-input-output-embed: output_projection.weight IS embed_tokens.weight (transformer.py:618-624)
         self.ln_eps = 1e-5; self.bn_eps = 1e-5; self.bn_momentum = 0.1
+        self.encoder_layerdrop = 0.0; self.decoder_layerdrop = 0.0    # LayerDrop rates (decided on the host by the model)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError(k)
@@ -247,6 +248,13 @@ class S2TEngine:
         if self.on_grads_ready is not None:
             for prefix in ready:
                 self.on_grads_ready(prefix)
+
+    def reset_wgrad(self):
+        """drop whatever the last backward queued but never launched (an exception between queueing and the flush: the out-of-memory
+        case the reference's train_step recovers from by zeroing the gradients and going on, fairseq/trainer.py:392-405) -- stale
+        (dY, X, dW) items must not be added to the next update's gradients.  The queue also keeps every queued dY alive until the
+        flush (~2.6 GB at the bench shape: DESIGN.md section 4)."""
+        self._wq, self._wq_ready, self._wq_post = [], [], []
 
     def out_proj(self, pfx):
         """parameter-name stem of a decoder's output projection: the embedding itself when input and output embeddings are shared
@@ -607,9 +615,14 @@ class S2TEngine:
                                self.G(pfx + "final_layer_norm.weight"), self.G(pfx + "final_layer_norm.bias"), dres=dy, drop=nxt)
 
     # ------------------------------------------------------------------ encoder
-    def encoder_forward(self, src_tokens, src_lengths, training, seed=0, return_all_hiddens=False):
-        """Returns dict(out [T'',B,D], lengths int64 [B] (device), lengths_host list, ctc_out, ctc_lengths, ...), ctx."""
+    def encoder_forward(self, src_tokens, src_lengths, training, seed=0, return_all_hiddens=False, keep=None):
+        """Returns dict(out [T'',B,D], lengths int64 [B] (device), lengths_host list, ctc_out, ctc_lengths, ...), ctx.
+        keep: LayerDrop decisions of this pass (--encoder-layerdrop, conv_transformer.py:238-243), one bool per layer, drawn by the
+        caller on the host; a dropped layer is absent from both schedules (and, as in the reference, from `states`)."""
         hp = self.hp
+        if keep is not None and hp.ctc_layer and not keep[hp.ctc_layer - 1]:
+            # the reference leaves x_ctc / ctc_padding_mask unbound in that case and dies with UnboundLocalError at its return
+            raise RuntimeError("LayerDrop removed encoder layer %d, the one --ctc-encoder-layer compresses after" % hp.ctc_layer)
         len_host = [int(v) for v in (src_lengths.tolist() if torch.is_tensor(src_lengths) else src_lengths)]
         # lengths after the two stride-2 convolutions: ceil(len / 2) twice (conv_transformer.py:213), on the host, one upload each for
         # the two integer widths the kernels read
@@ -619,10 +632,13 @@ class S2TEngine:
         x, sub = self.subsample_fwd(src_tokens, len4_32, training, seed * 1000)
         T4, B, D = x.shape
         klen = len4_32 if min(lens_host) < T4 else None             # create_mask -> None when nothing is padded
-        ctx = dict(sub=sub, layers=[], ctc=None, T4=T4, B=B)
+        ctx = dict(sub=sub, layers=[], ctc=None, T4=T4, B=B, state_layers=[])
         out = dict(ctc_out=None, ctc_lengths=None, ctc_lengths_host=None, pred=None, states=[] if return_all_hiddens else None)
         cur_len, cur_len_host, cur_klen = len4, lens_host, klen
         for l in range(hp.enc_layers):
+            if keep is not None and not keep[l]:
+                ctx["layers"].append(None)
+                continue
             pfx = "encoder.layers.%d." % l
             x, ca = self.self_attn_block_fwd(pfx, x, cur_klen, False, training, seed * 1000 + 10 * (l + 1),
                                              dist_penalty=bool(hp.distance_penalty))
@@ -649,10 +665,11 @@ class S2TEngine:
                 cur_klen = new_len.to(torch.int32) if min(new_len_host) < Tout else None
             if return_all_hiddens:
                 out["states"].append(x)
+                ctx["state_layers"].append(l)
         Tn = x.shape[0]
         xn, mean, rstd = K.layernorm_fwd(x.view(Tn * B, D), self.P("encoder.layer_norm.weight"), self.P("encoder.layer_norm.bias"), hp.ln_eps)
         ctx["final"] = dict(x=x.view(Tn * B, D), mean=mean, rstd=rstd)
-        if return_all_hiddens:
+        if return_all_hiddens and out["states"]:
             out["states"][-1] = xn.view(Tn, B, D)
         out.update(out=xn.view(Tn, B, D), lengths=cur_len, lengths_host=cur_len_host, klen=cur_klen)
         return out, ctx
@@ -666,42 +683,49 @@ class S2TEngine:
         if d_out is None:
             d_out = torch.zeros_like(f["x"])
         d_out = d_out.reshape(-1, D).contiguous()
-        if d_states and (hp.enc_layers - 1) in d_states:
-            d_out = K.add_inplace(d_states[hp.enc_layers - 1].reshape(-1, D).contiguous(), d_out.clone())
+        kept = [l for l in range(hp.enc_layers) if ctx["layers"][l] is not None]         # LayerDrop: the layers that ran
+        top = kept[-1] if kept else -1
+        if d_states and top in d_states:
+            d_out = K.add_inplace(d_states[top].reshape(-1, D).contiguous(), d_out.clone())
+
         def touched(l):
             """the gradient entering layer l's output is modified between the blocks (CTC tap / compression): no fused mask"""
-            return l < 0 or bool(d_states and l in d_states and l != hp.enc_layers - 1) or \
+            return l < 0 or bool(d_states and l in d_states and l != top) or \
                 (ctx["ctc"] is not None and ctx["ctc"]["layer"] == l)
 
         def ffn_drop(l):
+            if l < 0:
+                return None
             cf = ctx["layers"][l][1]
             return (cf["p"], cf["seed"] + 4) if self.fuse_bwd_dropout and cf["p"] > 0 and not touched(l) else None
 
         dxd = None
-        nxt = ffn_drop(hp.enc_layers - 1)
+        nxt = ffn_drop(top)
         dx = K.layernorm_bwd(d_out.reshape(-1, D).contiguous(), f["x"], f["mean"], f["rstd"], self.P("encoder.layer_norm.weight"),
                              self.G("encoder.layer_norm.weight"), self.G("encoder.layer_norm.bias"), drop=nxt)
         if nxt is not None:
             dx, dxd = dx
         for l in reversed(range(hp.enc_layers)):
             pfx = "encoder.layers.%d." % l
-            if d_states and l in d_states and l != hp.enc_layers - 1:
-                K.add_inplace(d_states[l].reshape(-1, D).contiguous(), dx)
-            if ctx["ctc"] is not None and ctx["ctc"]["layer"] == l:
-                cc = ctx["ctc"]
-                dxk = torch.empty((cc["Tn"], B, D), dtype=self.dtype, device=self.dev)
-                K.ctc_compress_bwd(dx.view(cc["Tout"], B, D), cc["w"], cc["seg"], dxk)
-                dxk = dxk.view(cc["Tn"] * B, D)
-                if d_ctc_out is not None:
-                    self.linear_bwd(d_ctc_out.reshape(-1, hp.V_src), cc["x"], "encoder.ctc_fc", dx_out=dxk, dx_accumulate=True)
-                dx = dxk
-            ca, cf = ctx["layers"][l]
-            nxt = (ca["p"], ca["seed"] + 2) if self.fuse_bwd_dropout and ca["p"] > 0 else None
-            dx = self.ffn_block_bwd(pfx, cf, dx, d=dxd, nxt=nxt)
-            dx, dxd = dx if nxt is not None else (dx, None)
-            nxt = ffn_drop(l - 1) if l > 0 else None
-            dx = self.self_attn_block_bwd(pfx, ca, dx, d=dxd, nxt=nxt)
-            dx, dxd = dx if nxt is not None else (dx, None)
+            if ctx["layers"][l] is not None:
+                below = max([k for k in kept if k < l], default=-1)          # the next layer down that ran
+                if d_states and l in d_states and l != top:
+                    K.add_inplace(d_states[l].reshape(-1, D).contiguous(), dx)
+                if ctx["ctc"] is not None and ctx["ctc"]["layer"] == l:
+                    cc = ctx["ctc"]
+                    dxk = torch.empty((cc["Tn"], B, D), dtype=self.dtype, device=self.dev)
+                    K.ctc_compress_bwd(dx.view(cc["Tout"], B, D), cc["w"], cc["seg"], dxk)
+                    dxk = dxk.view(cc["Tn"] * B, D)
+                    if d_ctc_out is not None:
+                        self.linear_bwd(d_ctc_out.reshape(-1, hp.V_src), cc["x"], "encoder.ctc_fc", dx_out=dxk, dx_accumulate=True)
+                    dx = dxk
+                ca, cf = ctx["layers"][l]
+                nxt = (ca["p"], ca["seed"] + 2) if self.fuse_bwd_dropout and ca["p"] > 0 else None
+                dx = self.ffn_block_bwd(pfx, cf, dx, d=dxd, nxt=nxt)
+                dx, dxd = dx if nxt is not None else (dx, None)
+                nxt = ffn_drop(below)
+                dx = self.self_attn_block_bwd(pfx, ca, dx, d=dxd, nxt=nxt)
+                dx, dxd = dx if nxt is not None else (dx, None)
             if l == hp.enc_layers - 1:
                 self._ready("encoder.layer_norm.")
             if hp.ctc_layer == l + 1:
@@ -715,7 +739,8 @@ class S2TEngine:
         self.flush_wgrad()
 
     # ------------------------------------------------------------------ decoder
-    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder."):
+    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None):
+        """keep: LayerDrop decisions (--decoder-layerdrop, fairseq/modules/layer_drop.py:11-44), one bool per layer, drawn by the caller"""
         hp = self.hp
         B, L = prev_tokens.shape
         D = hp.D
@@ -730,6 +755,9 @@ class S2TEngine:
         enc2d = enc_out.reshape(Ts * B, D)
         ctx = dict(tok=tok, layers=[], B=B, L=L, Ts=Ts, scale=scale, p=p, seed=seed, pfx=pfx)
         for l in range(hp.dec_layers):
+            if keep is not None and not keep[l]:
+                ctx["layers"].append(None)
+                continue
             lp = pfx + "layers.%d." % l
             s = seed * 1000 + 510 + 10 * l
             x, c1 = self.self_attn_block_fwd(lp, x, tlen, True, training, s)
@@ -757,11 +785,29 @@ class S2TEngine:
             st["spare"].append(torch.empty((max_steps, N, 3 * D), dtype=self.dtype, device=self.dev))
         return st
 
-    def decoder_reorder(self, st, order):
-        """Beam re-ordering of the self-attention caches (transformer.py:840-852 reorder_incremental_state).  The encoder-side
-        K/V are identical for all hypotheses of a sentence and sentences are never compacted here, so they stay put
-        (multihead_attention.py:385-386 makes the same shortcut).  Pure data movement (gather of rows)."""
+    def decoder_reorder(self, st, order, encoder_side=False):
+        """Beam re-ordering of the self-attention caches (transformer.py:840-852 reorder_incremental_state).  Pure data movement
+        (gather of rows).  This package's generator never compacts sentences out of the batch and the hypotheses of one sentence
+        share their encoder-side K/V, so for it those stay put (multihead_attention.py:385-386 makes the same shortcut).
+        encoder_side=True is the general contract of the reference's interface: its own SequenceGenerator drops finished sentences
+        (fairseq/sequence_generator.py:430-470), so the encoder-side K/V, the key lengths and the batch size follow `order` too."""
         n = st["steps"]
+        newN = int(order.numel())
+        if encoder_side:
+            st["kv_enc"] = [kv.index_select(1, order) for kv in st["kv_enc"]]
+            if st["klen"] is not None:
+                st["klen"] = st["klen"].index_select(0, order)
+        if newN != st["N"]:
+            if not encoder_side:
+                raise ValueError("decoder_reorder: %d hypotheses -> %d needs encoder_side=True" % (st["N"], newN))
+            for l in range(len(st["cache"])):
+                old = st["cache"][l]
+                st["cache"][l] = torch.empty((st["max_steps"], newN, old.shape[2]), dtype=old.dtype, device=old.device)
+                if n:
+                    torch.index_select(old[:n], 1, order, out=st["cache"][l][:n])
+                st["spare"][l] = torch.empty_like(st["cache"][l])
+            st["N"] = newN
+            return
         if n == 0:
             return
         for l in range(len(st["cache"])):
@@ -806,26 +852,29 @@ class S2TEngine:
         def drop_of(c, off):
             return (c["p"], c["seed"] + off) if self.fuse_bwd_dropout and c["p"] > 0 else None
 
-        nxt = drop_of(ctx["layers"][hp.dec_layers - 1][2], 4)
+        kept = [l for l in range(hp.dec_layers) if ctx["layers"][l] is not None]         # LayerDrop: the layers that ran
+        nxt = drop_of(ctx["layers"][kept[-1]][2], 4) if kept else None
         dx = K.layernorm_bwd(dxn, f["x"], f["mean"], f["rstd"], self.P(pfx + "layer_norm.weight"),
                              self.G(pfx + "layer_norm.weight"), self.G(pfx + "layer_norm.bias"), drop=nxt)
         dx, dxd = dx if nxt is not None else (dx, None)
-        fresh = denc is None and hp.dec_layers > 0      # the top layer's K/V data gradient WRITES the buffer: no fill, no read of zeros
+        fresh = denc is None and len(kept) > 0          # the top layer's K/V data gradient WRITES the buffer: no fill, no read of zeros
         if denc is None:
             denc = (torch.empty if fresh else torch.zeros)((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
         for l in reversed(range(hp.dec_layers)):
             lp = pfx + "layers.%d." % l
-            c1, c2, c3 = ctx["layers"][l]
-            nxt = drop_of(c2, 2)
-            dx = self.ffn_block_bwd(lp, c3, dx, d=dxd, nxt=nxt)
-            dx, dxd = dx if nxt is not None else (dx, None)
-            nxt = drop_of(c1, 2)
-            dx = self.cross_attn_block_bwd(lp, c2, dx, denc, d=dxd, nxt=nxt, accumulate=not fresh)
-            fresh = False
-            dx, dxd = dx if nxt is not None else (dx, None)
-            nxt = drop_of(ctx["layers"][l - 1][2], 4) if l > 0 else None
-            dx = self.self_attn_block_bwd(lp, c1, dx, d=dxd, nxt=nxt)
-            dx, dxd = dx if nxt is not None else (dx, None)
+            if ctx["layers"][l] is not None:
+                c1, c2, c3 = ctx["layers"][l]
+                below = max([k for k in kept if k < l], default=-1)
+                nxt = drop_of(c2, 2)
+                dx = self.ffn_block_bwd(lp, c3, dx, d=dxd, nxt=nxt)
+                dx, dxd = dx if nxt is not None else (dx, None)
+                nxt = drop_of(c1, 2)
+                dx = self.cross_attn_block_bwd(lp, c2, dx, denc, d=dxd, nxt=nxt, accumulate=not fresh)
+                fresh = False
+                dx, dxd = dx if nxt is not None else (dx, None)
+                nxt = drop_of(ctx["layers"][below][2], 4) if below >= 0 else None
+                dx = self.self_attn_block_bwd(lp, c1, dx, d=dxd, nxt=nxt)
+                dx, dxd = dx if nxt is not None else (dx, None)
             if l == hp.dec_layers - 1:
                 self._ready(pfx + "output_projection.")
                 self._ready(pfx + "layer_norm.")

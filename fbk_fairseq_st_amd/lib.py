@@ -163,25 +163,20 @@ def ptr(t):
     return t.data_ptr()
 
 
-_DEV_INDEX = None
+_GET_DEVICE = torch._C._cuda_getDevice          # current device index of this thread, ~0.1 us (no Python-level bookkeeping)
 
 
 def device_index():
-    """index of the GPU this process drives (looked up once: one process, one GPU)"""
-    global _DEV_INDEX
-    if _DEV_INDEX is None:
-        _DEV_INDEX = torch.cuda.current_device()
-    return _DEV_INDEX
+    """index of torch's CURRENT device (not cached: a process that calls kernels before torch.cuda.set_device, or drives a second
+    GPU from a tool, must never launch on device 0's stream with device-N pointers)"""
+    return _GET_DEVICE()
 
 
 def stream():
-    """raw hipStream_t of torch's current stream.  torch.cuda.current_stream() costs ~4 us of Python per call (device-index and
-    availability lookups); with ~1100 launches per update that is host time the small decoder-side kernels cannot hide, so the raw
-    handle is fetched through the C entry point (one process drives one GPU: the device index is looked up once)."""
-    global _DEV_INDEX
-    if _DEV_INDEX is None:
-        _DEV_INDEX = torch.cuda.current_device()
-    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
+    """raw hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() costs ~4 us of Python per
+    call (stream object construction); with ~1100 launches per update that is host time the small decoder-side kernels cannot
+    hide, so the raw handle is fetched through the two C entry points directly."""
+    return torch._C._cuda_getCurrentRawStream(_GET_DEVICE())
 
 
 def require_cuda(*ts):

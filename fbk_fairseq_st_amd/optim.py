@@ -60,13 +60,66 @@ class ArenaAdam:
         self.lr = float(lr)
 
     def state_dict(self):
+        """this build's own compact layout: the two moment vectors in arena order"""
         a = self.arena
         return {"step": self.step_count, "lr": self.lr, "exp_avg": a.exp_avg.cpu(), "exp_avg_sq": a.exp_avg_sq.cpu()}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, reference_names=None):
+        """takes either layout: the compact one above, or the reference's (a torch.optim state dict, see reference_state_dict)"""
+        if "state" in sd and "param_groups" in sd:
+            return self.load_reference_state_dict(sd, reference_names)
         a = self.arena
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
         a.exp_avg.copy_(sd["exp_avg"]); a.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+    # ---- the reference's optimizer-state layout (fairseq/checkpoint_utils.py:245-286 stores `optimizer.state_dict()` =
+    # torch.optim.Optimizer.state_dict() of fairseq/optim/adam.py:110-202): {"state": {i: {"step", "exp_avg", "exp_avg_sq"}},
+    # "param_groups": [{"lr", "betas", "eps", "weight_decay", "amsgrad", "params": [0..n-1]}]} where i counts the parameters in the
+    # order the trainer collected them (model.named_parameters() then criterion's, requires_grad only: trainer.py:140-146).
+    def _moment_views(self, ref_name):
+        from .conv_transformer import reference_slot
+        a = self.arena
+        an, blk, nblk = reference_slot(ref_name)
+        if not a.has(an):
+            raise KeyError("optimizer state for %r: no parameter %r in the arena" % (ref_name, an))
+        m, v = a._view(a.exp_avg, an), a._view(a.exp_avg_sq, an)
+        if blk is not None:
+            rows = m.shape[0] // nblk
+            m, v = m[blk * rows:(blk + 1) * rows], v[blk * rows:(blk + 1) * rows]
+        return m, v
+
+    def reference_state_dict(self, reference_names):
+        state = {}
+        if self.step_count > 0:                               # torch creates a parameter's state at its first step
+            for i, n in enumerate(reference_names):
+                m, v = self._moment_views(n)
+                state[i] = {"step": self.step_count, "exp_avg": m.detach().cpu().clone(), "exp_avg_sq": v.detach().cpu().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "params": list(range(len(reference_names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_reference_state_dict(self, sd, reference_names):
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if reference_names is None or len(ids) != len(reference_names):
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group "
+                             "(%d parameters in the file, %d here)" % (len(ids), len(reference_names or ())))
+        steps = set()
+        with torch.no_grad():
+            for i, n in zip(ids, reference_names):
+                st = sd["state"].get(i)
+                m, v = self._moment_views(n)
+                if st is None:                                # never stepped in the run that wrote the file (gradient always None)
+                    m.zero_(); v.zero_()
+                    continue
+                if tuple(st["exp_avg"].shape) != tuple(m.shape):
+                    raise ValueError("optimizer state of %s has shape %s, the parameter %s" % (n, tuple(st["exp_avg"].shape), tuple(m.shape)))
+                m.copy_(st["exp_avg"].to(dtype=m.dtype)); v.copy_(st["exp_avg_sq"].to(dtype=v.dtype))
+                steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): one fused Adam launch keeps ONE step count" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        # hyper-parameters: the running optimizer's win over the file's (fairseq_optimizer.py:62-77, optimizer_overrides)
 
 
 class InverseSquareRootSchedule:

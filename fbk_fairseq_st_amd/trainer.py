@@ -35,7 +35,8 @@ class Trainer:
             # trainer's device must be the current one before anything is allocated or launched (fairseq_cli/train.py:36-37)
             torch.cuda.set_device(self.device)
         if compute_dtype is None:
-            compute_dtype = torch.bfloat16 if getattr(args, "bf16", False) else torch.float32
+            bf16 = getattr(args, "bf16", False) or getattr(args, "compute_dtype", None) == "bf16"
+            compute_dtype = torch.bfloat16 if bf16 else torch.float32
         extra = criterion.arena_params() if hasattr(criterion, "arena_params") else None
         self.arena = model.materialize(self.device, compute_dtype, extra=extra)
         lr = args.lr[0] if isinstance(args.lr, (list, tuple)) else args.lr
@@ -119,6 +120,9 @@ class Trainer:
         self.model.train(); self.criterion.train()
         self.optimizer.zero_grad()
         self.reducer.reset()
+        reset = getattr(self.model.engine, "reset_wgrad", None)
+        if reset is not None:
+            reset()                          # nothing queued by an update that died half-way may reach this one
         logs, sample_size, is_dummy = [], 0, False
         for i, sample in enumerate(samples):
             s = self._prepare_sample(sample)
@@ -156,27 +160,37 @@ class Trainer:
 
     # ---- checkpoints (fairseq/trainer.py:173-266, fairseq/checkpoint_utils.py:245-285): the reference's file layout -- "args",
     # "model" (reference parameter names, f32 masters), "criterion", "optimizer_history", "extra_state", "last_optimizer_state".
-    # The optimizer state is this build's own (Adam moments as two flat arena-ordered vectors), so a reference checkpoint
-    # restores model + criterion + schedule position and restarts the moments (the reference's --reset-optimizer behaviour).
+    # The optimizer state is written in the reference's layout too (a torch.optim state dict keyed by the position of each parameter
+    # in the reference's own parameter order, per-parameter Adam moments split out of the fused arena tensors; optimizer_name
+    # "FairseqAdam"), so a checkpoint of the reference resumes here WITH its moments and one of ours resumes there.  Files of
+    # earlier builds (optimizer_name "ArenaAdam": two flat arena-ordered vectors) still load.
+    def optimizer_parameter_names(self):
+        """the reference's optimizer parameter order for this model + criterion (trainer.py:140-146: requires_grad only)"""
+        from .conv_transformer import reference_slot
+        frozen = set(getattr(self.model, "_frozen_names", ()) or ())
+        names = [n for n in self.model.reference_parameter_names() if reference_slot(n)[0] not in frozen]
+        return names + [n for n, _ in self.criterion.named_parameters()]
+
     def save_checkpoint(self, filename, extra_state=None):
         if D.get_rank() != 0:                                       # only the data-parallel master writes (trainer.py:175)
             return
         state = {"args": self.args, "model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
                  "optimizer_history": self._optim_history + [{"criterion_name": self.criterion.__class__.__name__,
-                                                              "optimizer_name": self.optimizer.__class__.__name__,
+                                                              "optimizer_name": "FairseqAdam",
                                                               "lr_scheduler_state": self.lr_scheduler.state_dict(),
                                                               "num_updates": self.num_updates}],
                  "extra_state": dict(extra_state or {})}
         if any(True for _ in self.criterion.parameters()):
             state["criterion"] = {k: v.detach().cpu() for k, v in self.criterion.state_dict().items()}
         if not getattr(self.args, "no_save_optimizer_state", False):
-            state["last_optimizer_state"] = self.optimizer.state_dict()
+            state["last_optimizer_state"] = self.optimizer.reference_state_dict(self.optimizer_parameter_names())
         tmp = filename + ".tmp"
         torch.save(state, tmp)
         os.replace(tmp, filename)                                   # a reader never sees a half-written file
 
     def load_checkpoint(self, filename, reset_optimizer=False, reset_lr_scheduler=False, allow_non_strict_loading=False):
-        """-> extra_state of the file, or None when it does not exist (trainer.py:189-266)."""
+        """-> extra_state of the file, or None when it does not exist (trainer.py:189-266).  As in the reference, --reset-optimizer
+        skips the optimizer state AND the update counter / schedule position (they ride on the same branch, trainer.py:232-251)."""
         if not os.path.isfile(filename):
             return None
         state = torch.load(filename, map_location="cpu", weights_only=False)
@@ -191,9 +205,9 @@ class Trainer:
             h = self._optim_history[-1]
             assert h["criterion_name"] == self.criterion.__class__.__name__, \
                 "Criterion does not match; please reset the optimizer (--reset-optimizer)."
-            assert h["optimizer_name"] == self.optimizer.__class__.__name__ and "exp_avg" in last \
-                and last["exp_avg"].numel() == self.arena.numel, "Optimizer does not match; please reset the optimizer (--reset-optimizer)."
-            self.optimizer.load_state_dict(last)
+            assert h["optimizer_name"] in ("FairseqAdam", "ArenaAdam"), \
+                "Optimizer does not match; please reset the optimizer (--reset-optimizer)."
+            self.optimizer.load_state_dict(last, self.optimizer_parameter_names())
             self.num_updates = int(h["num_updates"])
             if not reset_lr_scheduler:
                 self.lr_scheduler.load_state_dict(h.get("lr_scheduler_state") or {})
@@ -206,7 +220,10 @@ class Trainer:
         agg = {k: 0.0 for k in getattr(self, "_log_keys", ())}     # same keys on every rank, also on one whose update was a dummy
         for l in logs:
             for k, v in l.items():
-                agg[k] = agg.get(k, 0.0) + (float(v) if not torch.is_tensor(v) else float(v.item()))
+                try:                         # device scalars, python numbers and statistics still on the logging thread all end here
+                    agg[k] = agg.get(k, 0.0) + (float(v) if not torch.is_tensor(v) else float(v.item()))
+                except Exception as e:
+                    raise RuntimeError("logging statistic %r of update %d failed: %s" % (k, self.num_updates, e)) from e
         agg["gnorm"] = float(gnorm.item())
         if self.world > 1:
             g = agg.pop("gnorm")

@@ -12,7 +12,10 @@
  * Conventions
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless noted; no ownership
  *     transfer; outputs are caller-allocated; calls are stream-ordered on `stream` (a hipStream_t,
- *     NULL = default stream) and re-entrant per stream; no call synchronises the device.
+ *     NULL = default stream) and re-entrant per stream; no call synchronises the device.  Internal scratch
+ *     (workgroup partial sums of s2t_lsce / s2t_kd_loss / s2t_grad_norm_clip / s2t_conv1_bwd_bn, the cached work
+ *     tables of s2t_wgrad_group) is keyed by (current device, stream) under a mutex: concurrent calls of one entry
+ *     point on different streams, devices or host threads do not share it.
  *   - dtype: S2T_F32 = 0 (parity path, exact-f32 MFMA), S2T_BF16 = 1 (bf16 storage, f32 accumulate).
  *   - return 0 on success; -22 (EINVAL) bad argument; -95 (ENOTSUP) unsupported shape/dtype;
  *     -(1000 + hipError_t) when the HIP runtime reported an error at launch.

@@ -115,12 +115,18 @@ def compare_grads(mine, ref, tol, cos_min=None, what=""):
         if err > worst[0]:
             worst = (err, k)
         assert err <= tol, "%s gradient norm of %s: %.6g vs oracle %.6g (rel %.3e > %.1e)" % (what, k, a, b, err, tol)
+    wcos = (1.0, None)
     if cos_min is not None:
-        for k in ("encoder.fc3.weight", "encoder.layers.0.fc1.weight", "encoder.layers.7.self_attn.q_proj.weight",
-                  "decoder.embed_tokens.weight", "decoder.layers.0.encoder_attn.k_proj.weight", "encoder.convolutions.1.weight"):
-            if k in ref:
-                c = float(torch.nn.functional.cosine_similarity(mine[k].reshape(1, -1).double(), ref[k].reshape(1, -1).double()))
-                assert c >= cos_min, "%s gradient direction of %s: cosine %.5f" % (what, k, c)
+        # direction of EVERY gradient tensor that carries signal (norm above 1e-3 of the largest): cosine against the oracle
+        big = 1e-3 * max(float(g.norm()) for g in ref.values())
+        for k, g in ref.items():
+            if k.endswith("_float_tensor") or k.endswith("k_proj.bias") or float(g.norm()) < big:
+                continue
+            c = float(torch.nn.functional.cosine_similarity(mine[k].reshape(1, -1).double(), g.reshape(1, -1).double()))
+            if c < wcos[0]:
+                wcos = (c, k)
+            assert c >= cos_min, "%s gradient direction of %s: cosine %.6f < %.6f" % (what, k, c, cos_min)
+    print("MEASURED %s: worst gradient-norm error %.3e (%s), worst cosine %.6f (%s)" % (what, worst[0], worst[1], wcos[0], wcos[1]))
     return worst
 
 
@@ -138,7 +144,21 @@ def rel(a, b):
 # (With a plain float32 log-space CTC recursion in the product the error was 1e-3 for EVERYTHING below the CTC tap: alpha + beta - log P
 # cancels numbers near -3,000.  The oracle runs its recursion in float64; the kernels now keep every step's vector relative to its
 # maximum and normalise the posteriors per frame: 4e-6 from float64 where torch's own f32 ctc_loss is 6e-4, tools/ctc_accuracy.py.)
-TOL = {torch.float32: dict(loss=1e-4, grad=1e-3, cos=0.9999), torch.bfloat16: dict(loss=2e-2, grad=1e-1, cos=0.99)}
+# bf16 (bf16 storage, f32 accumulation, f32 masters) against the f32 oracle: bounds = ~2x the worst case MEASURED on an MI355X over the
+# cases of this file (every test prints its own "MEASURED ..." line; profiles/r03_parity_measured.txt holds the run the bounds come from):
+#   loss                  worst 2.8e-3 (l preset, ragged)                                -> 6e-3
+#   gradient norms        worst 1.2e-2 ctc_multi_loss m / l, 2.0e-2 KD, 2.3e-2 shared embedding, 4.4e-2 dual decoder (encoder.bn.0.weight)
+#                                                                                        -> 5e-2 (dual decoder: 9e-2)
+#   gradient direction    cosine on EVERY tensor whose norm is above 1e-3 of the largest: worst 0.9972 ctc_multi_loss, 0.9951 shared
+#                         embedding, 0.9968 dual decoder, 0.9915 KD (decoder.layers.5.encoder_attn.q_proj.weight)   -> 0.99 (KD: 0.983)
+TOL = {torch.float32: dict(loss=1e-4, grad=1e-3, cos=0.9999), torch.bfloat16: dict(loss=6e-3, grad=5e-2, cos=0.99)}
+TOL_BF16_KD = dict(loss=6e-3, grad=5e-2, cos=0.983)
+TOL_BF16_DUAL = dict(loss=6e-3, grad=9e-2, cos=0.99)
+
+
+# frames whose arg-max over the engine's bf16-computed logits differs from the arg-max over the f32 oracle's logits (near-ties between
+# the handful of boosted units of build()): measured 16 / 750, 14 / 873, 12 / 763 = 1.6-2.1 %  -> bound 4 %
+BF16_MAX_FLIP_FRACTION = 0.04
 
 
 def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
@@ -173,7 +193,8 @@ def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
     else:
         flips = sum(int((pred_ref[b, :len4[b]] != int_ref.argmax_first_np(
             torch.softmax(enc.ctc_out.detach()[:, b], -1).numpy())[:len4[b]]).sum()) for b in range(len(len4)))
-        print("bf16: %d of %d frames pick another unit than the f32 oracle's logits would" % (flips, int(len4.sum())))
+        print("MEASURED bf16: %d of %d frames pick another unit than the f32 oracle's logits would" % (flips, int(len4.sum())))
+        assert flips <= BF16_MAX_FLIP_FRACTION * int(len4.sum()), (flips, int(len4.sum()))
     t = TOL[dtype]
     assert ss == oss
     assert rel(loss, oloss) <= t["loss"], ("loss", float(loss), float(oloss))
@@ -185,6 +206,19 @@ def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
     worst = compare_grads(engine_grads(model), ograds, t["grad"], t["cos"], what="%s %s" % (arch, dtype))
     print("%s %s: loss %.6f (oracle %.6f), worst gradient-norm error %.2e at %s, frames %s -> %s" %
           (arch, dtype, float(loss), float(oloss), worst[0], worst[1], list(len4), last["lengths_host"]))
+
+
+# ------------------------------------------------------------------------------------------------ Cfg2
+def test_cfg2_s_fp32_32x1000():
+    """BASELINE.json configs[1] at its full shape: s2t_transformer_s, 32 utterances x 1000 frames x 80 mel, fp32,
+    ctc_multi_loss with compression as in examples/speech_recognition/criterions/ctc_multi_loss.py:140-168"""
+    check_ctc_multi_loss("s2t_transformer_s", torch.float32, B=32, T=1000, L=30, lengths=None, seed=12)
+
+
+def test_cfg2_s_fp32_32x1000_ragged():
+    rs = np.random.RandomState(5)
+    lengths = sorted([1000] + [int(v) for v in rs.randint(300, 1000, 31)], reverse=True)
+    check_ctc_multi_loss("s2t_transformer_s", torch.float32, B=32, T=1000, L=30, lengths=lengths, seed=13)
 
 
 # ------------------------------------------------------------------------------------------------ Cfg3
@@ -239,7 +273,7 @@ def test_cfg5_m_knowledge_distillation(dtype):
         logits = s2t_ref.decoder_forward(Wg, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
         return (s2t_ref.kd_loss(logits, sample["target"], tidx, tlog, 0.6, 2.0, cfg["pad"]),)
     (oloss,), ograds = oracle_grads(W, run)
-    t = TOL[dtype]
+    t = TOL[dtype] if dtype == torch.float32 else TOL_BF16_KD
     assert ss == sample["ntokens"]
     assert rel(loss, oloss) <= t["loss"], (float(loss), float(oloss))
     compare_grads(engine_grads(model), ograds, t["grad"], t["cos"], what="kd %s" % dtype)
@@ -273,8 +307,9 @@ def test_shared_decoder_input_output_embedding(dtype):
     assert float(ograds["decoder.embed_tokens.weight"].norm()) > 0
 
 
-def test_cfg5_m_dual_decoder_loss():
-    a, task, model, crit, cfg, W = build("conv_transformer_dualdecoder_big2", torch.float32, criterion="cross_entropy_dualdecoder",
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_cfg5_m_dual_decoder_loss(dtype):
+    a, task, model, crit, cfg, W = build("conv_transformer_dualdecoder_big2", dtype, criterion="cross_entropy_dualdecoder",
                                          dual=True, encoder_layers=12, auxiliary_loss_weight=0.3, primary_loss_weight=0.7)
     sample = batch(task, 3, 1000, 30, 26, 8, lengths=[1000, 910, 505])
     tr = sample["transcript_target"]
@@ -284,10 +319,12 @@ def test_cfg5_m_dual_decoder_loss():
     loss, ss, log = crit(model, to_dev(sample))
     loss.backward()
     (oloss, olog, _, _), ograds = oracle_grads(W, lambda Wg: s2t_ref.dual_decoder_loss(Wg, cfg, sample, 0.1, 0.7, 0.3, training=True))
-    assert rel(loss, oloss) <= 1e-4, (float(loss), float(oloss))
+    t = TOL[dtype] if dtype == torch.float32 else TOL_BF16_DUAL
+    assert rel(loss, oloss) <= t["loss"], (float(loss), float(oloss))
     for k in ("primary_loss", "auxiliary_loss", "primary_nll_loss", "auxiliary_nll_loss"):
-        assert rel(log[k], olog[k]) <= 1e-4, k
-    compare_grads(engine_grads(model), ograds, 1e-3, 0.9999, what="dual")
+        assert rel(log[k], olog[k]) <= t["loss"], k
+    print("MEASURED dual %s: loss error %.3e" % (dtype, rel(loss, oloss)))
+    compare_grads(engine_grads(model), ograds, t["grad"], t["cos"], what="dual %s" % dtype)
 
 
 def test_cfg5_m_beam5_generation():
@@ -308,6 +345,50 @@ def test_cfg5_m_beam5_generation():
             assert h["tokens"].tolist() == ot.tolist()
             assert abs(float(h["score"]) - osc) < 1e-4
             np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), ops, atol=1e-4)
+
+
+def test_cfg5_m_beam5_generation_bf16():
+    """beam-5 on the m preset in bf16 mode.  A bf16 forward can legitimately order two near-tied candidates differently from the f32
+    oracle, so the statement that holds is about scores: (1) every hypothesis the engine returns, re-scored by the f32 oracle with
+    its tokens forced, has the positional scores the engine reported within BF16_GEN_ATOL; (2) the engine's best hypothesis of every
+    sentence is the oracle's best, or its oracle score is within BF16_GEN_ATOL of the oracle's best (a near-tie).  The number of
+    (sentence, rank) slots with identical tokens is printed, not bounded: on random-init weights the candidates of a beam are
+    near-ties throughout (measured: 0 of 15 identical while every score agrees to 6e-2 and the best hypotheses are 1e-2 apart)."""
+    from fbk_fairseq_st_amd.sequence_generator import SequenceGenerator
+    a, task, model, crit, cfg, W = build("s2t_transformer_m", torch.bfloat16, criterion="label_smoothed_cross_entropy")
+    sample = batch(task, 3, 1000, 8, 8, 9, lengths=[1000, 731, 402])
+    src, lens = sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"]
+    opts = dict(beam_size=5, max_len_a=0.0, max_len_b=24, min_len=1, len_penalty=1.0, unk_penalty=0.0, temperature=1.0)
+    model.eval()
+    gen = SequenceGenerator([model], task.target_dictionary, **opts)
+    hyps = gen.generate([model], dict(net_input=dict(src_tokens=src.to(DEV), src_lengths=lens.to(DEV))))
+    orc = s2t_ref.beam_search(W, cfg, src, lens, 5, 0.0, 24, 1, 1.0, 0.0, 1.0)
+    enc, _ = s2t_ref.encoder_forward(W, cfg, src, lens, training=False)
+    same = total = 0
+    worst_pos = worst_best = 0.0
+    for b, (hs, os_) in enumerate(zip(hyps, orc)):
+        assert len(hs) == len(os_) == 5
+        n = int(enc.src_lengths[b])
+        eo = enc.encoder_out[:n, b:b + 1]
+        rescored = []
+        for h in hs:
+            toks = h["tokens"].cpu()
+            prev = torch.cat([torch.tensor([2]), toks[:-1]]).view(1, -1)
+            lp = torch.log_softmax(s2t_ref.decoder_forward(W, cfg, prev, eo, None).float(), -1)[0]
+            pos = lp.gather(1, toks.view(-1, 1)).view(-1)
+            worst_pos = max(worst_pos, float((pos - h["positional_scores"].float().cpu()).abs().max()))
+            rescored.append(float(pos.sum()) / len(toks))
+        for h, (ot, osc, ops) in zip(hs, os_):
+            total += 1
+            same += int(h["tokens"].tolist() == ot.tolist())
+        if hs[0]["tokens"].tolist() != os_[0][0].tolist():
+            worst_best = max(worst_best, abs(rescored[0] - os_[0][1]))
+    print("MEASURED bf16 beam-5: %d of %d (sentence, rank) slots identical to the f32 oracle; positional scores within %.3e of the "
+          "oracle's re-scoring; best-hypothesis near-tie gap %.3e" % (same, total, worst_pos, worst_best))
+    assert worst_pos <= BF16_GEN_ATOL and worst_best <= BF16_GEN_ATOL
+
+
+BF16_GEN_ATOL = 0.12            # log-probability units (scores are ~ -9 = -ln 8000): 2x the measured 6.0e-2
 
 
 def test_cfg5_m_two_phase_generation():

@@ -1,0 +1,168 @@
+"""The reference's own Trainer / SequenceGenerator / checkpoints over the plug-in (drop-in boundary).
+
+Fixtures (made in the build container by running the REAL reference, scripts committed next to them):
+  tests/golden/reference_trainer.json   make_trainer_fixture.py: fairseq's unchanged `Trainer.train_step` drives a plug-in model --
+                                        `--optimizer adam` resolves to the arena Adam, `p.grad` stays aliased through the reference's
+                                        `zero_grad`, three updates land where clip + Adam + inverse-sqrt predict, checkpoint resume;
+                                        the reference's `SequenceGenerator` over the plug-in decoder reproduces generate.npz
+  tests/golden/param_order.json         make_param_order_fixture.py: `named_parameters()` order of the reference's models (the key
+                                        space of its optimizer checkpoints) + a reference checkpoint crossing over both ways
+Here, without the reference: the package's restatement of that parameter order, the reference-layout optimizer state round trip of
+this package's own Trainer, the fixtures' claims; with /root/reference present both scripts are re-run (`--check`).
+The HIP side is replaced by tests/cpu_stubs.py (host logic is the subject; the kernels are covered by the -m gpu tests).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import cpu_stubs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+ORDER = json.load(open(os.path.join(HERE, "golden", "param_order.json")))
+TRAINER = json.load(open(os.path.join(HERE, "golden", "reference_trainer.json")))
+HAVE_REF = os.path.isdir("/root/reference/fairseq")
+
+
+def _build(variant, D=32, H=2, Ff=64, EL=2, DL=1):
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import apply_arch, namespace
+    kw = dict(arch="conv_transformer", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy", label_smoothing=0.1,
+              ctc_compress_out=False, ctc_encoder_layer=1, ctc_weight=1.0, encoder_embed_dim=D, encoder_ffn_embed_dim=Ff,
+              encoder_attention_heads=H, encoder_layers=EL, decoder_layers=DL, decoder_embed_dim=D, decoder_ffn_embed_dim=Ff,
+              decoder_attention_heads=H, no_attn_2d=True, input_feat_per_channel=80, lr=[1e-3], adam_betas="(0.9, 0.98)", adam_eps=1e-8,
+              weight_decay=0.0, clip_norm=5.0, warmup_updates=10, seed=5)
+    if variant == "ctc_compress":
+        kw["ctc_compress_out"] = True
+    elif variant == "attn2d_distance_penalty":
+        kw.update(no_attn_2d=False, distance_penalty="log")
+    elif variant == "shared_embeddings":
+        kw["share_decoder_input_output_embed"] = True
+    elif variant == "dual_decoder":
+        kw.update(arch="conv_transformer_dualdecoder", criterion="cross_entropy_dualdecoder")
+    a = namespace(**kw)
+    apply_arch(a)
+    tgt, src = Dictionary.synthetic(96), Dictionary.synthetic(59)
+    src.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationCTCTask(a, tgt, src)
+    return a, task, task.build_model(a), task.build_criterion(a)
+
+
+@pytest.mark.parametrize("variant", sorted(ORDER["orders"]))
+def test_reference_parameter_order(variant):
+    a, task, model, crit = _build(variant)
+    assert model.reference_parameter_names() == ORDER["orders"][variant]["model"]
+    assert [n for n, _ in crit.named_parameters()] == ORDER["orders"][variant]["criterion"]
+    # every reference name has a home in the fused arena layout
+    from fbk_fairseq_st_amd.conv_transformer import reference_slot
+    shapes = model.hp.param_shapes()
+    for n in model.reference_parameter_names():
+        assert reference_slot(n)[0] in shapes, n
+
+
+def test_optimizer_state_round_trip_in_the_reference_layout(tmp_path):
+    """Trainer.save_checkpoint writes a torch.optim-style state over the reference's parameter order; a fresh trainer resumes with it"""
+    from fbk_fairseq_st_amd.trainer import Trainer
+    a, task, model, crit = _build("ctc_compress")
+    with cpu_stubs.cpu_kernels():
+        tr = Trainer(a, task, model, crit, device="cpu", compute_dtype=torch.float32)
+        g = torch.Generator().manual_seed(0)
+        tr.arena.exp_avg.copy_(torch.randn(tr.arena.numel, generator=g))
+        tr.arena.exp_avg_sq.copy_(torch.rand(tr.arena.numel, generator=g))
+        tr.optimizer.step_count, tr.num_updates = 7, 7
+        path = str(tmp_path / "checkpoint_last.pt")
+        tr.save_checkpoint(path, {"train_iterator": {"epoch": 2}})
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        names = tr.optimizer_parameter_names()
+        last = ck["last_optimizer_state"]
+        assert ck["optimizer_history"][-1]["optimizer_name"] == "FairseqAdam"
+        assert sorted(last["state"]) == list(range(len(names))) and last["param_groups"][0]["params"] == list(range(len(names)))
+        D = a.encoder_embed_dim
+        iq, ik = names.index("encoder.layers.1.self_attn.q_proj.weight"), names.index("decoder.layers.0.encoder_attn.v_proj.bias")
+        assert tuple(last["state"][iq]["exp_avg"].shape) == (D, D) and tuple(last["state"][ik]["exp_avg"].shape) == (D,)
+        fused = tr.arena._view(tr.arena.exp_avg, "encoder.layers.1.self_attn.qkv.weight")
+        assert torch.equal(last["state"][iq]["exp_avg"], fused[:D])                     # q block of the fused q|k|v tensor
+        assert all(int(s["step"]) == 7 for s in last["state"].values())
+        a2, task2, model2, crit2 = _build("ctc_compress")
+        tr2 = Trainer(a2, task2, model2, crit2, device="cpu", compute_dtype=torch.float32)
+        assert tr2.load_checkpoint(path) == {"train_iterator": {"epoch": 2}}
+        assert tr2.num_updates == 7 and tr2.optimizer.step_count == 7
+        # the arena's alignment gaps between parameters hold no state: compare parameter by parameter
+        for n in tr.arena.slices:
+            assert torch.equal(tr2.arena._view(tr2.arena.exp_avg, n), tr.arena._view(tr.arena.exp_avg, n)), n
+            assert torch.equal(tr2.arena._view(tr2.arena.exp_avg_sq, n), tr.arena._view(tr.arena.exp_avg_sq, n)), n
+            assert torch.equal(tr2.arena.p(n), tr.arena.p(n)), n
+        # a state whose group size does not match is refused with torch's message, not silently mis-assigned
+        bad = {"state": {}, "param_groups": [dict(last["param_groups"][0], params=list(range(3)))]}
+        with pytest.raises(ValueError, match="doesn't match the size"):
+            tr2.optimizer.load_state_dict(bad, names)
+
+
+def test_fixture_reference_trainer_trains_the_plugin():
+    t = TRAINER["trainer"]
+    assert t["adam_is_the_arena_adam"] and t["is_fairseq_optimizer"] and t["optimizer_class_name"] == "FairseqAdam"
+    assert [u["num_updates"] for u in t["updates"]] == [1, 2, 3]
+    for u in t["updates"]:
+        assert u["grad_still_aliases_arena"] and u["gnorm"] == u["gnorm_expected"]
+        assert {"loss", "nll_loss"} <= set(u["logged_keys"])
+    c = t["checkpoint"]
+    assert c["optimizer_name"] == "FairseqAdam" and c["n_state_entries"] == c["n_reference_params"] and c["steps"] == [3]
+    assert c["extra_state_round_trip"] and c["num_updates_restored"] == 3
+    g = TRAINER["reference_sequence_generator"]
+    assert g["a"]["tokens_identical"] and g["b"]["tokens_identical"]
+    x = ORDER["checkpoint_crossover"]
+    assert x["weights_identical_both_ways"] and x["moments_identical_both_ways"] and x["parameters_with_adam_state"] > 70
+
+
+def test_toy_engine_gradients_are_the_autograd_gradients():
+    """the stand-in engine the trainer fixture runs on computes what cpu_stubs.toy_forward defines (so the fixture's 'expected' side,
+    which differentiates toy_forward independently, is a real check of the plumbing in between)"""
+    from oracle import s2t_ref
+    a, task, model, crit = _build("plain")
+    a.criterion = "label_smoothed_cross_entropy"
+    crit = task.build_criterion(a)
+    model.materialize("cpu", torch.float32)
+    model.engine = cpu_stubs.ToyEngine(model)
+    g = torch.Generator().manual_seed(1)
+    B, T, L, V = 2, 21, 5, len(task.target_dictionary)
+    tgt = torch.randint(4, V, (B, L), generator=g)
+    prev = torch.cat([torch.full((B, 1), 2, dtype=torch.long), tgt[:, :-1]], 1)
+    sample = {"ntokens": B * L, "target": tgt, "net_input": {"src_tokens": torch.randn(B, T, 80, generator=g),
+                                                            "src_lengths": torch.full((B,), T, dtype=torch.long), "prev_output_tokens": prev}}
+    with cpu_stubs.cpu_kernels():
+        model.train()
+        loss, ss, log = crit(model, sample)
+        loss.backward()
+    W = {n: model.arena.p(n).detach().clone().requires_grad_(True) for n in model.arena.slices}
+    _, logits = cpu_stubs.toy_forward(W, sample["net_input"]["src_tokens"], prev)
+    ref, _ = s2t_ref.label_smoothed_nll(logits.transpose(0, 1), tgt, 0.1, 1)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    for n in ("encoder.fc3.weight", "decoder.embed_tokens.weight", "decoder.output_projection.weight"):
+        assert torch.allclose(model.arena.g(n), W[n].grad, atol=1e-6), n
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two rank processes with the torch.distributed.run environment (here, with
+    no GPU, each of them stops at the device check -- which is the evidence that two were started)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the ranks would really start")
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") == 2, r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+@pytest.mark.parametrize("script", ["make_trainer_fixture.py", "make_param_order_fixture.py"])
+def test_fixtures_regenerate_identically_through_the_reference(script):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "golden", script), "--check"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
