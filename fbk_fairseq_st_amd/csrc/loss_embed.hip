@@ -421,6 +421,35 @@ extern "C" int s2t_log_softmax(int dtype, const void* logits, float* out, long r
     return S2T_OK;
 }
 
+// Ensemble of M models (fairseq/sequence_generator.py:757-768): log of the MEAN probability = logsumexp over the members' log-
+// probabilities - log M, element-wise over the [hypotheses, V] rows.  One pass, HBM-bound; members by pointer (M <= 8).
+struct EnsPtrs { const float* p[8]; };
+__global__ __launch_bounds__(256) void ensemble_lse_kernel(EnsPtrs in, int n, float* __restrict__ out, size_t numel, float log_n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (size_t)gridDim.x * 256) {
+        float x[8];
+        float m = -INFINITY;
+        for (int j = 0; j < n; ++j) { x[j] = in.p[j][i]; m = fmaxf(m, x[j]); }
+        float r = -INFINITY;
+        if (m > -INFINITY) {
+            float s = 0.f;
+            for (int j = 0; j < n; ++j) s += expf(x[j] - m);
+            r = m + logf(s) - log_n;
+        }
+        out[i] = r;
+    }
+}
+extern "C" int s2t_ensemble_lse(int n, const float* const* lprobs, float* out, size_t numel, void* stream) {
+    if (numel == 0) return S2T_OK;
+    if (n < 1 || n > 8 || !lprobs || !out) return S2T_EINVAL;
+    EnsPtrs ptrs;
+    for (int j = 0; j < 8; ++j) { ptrs.p[j] = j < n ? lprobs[j] : nullptr; if (j < n && !lprobs[j]) return S2T_EINVAL; }
+    size_t blocks = (numel + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ensemble_lse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ptrs, n, out, numel, logf((float)n));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
 
 // ------------------------------------------------------------------ top-k of logit rows (teacher dump for knowledge distillation)
 // vals[row][0..K) = the K largest logits of the row in descending order, idx = their columns (ties: lower column first)

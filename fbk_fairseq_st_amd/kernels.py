@@ -484,6 +484,16 @@ def log_softmax(logits, temperature=1.0):
     return out
 
 
+def ensemble_lse(lprobs):
+    """list of f32 [rows, V] log-probabilities (one per ensemble member) -> log of their mean probability, element-wise"""
+    n = len(lprobs)
+    assert 1 <= n <= 8 and all(t.dtype == torch.float32 and t.is_contiguous() and t.shape == lprobs[0].shape for t in lprobs)
+    out = torch.empty_like(lprobs[0])
+    arr = (ctypes.c_void_p * n)(*[L.ptr(t) for t in lprobs])
+    L.check(_lib().s2t_ensemble_lse(n, ctypes.addressof(arr), L.ptr(out), out.numel(), L.stream()), "s2t_ensemble_lse")
+    return out
+
+
 def embed_bwd(tokens, dout, dW, scale, pad):
     B, Ln = tokens.shape
     D = dW.shape[1]

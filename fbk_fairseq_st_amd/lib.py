@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5              # s2t_abi_version() of the library this binding was written against
+ABI_VERSION = 6              # s2t_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD, ACT_RELU_MASK, ACT_RELU_BWD_MASK = 0, 1, 2, 3, 4, 5, 6
 
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
@@ -58,6 +58,7 @@ SIGNATURES = {
     "s2t_kd_loss": [c_int, P, P, P, P, P, P, c_long, c_int, c_int, c_int, c_float, c_float, c_int, c_float, P],
     "s2t_embed_fwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P],
     "s2t_log_softmax": [c_int, P, P, c_long, c_int, c_int, c_float, P],
+    "s2t_ensemble_lse": [c_int, P, P, c_size_t, P],
     "s2t_embed_bwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
     "s2t_act_bwd": [c_int, P, P, P, c_size_t, c_int, c_float, c_ull, P],
     "s2t_add_inplace": [c_int, P, P, c_size_t, P],

@@ -12,8 +12,9 @@ batch, so the decoder state never needs the `batch_idxs` re-indexing and the enc
 re-gathered; every floating-point operation of a step (embedding, the six decoder layers with
 in-place K/V rows, output projection, log-softmax) is a libs2t_hip.so kernel; torch is used for the
 integer selection bookkeeping (top-k, gathers of token/score rows) exactly as the reference does.
-Ensembles, sampling, prefix tokens, n-gram blocking and attention/alignment output are not part of this
-path (they raise).  `TwoPhaseSequenceGenerator` runs the same loop twice for dual-decoder
+Ensembles (EnsembleModel.forward_decoder :711-770: every member runs its own encoder and incremental decoder, the
+log-probabilities meet in one logsumexp kernel), prefix tokens (:270-280,449-476) and n-gram blocking (:617-650) follow the
+reference; sampling and attention / alignment output are not part of this path (they raise).  `TwoPhaseSequenceGenerator` runs the same loop twice for dual-decoder
 models: transcripts with the auxiliary decoder, then translations seeded by the transcript scores.
 """
 import math
@@ -61,8 +62,8 @@ class SequenceGenerator:
                  unk_penalty=0.0, retain_dropout=False, temperature=1.0, match_source_len=False, no_repeat_ngram_size=0,
                  search_strategy=None, eos=None):
         self.models = list(models) if isinstance(models, (list, tuple)) else [models]
-        if len(self.models) != 1:
-            raise NotImplementedError("ensembles are outside the S2T hot path")
+        if not 1 <= len(self.models) <= 8:
+            raise ValueError("an ensemble of 1..8 models (s2t_ensemble_lse), got %d" % len(self.models))
         self.pad, self.unk = tgt_dict.pad(), tgt_dict.unk()
         self.eos = tgt_dict.eos() if eos is None else eos
         self.vocab_size = len(tgt_dict)
@@ -71,32 +72,32 @@ class SequenceGenerator:
         self.normalize_scores, self.len_penalty, self.unk_penalty = normalize_scores, len_penalty, unk_penalty
         self.temperature = temperature
         assert temperature > 0, "--temperature must be greater than 0"
-        if match_source_len or no_repeat_ngram_size > 0 or retain_dropout:
-            raise NotImplementedError("match_source_len / no_repeat_ngram_size / retain_dropout are outside the S2T hot path")
+        if match_source_len or retain_dropout:
+            raise NotImplementedError("match_source_len / retain_dropout are outside the S2T hot path")
+        self.no_repeat_ngram_size = int(no_repeat_ngram_size)
         self.search = BeamSearch(tgt_dict) if search_strategy is None else search_strategy
 
     # ------------------------------------------------------------------ API of the reference
     @torch.no_grad()
     def generate(self, models, sample, prefix_tokens=None, bos_token=None, **unused):
-        if prefix_tokens is not None:
-            raise NotImplementedError("prefix_tokens")
-        model = self.models[0]                                            # the reference also ignores `models` here (:149-161)
-        was_training = model.training
-        model.eval()                                                      # sequence_generator.py:86-87
+        was_training = [m.training for m in self.models]                  # the reference also ignores `models` here (:149-161)
+        for m in self.models:
+            m.eval()                                                      # sequence_generator.py:86-87
         try:
-            return self._generate(model, sample, bos_token)
+            return self._generate(self.models[0], sample, bos_token, prefix_tokens=prefix_tokens)
         finally:
-            model.train(was_training)
+            for m, t in zip(self.models, was_training):
+                m.train(t)
 
-    def _generate(self, model, sample, bos_token):
+    def _generate(self, model, sample, bos_token, prefix_tokens=None):
         net_input = sample["net_input"]
         src_tokens = net_input["src_tokens"]
         B, src_len = src_tokens.shape[0], src_tokens.shape[1]
-        max_len = min(int(self.max_len_a * src_len + self.max_len_b), model.max_decoder_positions() - 1)
+        max_len = min(int(self.max_len_a * src_len + self.max_len_b), min(m.max_decoder_positions() for m in self.models) - 1)
         assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
-        enc = self._encode(model, net_input)
-        hyps = self._beam_search(model.decoder, enc, B, src_tokens.device, max_len, self.search, bos_token,
-                                 self.pad, self.unk, self.eos, self.vocab_size)
+        encs = [self._encode(m, net_input) for m in self.models]
+        hyps = self._beam_search([m.decoder for m in self.models], encs, B, src_tokens.device, max_len, self.search, bos_token,
+                                 self.pad, self.unk, self.eos, self.vocab_size, prefix_tokens=prefix_tokens)
         for hs in hyps:
             for h in hs:
                 h.pop("origin")
@@ -109,12 +110,17 @@ class SequenceGenerator:
         order0 = torch.arange(B, device=net_input["src_tokens"].device).repeat_interleave(self.beam_size)
         return model.encoder.reorder_encoder_out(enc, order0)
 
-    def _beam_search(self, decoder, enc, B, dev, max_len, search, bos_token, pad, unk, eos, V, prev_scores=None):
-        """The search loop of sequence_generator.py:198-500 over `decoder` (incremental HIP decoder).  prev_scores [B, beam, 1]:
-        starting scores of the slots for a HierarchicalBeamSearch.  Every hypothesis also records `origin`, the slot of step 0 it
-        descends from.  Returns per sentence the finalized hypotheses, best first."""
+    def _beam_search(self, decoder, enc, B, dev, max_len, search, bos_token, pad, unk, eos, V, prev_scores=None, prefix_tokens=None):
+        """The search loop of sequence_generator.py:198-500 over `decoder` (incremental HIP decoder; a LIST of decoders with a list
+        of encoder outputs = an ensemble).  prev_scores [B, beam, 1]: starting scores of the slots for a HierarchicalBeamSearch.
+        prefix_tokens int64 [B, P]: forced first tokens (pad = free).  Every hypothesis also records `origin`, the slot of step 0
+        it descends from.  Returns per sentence the finalized hypotheses, best first."""
         beam = self.beam_size
-        state = decoder.begin_incremental(enc, max_len + 1)
+        decoders = list(decoder) if isinstance(decoder, (list, tuple)) else [decoder]
+        encs = list(enc) if isinstance(decoder, (list, tuple)) else [enc]
+        states = [d.begin_incremental(e, max_len + 1) for d, e in zip(decoders, encs)]
+        if prefix_tokens is not None:
+            prefix_tokens = prefix_tokens.to(dev)
 
         N = B * beam
         scores = torch.zeros((N, max_len + 1), dtype=torch.float32, device=dev)
@@ -131,18 +137,24 @@ class SequenceGenerator:
 
         reorder = None
         for step in range(max_len + 1):                                   # one extra step for the EOS marker
-            if reorder is not None:
-                decoder.reorder_incremental(state, reorder)
-            logits = decoder.step_incremental(state, tokens[:, step])
-            lprobs = K.log_softmax(logits, self.temperature)              # f32 [N, V]
+            member = []
+            for d, st in zip(decoders, states):
+                if reorder is not None:
+                    d.reorder_incremental(st, reorder)
+                member.append(K.log_softmax(d.step_incremental(st, tokens[:, step]), self.temperature))      # f32 [N, V]
+            lprobs = member[0] if len(member) == 1 else K.ensemble_lse(member)       # log of the members' mean probability
             lprobs[lprobs != lprobs] = -math.inf
             lprobs[:, pad] = -math.inf
             lprobs[:, unk] -= self.unk_penalty
             if step >= max_len:
                 lprobs[:, :eos] = -math.inf
                 lprobs[:, eos + 1:] = -math.inf
-            elif step < self.min_len:
+            if prefix_tokens is not None and step < prefix_tokens.shape[1] and step < max_len:
+                lprobs, tokens, scores = self._prefix_tokens(step, lprobs, scores, tokens, prefix_tokens, beam, pad, eos)
+            elif step < self.min_len:                                      # (does not apply inside a prefix: :270-280)
                 lprobs[:, eos] = -math.inf
+            if self.no_repeat_ngram_size > 0:
+                self._no_repeat_ngram(tokens, lprobs, step)
 
             if prev_scores is not None:
                 cand_scores, cand_tok, cand_beam = search.step(step, lprobs.view(B, beam, V), scores.view(B, beam, -1), prev_scores)
@@ -181,6 +193,45 @@ class SequenceGenerator:
             idx = sorted(range(len(hyps)), key=lambda i: hyps[i]["score"].item())
             out.append([hyps[i] for i in reversed(idx)])
         return out
+
+    @staticmethod
+    def _prefix_tokens(step, lprobs, scores, tokens, prefix_tokens, beam, pad, eos):
+        """sequence_generator.py:449-481: rows whose sentence has a forced token at `step` may only continue with it (its own
+        log-probability kept); when the forced token is EOS every slot of the sentence becomes a copy of the first one.
+        Index bookkeeping only (gather / scatter / fill)."""
+        ptok = prefix_tokens[:, step].unsqueeze(-1).repeat(1, beam).view(-1)
+        plp = lprobs.gather(-1, ptok.unsqueeze(-1))
+        mask = ptok.ne(pad)
+        forced = torch.full_like(lprobs, -math.inf).scatter_(-1, ptok.unsqueeze(-1), plp)
+        lprobs = torch.where(mask.unsqueeze(-1), forced, lprobs)
+        eos_mask = ptok.eq(eos)
+        if bool(eos_mask.any()):
+            rows = eos_mask.view(-1, beam)[:, 0]
+            first = tokens[eos_mask].view(-1, beam, tokens.shape[-1])[:, 0, 1:step + 1]
+            assert bool((first == prefix_tokens[rows][:, :step]).all())
+
+            def rep(t):
+                t = t.view(-1, beam, t.shape[-1])
+                t[rows] = t[rows][:, :1, :]
+                return t.view(-1, t.shape[-1])
+            tokens, scores, lprobs = rep(tokens), rep(scores), rep(lprobs)
+        return lprobs, tokens, scores
+
+    def _no_repeat_ngram(self, tokens, lprobs, step):
+        """sequence_generator.py:596-650: a hypothesis may not produce a token that completes an n-gram it already contains.
+        Host-side integer work on the token rows, as in the reference (one device-to-host copy of `tokens` per step)."""
+        n = self.no_repeat_ngram_size
+        if step + 2 - n < 0:
+            return
+        rows = tokens[:, :step + 1].tolist()
+        ban_r, ban_c = [], []
+        for r, g in enumerate(rows):
+            head = g[len(g) - (n - 1):] if n > 1 else []
+            for j in range(len(g) - n + 1):
+                if g[j:j + n - 1] == head:
+                    ban_r.append(r); ban_c.append(g[j + n - 1])
+        if ban_r:
+            lprobs[torch.tensor(ban_r, device=lprobs.device), torch.tensor(ban_c, device=lprobs.device)] = -math.inf
 
     def _finalize(self, step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len, eos, origin):
         """sequence_generator.py:502-600 finalize_hypos: hypotheses ending in EOS among the top `beam` candidates."""
@@ -225,7 +276,10 @@ class TwoPhaseSequenceGenerator(SequenceGenerator):
         if self.beam_size > self.src_vocab_size - 1:
             raise ValueError("beam larger than the transcript vocabulary")
 
-    def _generate(self, model, sample, bos_token):
+    def _generate(self, model, sample, bos_token, prefix_tokens=None):
+        if prefix_tokens is not None or len(self.models) != 1:
+            raise NotImplementedError("the two-phase generator takes one dual-decoder model and no prefix tokens "
+                                      "(twophase_sequence_generator.py:127-170)")
         net_input = sample["net_input"]
         src_tokens = net_input["src_tokens"]
         dev = src_tokens.device

@@ -250,6 +250,9 @@ int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float
                   int B, int L, int D, float scale, int pad, int pos_offset, void* stream);
 /* f32 log-probabilities of one decoding step (fairseq/sequence_generator.py:711-768) */
 int s2t_log_softmax(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream);
+/* ensemble of n <= 8 models (fairseq/sequence_generator.py:757-768 EnsembleModel.forward_decoder): out = logsumexp_j lprobs[j] - log n,
+ * element-wise over numel f32 values; `lprobs` is a HOST array of n device pointers */
+int s2t_ensemble_lse(int n, const float* const* lprobs, float* out, size_t numel, void* stream);
 int s2t_embed_bwd(int dtype, const long long* tokens, const void* dout, float* dW, int B, int L, int D,
                   float scale, int pad, void* stream);
 /* out = dropout(dy) * act'(y): act 1 = relu (y = post-activation), act 2 = gelu (y = pre-activation); the dropout (p_drop > 0, mask

@@ -249,7 +249,10 @@ def encoder_forward(W, cfg, src_tokens, src_lengths, training=False, trace=None,
     mask = length_mask(lengths, x.shape[0])
     x_ctc = ctc_mask = pred = new_lengths = None
     states = []
-    for l in range(cfg["enc_layers"]):
+    keep = cfg.get("enc_keep")            # LayerDrop decisions of this pass (conv_transformer.py:238-243): a dropped layer is skipped,
+    for l in range(cfg["enc_layers"]):    # together with the CTC compression and the encoder_states entry that hang off it
+        if keep is not None and not keep[l]:
+            continue
         x = encoder_layer(W, cfg, "encoder.layers.%d." % l, x, mask)
         if cfg["ctc_layer"] and cfg["ctc_layer"] == l + 1:
             ctc_mask = mask
@@ -278,7 +281,10 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
     self_pad = prev_output_tokens.eq(pad)
     self_pad = self_pad if bool(self_pad.any()) else None                     # :739-741
     pre = cfg["dec_pre_ln"]
+    dkeep = cfg.get("dec_keep")           # --decoder-layerdrop (fairseq/modules/layer_drop.py:39-44)
     for l in range(cfg["dec_layers"]):
+        if dkeep is not None and not dkeep[l]:
+            continue
         p = pfx + "layers.%d." % l
         r = x
         if pre:
@@ -309,27 +315,45 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
 
 # ------------------------------------------------------------------ generation (a22)
 def _beam_search_sentence(W, cfg, eo, n, beam, max_len, min_len, len_penalty, unk_penalty, temperature, normalize, eos, unk,
-                          pfx="decoder.", prev_scores=None):
+                          pfx="decoder.", prev_scores=None, prefix=None, no_repeat_ngram=0):
     """One sentence of SequenceGenerator._generate + BeamSearch.step (fairseq/sequence_generator.py:163-500, fairseq/search.py:50-85),
     without incremental state (the full prefix is re-decoded every step).  prev_scores [beam]: HierarchicalBeamSearch.step
     (twophase_sequence_generator.py:22-49) -- at step 0 EVERY beam slot competes, each starting from its own score.
+    W / eo / n may be LISTS (one entry per model of an ensemble, EnsembleModel.forward_decoder :711-770: the models' log-probabilities
+    are averaged in probability space, logsumexp - log M); prefix: forced first target tokens of this sentence (1-D, pad = free,
+    _prefix_tokens :449-476); no_repeat_ngram: n-gram blocking (_no_repeat_ngram :617-650).
     Returns (tokens, score, positional_scores, origin slot) tuples sorted best first."""
     pad = cfg["pad"]
+    Ws, eos_, ns = (W, eo, n) if isinstance(W, (list, tuple)) else ([W], [eo], [n])
     toks = torch.full((beam, 1), eos, dtype=torch.long)
     cum = torch.zeros((beam, 0))
     blacklist = [False] * beam
     origin = list(range(beam))
     fin = []
     for step in range(max_len + 1):
-        logits = decoder_forward(W, cfg, toks, eo.expand(n, beam, eo.shape[2]), None, pfx=pfx)[:, -1, :]
-        lp = torch.log_softmax(logits / temperature, dim=-1)
+        lps = [torch.log_softmax(decoder_forward(Wi, cfg, toks, ei.expand(ni, beam, ei.shape[2]), None, pfx=pfx)[:, -1, :] / temperature,
+                                 dim=-1) for Wi, ei, ni in zip(Ws, eos_, ns)]
+        lp = lps[0] if len(lps) == 1 else torch.logsumexp(torch.stack(lps, 0), 0) - math.log(len(lps))
         lp[lp != lp] = -math.inf
         lp[:, pad] = -math.inf
         lp[:, unk] -= unk_penalty
         if step >= max_len:
             keep = lp[:, eos].clone(); lp[:] = -math.inf; lp[:, eos] = keep
+        if prefix is not None and step < prefix.numel() and step < max_len:
+            t = int(prefix[step])
+            if t != pad:                                   # every slot may only continue with the forced token
+                keep = lp[:, t].clone(); lp[:] = -math.inf; lp[:, t] = keep
+            if t == eos:                                   # :462-475: all slots become copies of the first one
+                toks = toks[:1].expand(beam, -1).clone(); cum = cum[:1].expand(beam, -1).clone(); lp = lp[:1].expand(beam, -1).clone()
         elif step < min_len:
             lp[:, eos] = -math.inf
+        if no_repeat_ngram > 0 and step + 2 - no_repeat_ngram >= 0:
+            for i in range(beam):                          # tokens that would complete an n-gram this hypothesis already contains
+                g = toks[i].tolist()
+                head = g[len(g) - (no_repeat_ngram - 1):] if no_repeat_ngram > 1 else []
+                for j in range(len(g) - no_repeat_ngram + 1):
+                    if g[j:j + no_repeat_ngram - 1] == head:
+                        lp[i, g[j + no_repeat_ngram - 1]] = -math.inf
         V = lp.shape[1]
         if step == 0:
             cand = lp[0] if prev_scores is None else (lp + prev_scores.view(-1, 1)).reshape(-1)
@@ -364,17 +388,20 @@ def _beam_search_sentence(W, cfg, eo, n, beam, max_len, min_len, len_penalty, un
 
 
 def beam_search(W, cfg, src_tokens, src_lengths, beam, max_len_a=0.0, max_len_b=200, min_len=1, len_penalty=1.0,
-                unk_penalty=0.0, temperature=1.0, normalize=True, eos=2, unk=3, max_positions=1000):
-    """SequenceGenerator.generate, one sentence at a time.  Returns per sentence a list of (tokens, score, positional_scores)
-    sorted best first."""
-    enc, _ = encoder_forward(W, cfg, src_tokens, src_lengths, training=False)
+                unk_penalty=0.0, temperature=1.0, normalize=True, eos=2, unk=3, max_positions=1000, prefix_tokens=None,
+                no_repeat_ngram_size=0):
+    """SequenceGenerator.generate, one sentence at a time.  W: one weight dict or a list of them (ensemble of models of one
+    configuration).  Returns per sentence a list of (tokens, score, positional_scores) sorted best first."""
+    Ws = list(W) if isinstance(W, (list, tuple)) else [W]
+    encs = [encoder_forward(Wi, cfg, src_tokens, src_lengths, training=False)[0] for Wi in Ws]
     B, src_len = src_tokens.shape[0], src_tokens.shape[1]
     max_len = min(int(max_len_a * src_len + max_len_b), max_positions - 1)
     results = []
     for b in range(B):
-        n = int(enc.src_lengths[b])
-        eo = enc.encoder_out[:n, b:b + 1]                                            # this sentence's frames only: no padding mask needed
-        hyps = _beam_search_sentence(W, cfg, eo, n, beam, max_len, min_len, len_penalty, unk_penalty, temperature, normalize, eos, unk)
+        ns = [int(e.src_lengths[b]) for e in encs]
+        eos_ = [e.encoder_out[:n, b:b + 1] for e, n in zip(encs, ns)]                # this sentence's frames only: no padding mask needed
+        hyps = _beam_search_sentence(Ws, cfg, eos_, ns, beam, max_len, min_len, len_penalty, unk_penalty, temperature, normalize, eos, unk,
+                                     prefix=None if prefix_tokens is None else prefix_tokens[b], no_repeat_ngram=no_repeat_ngram_size)
         results.append([h[:3] for h in hyps])
     return results
 

@@ -473,6 +473,62 @@ def run_generate_case():
     np.savez_compressed(os.path.join(OUT, "generate.npz"), **out)
 
 
+def run_generate_ext_case():
+    """SequenceGenerator features around the plain beam search (fairseq/sequence_generator.py): `e` an ENSEMBLE of two models
+    (EnsembleModel.forward_decoder :711-770; configuration of generate.npz case `b` without CTC compression -- the reference averages
+    the members' attention maps, so their encoder lengths must agree -- weights from seeds 700 / 750), `p` PREFIX TOKENS of
+    different lengths incl. one sentence without (:270-280,449-476) and `n` n-gram blocking (--no-repeat-ngram-size 2, :617-650)
+    on the configuration of case `a` (CTC compression after layer 2, seed 600)."""
+    from fairseq.sequence_generator import SequenceGenerator
+
+    def mk(tagname, m, seeds):
+        crit = ("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy") if m["compress"] else \
+               ("label_smoothed_cross_entropy", "--label-smoothing", "0.1")
+        cfg = s2t_ref.default_cfg(D=m["D"], heads=m["H"], ffn=m["Ff"], enc_layers=m["EL"], dec_layers=m["DL"],
+                                  ctc_layer=m["ctc_layer"] if m["compress"] else 0)
+        models = []
+        for seed in seeds:
+            args, task, model, criterion, V_src, V_tgt = build("genx%s%d" % (tagname, seed), m["D"], m["H"], m["Ff"], m["EL"], m["DL"],
+                                                               m["ctc_layer"], m["compress"], criterion=crit)
+            W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=m["compress"]), seed)
+            W["decoder.output_projection.weight"][2] *= 4.0
+            load_weights(model, criterion, W)
+            model.eval()
+            models.append(model)
+        s = make_sample(seeds[0] + 1, m["lens"], [4] * len(m["lens"]), [3] * len(m["lens"]), V_src, V_tgt, V_src - 1)
+        return task, models, s, V_src, V_tgt
+
+    ma = dict(D=64, H=2, Ff=128, EL=3, DL=2, ctc_layer=2, compress=True, lens=[61, 50, 37])
+    mb = dict(D=64, H=2, Ff=128, EL=2, DL=2, ctc_layer=0, compress=False, lens=[48, 48, 33])
+    task_a, models_a, s_a, V_src, V_tgt = mk("a", ma, (600,))
+    task_b, models_b, s_b, _, _ = mk("b", mb, (700, 750))
+    prefix = torch.tensor([[17, 45, 9], [33, 1, 1], [1, 1, 1]])            # pad = 1: free from there on
+    cases = {"e": (task_b, models_b, s_b, dict(beam_size=4, max_len_a=0, max_len_b=10, min_len=1), None, mb, (700, 750)),
+             "p": (task_a, models_a, s_a, dict(beam_size=4, max_len_a=0, max_len_b=10, min_len=1), prefix, ma, (600,)),
+             "n": (task_a, models_a, s_a, dict(beam_size=4, max_len_a=0, max_len_b=14, min_len=8, no_repeat_ngram_size=2), None, ma, (600,))}
+    out = {"prefix_tokens": prefix.numpy()}
+    for tag, (task, ms, s, g, pre, m, seeds) in cases.items():
+        gen = SequenceGenerator(ms, task.target_dictionary, **g)
+        hyps = gen.generate(ms, to_ref_sample(s), prefix_tokens=pre)
+        B, beam = len(hyps), g["beam_size"]
+        Lmax = max(len(h["tokens"]) for hs in hyps for h in hs)
+        tok = np.full((B, beam, Lmax), -1, np.int64); sc = np.full((B, beam), np.nan, np.float64)
+        ps = np.zeros((B, beam, Lmax), np.float32); nh = np.zeros((B,), np.int64)
+        for b, hs in enumerate(hyps):
+            nh[b] = len(hs)
+            for i, h in enumerate(hs):
+                n = len(h["tokens"])
+                tok[b, i, :n] = h["tokens"].numpy(); sc[b, i] = float(h["score"]); ps[b, i, :n] = h["positional_scores"].numpy()
+        out.update({tag + "_src_tokens": s["src_tokens"], tag + "_src_lengths": s["src_lengths"],
+                    tag + "_tokens": tok, tag + "_scores": sc, tag + "_pos_scores": ps, tag + "_nhyp": nh,
+                    tag + "_meta": np.array([m["D"], m["H"], m["Ff"], m["EL"], m["DL"], m["ctc_layer"], int(m["compress"]), V_src, V_tgt,
+                                             V_src - 1] + list(seeds), np.int64),
+                    tag + "_gen": np.array([g["beam_size"], g["max_len_a"], g["max_len_b"], g["min_len"], g.get("no_repeat_ngram_size", 0)],
+                                           np.float64)})
+        print("genx", tag, [[(h["tokens"].tolist(), round(float(h["score"]), 4)) for h in hs[:2]] for hs in hyps])
+    np.savez_compressed(os.path.join(OUT, "generate_ext.npz"), **out)
+
+
 def run_twophase_case():
     """G18: TwoPhaseSequenceGenerator (examples/speech_recognition/twophase_sequence_generator.py) on the dual-decoder
     model: beam search with the auxiliary (transcript) decoder, then HierarchicalBeamSearch with the target decoder seeded by the
@@ -858,7 +914,58 @@ def run_teacher_case():
     print("teacher", len(outputs), batch["teacher_output"][0].shape, sorted(f for f in os.listdir(d) if "top" in f))
 
 
+def run_layerdrop_case():
+    """LayerDrop (--encoder-layerdrop / --decoder-layerdrop, conv_transformer.py:172,238-243 and fairseq/modules/layer_drop.py):
+    train-mode loss and gradient norms of the reference with torch's CPU generator seeded right before the forward, plus the
+    keep / drop decisions those seeds produce (replayed with the same draws the reference makes: one `torch.empty(1).uniform_()`
+    per encoder layer, then one vector for the decoder's LayerDropModuleList).  Sub-case `nc`: criterion-owned CTC head on
+    encoder_states[0] (the list only holds layers that ran); sub-case `c`: CTC compression after layer 2 (seed chosen so that
+    layer 2 runs: the reference dies with UnboundLocalError when that layer is dropped)."""
+    D, H, Ff, EL, DL = 64, 2, 128, 6, 3
+    pe, pd = 0.4, 0.3
+    out = {"rates": np.array([pe, pd])}
+    for tag, compress, ctc_layer, seed, fwd_seed in (("nc", False, 1, 400, 11), ("c", True, 2, 500, 31)):
+        args, task, model, crit, V_src, V_tgt = build("layerdrop_" + tag, D, H, Ff, EL, DL, ctc_layer, compress,
+                                                      extra=["--encoder-layerdrop", str(pe), "--decoder-layerdrop", str(pd)])
+        blank = task.source_dictionary.index("<ctc_blank>")
+        cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer if compress else 0)
+        W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+        load_weights(model, crit, W)
+        s = make_sample(seed + 1, [57, 44, 31], [6, 5, 4], [5, 4, 4], V_src, V_tgt, blank)
+        sample = to_ref_sample(s)
+        torch.manual_seed(fwd_seed)
+        enc_keep = [bool(float(torch.empty(1).uniform_()) > pe) for _ in range(EL)]
+        dec_keep = [bool(d > pd) for d in torch.empty(DL).uniform_().tolist()]
+        assert not all(enc_keep) and any(enc_keep) and not all(dec_keep), (enc_keep, dec_keep)
+        assert not compress or enc_keep[ctc_layer - 1]
+        model.train(); crit.train()
+        model.zero_grad(); crit.zero_grad()
+        torch.manual_seed(fwd_seed)
+        loss, sample_size, log = crit(model, sample)
+        loss.backward()
+        gn = {}
+        for k, p in list(model.named_parameters()) + [("criterion." + k, p) for k, p in crit.named_parameters()]:
+            gn[k] = float(p.grad.norm()) if p.grad is not None else 0.0
+        for k, v in s.items():
+            if isinstance(v, np.ndarray):
+                out["%s_in_%s" % (tag, k)] = v
+        out[tag + "_in_ntokens"] = np.int64(s["ntokens"])
+        out[tag + "_meta"] = np.array([D, H, Ff, EL, DL, ctc_layer, int(compress), V_src, V_tgt, blank, seed, fwd_seed], np.int64)
+        out[tag + "_enc_keep"] = np.array(enc_keep); out[tag + "_dec_keep"] = np.array(dec_keep)
+        out[tag + "_loss"] = np.float64(loss.item()); out[tag + "_sample_size"] = np.int64(sample_size)
+        for k, v in log.items():
+            out["%s_log_%s" % (tag, k)] = np.float64(float(v))
+        out[tag + "_gradnorm_keys"] = np.array(sorted(gn))
+        out[tag + "_gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], np.float64)
+        print("layerdrop", tag, "keep", enc_keep, dec_keep, "loss", loss.item())
+    np.savez_compressed(os.path.join(OUT, "layerdrop.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "generate_ext":
+        run_generate_ext_case(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "layerdrop":
+        run_layerdrop_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "twophase":
         run_twophase_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn2d":

@@ -75,3 +75,49 @@ def twophase_case(tag):
         exp.append(hs)
     meta = dict(V_src=V_src, V_tgt=V_tgt, blank=blank, seed=seed, D=D, H=H, Ff=Ff, EL=EL, DL=DL)
     return cfg, W, torch.from_numpy(g[tag + "_src_tokens"]), torch.from_numpy(g[tag + "_src_lengths"]), opts, exp, meta
+
+
+def layerdrop_case(tag):
+    """fixture layerdrop.npz, sub-case `nc` (criterion-owned CTC head on encoder_states[0]) or `c` (compression after layer 2):
+    cfg, weights, sample, the keep / drop decisions of the reference's seeded forward and its loss / logging / gradient norms"""
+    g = load_golden("layerdrop")
+    D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed, fwd_seed = [int(v) for v in g[tag + "_meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer if compress else 0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    t = lambda k: torch.from_numpy(g["%s_in_%s" % (tag, k)])
+    sample = dict(id=t("id"), ntokens=int(g[tag + "_in_ntokens"]), nsentences=int(g[tag + "_in_src_lengths"].shape[0]),
+                  net_input=dict(src_tokens=t("src_tokens"), src_lengths=t("src_lengths"), prev_output_tokens=t("prev_output_tokens")),
+                  target=t("target"), target_lengths=t("target_lengths"), transcript_target=t("transcript_target"),
+                  transcript_target_lengths=t("transcript_target_lengths"), ctc_encoder_layer=ctc_layer)
+    meta = dict(V_src=V_src, V_tgt=V_tgt, blank=blank, seed=seed, fwd_seed=fwd_seed, ctc_layer=ctc_layer, compress=bool(compress),
+                enc_keep=[bool(v) for v in g[tag + "_enc_keep"]], dec_keep=[bool(v) for v in g[tag + "_dec_keep"]],
+                rates=[float(v) for v in g["rates"]])
+    return g, cfg, W, sample, meta
+
+
+def generate_ext_case(tag):
+    """fixture generate_ext.npz: `e` ensemble of two models, `p` prefix tokens, `n` n-gram blocking.  Returns cfg, the list of weight
+    dicts (one per ensemble member), inputs, generator options (incl. prefix_tokens / no_repeat_ngram_size) and expected hypotheses"""
+    g = load_golden("generate_ext")
+    meta = [int(v) for v in g[tag + "_meta"]]
+    D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank = meta[:10]
+    seeds = meta[10:]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer if compress else 0)
+    Ws = []
+    for seed in seeds:
+        W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=bool(compress)), seed)
+        W["decoder.output_projection.weight"][2] *= 4.0
+        Ws.append(W)
+    beam, la, lb, mn, ngram = [float(v) for v in g[tag + "_gen"]]
+    opts = dict(beam_size=int(beam), max_len_a=la, max_len_b=int(lb), min_len=int(mn), no_repeat_ngram_size=int(ngram))
+    prefix = torch.from_numpy(g["prefix_tokens"]) if tag == "p" else None
+    exp = []
+    for b in range(g[tag + "_tokens"].shape[0]):
+        hs = []
+        for i in range(int(g[tag + "_nhyp"][b])):
+            t = g[tag + "_tokens"][b, i]
+            n = int((t >= 0).sum())
+            hs.append((t[:n], float(g[tag + "_scores"][b, i]), g[tag + "_pos_scores"][b, i, :n]))
+        exp.append(hs)
+    meta = dict(V_src=V_src, V_tgt=V_tgt, blank=blank, ctc_layer=ctc_layer, compress=bool(compress), seeds=seeds)
+    return cfg, Ws, torch.from_numpy(g[tag + "_src_tokens"]), torch.from_numpy(g[tag + "_src_lengths"]), opts, prefix, exp, meta

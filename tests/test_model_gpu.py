@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import model_case
+from helpers import layerdrop_case, model_case
 from oracle import s2t_ref
 
 pytestmark = pytest.mark.gpu
@@ -705,4 +705,97 @@ def test_two_phase_generator_matches_reference(tag):
             assert h["tokens"].tolist() == et.tolist() == ot.tolist()
             assert h["aux_tokens"].tolist() == ea.tolist() == oa.tolist()
             assert abs(float(h["score"]) - esc) < 1e-4 and abs(float(h["score"]) - osc) < 1e-4
+            np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), eps, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["nc", "c"])
+def test_layerdrop_matches_reference(tag):
+    """--encoder-layerdrop 0.4 --decoder-layerdrop 0.3 (conv_transformer.py:238-243, fairseq/modules/layer_drop.py): seeded like the
+    reference run, the model draws the same decisions from torch's CPU generator, the dropped layers vanish from the forward AND
+    the backward schedule (zero gradients), `encoder_states` only lists layers that ran; loss / logging 1e-4, gradient norms 5e-4"""
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.conv_transformer import fused_to_reference
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import namespace
+    g, cfg, W, sample, meta = layerdrop_case(tag)
+    args = namespace(arch="conv_transformer", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+                     label_smoothing=0.1, ctc_compress_out=meta["compress"], ctc_encoder_layer=meta["ctc_layer"], ctc_weight=1.0,
+                     encoder_embed_dim=cfg["D"], encoder_ffn_embed_dim=cfg["ffn"], encoder_attention_heads=cfg["heads"],
+                     encoder_layers=cfg["enc_layers"], decoder_layers=cfg["dec_layers"], no_attn_2d=True,
+                     decoder_embed_dim=cfg["D"], decoder_ffn_embed_dim=cfg["ffn"], decoder_attention_heads=cfg["heads"],
+                     input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False,
+                     encoder_layerdrop=meta["rates"][0], decoder_layerdrop=meta["rates"][1])
+    tgt, src = Dictionary.synthetic(96), Dictionary.synthetic(59)
+    src.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationCTCTask(args, tgt, src)
+    model, crit = task.build_model(args), task.build_criterion(args)
+    model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+    with torch.no_grad():
+        crit.ctc_aware_model.fc_out.weight.copy_(W["criterion.ctc_aware_model.fc_out.weight"])
+        crit.ctc_aware_model.fc_out.bias.copy_(W["criterion.ctc_aware_model.fc_out.bias"])
+    model.hp.sub_dropout = 0.0
+    model.materialize(DEV, torch.float32, extra=crit.arena_params())
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    torch.manual_seed(meta["fwd_seed"])
+    loss, ss, log = crit(model, to_dev(sample))
+    loss.backward()
+    torch.cuda.synchronize()
+    close(loss, g[tag + "_loss"], 1e-4, "loss")
+    assert ss == int(g[tag + "_sample_size"])
+    for k in ("ctc_loss", "nll_loss", "ctc_errors", "ctc_total"):
+        close(float(log[k]), g["%s_log_%s" % (tag, k)], 1e-4, k)
+    mine = fused_to_reference({n: model.arena.g(n).detach().float().cpu() for n in model.arena.slices})
+    for k, ref in zip([str(k) for k in g[tag + "_gradnorm_keys"]], g[tag + "_gradnorm_vals"]):
+        if k.endswith("_float_tensor"):
+            continue
+        a = float(mine[k].norm())
+        assert abs(a - ref) <= 5e-4 * max(1.0, ref), (k, a, ref)
+    for l, kept in enumerate(meta["enc_keep"]):
+        if not kept:
+            assert float(mine["encoder.layers.%d.fc2.weight" % l].norm()) == 0.0
+    # eval mode: every layer runs (the draws still happen, as in the reference)
+    model.eval(); crit.eval()
+    with torch.no_grad():
+        l_eval, _, _ = crit(model, to_dev(sample))
+    (oloss, _, _, _, _, _) = s2t_ref.ctc_multi_loss(W, cfg, sample, 0.1, 1.0, meta["blank"], training=False)
+    close(l_eval, float(oloss), 1e-4, "eval loss")
+
+
+@pytest.mark.parametrize("tag", ["e", "p", "n"])
+def test_beam_search_ensemble_prefix_ngram_match_reference_generator(tag):
+    """ensemble of two models (log of the mean probability: s2t_ensemble_lse), prefix tokens of different lengths, n-gram blocking:
+    the hypotheses of the reference's SequenceGenerator (fixture generate_ext.npz), tokens exact, scores 1e-4"""
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import namespace
+    from fbk_fairseq_st_amd.sequence_generator import SequenceGenerator
+    from helpers import generate_ext_case
+    cfg, Ws, src, lens, opts, prefix, exp, meta = generate_ext_case(tag)
+    crit = dict(criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy") if meta["compress"] else \
+        dict(criterion="label_smoothed_cross_entropy")
+    args = namespace(arch="conv_transformer", label_smoothing=0.1, ctc_compress_out=meta["compress"], ctc_encoder_layer=meta["ctc_layer"],
+                     ctc_weight=1.0, encoder_embed_dim=cfg["D"], encoder_ffn_embed_dim=cfg["ffn"], encoder_attention_heads=cfg["heads"],
+                     encoder_layers=cfg["enc_layers"], decoder_layers=cfg["dec_layers"], no_attn_2d=True, decoder_embed_dim=cfg["D"],
+                     decoder_ffn_embed_dim=cfg["ffn"], decoder_attention_heads=cfg["heads"], input_feat_per_channel=80, dropout=0.0,
+                     attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False, max_target_positions=1000, **crit)
+    tgt, sd = Dictionary.synthetic(96), Dictionary.synthetic(59)
+    sd.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationCTCTask(args, tgt, sd)
+    models = []
+    for W in Ws:
+        m = task.build_model(args)
+        m.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+        m.materialize(DEV, torch.float32)
+        m.eval()
+        models.append(m)
+    gen = SequenceGenerator(models, task.target_dictionary, **opts)
+    hyps = gen.generate(models, dict(net_input=dict(src_tokens=src.to(DEV), src_lengths=lens.to(DEV))),
+                        prefix_tokens=None if prefix is None else prefix.to(DEV))
+    assert len(hyps) == len(exp)
+    for hs, es in zip(hyps, exp):
+        assert len(hs) == len(es)
+        for h, (et, esc, eps) in zip(hs, es):
+            assert h["tokens"].tolist() == et.tolist()
+            assert abs(float(h["score"]) - esc) < 1e-4
             np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), eps, atol=1e-4)

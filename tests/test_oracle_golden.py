@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import int_ref, s2t_ref
-from helpers import load_golden, model_case
+from helpers import layerdrop_case, load_golden, model_case
 
 TOL = 1e-4
 
@@ -306,3 +306,42 @@ def test_conv_attention_2d_matches_reference():
     close(float(l3), float(g["eval_loss"]), what="eval loss")
     close(enc3.encoder_out, g["eval_encoder_out"], what="eval encoder_out")
     assert enc3.src_lengths.tolist() == g["eval_src_lengths_out"].tolist()
+
+
+@pytest.mark.parametrize("tag", ["nc", "c"])
+def test_layerdrop_matches_reference(tag):
+    """--encoder-layerdrop / --decoder-layerdrop: the oracle with the reference's keep / drop decisions reproduces the reference's
+    seeded train-mode forward + backward (dropped layers: no contribution, zero gradient, no encoder_states entry)"""
+    g, cfg, W, sample, meta = layerdrop_case(tag)
+    cfg = dict(cfg, enc_keep=meta["enc_keep"], dec_keep=meta["dec_keep"])
+    Wg = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in W.items()}
+    loss, ss, log, enc, logits, _ = s2t_ref.ctc_multi_loss(Wg, cfg, sample, 0.1, 1.0, meta["blank"], training=True)
+    loss.backward()
+    close(float(loss.detach()), float(g[tag + "_loss"]), what="loss")
+    assert ss == int(g[tag + "_sample_size"])
+    for k in ("ctc_loss", "nll_loss", "ctc_errors", "ctc_total"):
+        close(log[k], float(g["%s_log_%s" % (tag, k)]), what=k)
+    for k, ref in zip([str(k) for k in g[tag + "_gradnorm_keys"]], g[tag + "_gradnorm_vals"]):
+        gk = Wg[k].grad if k in Wg else None
+        mine = float(gk.norm()) if gk is not None else 0.0
+        assert abs(mine - ref) <= 2e-4 * max(1.0, ref), (k, mine, ref)
+    dropped = [l for l, k in enumerate(meta["enc_keep"]) if not k]
+    assert dropped and all(float(Wg["encoder.layers.%d.fc1.weight" % l].grad.norm() if Wg["encoder.layers.%d.fc1.weight" % l].grad is not None
+                                 else 0.0) == 0.0 for l in dropped)
+
+
+@pytest.mark.parametrize("tag", ["e", "p", "n"])
+def test_beam_search_ensemble_prefix_ngram_match_reference_generator(tag):
+    """ensembles (EnsembleModel.forward_decoder), prefix tokens (_prefix_tokens) and n-gram blocking (_no_repeat_ngram) of the
+    reference's SequenceGenerator: tokens exact, scores 1e-4"""
+    from helpers import generate_ext_case
+    cfg, Ws, src, lens, o, prefix, exp, _ = generate_ext_case(tag)
+    got = s2t_ref.beam_search(Ws, cfg, src, lens, o["beam_size"], o["max_len_a"], o["max_len_b"], o["min_len"],
+                              prefix_tokens=prefix, no_repeat_ngram_size=o["no_repeat_ngram_size"])
+    assert len(got) == len(exp)
+    for hs, es in zip(got, exp):
+        assert len(hs) == len(es)
+        for (t, s, ps), (et, es_, eps) in zip(hs, es):
+            assert t.tolist() == et.tolist()
+            assert abs(s - es_) < 1e-4
+            np.testing.assert_allclose(ps.numpy(), eps, atol=1e-4)
