@@ -46,8 +46,10 @@ sys.path.insert(0, REPO)
 
 # kernel behind each profiled family (names as they appear in the rocprofv3 kernel trace, profiles/)
 KERNEL_OF = {"wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward pass in one launch: 256x256 tiles owned over all tokens, LDS-DMA, no split-K)",
-             "gemm_nt": "gemm256_kernel<bf16, TB=false> (Y = X W^T: 256/192 x 256 x 64, LDS-DMA, persistent) + gemm_fast_kernel 128x128 for the small products",
-             "gemm_nn": "gemm256_kernel<bf16, TB=true> (dX = dY W) + gemm_fast_kernel 128x128 for the small products",
+             "gemm256_nt": "gemm256_kernel<bf16, TB=false> (Y = X W^T: 256/192 x 256 x 64, LDS-DMA, one persistent workgroup per CU)",
+             "gemm256_nn": "gemm256_kernel<bf16, TB=true> (dX = dY W: 256/192 x 256 x 64, LDS-DMA, one persistent workgroup per CU)",
+             "gemm_nt": "gemm_fast_kernel<.., 128, 128, 8 waves> (register-staged; products the LDS-DMA kernels do not take: decoder side, f32)",
+             "gemm_nn": "gemm_fast_kernel<.., 128, 128, 8 waves>, data-gradient form (register-staged)",
              "gemm_tn": "gemm_tn2_kernel (dW of the fc3 projection: 128x128 tile, split-K atomics)",
              "gemm_tn_small": "gemm_fast_kernel<.., 64, 64, 4 waves> (small dW)", "gemm_nt_small": "gemm_fast_kernel<.., 64, 64, 4 waves>",
              "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (implicit-GEMM convolutions)",
@@ -313,8 +315,8 @@ def main():
         torch.cuda.synchronize()
         K.prof_enable(False)
     if args.roofline and rank == 0:
-        names = ("wgrad_group", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small", "gemm_gather", "conv2_fwd",
-                 "conv2_dgrad", "attn_fwd", "attn_bwd")
+        names = ("wgrad_group", "gemm256_nt", "gemm256_nn", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small",
+                 "gemm_nt_small", "gemm_nn_small", "gemm_gather", "conv2_fwd", "conv2_dgrad", "attn_fwd", "attn_bwd")
         fam = {f: K.prof_read(f) for f in names}
         gemms = {f: v for f, v in fam.items() if not f.startswith("attn") and v["launches"] > 0 and v["ms"] > 0}     # every MFMA product family
         if gemms:

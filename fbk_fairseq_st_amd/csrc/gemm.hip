@@ -16,7 +16,7 @@
 #include "common.hpp"
 #include "prof.hpp"
 #include "gemm_epilogue.hpp"
-int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st);   // gemm256.hip
+int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st, bool dry_run);   // gemm256.hip
 #include <cstdlib>
 #include <type_traits>
 
@@ -811,14 +811,16 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
     // families for the roofline report (one kernel template each): dW-shaped (TN), forward (NT), dX-shaped (NN) products on
     // 128x128 tiles, their small-problem 64x64 forms, and the implicit-GEMM convolution
+    // ONE KERNEL TEMPLATE per family: the 256 x 256 x 64 LDS-DMA kernel in its forward (NT) and data-gradient (NN) forms, and the
+    // register-staged kernels of this file
     static const char* const kFam[3][2] = {{"gemm_nt", "gemm_nt_small"}, {"gemm_nn", "gemm_nn_small"}, {"gemm_tn", "gemm_tn_small"}};
-    ProfScope prof(mapA || mapB ? "gemm_gather" : kFam[trans_a ? 2 : (trans_b ? 1 : 0)][small ? 1 : 0], st, 2.0 * M * (double)N * K,
-                   esz * ((double)M * K + (double)N * K) + osz * (double)M * N);
-    if (in_dtype == S2T_BF16 && !trans_a && !small) {         // big forward / data-gradient products: 256 x 256 x 64 LDS-DMA kernel
-        if (g_s2t_opt_gemm256) {
-            const int r = s2t_gemm256_try(a, out_dtype, trans_b, st);
-            if (r != 0) return r < 0 ? r : S2T_OK;
-        }
+    // big forward / data-gradient products: 256 x 256 x 64 LDS-DMA kernel
+    const bool big = in_dtype == S2T_BF16 && !trans_a && !small && g_s2t_opt_gemm256 && s2t_gemm256_try(a, out_dtype, trans_b, st, true) == 1;
+    ProfScope prof(mapA || mapB ? "gemm_gather" : (big ? (trans_b ? "gemm256_nn" : "gemm256_nt") : kFam[trans_a ? 2 : (trans_b ? 1 : 0)][small ? 1 : 0]),
+                   st, 2.0 * M * (double)N * K, esz * ((double)M * K + (double)N * K) + osz * (double)M * N);
+    if (big) {
+        const int r = s2t_gemm256_try(a, out_dtype, trans_b, st, false);
+        if (r != 0) return r < 0 ? r : S2T_OK;
     }
     if (act == ACT_RELU_MASK || act == ACT_RELU_BWD_MASK) return S2T_ENOTSUP;   // the 1-bit record exists only in the 256-wide kernel's tile order
 #define S2T_PICK(TI_, TO_)                                                                   \

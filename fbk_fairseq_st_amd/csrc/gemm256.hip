@@ -460,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 
 // Shapes this kernel takes: bf16 operands, K a multiple of 64, at least two K-tiles, 16-byte aligned rows, operands below 4 GiB
 // (32-bit byte offsets), no gather maps, no split-K.  Returns 0 when the product is not for this kernel (the caller falls
-// through to gemm.hip), 1 when launched, < 0 on error.
+// through to gemm.hip), 1 when launched (dry_run: when it would be), < 0 on error.
 // row-tile height: the one that needs less time on 256 CUs = rounds x rows per tile (ties go to 256: fewer B re-reads).  Returns the
 // number of tiles, 0 when the product has too few of them for this kernel.
 static long g256_tiles(int M, int N, bool& use192) {
@@ -484,7 +484,7 @@ extern "C" size_t s2t_gemm_relu_mask_bytes(int M, int N, int K) {
     return (size_t)g256_tiles(M, N, use192) * 8192;
 }
 
-int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st) {
+int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t st, bool dry_run) {
     if (a.mapA || a.mapB || a.mapC || a.splitk != 1 || a.rowsum) return 0;
     if (a.K % BK || a.K < 2 * BK || a.M < 256 || a.N < 256) return 0;
     if (a.N & 7) {
@@ -516,6 +516,7 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     bool use192 = false;
     const int tiles = (int)g256_tiles(a.M, a.N, use192);
     if (!tiles) return 0;
+    if (dry_run) return 1;                         // every gate passed: the caller names the launch (profiling family) before it happens
     const int grid = tiles < 256 ? tiles : 256;
     const size_t lds = 2 * BUF;
     bool done = false;

@@ -101,14 +101,97 @@ _lib = None
 
 
 def build(verbose=False):
-    """Compile csrc/*.hip for gfx950 into libs2t_hip.so (hipcc cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 into libs2t_hip.so (hipcc cross-compiles without a GPU), then the CPython binding of its C ABI."""
     cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 4))]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("building libs2t_hip.so failed:\n" + res.stdout[-4000:])
     if verbose:
         print(res.stdout[-2000:])
+    build_fastcall()
     return LIB_PATH
+
+
+# ---- the binding itself.  ctypes converts every argument of a call through Python-level machinery: 4.0 us for the 30 arguments of
+# s2t_gemm_gather against 0.3 us for a METH_FASTCALL wrapper doing the same conversions in C (measured in the build container).  At
+# ~1,100 launches per update that is ~4 ms of host time -- more than the kernels of an 8-utterance batch take -- so the binding is a
+# small CPython extension GENERATED from the signature table below: one wrapper per entry point of include/s2t_hip.h, which it
+# includes (the C compiler checks every generated call against the header's prototype).  Same names, same arguments, same return
+# values as the ctypes binding, which stays as the way in when the extension is absent (S2T_HIP_LIB diagnostic twins, a tree that was
+# never built here): both call the same libs2t_hip.so, neither computes anything.
+FAST_PATH = os.path.join(_HERE, "_s2t_fastcall.so")
+_HOST_SIDE = ("s2t_host_batch_by_size", "s2t_host_ctc_uer")          # CPU work: release the GIL around the call, as ctypes does
+
+
+def _fastcall_source():
+    out = ['#define PY_SSIZE_T_CLEAN', '#include <Python.h>', '#include "s2t_hip.h"', '',
+           'static inline unsigned long long as_ptr(PyObject* o) { return o == Py_None ? 0ull : PyLong_AsUnsignedLongLongMask(o); }', '']
+    names = sorted(SIGNATURES)
+    for name in names:
+        at = SIGNATURES[name]
+        n = len(at)
+        decl, call = [], []
+        for i, t in enumerate(at):
+            if t in (c_float, c_double):
+                decl.append("    const double a%d = PyFloat_AsDouble(args[%d]);" % (i, i))
+                call.append("(%s)a%d" % ("float" if t is c_float else "double", i))
+            elif t is P:
+                decl.append("    const unsigned long long a%d = as_ptr(args[%d]);" % (i, i))
+                call.append("(void*)a%d" % i)
+            elif t is ctypes.c_char_p:
+                decl.append("    const char* a%d = PyBytes_AsString(args[%d]);" % (i, i))
+                call.append("a%d" % i)
+            elif t is c_ull:
+                decl.append("    const unsigned long long a%d = PyLong_AsUnsignedLongLongMask(args[%d]);" % (i, i))
+                call.append("a%d" % i)
+            else:                                  # c_int, c_long, c_longlong, c_size_t
+                decl.append("    const long long a%d = PyLong_AsLongLong(args[%d]);" % (i, i))
+                call.append({c_int: "(int)a%d", c_long: "(long)a%d", c_longlong: "(long long)a%d", c_size_t: "(size_t)a%d"}[t] % i)
+        out.append("static PyObject* w_%s(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {" % name)
+        out.append('    if (nargs != %d) { PyErr_SetString(PyExc_TypeError, "%s takes %d arguments"); return NULL; }' % (n, name, n))
+        out += decl
+        out.append("    if (PyErr_Occurred()) return NULL;")
+        # the header's prototypes carry const / typed pointers: go through a function pointer of the table's erased types
+        proto = ", ".join({c_float: "float", c_double: "double", P: "void*", ctypes.c_char_p: "const char*", c_ull: "unsigned long long",
+                           c_int: "int", c_long: "long", c_longlong: "long long", c_size_t: "size_t"}[t] for t in at) or "void"
+        ret = "size_t" if name == "s2t_gemm_relu_mask_bytes" else "int"
+        out.append("    %s (*fn)(%s) = (%s (*)(%s))%s;" % (ret, proto, ret, proto, name))
+        if name in _HOST_SIDE:
+            out.append("    %s r;" % ret)
+            out.append("    Py_BEGIN_ALLOW_THREADS")
+            out.append("    r = fn(%s);" % ", ".join(call))
+            out.append("    Py_END_ALLOW_THREADS")
+        else:
+            out.append("    const %s r = fn(%s);" % (ret, ", ".join(call)))
+        out.append("    return %s;" % ("PyLong_FromSize_t(r)" if ret == "size_t" else "PyLong_FromLong((long)r)"))
+        out.append("}")
+    out.append("static PyObject* w_s2t_build_info(PyObject* self, PyObject* const* args, Py_ssize_t nargs) { return PyBytes_FromString(s2t_build_info()); }")
+    out.append("static PyMethodDef methods[] = {")
+    for name in names + ["s2t_build_info"]:
+        out.append('    {"%s", (PyCFunction)(void (*)(void))w_%s, METH_FASTCALL, ""},' % (name, name))
+    out.append("    {NULL, NULL, 0, NULL}};")
+    out.append('static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_s2t_fastcall", "generated binding of include/s2t_hip.h", -1, methods};')
+    out.append("PyMODINIT_FUNC PyInit__s2t_fastcall(void) { return PyModule_Create(&moddef); }")
+    return "\n".join(out) + "\n"
+
+
+def build_fastcall():
+    """generate + compile the CPython binding next to libs2t_hip.so (gcc; links the library by its path relative to $ORIGIN)"""
+    import sysconfig
+    obj = os.path.join(CSRC, "_obj")
+    os.makedirs(obj, exist_ok=True)
+    src = os.path.join(obj, "s2t_fastcall.c")
+    text = _fastcall_source()
+    if not (os.path.exists(src) and open(src).read() == text and os.path.exists(FAST_PATH)
+            and os.path.getmtime(FAST_PATH) >= os.path.getmtime(os.path.join(_HERE, "libs2t_hip.so"))):
+        with open(src, "w") as f:
+            f.write(text)
+        cmd = ["gcc", "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], "-I" + os.path.join(os.path.dirname(_HERE), "include"),
+               src, "-o", FAST_PATH, "-L" + _HERE, "-l:libs2t_hip.so", "-Wl,-rpath,$ORIGIN"]
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("building the CPython binding failed:\n" + res.stdout[-4000:])
+    return FAST_PATH
 
 
 def load():
@@ -130,8 +213,24 @@ def load():
     if lib.s2t_abi_version() != ABI_VERSION:
         raise ImportError("libs2t_hip.so at %s has ABI version %d, this package binds version %d -- rebuild it (make -C %s)"
                           % (LIB_PATH, lib.s2t_abi_version(), ABI_VERSION, CSRC))
-    _lib = lib
-    return lib
+    _lib = _load_fastcall(lib) or lib
+    return _lib
+
+
+def _load_fastcall(ctypes_lib):
+    """the generated CPython binding when it is there, matches this table and sits on the library just loaded; else None (ctypes)"""
+    if os.environ.get("S2T_HIP_LIB") or os.environ.get("S2T_HIP_CTYPES") or not os.path.exists(FAST_PATH):
+        return None
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location("_s2t_fastcall", FAST_PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    except Exception:
+        return None
+    if any(not hasattr(mod, n) for n in SIGNATURES) or mod.s2t_abi_version() != ABI_VERSION:
+        return None
+    return mod
 
 
 class S2THipError(RuntimeError):

@@ -45,3 +45,29 @@ def test_host_ctc_uer_matches_golden():
     pred = torch.from_numpy(g["lp"]).argmax(-1).to(torch.int32)
     e, n = K.host_ctc_uer(pred, torch.from_numpy(g["in_len"]), torch.from_numpy(g["tgt"]), torch.from_numpy(g["tgt_len"]), int(g["blank"]))
     assert (e, n) == (float(g["errors"]), float(g["total"]))
+
+
+def test_generated_cpython_binding_matches_the_ctypes_binding():
+    """lib.build_fastcall() generates one METH_FASTCALL wrapper per entry of lib.SIGNATURES (compiled against include/s2t_hip.h); it
+    must expose the same names and answer the argument-validation calls exactly like ctypes (no GPU needed)"""
+    import ctypes
+    L.build_fastcall()
+    fast = L._load_fastcall(None)
+    assert fast is not None, "the generated binding did not load"
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for name, argtypes in L.SIGNATURES.items():
+        assert hasattr(fast, name), name
+        getattr(raw, name).argtypes = argtypes
+    raw.s2t_gemm_relu_mask_bytes.restype = ctypes.c_size_t
+    calls = [("s2t_gemm", (0, 0, 0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, None, 0, 0, 0, 1, 1.0, None)),
+             ("s2t_gemm", (0, 0, 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, None, 0, 0, 0, 1, 1.0, None)),
+             ("s2t_layernorm_fwd", (0, None, None, None, None, None, None, 4, 2048, 1e-5, None)),
+             ("s2t_ctc_rle", (None, None, None, None, None, None, None, None, 4, 2, 0, None)),
+             ("s2t_gemm_relu_mask_bytes", (24000, 2048, 512)), ("s2t_gemm_relu_mask_bytes", (2560, 2048, 512)),
+             ("s2t_dropout", (1, None, None, 0, 0.1, 2 ** 63 + 5, None)), ("s2t_abi_version", ())]
+    for name, args in calls:
+        assert getattr(fast, name)(*args) == getattr(raw, name)(*args), name
+    assert fast.s2t_set_option(b"no_such_option", 1) == -22 and fast.s2t_build_info() == L.load().s2t_build_info()
+    import pytest
+    with pytest.raises(TypeError):
+        fast.s2t_abi_version(1)

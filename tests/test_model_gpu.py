@@ -755,6 +755,7 @@ def test_layerdrop_matches_reference(tag):
         if not kept:
             assert float(mine["encoder.layers.%d.fc2.weight" % l].norm()) == 0.0
     # eval mode: every layer runs (the draws still happen, as in the reference)
+    model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})     # restore the BatchNorm running statistics
     model.eval(); crit.eval()
     with torch.no_grad():
         l_eval, _, _ = crit(model, to_dev(sample))
