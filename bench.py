@@ -283,6 +283,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the S2T hot path has no CPU fallback")
+    # host-side tensor work (collate of the loader-fed configurations, the CPU baseline): torch's intra-op pool defaults to one thread
+    # per core, and on the 256-core GPU boxes that made the collate of cfg4_l_bucketed ten times slower than with 32 (234 vs 27 ms per
+    # update whenever --no-cpu-baseline skipped the place that used to set it)
+    torch.set_num_threads(max(1, min(args.cpu_threads, (os.cpu_count() or 1) // max(world, 1))))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from fbk_fairseq_st_amd import distributed as D

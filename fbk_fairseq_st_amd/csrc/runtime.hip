@@ -61,7 +61,7 @@ void* s2t_scratch(int slot, hipStream_t st, size_t bytes, hipError_t* err) {
     return b.p;
 }
 
-extern "C" int s2t_abi_version(void) { return 6; }
+extern "C" int s2t_abi_version(void) { return 7; }
 extern "C" const char* s2t_build_info(void) { return "libs2t_hip gfx950 (CDNA4, wave64, MFMA) built " __DATE__ " " __TIME__; }
 extern "C" int s2t_set_option(const char* key, int value) {
     if (!key) return S2T_EINVAL;

@@ -8,12 +8,14 @@ corresponding backward passes.  No torch arithmetic is used: every FLOP is a cal
 torch only allocates buffers and does integer index bookkeeping.  Gradients of parameters are
 accumulated by the kernels directly into the arena's flat f32 gradient buffer.
 """
+import ctypes
 import math
 import os
 
 import torch
 
 from . import kernels as K
+from . import lib as L
 
 
 A2D_HEADS = 4                # ConvAttention2D(out_channels, 4, dropout) -- conv_transformer.py:155-157
@@ -190,6 +192,16 @@ class S2TEngine:
         # the launch that holds their products (flush_wgrad).
         self.defer_wgrad = arena.compute_dtype == torch.bfloat16
         self._wq, self._wq_ready, self._wq_post = [], [], []     # _wq_post: what must follow the grouped launch (re-ordering a dW)
+        # One C call per Transformer layer and direction (csrc/layer.hip: the block schedules below restated in C++, launch for
+        # launch): from Python a launch costs 6-12 us of host time, from C ~2.5 us, and with 8 utterances per GPU the host's launch
+        # rate is what bounds the update.  bf16 path with deferred weight gradients; the per-kernel schedules below remain the
+        # reference the tests hold it to (bit for bit) and the path of f32 mode.
+        self.composite = self.defer_wgrad
+        self._descs = {}
+        self._call = L.LayerCall()
+        self._items = (L.WgradProblem * K.WGRAD_GROUP_MAX)()     # weight-gradient products appended by the layer calls
+        self._n_items = 0
+        self._keep = []                                          # their operands' owners, until the grouped launch
         # None: the encoder's queued weight gradients are computed in ONE launch after its backward pass (best packing of the CUs).
         # k: also after every k-th layer from the top.  The Trainer sets k = enc_layers / 2 when gradients are all-reduced: two
         # launches of six layers pack as well as one of twelve (576 / 2 tiles each over 256 CUs, tail cut), and half of the encoder's
@@ -231,14 +243,26 @@ class S2TEngine:
 
     def _ready(self, prefix):
         """every gradient of parameters named prefix* has been computed -- or queued: then the report waits for the flush"""
-        if self._wq or self._wq_ready:
+        if self._wq or self._n_items or self._wq_ready:
             self._wq_ready.append(prefix)
         elif self.on_grads_ready is not None:
             self.on_grads_ready(prefix)
 
     def flush_wgrad(self):
         """launch the queued weight-gradient products (one grouped kernel) and report the parameter groups that waited for them"""
-        if self._wq:
+        if self._n_items:
+            # products appended by the layer calls first, then the ones queued from Python, in ONE launch
+            n = self._n_items
+            for (dy, x, dw, db) in self._wq:
+                if n >= K.WGRAD_GROUP_MAX:
+                    K.wgrad_group_raw(n, ctypes.addressof(self._items)); n = 0
+                p = self._items[n]; n += 1
+                p.dY = dy.data_ptr(); p.X = x.data_ptr(); p.dW = dw.data_ptr(); p.db = db.data_ptr() if db is not None else None
+                p.n_out = dy.shape[1]; p.n_in = x.shape[1]; p.tokens = dy.shape[0]
+                p.ldy = dy.stride(0); p.ldx = x.stride(0); p.ldw = dw.stride(0)
+            K.wgrad_group_raw(n, ctypes.addressof(self._items))
+            self._n_items, self._wq, self._keep = 0, [], []
+        elif self._wq:
             K.wgrad_group(self._wq)
             self._wq = []
         post, self._wq_post = self._wq_post, []
@@ -255,6 +279,7 @@ class S2TEngine:
         (dY, X, dW) items must not be added to the next update's gradients.  The queue also keeps every queued dY alive until the
         flush (~2.6 GB at the bench shape: DESIGN.md section 4)."""
         self._wq, self._wq_ready, self._wq_post = [], [], []
+        self._n_items, self._keep = 0, []
 
     def out_proj(self, pfx):
         """parameter-name stem of a decoder's output projection: the embedding itself when input and output embeddings are shared
@@ -614,6 +639,77 @@ class S2TEngine:
         return K.layernorm_bwd(dh, c["x"], c["mean"], c["rstd"], self.P(pfx + "final_layer_norm.weight"),
                                self.G(pfx + "final_layer_norm.weight"), self.G(pfx + "final_layer_norm.bias"), dres=dy, drop=nxt)
 
+    # ------------------------------------------------------------------ one layer per C call (csrc/layer.hip)
+    def _layer_desc(self, pfx, decoder, T, B, Ts, causal, dist_penalty):
+        key = (pfx, T, B, Ts, causal, dist_penalty)
+        e = self._descs.get(key)
+        if e is None:
+            hp = self.hp
+            d = L.LayerDesc(dtype=L.BF16, decoder=int(decoder), T=T, B=B, D=hp.D, heads=hp.heads, ffn=hp.ffn, Ts=Ts, gelu=int(hp.act == "gelu"),
+                            causal=int(causal), dist_penalty=int(bool(dist_penalty)), ln_eps=hp.ln_eps, p_drop=hp.dropout,
+                            p_attn=hp.attention_dropout, p_act=hp.activation_dropout)
+            names = {"qkv": "self_attn.qkv", "o": "self_attn.out_proj", "fc1": "fc1", "fc2": "fc2"}
+            lns = {"ln1": "self_attn_layer_norm", "ln2": "final_layer_norm"}
+            if decoder:
+                names.update(xq="encoder_attn.q_proj", xkv="encoder_attn.kv", xo="encoder_attn.out_proj")
+                lns["lnx"] = "encoder_attn_layer_norm"
+            for k, n in names.items():
+                setattr(d, "w_" + k, self.W(pfx + n + ".weight").data_ptr()); setattr(d, "b_" + k, self.P(pfx + n + ".bias").data_ptr())
+                setattr(d, "g_w_" + k, self.G(pfx + n + ".weight").data_ptr()); setattr(d, "g_b_" + k, self.G(pfx + n + ".bias").data_ptr())
+            for k, n in lns.items():
+                setattr(d, k + "_g", self.P(pfx + n + ".weight").data_ptr()); setattr(d, k + "_b", self.P(pfx + n + ".bias").data_ptr())
+                setattr(d, "g_" + k + "_g", self.G(pfx + n + ".weight").data_ptr()); setattr(d, "g_" + k + "_b", self.G(pfx + n + ".bias").data_ptr())
+            e = self._descs[key] = dict(desc=d, addr=ctypes.addressof(d), ws={}, tmp=K.layer_tmp_bytes(d))
+        return e
+
+    def layer_fwd(self, pfx, x, training, seeds, self_klen=None, causal=False, dist_penalty=False, enc2d=None, Ts=0, enc_klen=None):
+        """x [T,B,D] -> the layer's output; seeds = (sa_attn, sa_out, xa_attn, xa_out, ffn_act, ffn_out)"""
+        T, B, D = x.shape
+        decoder = enc2d is not None
+        e = self._layer_desc(pfx, decoder, T, B, Ts, causal, dist_penalty)
+        nws = e["ws"].get(training)
+        if nws is None:
+            nws = e["ws"][training] = K.layer_ws_bytes(e["desc"], training)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=self.dev)
+        y = torch.empty((T, B, D), dtype=self.dtype, device=self.dev)
+        c = self._call
+        c.training = int(training)
+        c.self_klen = self_klen.data_ptr() if self_klen is not None else None
+        c.enc_klen = enc_klen.data_ptr() if enc_klen is not None else None
+        c.seed_sa_attn, c.seed_sa_out, c.seed_xa_attn, c.seed_xa_out, c.seed_ffn_act, c.seed_ffn_out = seeds
+        c.x = x.data_ptr(); c.enc = enc2d.data_ptr() if decoder else None; c.y = y.data_ptr(); c.ws = ws.data_ptr()
+        K.layer_fwd(e["addr"], ctypes.addressof(c))
+        p = self.hp.dropout if training else 0.0
+        return y, dict(composite=True, e=e, ws=ws, x=x, enc2d=enc2d, self_klen=self_klen, enc_klen=enc_klen, seeds=seeds, training=training,
+                       p=p, T=T, B=B, Ts=Ts)
+
+    def layer_bwd(self, cl, dy, dyd, nxt, denc=None, denc_accumulate=False):
+        """dy [T*B, D] gradient w.r.t. the layer output (dyd: its dropout with the FFN's output mask, or None); nxt = (p, seed) of the
+        dropout that consumes the result next.  Returns (dx, dropout(dx) or None); the weight-gradient products are appended to the
+        engine's list for the grouped launch."""
+        e = cl["e"]
+        tmp = torch.empty((e["tmp"],), dtype=torch.uint8, device=self.dev)
+        dx = torch.empty_like(dy)
+        dxd = torch.empty_like(dy) if nxt is not None else None
+        c = self._call
+        c.training = int(cl["training"])
+        sk, ek = cl["self_klen"], cl["enc_klen"]
+        c.self_klen = sk.data_ptr() if sk is not None else None
+        c.enc_klen = ek.data_ptr() if ek is not None else None
+        c.seed_sa_attn, c.seed_sa_out, c.seed_xa_attn, c.seed_xa_out, c.seed_ffn_act, c.seed_ffn_out = cl["seeds"]
+        c.x = cl["x"].data_ptr(); c.enc = cl["enc2d"].data_ptr() if cl["enc2d"] is not None else None; c.ws = cl["ws"].data_ptr()
+        c.dy = dy.data_ptr(); c.dy_drop = dyd.data_ptr() if dyd is not None else None
+        c.dx = dx.data_ptr(); c.dx_drop = dxd.data_ptr() if dxd is not None else None
+        c.nxt_p, c.nxt_seed = nxt if nxt is not None else (0.0, 0)
+        c.denc = denc.data_ptr() if denc is not None else None
+        c.denc_accumulate = int(denc_accumulate)
+        c.tmp = tmp.data_ptr()
+        c.items = ctypes.addressof(self._items); c.max_items = K.WGRAD_GROUP_MAX; c.n_items = self._n_items
+        K.layer_bwd(e["addr"], ctypes.addressof(c))
+        self._n_items = c.n_items
+        self._keep.append((tmp, cl["ws"], cl["x"], cl["enc2d"], dy, dyd))
+        return dx, dxd
+
     # ------------------------------------------------------------------ encoder
     def encoder_forward(self, src_tokens, src_lengths, training, seed=0, return_all_hiddens=False, keep=None):
         """Returns dict(out [T'',B,D], lengths int64 [B] (device), lengths_host list, ctc_out, ctc_lengths, ...), ctx.
@@ -640,10 +736,15 @@ class S2TEngine:
                 ctx["layers"].append(None)
                 continue
             pfx = "encoder.layers.%d." % l
-            x, ca = self.self_attn_block_fwd(pfx, x, cur_klen, False, training, seed * 1000 + 10 * (l + 1),
-                                             dist_penalty=bool(hp.distance_penalty))
-            x, cf = self.ffn_block_fwd(pfx, x, training, seed * 1000 + 10 * (l + 1))
-            ctx["layers"].append((ca, cf))
+            s0 = seed * 1000 + 10 * (l + 1)
+            if self.composite and self.defer_wgrad:
+                x, cl = self.layer_fwd(pfx, x, training, (s0 + 1, s0 + 2, 0, 0, s0 + 3, s0 + 4), self_klen=cur_klen,
+                                       dist_penalty=bool(hp.distance_penalty))
+                ctx["layers"].append(cl)
+            else:
+                x, ca = self.self_attn_block_fwd(pfx, x, cur_klen, False, training, s0, dist_penalty=bool(hp.distance_penalty))
+                x, cf = self.ffn_block_fwd(pfx, x, training, s0)
+                ctx["layers"].append((ca, cf))
             if hp.ctc_layer == l + 1:
                 Tn = x.shape[0]
                 x2 = x.view(Tn * B, D)
@@ -696,8 +797,9 @@ class S2TEngine:
         def ffn_drop(l):
             if l < 0:
                 return None
-            cf = ctx["layers"][l][1]
-            return (cf["p"], cf["seed"] + 4) if self.fuse_bwd_dropout and cf["p"] > 0 and not touched(l) else None
+            cl = ctx["layers"][l]
+            p, sd = (cl["p"], cl["seeds"][5]) if isinstance(cl, dict) else (cl[1]["p"], cl[1]["seed"] + 4)
+            return (p, sd) if self.fuse_bwd_dropout and p > 0 and not touched(l) else None
 
         dxd = None
         nxt = ffn_drop(top)
@@ -719,13 +821,16 @@ class S2TEngine:
                     if d_ctc_out is not None:
                         self.linear_bwd(d_ctc_out.reshape(-1, hp.V_src), cc["x"], "encoder.ctc_fc", dx_out=dxk, dx_accumulate=True)
                     dx = dxk
-                ca, cf = ctx["layers"][l]
-                nxt = (ca["p"], ca["seed"] + 2) if self.fuse_bwd_dropout and ca["p"] > 0 else None
-                dx = self.ffn_block_bwd(pfx, cf, dx, d=dxd, nxt=nxt)
-                dx, dxd = dx if nxt is not None else (dx, None)
-                nxt = ffn_drop(below)
-                dx = self.self_attn_block_bwd(pfx, ca, dx, d=dxd, nxt=nxt)
-                dx, dxd = dx if nxt is not None else (dx, None)
+                if isinstance(ctx["layers"][l], dict):
+                    dx, dxd = self.layer_bwd(ctx["layers"][l], dx, dxd, ffn_drop(below))
+                else:
+                    ca, cf = ctx["layers"][l]
+                    nxt = (ca["p"], ca["seed"] + 2) if self.fuse_bwd_dropout and ca["p"] > 0 else None
+                    dx = self.ffn_block_bwd(pfx, cf, dx, d=dxd, nxt=nxt)
+                    dx, dxd = dx if nxt is not None else (dx, None)
+                    nxt = ffn_drop(below)
+                    dx = self.self_attn_block_bwd(pfx, ca, dx, d=dxd, nxt=nxt)
+                    dx, dxd = dx if nxt is not None else (dx, None)
             if l == hp.enc_layers - 1:
                 self._ready("encoder.layer_norm.")
             if hp.ctc_layer == l + 1:
@@ -760,6 +865,11 @@ class S2TEngine:
                 continue
             lp = pfx + "layers.%d." % l
             s = seed * 1000 + 510 + 10 * l
+            if self.composite and self.defer_wgrad:
+                x, cl = self.layer_fwd(lp, x, training, (s + 1, s + 2, s + 4, s + 5, s + 7, s + 8), self_klen=tlen, causal=True,
+                                       enc2d=enc2d, Ts=Ts, enc_klen=enc_klen32)
+                ctx["layers"].append(cl)
+                continue
             x, c1 = self.self_attn_block_fwd(lp, x, tlen, True, training, s)
             x, c2 = self.cross_attn_block_fwd(lp, x, enc2d, Ts, enc_klen32, training, s + 3)
             x, c3 = self.ffn_block_fwd(lp, x, training, s + 4)
@@ -852,8 +962,15 @@ class S2TEngine:
         def drop_of(c, off):
             return (c["p"], c["seed"] + off) if self.fuse_bwd_dropout and c["p"] > 0 else None
 
+        def out_drop(l):
+            """(p, seed) of the dropout on layer l's output (its FFN's), for whoever produces the gradient that enters it"""
+            cl = ctx["layers"][l]
+            if isinstance(cl, dict):
+                return (cl["p"], cl["seeds"][5]) if self.fuse_bwd_dropout and cl["p"] > 0 else None
+            return drop_of(cl[2], 4)
+
         kept = [l for l in range(hp.dec_layers) if ctx["layers"][l] is not None]         # LayerDrop: the layers that ran
-        nxt = drop_of(ctx["layers"][kept[-1]][2], 4) if kept else None
+        nxt = out_drop(kept[-1]) if kept else None
         dx = K.layernorm_bwd(dxn, f["x"], f["mean"], f["rstd"], self.P(pfx + "layer_norm.weight"),
                              self.G(pfx + "layer_norm.weight"), self.G(pfx + "layer_norm.bias"), drop=nxt)
         dx, dxd = dx if nxt is not None else (dx, None)
@@ -862,7 +979,12 @@ class S2TEngine:
             denc = (torch.empty if fresh else torch.zeros)((ctx["Ts"] * B, D), dtype=self.dtype, device=self.dev)
         for l in reversed(range(hp.dec_layers)):
             lp = pfx + "layers.%d." % l
-            if ctx["layers"][l] is not None:
+            if isinstance(ctx["layers"][l], dict):
+                below = max([k for k in kept if k < l], default=-1)
+                dx, dxd = self.layer_bwd(ctx["layers"][l], dx, dxd, out_drop(below) if below >= 0 else None, denc=denc,
+                                         denc_accumulate=not fresh)
+                fresh = False
+            elif ctx["layers"][l] is not None:
                 c1, c2, c3 = ctx["layers"][l]
                 below = max([k for k in kept if k < l], default=-1)
                 nxt = drop_of(c2, 2)
@@ -872,7 +994,7 @@ class S2TEngine:
                 dx = self.cross_attn_block_bwd(lp, c2, dx, denc, d=dxd, nxt=nxt, accumulate=not fresh)
                 fresh = False
                 dx, dxd = dx if nxt is not None else (dx, None)
-                nxt = drop_of(ctx["layers"][below][2], 4) if below >= 0 else None
+                nxt = out_drop(below) if below >= 0 else None
                 dx = self.self_attn_block_bwd(lp, c1, dx, d=dxd, nxt=nxt)
                 dx, dxd = dx if nxt is not None else (dx, None)
             if l == hp.dec_layers - 1:

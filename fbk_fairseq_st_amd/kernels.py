@@ -113,6 +113,32 @@ def wgrad_group(items):
         L.check(fn(len(chunk), ctypes.addressof(arr), L.stream()), "s2t_wgrad_group")
 
 
+def wgrad_group_raw(n, items_addr):
+    """launch n S2TWgradProblem entries of a host array the caller filled (engine: the products its layer calls appended)"""
+    if n:
+        L.check(_lib().s2t_wgrad_group(int(n), int(items_addr), L.stream()), "s2t_wgrad_group")
+
+
+def layer_ws_bytes(desc, training):
+    return int(_lib().s2t_layer_ws_bytes(ctypes.addressof(desc), int(training)))
+
+
+def layer_tmp_bytes(desc):
+    return int(_lib().s2t_layer_bwd_tmp_bytes(ctypes.addressof(desc)))
+
+
+def layer_fwd(desc_addr, call_addr):
+    rc = _lib().s2t_layer_fwd(desc_addr, call_addr, L.stream())
+    if rc:
+        L.check(rc, "s2t_layer_fwd")
+
+
+def layer_bwd(desc_addr, call_addr):
+    rc = _lib().s2t_layer_bwd(desc_addr, call_addr, L.stream())
+    if rc:
+        L.check(rc, "s2t_layer_bwd")
+
+
 def wgrad_group_ok(dy, x):
     """shapes the grouped kernel takes (otherwise: linear_wgrad)"""
     return (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6              # s2t_abi_version() of the library this binding was written against
+ABI_VERSION = 7              # s2t_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD, ACT_RELU_MASK, ACT_RELU_BWD_MASK = 0, 1, 2, 3, 4, 5, 6
 
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
@@ -87,6 +87,10 @@ SIGNATURES = {
     "s2t_a2d_time_bwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
     "s2t_a2d_freq_fwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
     "s2t_a2d_freq_bwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_ull, P],
+    "s2t_layer_ws_bytes": [P, c_int],                           # returns size_t
+    "s2t_layer_bwd_tmp_bytes": [P],                             # returns size_t
+    "s2t_layer_fwd": [P, P, P],
+    "s2t_layer_bwd": [P, P, P],
     "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],
     "s2t_host_ctc_uer": [P, P, c_int, c_int, P, P, c_int, c_int, P, P],
 }
@@ -95,6 +99,27 @@ class WgradProblem(ctypes.Structure):
     """S2TWgradProblem of include/s2t_hip.h"""
     _fields_ = [("dY", c_void_p), ("X", c_void_p), ("dW", c_void_p), ("db", c_void_p),
                 ("n_out", c_int), ("n_in", c_int), ("tokens", c_int), ("ldy", c_int), ("ldx", c_int), ("ldw", c_int)]
+
+
+_LAYER_W = ("qkv", "o", "xq", "xkv", "xo", "fc1", "fc2")
+_LAYER_LN = ("ln1_g", "ln1_b", "lnx_g", "lnx_b", "ln2_g", "ln2_b")
+
+
+class LayerDesc(ctypes.Structure):
+    """S2TLayerDesc of include/s2t_hip.h"""
+    _fields_ = ([(n, c_int) for n in ("dtype", "decoder", "T", "B", "D", "heads", "ffn", "Ts", "gelu", "causal", "dist_penalty")] +
+                [(n, c_float) for n in ("ln_eps", "p_drop", "p_attn", "p_act")] +
+                [("w_" + n, c_void_p) for n in _LAYER_W] + [("b_" + n, c_void_p) for n in _LAYER_W] + [(n, c_void_p) for n in _LAYER_LN] +
+                [("g_w_" + n, c_void_p) for n in _LAYER_W] + [("g_b_" + n, c_void_p) for n in _LAYER_W] + [("g_" + n, c_void_p) for n in _LAYER_LN])
+
+
+class LayerCall(ctypes.Structure):
+    """S2TLayerCall of include/s2t_hip.h"""
+    _fields_ = [("training", c_int), ("self_klen", c_void_p), ("enc_klen", c_void_p),
+                ("seed_sa_attn", c_ull), ("seed_sa_out", c_ull), ("seed_xa_attn", c_ull), ("seed_xa_out", c_ull), ("seed_ffn_act", c_ull),
+                ("seed_ffn_out", c_ull), ("x", c_void_p), ("enc", c_void_p), ("y", c_void_p), ("ws", c_void_p),
+                ("dy", c_void_p), ("dy_drop", c_void_p), ("dx", c_void_p), ("dx_drop", c_void_p), ("nxt_p", c_float), ("nxt_seed", c_ull),
+                ("denc", c_void_p), ("denc_accumulate", c_int), ("tmp", c_void_p), ("items", c_void_p), ("max_items", c_int), ("n_items", c_int)]
 
 
 _lib = None
@@ -121,6 +146,7 @@ def build(verbose=False):
 # never built here): both call the same libs2t_hip.so, neither computes anything.
 FAST_PATH = os.path.join(_HERE, "_s2t_fastcall.so")
 _HOST_SIDE = ("s2t_host_batch_by_size", "s2t_host_ctc_uer")          # CPU work: release the GIL around the call, as ctypes does
+_SIZE_T_RESULT = ("s2t_gemm_relu_mask_bytes", "s2t_layer_ws_bytes", "s2t_layer_bwd_tmp_bytes")
 
 
 def _fastcall_source():
@@ -154,7 +180,7 @@ def _fastcall_source():
         # the header's prototypes carry const / typed pointers: go through a function pointer of the table's erased types
         proto = ", ".join({c_float: "float", c_double: "double", P: "void*", ctypes.c_char_p: "const char*", c_ull: "unsigned long long",
                            c_int: "int", c_long: "long", c_longlong: "long long", c_size_t: "size_t"}[t] for t in at) or "void"
-        ret = "size_t" if name == "s2t_gemm_relu_mask_bytes" else "int"
+        ret = "size_t" if name in _SIZE_T_RESULT else "int"
         out.append("    %s (*fn)(%s) = (%s (*)(%s))%s;" % (ret, proto, ret, proto, name))
         if name in _HOST_SIDE:
             out.append("    %s r;" % ret)
@@ -208,7 +234,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_int
     lib.s2t_build_info.restype = ctypes.c_char_p
-    lib.s2t_gemm_relu_mask_bytes.restype = c_size_t
+    for name in _SIZE_T_RESULT:
+        getattr(lib, name).restype = c_size_t
     lib.s2t_build_info.argtypes = []
     if lib.s2t_abi_version() != ABI_VERSION:
         raise ImportError("libs2t_hip.so at %s has ABI version %d, this package binds version %d -- rebuild it (make -C %s)"

@@ -161,6 +161,46 @@ int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mea
                       const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
                       int M, int D, void* dx_drop, float p_drop, unsigned long long seed, void* stream);
 
+/* ---- one Transformer layer per call ------------------------------------------------------------------
+ * fairseq/modules/transformer_layer.py:87-139 (encoder layer) and :243-377 (decoder layer), pre-LN form, bf16 path: the kernels of
+ * a layer in the order the host engine issues them (LayerNorm, projections with fused bias / residual / dropout epilogues, flash
+ * attention, FFN with the 1-bit ReLU record or the GELU pre-activation), behind ONE entry point per direction.  Nothing new is
+ * computed here -- every launch is one of the entry points above -- but a small batch (8 utterances per GPU: SURVEY.md 8-d) is
+ * bound by the HOST's launch rate, and a layer is 7-13 launches forward and 9-20 backward.
+ * S2TLayerDesc: shapes, rates and parameter pointers of one layer (fixed per model and batch shape); S2TLayerCall: the operands of
+ * one call.  Activations are time-major rows (t*B + b) of D elements; `ws` keeps what the backward needs (s2t_layer_ws_bytes),
+ * `tmp` is scratch of the backward (s2t_layer_bwd_tmp_bytes; it holds the dY operands of the layer's weight-gradient products,
+ * which s2t_layer_bwd does NOT launch: it appends them to `items` for a later s2t_wgrad_group, so `ws`, `tmp`, `x` and `enc` must
+ * stay alive until then).  Dropout seeds are per site, exactly the ones the per-kernel path passes. */
+typedef struct S2TLayerDesc {
+    int dtype, decoder;                 /* S2T_BF16; 0 = self-attention + FFN, 1 = + encoder attention in between */
+    int T, B, D, heads, ffn, Ts;        /* Ts: source positions (decoder) */
+    int gelu, causal, dist_penalty;     /* activation (0 ReLU); mask / distance penalty of the self-attention */
+    float ln_eps, p_drop, p_attn, p_act;
+    const void *w_qkv, *w_o, *w_xq, *w_xkv, *w_xo, *w_fc1, *w_fc2;                  /* [out][in], compute dtype */
+    const float *b_qkv, *b_o, *b_xq, *b_xkv, *b_xo, *b_fc1, *b_fc2;
+    const float *ln1_g, *ln1_b, *lnx_g, *lnx_b, *ln2_g, *ln2_b;
+    float *g_w_qkv, *g_w_o, *g_w_xq, *g_w_xkv, *g_w_xo, *g_w_fc1, *g_w_fc2;         /* f32 gradient slices (backward) */
+    float *g_b_qkv, *g_b_o, *g_b_xq, *g_b_xkv, *g_b_xo, *g_b_fc1, *g_b_fc2;
+    float *g_ln1_g, *g_ln1_b, *g_lnx_g, *g_lnx_b, *g_ln2_g, *g_ln2_b;
+} S2TLayerDesc;
+typedef struct S2TLayerCall {
+    int training;
+    const int* self_klen; const int* enc_klen;            /* key lengths [B] or NULL */
+    unsigned long long seed_sa_attn, seed_sa_out, seed_xa_attn, seed_xa_out, seed_ffn_act, seed_ffn_out;
+    const void* x; const void* enc; void* y; void* ws;    /* forward: y = layer(x [T*B][D], enc [Ts*B][D]) */
+    /* backward: dy = gradient w.r.t. y; dy_drop = dropout(dy) with the FFN's output mask when the producer of dy already wrote it
+     * (else NULL); dx, and when nxt_p > 0 also dx_drop = dropout(dx, nxt_p, nxt_seed) for the consumer of dx; the encoder-output
+     * gradient is written (denc_accumulate = 0) or added to denc [Ts*B][D] */
+    const void* dy; const void* dy_drop; void* dx; void* dx_drop; float nxt_p; unsigned long long nxt_seed;
+    void* denc; int denc_accumulate; void* tmp;
+    S2TWgradProblem* items; int max_items; int n_items;   /* host array; n_items is advanced by the products appended */
+} S2TLayerCall;
+size_t s2t_layer_ws_bytes(const S2TLayerDesc* L, int training);
+size_t s2t_layer_bwd_tmp_bytes(const S2TLayerDesc* L);
+int s2t_layer_fwd(const S2TLayerDesc* L, S2TLayerCall* c, void* stream);
+int s2t_layer_bwd(const S2TLayerDesc* L, S2TLayerCall* c, void* stream);
+
 /* ---- convolutional subsampler (conv_transformer.py:202-232) ----------------------------------------
  * conv1: x [B][T][F] f32 -> y [B][T2][F2][C] (channels-last) = act(conv3x3 s2 p1 + bias), act = S2T_ACT_RELU | S2T_ACT_GELU
  * (--activation-fn, conv_transformer.py:140-142,212); with GELU the pre-activation goes to `pre` (same shape, needed by the

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     # every declared function is also bound with argtypes in the ctypes layer
     bound = set(L.SIGNATURES) | {"s2t_build_info"}
     assert set(syms) <= bound, set(syms) - bound
-    assert lib.s2t_abi_version() == 6
+    assert lib.s2t_abi_version() == 7
     assert b"gfx950" in lib.s2t_build_info()
 
 
@@ -58,7 +58,8 @@ def test_generated_cpython_binding_matches_the_ctypes_binding():
     for name, argtypes in L.SIGNATURES.items():
         assert hasattr(fast, name), name
         getattr(raw, name).argtypes = argtypes
-    raw.s2t_gemm_relu_mask_bytes.restype = ctypes.c_size_t
+    for name in L._SIZE_T_RESULT:
+        getattr(raw, name).restype = ctypes.c_size_t
     calls = [("s2t_gemm", (0, 0, 0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, None, 0, 0, 0, 1, 1.0, None)),
              ("s2t_gemm", (0, 0, 0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, None, 0, None, None, 0, 0, 0, 1, 1.0, None)),
              ("s2t_layernorm_fwd", (0, None, None, None, None, None, None, 4, 2048, 1e-5, None)),
