@@ -55,7 +55,7 @@ KERNEL_OF = {"wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward p
              "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (implicit-GEMM convolutions)",
              "conv2_fwd": "conv2_fwd_kernel (3x3 stride-2 convolution, input rows staged once in LDS, weights in registers)",
              "conv2_dgrad": "conv2_dgrad_kernel (its data gradient, four pixel-parity classes in one launch)"}
-TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_F32_TFLOPS = 157.3
 
@@ -190,7 +190,46 @@ def cpu_baseline(args, a, ref_sd, task):
                       % (Bc, args.frames, args.cpu_updates)}
 
 
-def extra_config(name, arch, dtype, device, steps, warmup, batch=None, frames=1500, tgt_len=40, ctc_layer=8, lengths=None, max_tokens=None):
+FAMILIES = ("wgrad_group", "gemm256_nt", "gemm256_nn", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small",
+            "gemm_gather", "conv2_fwd", "conv2_dgrad", "attn_fwd", "attn_bwd")
+
+
+def roofline_of(trainer, next_batch, prof_steps, dtype, instrument=True, traffic=True):
+    """`prof_steps` instrumented updates (HIP events around every MFMA-product launch, inside the library, on the launch stream) ->
+    the roofline object of the dominant kernel: the product family (one kernel template each, KERNEL_OF) with the most time per update"""
+    from fbk_fairseq_st_amd import kernels as K
+    if instrument:
+        K.prof_reset(); K.prof_enable(True)
+    for _ in range(prof_steps):
+        trainer.train_step([next_batch()])
+    torch.cuda.synchronize()
+    K.prof_enable(False)
+    if not instrument:
+        return None
+    fam = {f: K.prof_read(f) for f in FAMILIES}
+    gemms = {f: v for f, v in fam.items() if not f.startswith("attn") and v["launches"] > 0 and v["ms"] > 0}     # every MFMA product family
+    if not gemms:
+        return None
+    dom = max(gemms, key=lambda f: gemms[f]["ms"])
+    gm = gemms[dom]
+    ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    tot_fl = sum(v["flops"] for v in gemms.values()); tot_ms = sum(v["ms"] for v in gemms.values())
+    roof = {"bound": "mfma", "kernel": KERNEL_OF[dom], "family": dom,
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": hbm_traffic(dom) if traffic else None,
+            "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 2),
+            "launches_per_step": gm["launches"] // prof_steps,
+            "flop_per_launch": round(gm["flops"] / gm["launches"] / 1e9, 3), "flop_unit": "GFLOP",
+            "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
+            "tflops_by_family": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in gemms.items()},
+            "ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in fam.items() if v["launches"] > 0}}
+    if traffic:
+        roof["traffic_source"] = TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured by this run)"
+    return roof
+
+
+def extra_config(name, arch, dtype, device, steps, warmup, batch=None, frames=1500, tgt_len=40, ctc_layer=8, lengths=None, max_tokens=None, roofline=True):
     """one secondary workload; its model is freed before the next one is built"""
     a, task, model, crit, trainer, _ = build_all(arch, batch or 8, frames, tgt_len, ctc_layer, 1e-9, dtype, device)
     if lengths is None:
@@ -207,6 +246,10 @@ def extra_config(name, arch, dtype, device, steps, warmup, batch=None, frames=15
            "config": {"workload": "%s + ctc_multi_loss(ctc-compress-out @ layer %d) full update, %s" % (arch, ctc_layer, what),
                       "frames_per_step": round(frames_done / steps, 1), "frames_after_ctc_compression": round(enc_mean, 1)},
            "loss_finite": finite(stats)}
+    if roofline:
+        # the dominant MFMA product family of THIS workload (two instrumented updates after its timed region; no PMC traffic figure:
+        # the committed counter passes are of the headline command)
+        out["roofline"] = roofline_of(trainer, nxt, 2, dtype, traffic=False)
     del trainer, model, crit, task
     torch.cuda.empty_cache()
     return out
@@ -312,33 +355,7 @@ def main():
         # attention launch with two HIP events costs 2.2-2.5 ms per update, which would distort `value` by 12 % inside the timed region.
         # EVERY rank runs them (an update contains the gradient all-reduce: rank 0 alone would wait for the others forever); only
         # rank 0 instruments and reports.
-        if rank == 0:
-            K.prof_reset(); K.prof_enable(True)
-        for _ in range(args.prof_steps):
-            trainer.train_step([next_batch()])
-        torch.cuda.synchronize()
-        K.prof_enable(False)
-    if args.roofline and rank == 0:
-        names = ("wgrad_group", "gemm256_nt", "gemm256_nn", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small",
-                 "gemm_nt_small", "gemm_nn_small", "gemm_gather", "conv2_fwd", "conv2_dgrad", "attn_fwd", "attn_bwd")
-        fam = {f: K.prof_read(f) for f in names}
-        gemms = {f: v for f, v in fam.items() if not f.startswith("attn") and v["launches"] > 0 and v["ms"] > 0}     # every MFMA product family
-        if gemms:
-            # dominant kernel = the MFMA GEMM family with the most time per update (KERNEL_OF names its kernels)
-            dom = max(gemms, key=lambda f: gemms[f]["ms"])
-            gm = gemms[dom]
-            ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-            peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
-            tot_fl = sum(v["flops"] for v in gemms.values()); tot_ms = sum(v["ms"] for v in gemms.values())
-            roof = {"bound": "mfma", "kernel": KERNEL_OF[dom], "family": dom,
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": hbm_traffic(dom), "traffic_source": TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured by this run)",
-                    "avg_launch_us": round(gm["ms"] * 1e3 / gm["launches"], 2),
-                    "launches_per_step": gm["launches"] // args.prof_steps,
-                    "flop_per_launch": round(gm["flops"] / gm["launches"] / 1e9, 3), "flop_unit": "GFLOP",
-                    "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
-                    "tflops_by_family": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in gemms.items()},
-                    "ms_per_step": {k: round(v["ms"] / args.prof_steps, 3) for k, v in fam.items()}}
+        roof = roofline_of(trainer, next_batch, args.prof_steps, dtype, instrument=rank == 0)
     if world > 1:
         torch.distributed.barrier()
 
@@ -378,9 +395,10 @@ def main():
         rs = np.random.RandomState(4)
         mustc = [int(x) for x in np.clip(rs.lognormal(np.log(600.0), 0.7, 512), 50, 2000)]
         out["extra_configs"] = [
-            extra_config("cfg3_batch8", "s2t_transformer_m", torch.bfloat16, device, 20, 5, batch=8, frames=1500),
-            extra_config("cfg2_s_fp32", "s2t_transformer_s", torch.float32, device, 10, 3, batch=32, frames=1000, tgt_len=30),
-            extra_config("cfg4_l_bucketed", "s2t_transformer_l", torch.bfloat16, device, 20, 5, tgt_len=0, lengths=mustc, max_tokens=48000),
+            extra_config("cfg3_batch8", "s2t_transformer_m", torch.bfloat16, device, 20, 5, batch=8, frames=1500, roofline=args.roofline),
+            extra_config("cfg2_s_fp32", "s2t_transformer_s", torch.float32, device, 10, 3, batch=32, frames=1000, tgt_len=30, roofline=args.roofline),
+            extra_config("cfg4_l_bucketed", "s2t_transformer_l", torch.bfloat16, device, 20, 5, tgt_len=0, lengths=mustc, max_tokens=48000,
+                         roofline=args.roofline),
         ]
         ok = ok and all(e["loss_finite"] for e in out["extra_configs"])
     if rank == 0:

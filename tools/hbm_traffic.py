@@ -3,7 +3,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d <out>/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d <out>/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline
-    python tools/hbm_traffic.py <out>/fetch <out>/write profiles/r02_hbm_traffic.json
+    python tools/hbm_traffic.py <out>/fetch <out>/write profiles/r03_hbm_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes, so reads are
 doubled (the guide's correction for wide coalesced reads); WRITE_SIZE is exact for 16-byte stores and float atomics.
@@ -13,11 +13,12 @@ import collections, csv, glob, json, sys
 # (family, kernel-name substrings that must ALL occur): the 128x128 templates bench.py names in KERNEL_OF
 # (rocprofv3's demangler garbles the TB = true instantiations of gemm256_kernel into "gemm256_kernel<bool _Accum, bool, E, ...>":
 # that spelling therefore identifies the NN products)
-FAMILY = [("wgrad_group", ("wgrad_group_kernel",)), ("gemm_nn", ("gemm256_kernel", "_Accum")),
-          ("gemm_nt", ("gemm256_kernel", "Lb0E")), ("gemm_nn", ("gemm256_kernel", "Lb1E")),
-          ("gemm_nt", ("gemm256_kernel", "false")), ("gemm_nn", ("gemm256_kernel", "true")),
+FAMILY = [("wgrad_group", ("wgrad_group_kernel",)), ("gemm256_nn", ("gemm256_kernel", "_Accum")),
+          ("gemm256_nt", ("gemm256_kernel", "Lb0E")), ("gemm256_nn", ("gemm256_kernel", "Lb1E")),
+          ("gemm256_nt", ("gemm256_kernel", "false")), ("gemm256_nn", ("gemm256_kernel", "true")),
           ("gemm_tn", ("gemm_tn2_kernel",)), ("gemm_tn", ("gemm_fast_kernel", "true, true, 128, 128")), ("gemm_tn", ("gemm_fast_kernel", "Lb1ELb1ELi128ELi128")),
           ("gemm_nt", ("gemm_fast_kernel", "Lb0ELb0ELi128ELi128")), ("gemm_nn", ("gemm_fast_kernel", "Lb0ELb1ELi128ELi128")),
+          ("gemm_nt", ("gemm_fast_kernel", "false, false, 128, 128")), ("gemm_nn", ("gemm_fast_kernel", "false, true, 128, 128")),
           ("gemm_gather", ("gemm_kernel",)), ("conv2_fwd", ("conv2_fwd_kernel",)), ("conv2_dgrad", ("conv2_dgrad_kernel",)), ("attn_fwd", ("attn_fwd2",)), ("attn_bwd", ("attn_bwd_d",))]
 
 
