@@ -108,7 +108,6 @@ class _EncoderFn(torch.autograd.Function):
         ds = ({ctx.ectx["state_layers"][ctx.want_state]: d_state.contiguous()}
               if (ctx.want_state is not None and d_state is not None) else None)
         eng.encoder_backward(ctx.ectx, d_out, d_ctc if (has_ctc and d_ctc is not None) else None, ds)
-        ctx.enc._after_backward("encoder")
         return (None,) * 8
 
 
@@ -122,7 +121,6 @@ class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         denc = ctx.dec.engine.decoder_backward(ctx.dctx, dlogits if dlogits.stride(-1) == 1 else dlogits.contiguous())
-        ctx.dec._after_backward(ctx.dec.pfx.rstrip("."))
         c = ctx.dctx
         return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None, None
 
@@ -145,9 +143,7 @@ class _DualDecoderFn(torch.autograd.Function):
         eng = ctx.model.engine
         fix = lambda d: d if d.stride(-1) == 1 else d.contiguous()
         denc = eng.decoder_backward(ctx.c2, fix(d2))
-        ctx.model._notify_grads_ready("auxiliary_decoder")
         denc = eng.decoder_backward(ctx.c1, fix(d1), denc=denc)
-        ctx.model._notify_grads_ready("decoder")
         c = ctx.c1
         return None, None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None
 
@@ -179,9 +175,6 @@ class ConvolutionalTransformerEncoder(FairseqEncoder):
     @property
     def output_batch_first(self):
         return False                                            # conv_transformer.py:302-304
-
-    def _after_backward(self, part):
-        self.owner._notify_grads_ready(part)
 
     def forward(self, src_tokens, src_lengths, cls_input=None, return_all_hiddens=False, want_state=None, **unused):
         m = self.owner
@@ -245,9 +238,6 @@ class TransformerDecoder(FairseqIncrementalDecoder):
     @property
     def engine(self):
         return self.owner.engine
-
-    def _after_backward(self, part):
-        self.owner._notify_grads_ready(part)
 
     def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, **unused):
         m = self.owner
@@ -343,7 +333,6 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         self.arena = None
         self.compute_dtype = torch.float32
         self._seed_base, self._seed_ctr = 1, 0
-        self._grad_hooks = []
         self.extra_param_specs = {}            # e.g. the criterion-owned CTC head, added before materialize()
 
     # ---- parameter plumbing
@@ -490,13 +479,6 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         seed = int(getattr(self.args, "seed", 1)) + int(num_updates)
         if seed % 1000003 != self._seed_base:
             self.set_seed(seed)
-
-    def add_grads_ready_hook(self, fn):
-        self._grad_hooks.append(fn)
-
-    def _notify_grads_ready(self, part):
-        for fn in self._grad_hooks:
-            fn(part)
 
     # ---- reference-compatible state dict (split q/k/v, `encoder.bn.N.*` buffers, positional placeholders)
     def _local_attention_keys(self, sd, to_reference):

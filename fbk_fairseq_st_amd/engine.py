@@ -207,6 +207,12 @@ class S2TEngine:
         # launches of six layers pack as well as one of twelve (576 / 2 tiles each over 256 CUs, tail cut), and half of the encoder's
         # gradient bytes then travel over xGMI underneath the lower layers' backward instead of after it.
         self.wgrad_flush_layers = None
+        # True: the decoder's queued weight gradients go out at the end of ITS backward (data-parallel runs: ~130 MB of gradients
+        # then travel under the encoder's backward).  False: they wait for the encoder's flush and share its launch; measured on one GPU
+        # (tools/ab_engine_flag.py flush_decoder_wgrad): 15.63 ms per update against 15.48 with the separate launch -- the one work
+        # list packs the decoder's short reductions no better than its own launch does, and 0.4 ms of matrix work moves behind the
+        # encoder's backward where nothing overlaps it.  Kept as a switch for that measurement.
+        self.flush_decoder_wgrad = True
         self._a2d_prescale = None
         self.a2d_time_mfma = True        # time attention of ConvAttention2D on the MFMA attention kernels (False: the VALU kernels; tests compare the two)
         # LayerNorm backward also writes dropout(dx) for the block that consumes dx (one pass instead of two; identical bits)
@@ -1005,5 +1011,6 @@ class S2TEngine:
             K.dropout(dx, ctx["p"], ctx["seed"] * 1000 + 501, out=dx)
         K.embed_bwd(ctx["tok"], dx.view(L, B, D), self.G(pfx + "embed_tokens.weight"), ctx["scale"], hp.pad)
         self._ready(pfx + "embed_tokens.")
-        self.flush_wgrad()
+        if self.flush_decoder_wgrad:
+            self.flush_wgrad()
         return denc
