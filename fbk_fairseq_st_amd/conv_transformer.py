@@ -657,6 +657,8 @@ class ConvolutionalTransformerDualDecoder(ConvolutionalTransformerModel):
 
     def forward(self, src_tokens, src_lengths, prev_output_tokens, transcript_prev_output_tokens, **kwargs):
         self._ensure_engine(src_tokens.device)
+        if self.hp.decoder_layerdrop > 0:
+            raise NotImplementedError("--decoder-layerdrop with the dual-decoder model (the two decoders would need separate draws)")
         eo = self.encoder(src_tokens, src_lengths=src_lengths)
         klen = eo.src_lengths.to(torch.int32) if eo.encoder_padding_mask is not None else None
         l1, l2 = _DualDecoderFn.apply(self.anchor, self, prev_output_tokens, transcript_prev_output_tokens, eo.encoder_out,

@@ -271,6 +271,7 @@ class S2TEngine:
         elif self._wq:
             K.wgrad_group(self._wq)
             self._wq = []
+        self._keep = []
         post, self._wq_post = self._wq_post, []
         for fn in post:
             fn()
