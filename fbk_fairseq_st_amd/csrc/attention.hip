@@ -291,8 +291,34 @@ __device__ __forceinline__ float max_over_rows(float v) {
     r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return fmaxf(__builtin_bit_cast(float, (uint32_t)r[0]), __builtin_bit_cast(float, (uint32_t)r[1]));
 }
+// Diagnostic build only (make dbg; tools/attn_timeline.py): s_memtime at the phase boundaries of every tile, first and a middle
+// workgroup, lane 0 of each wave, into a buffer of their own (s2t_dbg_attn_stamps).  Each stamp waits for its own return
+// (lgkmcnt(0)), which perturbs the schedule.  [kernel 0 fwd / 1 dq / 2 dkv][workgroup slot 4][wave 4][tile 8][stamp 8]; tile 7 = entry, loop start, loop end, exit
+#ifdef S2T_ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;
+extern "C" int s2t_dbg_attn_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define ASTAMP_INIT(KID)                                                                                         \
+    const int lin_ = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                        \
+    const int slot_ = lin_ == 0 ? 0 : (lin_ == 700 ? 1 : (lin_ == 1100 ? 2 : (lin_ == 1500 ? 3 : -1)));                                                    \
+    unsigned long long* const stp_ = (g_attn_stamps && slot_ >= 0) ? g_attn_stamps + (((KID) * 4 + slot_) * 4 + (threadIdx.x >> 6)) * 64 : nullptr;
+#define ASTAMP(T, K)                                                                                             \
+    if (stp_ && (T) < 8) {                                                                                       \
+        unsigned long long t_;                                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                             \
+        if ((threadIdx.x & 63) == 0) stp_[(T) * 8 + (K)] = t_;                                                   \
+    }
+#define ASTAMP_EARLY(KID)  /* kernel entry: the init computes its own slot, the stamp goes to [tile 7][0] */                \
+    ASTAMP_INIT(KID) ASTAMP(7, 0)
+#else
+#define ASTAMP_INIT(KID)
+#define ASTAMP(T, K)
+#define ASTAMP_EARLY(KID)
+#endif
 __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
     constexpr int DH = 64;
+    ASTAMP_EARLY(0)
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
     int head;
@@ -303,15 +329,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
     const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
     const bf16* Vg = reinterpret_cast<const bf16*>(p.V) + (long)b * p.v_sb + (long)h * DH;
 
-    u32x4 qf[2][2];                                    // [query block][k-group of d]
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int row = qw + 16 * qb + r16;
-            qf[qb][g] = (u32x4){0, 0, 0, 0};
-            if (row < p.Tq) qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + (long)row * p.q_st + (4 * g + q) * 8);
-        }
     f32x4 o[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
@@ -351,17 +368,30 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
     // the whole dropout index space of this call in one 32-bit quad word (always, short of 17 G attention probabilities)
     const bool plain = !p.causal && !p.dist_pen && (uint64_t)p.B * p.H * p.Tq * (uint64_t)((p.Tk + 3) & ~3) < (1ull << 34);
 
-    // the Q fragments must have landed before the loop: left pending, the compiler's wait for them sits behind the loop's own
-    // prefetch in the in-order counter and becomes a vmcnt(0) -- the full latency of the K/V prefetch, exposed, every iteration
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0), the other counters untouched
+    // Prologue: the first K/V tile's DMA goes out BEFORE the Q fragment loads, so the two round trips to memory overlap (one after the
+    // other they were ~6,000 cycles of a workgroup's ~50,000).  The Q fragments must have landed before the loop: left pending, the
+    // compiler's wait for them sits behind the loop's own prefetch in the in-order counter and becomes a vmcnt(0) -- the full
+    // latency of the K/V prefetch, exposed, every iteration.
     if (ntile > 0) stage(0, smem);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                  // the DMA is not a register write: the compiler inserts no wait for it
+    u32x4 qf[2][2];                                    // [query block][k-group of d]
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int row = qw + 16 * qb + r16;
+            qf[qb][g] = (u32x4){0, 0, 0, 0};
+            if (row < p.Tq) qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + (long)row * p.q_st + (4 * g + q) * 8);
+        }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the DMA is not a register write, the compiler inserts no wait for it
     __syncthreads();
+    ASTAMP(7, 1)
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
         const char* sK = smem + (t & 1) * 16384;
         const char* sV = sK + 8192;
+        ASTAMP(t, 0)
         if (t + 1 < ntile) stage(kv0 + 64, smem + ((t + 1) & 1) * 16384);   // its readers of two tiles ago passed the last barrier
+        ASTAMP(t, 1)
         // ---- S^T = K Q^T
         f32x4 s[2][4];
 #pragma unroll
@@ -447,6 +477,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
         if (!(plain && kv0 + 64 <= klen)) softmax_tile(std::false_type{}, std::false_type{});
         else if (has_drop) softmax_tile(std::true_type{}, std::true_type{});
         else softmax_tile(std::true_type{}, std::false_type{});
+        ASTAMP(t, 2)
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -465,9 +496,13 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) o[qb][n] = mma16<bf16>(vf, pf[qb][kb], o[qb][n]);
             }
+        ASTAMP(t, 3)
         __builtin_amdgcn_s_waitcnt(0x0F70);                              // tile t + 1 has landed (this wave's share; the barrier covers the rest)
+        ASTAMP(t, 4)
         __syncthreads();
+        ASTAMP(t, 5)
     }
+    ASTAMP(7, 2)
     bf16* Og = reinterpret_cast<bf16*>(p.O) + (long)b * p.o_sb + (long)h * DH;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -485,6 +520,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
         }
         if (q == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Tq + qrow] = m[qb] * 0.693147180559945f + logf(lt);
     }
+    ASTAMP(7, 3)
 }
 
 // ------------------------------------------------------------------------------------ delta
@@ -756,6 +792,7 @@ __device__ __forceinline__ void stage2_dma(const bf16* A, long a_st, const bf16*
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     constexpr int DH = 64;
+    ASTAMP_EARLY(2)
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (Q 8 KiB | dO 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
     int head;
@@ -773,16 +810,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     // 8 fragments per lane in registers instead pushed the kernel past 256 VGPRs
     char* sKown = smem + 32768 + 1024;                              // [128 keys][64 d] K, then V
     char* sVown = sKown + 16384;
-    for (int cid = threadIdx.x; cid < 128 * 8; cid += 256) {
-        const int row = cid >> 3, c = cid & 7, key = bx * 128 + row;
-        u32x4 kk = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-        if (key < klen) {
-            kk = *reinterpret_cast<const u32x4*>(Kg + (long)key * p.k_st + c * 8);
-            vv = *reinterpret_cast<const u32x4*>(Vg + (long)key * p.v_st + c * 8);
-        }
-        *reinterpret_cast<u32x4*>(sKown + row * 128 + ((c ^ (row & 7)) << 4)) = kk;
-        *reinterpret_cast<u32x4*>(sVown + row * 128 + ((c ^ (row & 7)) << 4)) = vv;
-    }
     f32x4 dkT[2][4], dvT[2][4];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -800,22 +827,49 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     auto stage = [&](int qt, int stg) {
         stage2_dma(Qg, p.q_st, dOg, p.do_st, qt, p.Tq, smem + stg * 16384, wave, lane);
         if (wave < 2) {
-            const float* src = (wave == 0 ? lse : dlt) + min(qt + lane, p.Tq - 1);
-            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
-                                             (__attribute__((address_space(3))) void*)(sStat + stg * 128 + wave * 64), 4, 0, 0);
+            // rows past Tq (the last tile): LSE = +inf, so their probabilities -- and with them dS -- are exact zeros without a mask
+            // per element (their Q / dO rows repeat the last query: finite); the DMA writes nothing for the lanes that are off
+            float* dst = sStat + stg * 128 + wave * 64;
+            if (wave == 1 || qt + lane < p.Tq) {
+                const float* src = (wave == 0 ? lse : dlt) + min(qt + lane, p.Tq - 1);
+                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+            } else dst[lane] = INFINITY;
         }
     };
-    if (ntile > 0) stage(qstart, 0);
+    if (ntile > 0) stage(qstart, 0);                  // first: the DMA overlaps the loads of the own keys below (one round trip, not two)
+    {   // all eight loads of a thread go out together (keys past klen read the last row of the tensor and are zeroed by a select)
+        u32x4 kk[4], vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            const long key = min(bx * 128 + row, p.Tk - 1);
+            kk[i] = *reinterpret_cast<const u32x4*>(Kg + key * p.k_st + c * 8);
+            vv[i] = *reinterpret_cast<const u32x4*>(Vg + key * p.v_st + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cid = threadIdx.x + 256 * i, row = cid >> 3, c = cid & 7;
+            const bool in = bx * 128 + row < klen;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { kk[i][w] = in ? kk[i][w] : 0u; vv[i][w] = in ? vv[i][w] : 0u; }
+            *reinterpret_cast<u32x4*>(sKown + row * 128 + ((c ^ (row & 7)) << 4)) = kk[i];
+            *reinterpret_cast<u32x4*>(sVown + row * 128 + ((c ^ (row & 7)) << 4)) = vv[i];
+        }
+    }
     S2T_WAIT_VM0();
     __syncthreads();
     const float sc2 = p.scale * 1.44269504088896f;
     const bool generic = p.causal || p.dist_pen;
+    ASTAMP(7, 1)
     for (int t = 0; t < ntile; ++t) {
         const int qt = qstart + t * 64;
         const char* sQ = smem + (t & 1) * 16384;
         const char* sDO = sQ + 8192;
         const float* sL = sStat + (t & 1) * 128;
+        ASTAMP(t, 0)
         if (t + 1 < ntile) stage(qt + 64, (t + 1) & 1);
+        ASTAMP(t, 1)
         // EDGE: masks evaluated per element (query rows past Tq -- their tile rows repeat the last query --, the causal triangle,
         // the distance penalty); DROP: dropout on.  Common factors leave the inner loop: dS carries neither the softmax scale (dK is
         // scaled once at the end) nor, like P, the dropout's 1/(1-p) (it multiplies dP inside one fma, and dV at the end).
@@ -880,13 +934,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
             }
         }
         };
-        const bool edge = generic || qt + 64 > p.Tq;
+        const bool edge = generic;                       // a plain softmax has no edge: the query tail is handled by LSE = +inf
         if (p.p_drop > 0.f) { if (edge) tile(std::true_type{}, std::true_type{}); else tile(std::false_type{}, std::true_type{}); }
         else if (edge) tile(std::true_type{}, std::false_type{});
         else tile(std::false_type{}, std::false_type{});
+        ASTAMP(t, 3)
         S2T_WAIT_VM0();                                   // tile t + 1 has landed (this wave's share; the barrier covers the rest)
+        ASTAMP(t, 4)
         __syncthreads();
+        ASTAMP(t, 5)
     }
+    ASTAMP(7, 2)
     const float dv_scale = p.p_drop > 0.f ? drop_inv : 1.f;
     bf16* dKg = reinterpret_cast<bf16*>(p.dK) + (long)b * p.dk_sb + (long)h * DH;
     bf16* dVg = reinterpret_cast<bf16*>(p.dV) + (long)b * p.dv_sb + (long)h * DH;
@@ -906,10 +964,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
             *reinterpret_cast<u32x2*>(dVg + (long)key * p.dv_st + 16 * n + 4 * q) = w;
         }
     }
+    ASTAMP(7, 3)
 }
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
     constexpr int DH = 64;
+    ASTAMP_EARLY(1)
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
     int head;
@@ -923,30 +983,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
     const float* lse = p.LSE + ((long)b * p.H + h) * p.Tq;
     const float* dlt = p.Delta + ((long)b * p.H + h) * p.Tq;
 
+    int kv_end = klen;
+    if (p.causal) kv_end = min(kv_end, bx * 128 + 128);
+    const int ntile = (kv_end + 63) / 64;
+    if (ntile > 0) stage2_dma(Kg, p.k_st, Vg, p.v_st, 0, p.Tk, smem, wave, lane);      // first: overlaps the operand loads below
     u32x4 qf[2][2], dof[2][2];
     float L[2], Dl[2];
     const bf16* Og = reinterpret_cast<const bf16*>(p.O) + (long)b * p.o_sb + (long)h * DH;
+    // All thirteen loads of a lane go out back to back (rows past Tq read the last row and are zeroed by a select): inside
+    // `if (row < Tq)` blocks that also consumed them, each block waited out its own round trip to memory -- four in a row, ~10,000
+    // cycles of a workgroup's ~42,000.
+    u32x4 of[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const long row = min(qw + 16 * qb + r16, p.Tq - 1);
+        L[qb] = lse[row] * 1.44269504088896f;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + row * p.q_st + (4 * g + q) * 8);
+            dof[qb][g] = *reinterpret_cast<const u32x4*>(dOg + row * p.do_st + (4 * g + q) * 8);
+            of[qb][g] = *reinterpret_cast<const u32x4*>(Og + row * p.o_st + (4 * g + q) * 8);
+        }
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int row = qw + 16 * qb + r16;
-        L[qb] = row < p.Tq ? lse[row] * 1.44269504088896f : 0.f;
+        const bool in = row < p.Tq;
         float part = 0.f;                                   // Delta = rowsum(dO * O): this kernel owns the query, so it makes it
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            qf[qb][g] = dof[qb][g] = (u32x4){0, 0, 0, 0};
-            if (row < p.Tq) {
-                qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + (long)row * p.q_st + (4 * g + q) * 8);
-                dof[qb][g] = *reinterpret_cast<const u32x4*>(dOg + (long)row * p.do_st + (4 * g + q) * 8);
-                const u32x4 ov = *reinterpret_cast<const u32x4*>(Og + (long)row * p.o_st + (4 * g + q) * 8);
-                const bf16* oe = reinterpret_cast<const bf16*>(&ov);
-                const bf16* de = reinterpret_cast<const bf16*>(&dof[qb][g]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) part += (float)oe[e] * (float)de[e];
-            }
+            for (int w = 0; w < 4; ++w) { qf[qb][g][w] = in ? qf[qb][g][w] : 0u; dof[qb][g][w] = in ? dof[qb][g][w] : 0u; }
+            const bf16* oe = reinterpret_cast<const bf16*>(&of[qb][g]);
+            const bf16* de = reinterpret_cast<const bf16*>(&dof[qb][g]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part += (float)oe[e] * (float)de[e];
         }
+        L[qb] = in ? L[qb] : 0.f;
         part += __shfl_xor(part, 16); part += __shfl_xor(part, 32);
         Dl[qb] = part;
-        if (q == 0 && row < p.Tq) const_cast<float*>(dlt)[row] = part;         // the dK/dV kernel, launched after this one, reads it
+        if (q == 0 && in) const_cast<float*>(dlt)[row] = part;                 // the dK/dV kernel, launched after this one, reads it
     }
     f32x4 dqT[2][4];
 #pragma unroll
@@ -958,27 +1034,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
     const uint32_t drop_ks = drop_seed_key(p.seed), drop_hwm = drop_high_mix(p.seed, 0);   // < 2^34 elements (launcher): quad index in one word
     const uint32_t tkq = (uint32_t)((p.Tk + 3) >> 2);
 
-    int kv_end = klen;
-    if (p.causal) kv_end = min(kv_end, bx * 128 + 128);
-    const int ntile = (kv_end + 63) / 64;
     const float sc2 = p.scale * 1.44269504088896f;
     const bool generic = p.causal || p.dist_pen;
     // Q / dO fragments must have landed before the loop: left pending, the compiler's wait for them sits behind the loop's own
     // prefetch in the in-order counter and becomes a vmcnt(0), i.e. the whole K/V prefetch latency, exposed, every iteration
-    S2T_WAIT_VM0();
-    if (ntile > 0) stage2_dma(Kg, p.k_st, Vg, p.v_st, 0, p.Tk, smem, wave, lane);
-    S2T_WAIT_VM0();
+    S2T_WAIT_VM0();                                   // (the first K/V tile went out ahead of those loads: one round trip, not two)
     __syncthreads();
+    ASTAMP(7, 1)
     for (int t = 0; t < ntile; ++t) {
         const int kv0 = t * 64;
         const char* sK = smem + (t & 1) * 16384;
         const char* sV = sK + 8192;
+        ASTAMP(t, 0)
         if (t + 1 < ntile) stage2_dma(Kg, p.k_st, Vg, p.v_st, kv0 + 64, p.Tk, smem + ((t + 1) & 1) * 16384, wave, lane);
+        ASTAMP(t, 1)
         u32x4 sf[2][2];                                 // [query block][32-key block]: dS^T as B operand
         // EDGE: masks per element (keys past klen -- their tile rows hold whatever lies there --, the causal triangle, the distance
         // penalty).  dS carries neither the softmax scale (dQ is scaled once at the end) nor a separate 1/(1-p) multiply.
-        auto ds_tile = [&](auto edge_tag, auto drop_tag) {
-        constexpr bool EDGE = decltype(edge_tag)::value, DROP = decltype(drop_tag)::value;
+        // TAIL: the last key tile of a plain softmax (klen not a multiple of 64) -- the interior arithmetic plus one compare + select
+        // per element for the keys past klen (the generic EDGE path takes twice an interior tile's time)
+        auto ds_tile = [&](auto edge_tag, auto drop_tag, auto tail_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value, DROP = decltype(drop_tag)::value, TAIL = decltype(tail_tag)::value;
+        const int tail_thr = klen - kv0 - 4 * q;                           // key 16 j + 4 q + r is valid <=> 16 j + r < tail_thr
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32x4 ka[2], va[2];
@@ -1004,6 +1081,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
                         const int key = key0 + r;
                         e = (key < klen && (!p.causal || key <= qrow)) ? e : 0.f;
                     }
+                    if constexpr (TAIL) e = (16 * j + r < tail_thr) ? e : 0.f;
                     if constexpr (DROP) ds[r] = e * __builtin_fmaf(drop_field(hq, r) >= drop_th16 ? dp[r] : 0.f, drop_inv, -Dl[qb]);
                     else ds[r] = e * (dp[r] - Dl[qb]);
                 }
@@ -1011,10 +1089,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
             }
         }
         };
-        const bool edge = generic || kv0 + 64 > klen;
-        if (p.p_drop > 0.f) { if (edge) ds_tile(std::true_type{}, std::true_type{}); else ds_tile(std::false_type{}, std::true_type{}); }
-        else if (edge) ds_tile(std::true_type{}, std::false_type{});
-        else ds_tile(std::false_type{}, std::false_type{});
+        const bool tail = kv0 + 64 > klen;
+        if (generic) { if (p.p_drop > 0.f) ds_tile(std::true_type{}, std::true_type{}, std::false_type{}); else ds_tile(std::true_type{}, std::false_type{}, std::false_type{}); }
+        else if (p.p_drop > 0.f) { if (tail) ds_tile(std::false_type{}, std::true_type{}, std::true_type{}); else ds_tile(std::false_type{}, std::true_type{}, std::false_type{}); }
+        else if (tail) ds_tile(std::false_type{}, std::false_type{}, std::true_type{});
+        else ds_tile(std::false_type{}, std::false_type{}, std::false_type{});
+        ASTAMP(t, 2)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -1023,9 +1103,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) dqT[qb][n] = mma16<bf16>(kt, sf[qb][jb], dqT[qb][n]);
             }
+        ASTAMP(t, 3)
         S2T_WAIT_VM0();                                   // tile t + 1 has landed (this wave's share; the barrier covers the rest)
+        ASTAMP(t, 4)
         __syncthreads();
+        ASTAMP(t, 5)
     }
+    ASTAMP(7, 2)
     bf16* dQg = reinterpret_cast<bf16*>(p.dQ) + (long)b * p.dq_sb + (long)h * DH;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -1038,6 +1122,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
             *reinterpret_cast<u32x2*>(dQg + (long)qrow * p.dq_st + 16 * n + 4 * q) = w;
         }
     }
+    ASTAMP(7, 3)
 }
 
 // ------------------------------------------------------------------------------------ C ABI
