@@ -319,7 +319,7 @@ extern "C" int s2t_dbg_attn_stamps(void* buf) {
 __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     ASTAMP_EARLY(0)
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (K 8 KiB | V 8 KiB), 512 B of score offsets, Q 16 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
     int head;
     const int bx = head_xcd_remap(head, p.B * p.H, gridDim.x);
@@ -347,16 +347,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
     // at position c ^ swz(row): K rows are read back as b128 rows (swz = row & 7), V by transposing reads (swz = row & 6).
     // Rows past klen are NOT zeroed: the address is clamped to the last row of the tensor (finite data), their scores are masked
     // to -inf and their probabilities are exact zeros.
+    const uint32_t kst2 = (uint32_t)p.k_st * 2u, vst2 = (uint32_t)p.v_st * 2u;
     auto stage = [&](int kv0, char* st) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r8 = 8 * (wave + 4 * i), row = r8 + (lane >> 3), pos = lane & 7;
-            const long r = min(kv0 + row, p.Tk - 1);
+            // 32-bit byte offsets from the head's (uniform) base, one v_mad_u32_u24 each: row strides below 16 MiB and tensors below
+            // 4 GiB (checked by the launcher).  The 64-bit form was two quarter-rate multiplies and a 64-bit mad per address, every tile.
+            const uint32_t r = (uint32_t)min(kv0 + row, p.Tk - 1);
             char* dst = st + __builtin_amdgcn_readfirstlane(r8 * 128);
-            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(Kg + r * p.k_st + ((pos ^ (row & 7)) << 3)),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(Vg + r * p.v_st + ((pos ^ (row & 6)) << 3)),
-                                             (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+            const char* ka = reinterpret_cast<const char*>(Kg) + (__umul24(r, kst2) + (uint32_t)((pos ^ (row & 7)) << 4));
+            const char* va = reinterpret_cast<const char*>(Vg) + (__umul24(r, vst2) + (uint32_t)((pos ^ (row & 6)) << 4));
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)ka, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)va, (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
         }
     };
     const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
@@ -368,20 +371,31 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
     // the whole dropout index space of this call in one 32-bit quad word (always, short of 17 G attention probabilities)
     const bool plain = !p.causal && !p.dist_pen && (uint64_t)p.B * p.H * p.Tq * (uint64_t)((p.Tk + 3) & ~3) < (1ull << 34);
 
+    // Score offsets of the last key tile: 0 for its keys below klen, -inf past them; the row of zeros next to it serves every other
+    // tile.  The QK^T accumulators START from these (read from LDS, no VALU), so the tail of a plain softmax needs no mask per element
+    // and no second code path (a second path between QK^T and the softmax costs this kernel spilled registers).
+    float* sInit = reinterpret_cast<float*>(smem + 32768);              // [2][64]
+    if (threadIdx.x < 128) {
+        const int i = threadIdx.x & 63;
+        sInit[threadIdx.x] = (threadIdx.x < 64 || (ntile - 1) * 64 + i < klen) ? 0.f : -INFINITY;
+    }
     // Prologue: the first K/V tile's DMA goes out BEFORE the Q fragment loads, so the two round trips to memory overlap (one after the
     // other they were ~6,000 cycles of a workgroup's ~50,000).  The Q fragments must have landed before the loop: left pending, the
     // compiler's wait for them sits behind the loop's own prefetch in the in-order counter and becomes a vmcnt(0) -- the full
     // latency of the K/V prefetch, exposed, every iteration.
     if (ntile > 0) stage(0, smem);
-    u32x4 qf[2][2];                                    // [query block][k-group of d]
+    // The workgroup's 128 query rows are parked in LDS (LDS-DMA, the K tile's swizzle) and their fragments re-read every tile: 16
+    // VGPRs less than holding them (the kernel sits at its 168-register budget for three waves per SIMD).  Rows past Tq repeat the
+    // last query (finite); their columns are never stored.
+    char* sQ = smem + 32768 + 512;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int row = qw + 16 * qb + r16;
-            qf[qb][g] = (u32x4){0, 0, 0, 0};
-            if (row < p.Tq) qf[qb][g] = *reinterpret_cast<const u32x4*>(Qg + (long)row * p.q_st + (4 * g + q) * 8);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int r8 = 8 * (wave + 4 * i), row = r8 + (lane >> 3), pos = lane & 7;
+        const long r = min(bx * 128 + row, p.Tq - 1);
+        char* dst = sQ + __builtin_amdgcn_readfirstlane(r8 * 128);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(Qg + r * p.q_st + ((pos ^ (row & 7)) << 3)),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the DMA is not a register write, the compiler inserts no wait for it
     __syncthreads();
     ASTAMP(7, 1)
@@ -394,6 +408,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
         ASTAMP(t, 1)
         // ---- S^T = K Q^T
         f32x4 s[2][4];
+        const float* sInit0 = sInit + ((plain && t == ntile - 1) ? 64 : 0) + 4 * q;
+        u32x4 qf[2][2];                                // [query block][k-group of d]
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int row = wave * 32 + 16 * qb + r16;
+                qf[qb][g] = *reinterpret_cast<const u32x4*>(sQ + row * 128 + (((4 * g + q) ^ (row & 7)) << 4));
+            }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32x4 kf[2];
@@ -404,7 +427,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
             }
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                s[qb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                s[qb][j] = *reinterpret_cast<const f32x4*>(sInit0 + 16 * j);
 #pragma unroll
                 for (int g = 0; g < 2; ++g) s[qb][j] = mma16<bf16>(kf[g], qf[qb][g], s[qb][j]);
             }
@@ -474,7 +497,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd2_kernel(AttnArgs p) {
                 for (int n = 0; n < 4; ++n) o[qb][n] *= alpha;
             }
         };
-        if (!(plain && kv0 + 64 <= klen)) softmax_tile(std::false_type{}, std::false_type{});
+        if (!plain) softmax_tile(std::false_type{}, std::false_type{});
         else if (has_drop) softmax_tile(std::true_type{}, std::true_type{});
         else softmax_tile(std::true_type{}, std::false_type{});
         ASTAMP(t, 2)
@@ -779,13 +802,14 @@ __device__ __forceinline__ void stage2_dma(const bf16* A, long a_st, const bf16*
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r8 = 8 * (wave + 4 * i), row = r8 + (lane >> 3), pos = lane & 7;
-        const long r = min(r0 + row, nrows - 1);
-        const int ch = (pos ^ (row & 7)) << 3;
+        // 32-bit byte offsets from the (uniform) bases, one v_mad_u32_u24 each: row strides below 16 MiB, tensors below 4 GiB (launcher)
+        const uint32_t r = (uint32_t)min(r0 + row, nrows - 1);
+        const uint32_t ch = (uint32_t)((pos ^ (row & 7)) << 4);
         char* dst = st + __builtin_amdgcn_readfirstlane(r8 * 128);
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(A + r * a_st + ch),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(B + r * b_st + ch),
-                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+        const char* aa = reinterpret_cast<const char*>(A) + (__umul24(r, (uint32_t)a_st * 2u) + ch);
+        const char* ba = reinterpret_cast<const char*>(B) + (__umul24(r, (uint32_t)b_st * 2u) + ch);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)aa, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)ba, (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
     }
 }
 #define S2T_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)               /* vmcnt(0); lgkmcnt / expcnt untouched */
@@ -819,6 +843,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     const float drop_inv = 1.f / (1.f - p.p_drop);
     const uint32_t drop_ks = drop_seed_key(p.seed), drop_hwm = drop_high_mix(p.seed, 0);   // < 2^34 elements (launcher): quad index in one word
     const uint32_t tkq = (uint32_t)((p.Tk + 3) >> 2);                                        // quads per (padded) row of the index space
+    const uint32_t drop_thm1x2 = (drop_th16 - 1u) * 0x00010001u;
+    const uint32_t own_bit = ((r16 & 1) ? 0x00010000u : 1u) << ((r16 >> 1) & 1);            // key r16 & 3 of a quad: bits 0, 16, 1, 17
 
     const int qstart = p.causal ? bx * 128 : 0;                 // queries before the first key of the workgroup see nothing
     const int ntile = qstart < p.Tq ? (p.Tq - qstart + 63) / 64 : 0;
@@ -898,8 +924,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
                     dp = mma16<bf16>(da[g], row_frag128(sVown, krow, 4 * g + q), dp);
                 }
                 const int key = kw + 16 * kb + r16;
-                u32x2 hq = {0u, 0u};
-                if constexpr (DROP) hq = drop_hash4_lo(drop_ks, drop_hwm, qrow_quads + ((uint32_t)key >> 2));
+                // dropout: this lane hashes the quad (query 4q + (r16 & 3), keys 4 (r16 >> 2) ..+3) and turns its four fields into keep
+                // BITS at once (field >= threshold as a saturating packed subtract of threshold - 1 and a packed min with 1: keys 0 / 1
+                // -> bits 0 / 16 of one word, keys 2 / 3 of the other, merged as bits 0, 16, 1, 17).  The element (query 4q + r, own
+                // key) then costs one DPP quad broadcast fused into an AND with the own key's bit, one compare and the two selects --
+                // broadcasting both hash words and extracting a lane-dependent 16-bit field per element took 2.4x as many instructions.
+                uint32_t nib = 0u;
+                if constexpr (DROP) {
+                    const u32x2 hq = drop_hash4_lo(drop_ks, drop_hwm, qrow_quads + ((uint32_t)key >> 2));
+                    uint32_t dy, dx, ky, kx;
+                    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dy) : "v"(hq[1]), "v"(drop_thm1x2));
+                    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dx) : "v"(hq[0]), "v"(drop_thm1x2));
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(ky) : "v"(dy), "v"(0x00010001u));
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(kx) : "v"(dx), "v"(0x00010001u));
+                    nib = drop_th16 > 0 ? (ky | (kx << 1)) : 0x00030003u;    // a rate below 2^-16 keeps every element, as in every other kernel
+                }
                 float pv[4], ds[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -909,9 +948,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
                     float e = __builtin_amdgcn_exp2f(arg);
                     if constexpr (EDGE) e = (qrow < p.Tq && (!p.causal || key <= qrow)) ? e : 0.f;     // keys past klen: discarded at the store
                     if constexpr (DROP) {
-                        // the quad of (query 4q + r, own key) sits in lane (r16 & ~3) | r of the same 4-lane group -> DPP quad
-                        // broadcast, then take the own key's field
-                        const bool keep = drop_field((u32x2){quad_bcast(hq[0], r), quad_bcast(hq[1], r)}, r16 & 3) >= drop_th16;
+                        // the bits of (query 4q + r, keys of the own quad) sit in lane (r16 & ~3) | r of the same 4-lane group
+                        const bool keep = (quad_bcast(nib, r) & own_bit) != 0u;
                         pv[r] = keep ? e : 0.f;
                         ds[r] = e * __builtin_fmaf(keep ? dp[r] : 0.f, drop_inv, -Dl[r]);
                     } else {
@@ -1126,6 +1164,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------ C ABI
+// the second-generation kernels address the rows of a staged tensor by 32-bit byte offsets built with a 24-bit multiply
+static bool span32(long stride, int rows) {
+    return stride >= 0 && stride * 2 < (1l << 24) && (long)rows * stride * 2 + 256 < (1l << 32);
+}
 static bool strides_ok(int dtype, const long* s, int n) {
     const int e = dtype == S2T_BF16 ? 8 : 4;
     for (int i = 0; i < n; ++i) if (s[i] % e) return false;
@@ -1150,8 +1192,8 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
                         !((uintptr_t)a.dK & 7) && !((uintptr_t)a.dV & 7) && !((uintptr_t)a.dQ & 7);
         // the second-generation kernels keep the dropout quad index in one 32-bit word
         const bool idx32 = (unsigned long long)a.B * a.H * a.Tq * (unsigned long long)((a.Tk + 3) & ~3) < (1ull << 34);
-        dkv2 = !v1 && al && idx32 && a.Tk >= 128;
-        dq2 = !v1 && al && idx32 && (a.Tq >= 128 || (a.Tq >= S2T_ATTN_V2_MIN_TQ && a.Tk >= 128)) && !(a.o_st % 8) && !(a.o_sb % 8) && !((uintptr_t)a.O & 15);
+        dkv2 = !v1 && al && idx32 && a.Tk >= 128 && span32(a.q_st, a.Tq) && span32(a.do_st, a.Tq);
+        dq2 = !v1 && al && idx32 && span32(a.k_st, a.Tk) && span32(a.v_st, a.Tk) && (a.Tq >= 128 || (a.Tq >= S2T_ATTN_V2_MIN_TQ && a.Tk >= 128)) && !(a.o_st % 8) && !(a.o_sb % 8) && !((uintptr_t)a.O & 15);
         if (dq2) {                                       // first: it also writes Delta for the dK/dV kernel
             hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3((a.Tq + 127) / 128, a.H, a.B), dim3(256), 32768, st, a);
             S2T_LAUNCH_CHECK();
@@ -1221,9 +1263,9 @@ extern "C" int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int T
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("attn_fwd", st, 4.0 * B * H * (double)Tq * Tk * head_dim * (causal ? 0.5 : 1.0), 0.0);
     if (dtype == S2T_BF16 && head_dim == 64 && (Tq >= 128 || (Tq >= S2T_ATTN_V2_MIN_TQ && Tk >= 128)) && (o_st % 4) == 0 && (o_sb % 4) == 0 && ((uintptr_t)O & 7) == 0) {
-        const bool v1 = g_s2t_opt_attn_v1 != 0;                            // s2t_set_option("attn_v1")
+        const bool v1 = g_s2t_opt_attn_v1 != 0 || !span32(k_st, Tk) || !span32(v_st, Tk);     // s2t_set_option("attn_v1")
         if (!v1) {
-            hipLaunchKernelGGL(attn_fwd2_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 32768, st, a);
+            hipLaunchKernelGGL(attn_fwd2_kernel, dim3((Tq + 127) / 128, H, B), dim3(256), 32768 + 512 + 16384, st, a);
             S2T_LAUNCH_CHECK();
             return S2T_OK;
         }
