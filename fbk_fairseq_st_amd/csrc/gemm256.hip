@@ -224,11 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // reads of a half-tile that is re-staged in the very next super-phase must have RETURNED before this wave passes the barrier
 #define S2T_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT][4];                                                    // never zeroed: see FIRST below
 
     // fragment addresses (bytes inside a half-tile)
     const int swz0 = ((0 + q) ^ (r16 & 7)) << 4, swz1 = ((4 + q) ^ (r16 & 7)) << 4;
@@ -278,11 +274,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #define S2T_MT(V_)
 #define S2T_MEM_END()
 #endif
+    // FIRST (the first K-tile of an output tile): the first MFMA of every accumulator takes the constant 0 as its C operand, so no
+    // accumulator is ever zeroed by moves (128 v_mov per lane and tile, which the compiler emitted twice at the loop header)
 #define S2T_QUAD(MI, NI)                                                                                     \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                        \
             _Pragma("unroll") for (int i = 0; i < QM; ++i)                                                   \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
-                    acc[QM * (MI) + i][2 * (NI) + j] = mma16<bf16>(fb[NI][j][s], fa[i][s], acc[QM * (MI) + i][2 * (NI) + j]);
+                    acc[QM * (MI) + i][2 * (NI) + j] = mma16<bf16>(fb[NI][j][s], fa[i][s],                   \
+                        (FIRST && s == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[QM * (MI) + i][2 * (NI) + j]);
 #define S2T_MMA2(MI, NA, NB)                                                                                 \
     do {                                                                                                     \
         S2T_STAMP(0)                                                                                         \
@@ -314,7 +313,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     for (;;) {
         has_next = tile + G < tiles;
         if (has_next) offsets(tile + G, nxt);
-        for (int t = 0; t < nk; ++t) {
+        auto ktile = [&](int t, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const char* buf = smem + ((sbase + t) & 1) * BUF;
             // SPa: quadrants (A-h0 x B-h0), (A-h0 x B-h1).  The B-h1 fragments are read at the head of the MFMA cluster (their latency
             // hides under the first quadrant's MFMAs).  Re-stage, in the OTHER buffer: A-h1 (last read in SPb of K-tile t-1, reads
@@ -338,7 +338,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             S2T_BAR();
             S2T_MMA2(1, 1, 0);
             S2T_BAR();
-        }
+        };
+        ktile(0, std::true_type{});
+        for (int t = 1; t < nk; ++t) ktile(t, std::false_type{});
         // ---- this tile's epilogue (no barrier inside: the other group is one interval away in its own stream)
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -436,8 +438,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                                     buf_store(u32x4{t0, t1, t2, t3}, rX, vX[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldaux) * ES);
                                 }
                             }
-                            acc[QM * hm + ii][2 * pp] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            acc[QM * hm + ii][2 * pp + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                         }
                 }
                 if constexpr (MOUT) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.aux_out) + moff) = mk;
