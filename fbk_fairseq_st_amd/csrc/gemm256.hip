@@ -79,7 +79,7 @@ template <typename TO> struct Pack4 { typedef u32x2 type; };
 template <> struct Pack4<float> { typedef u32x4 type; };
 
 // arithmetic of one output quad (row, col .. col + 3); `pre` receives the GELU pre-activation (aux_out)
-template <typename TO, int ACT, int EXT>
+template <typename TO, int ACT, int EXT, bool DROP>
 __device__ __forceinline__ typename Pack4<TO>::type epi_quad(const GemmArgs& p, f32x4 v, f32x4 b4, typename Pack4<TO>::type ext,
                                                              uint32_t quad, uint32_t drop_ks, uint32_t drop_hwm, uint32_t drop_th, float drop_inv,
                                                              typename Pack4<TO>::type& pre_out) {
@@ -98,7 +98,9 @@ __device__ __forceinline__ typename Pack4<TO>::type epi_quad(const GemmArgs& p, 
         else if constexpr (ACT == ACT_GELU_BWD) x[e] *= gelu_grad_f(to_f32(xe[e]));
     }
     if constexpr (ACT == ACT_GELU) pre_out = *reinterpret_cast<const PK*>(pre);
-    if (p.p_drop > 0.f) {
+    // DROP = false: the caller knows p_drop == 0.  DROP = true: tested here, per quad, ON PURPOSE -- as one straight-line body the masked
+    // epilogue (1,081 VALU instructions) ran 7 % slower on fc1 than as per-quad blocks; the unmasked one ran 6 % faster straight-line
+    if (DROP && p.p_drop > 0.f) {
         // the output has fewer than 2^34 elements (host check): the quad index is one 32-bit word, the seed scramble and the
         // high-word term are per-launch constants (common.hpp drop_hash4_lo: the same mask as every other kernel)
         const u32x2 dh = drop_hash4_lo(drop_ks, drop_hwm, quad);
@@ -375,6 +377,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                     vE[pp] = ok ? (uint32_t)(((size_t)roww * lde + col) * ES) : 0xFFFFFFF0u;
                     vX[pp] = ok ? (uint32_t)(((size_t)roww * p.ldaux + col) * ES) : 0xFFFFFFF0u;
                 }
+                // The C stores leave in a TURNED lane order.  In the accumulator order the four lanes that share a 64-byte row segment
+                // are 16 lanes apart and the memory pipeline takes ~37 cycles per wave-store (tools/store_probe.hip); with four
+                // CONSECUTIVE lanes per segment it takes ~10.  The turn is a lane permutation (lane r16 + 16 q -> lane 4 r16 + chunk(q)) through
+                // a wave-private 1 KiB LDS slot (ds_write_b128 at the turned position, ds_read_b128 at the own one: LDS operations of a
+                // wave execute in order, no barrier), on the LDS pipe, which is idle in the epilogue; the store of a step is issued one step
+                // later so that its read-back has returned.
+                char* const turn = smem + 2 * BUF + wave * 2048;
+                const int turn_w = (4 * r16 + 2 * (q & 1) + (q >> 1)) * 16, turn_r = lane * 16;
+                uint32_t vT[2];                                           // byte offsets in the turned order: row lane / 4, chunk lane % 4
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int col = col0 + wc * 32 + pp * 128 + 8 * (lane & 3);
+                    const int row = row0 + wr * (2 * HR) + (lane >> 2);
+                    vT[pp] = col < p.N ? (uint32_t)(((size_t)row * p.ldc + col) * ES) : 0xFFFFFFF0u;
+                }
+                u32x4 pend = {0u, 0u, 0u, 0u};
+                uint32_t pend_v = 0xFFFFFFF0u, pend_s = 0u;
                 auto swap2 = [](uint32_t& x, uint32_t& y) {
                     const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
                     x = r[0]; y = r[1];
@@ -394,6 +413,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w & 0x7FFF7FFFu), "v"(0x00010001u));
                     return r;
                 };
+                // one straight-line body per dropout setting: with the test inside epi_quad every quad was its own basic block and the
+                // steps of a tile could not be interleaved by the scheduler (a wave is alone on its SIMD here: the other group is in its MFMAs)
+                auto epi_steps = [&](auto drop_tag) {
+                constexpr bool DROP = decltype(drop_tag)::value;
 #pragma unroll
                 for (int hm = 0; hm < 2; ++hm) {
                     u32x4 e16[QM][2];
@@ -414,8 +437,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             const uint32_t qa = (uint32_t)(((uint64_t)row * p.N + (colw + pp * 128)) >> 2);
                             PK pa, pb;
                             const int ms = (QM * hm + ii) * 2 + pp;              // step: pairs 4 (ms & 3) .. + 3 of record register ms >> 2
-                            const PK oa = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp], b4[2 * pp], PK{e0, e1}, qa, drop_ks, drop_hwm, drop_th, drop_inv, pa);
-                            const PK ob = epi_quad<TO, ACT, EXT>(p, acc[QM * hm + ii][2 * pp + 1], b4[2 * pp + 1], PK{e2, e3}, qa + 4, drop_ks, drop_hwm, drop_th, drop_inv, pb);
+                            const PK oa = epi_quad<TO, ACT, EXT, DROP>(p, acc[QM * hm + ii][2 * pp], b4[2 * pp], PK{e0, e1}, qa, drop_ks, drop_hwm, drop_th, drop_inv, pa);
+                            const PK ob = epi_quad<TO, ACT, EXT, DROP>(p, acc[QM * hm + ii][2 * pp + 1], b4[2 * pp + 1], PK{e2, e3}, qa + 4, drop_ks, drop_hwm, drop_th, drop_inv, pb);
                             uint32_t s0 = oa[0], s1 = oa[1], s2 = ob[0], s3 = ob[1];
                             if constexpr (MOUT) {
                                 uint32_t r = mk[ms >> 2];
@@ -430,7 +453,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                                 s2 &= ((r >> (13 - i0)) & LOHI) * 0xFFFFu; s3 &= ((r >> (12 - i0)) & LOHI) * 0xFFFFu;
                             }
                             swap2(s0, s2); swap2(s1, s3);
-                            buf_store(u32x4{s0, s1, s2, s3}, rC, vC[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES);
+                            {
+                                char* slot = turn + (ms & 1) * 1024;
+                                *reinterpret_cast<u32x4*>(slot + turn_w) = u32x4{s0, s1, s2, s3};
+                                const u32x4 back = *reinterpret_cast<const u32x4*>(slot + turn_r);
+                                if (ms > 0) buf_store(pend, rC, pend_v, pend_s);
+                                pend = back; pend_v = vT[pp]; pend_s = (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES;
+                            }
                             if constexpr (ACT == ACT_GELU) {
                                 if (p.aux_out) {
                                     uint32_t t0 = pa[0], t1 = pa[1], t2 = pb[0], t3 = pb[1];
@@ -440,6 +469,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             }
                         }
                 }
+                };
+                if (p.p_drop > 0.f) epi_steps(std::true_type{}); else epi_steps(std::false_type{});
+                buf_store(pend, rC, pend_v, pend_s);
                 if constexpr (MOUT) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.aux_out) + moff) = mk;
             }
         }
@@ -518,7 +550,7 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     if (!tiles) return 0;
     if (dry_run) return 1;                         // every gate passed: the caller names the launch (profiling family) before it happens
     const int grid = tiles < 256 ? tiles : 256;
-    const size_t lds = 2 * BUF;
+    const size_t lds = 2 * BUF + 16384;            // two K-tile buffers + the epilogue's lane-turn slots (8 waves x 2 KiB)
     bool done = false;
 #define S2T_G256(TO_, TB_, MT_, ACT_, EXT_)                                                                                  \
     if (!done && (out_dtype == S2T_BF16) == (sizeof(TO_) == 2) && (trans_b != 0) == TB_ && use192 == (MT_ == 6) &&          \
