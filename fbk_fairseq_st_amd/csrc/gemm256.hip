@@ -343,7 +343,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         };
         ktile(0, std::true_type{});
         for (int t = 1; t < nk; ++t) ktile(t, std::false_type{});
-        // ---- this tile's epilogue (no barrier inside: the other group is one interval away in its own stream)
+        // ---- this tile's epilogue (no barrier inside: the other group is one interval away in its own stream).  Running the two groups'
+        // epilogues in the SAME interval (group 0 idling through group 1's last cluster, group 1 closing an extra interval after its own)
+        // was tried: 7,800 -> 7,000 cycles per boundary, but the masked epilogue then stored corrupted values through the lane turn
+        // (not understood; it does not happen with one epilogue per SIMD at a time, which tools/gemm_turn_check.py holds to a twin built
+        // with -DS2T_NOTURN bit for bit)
         __builtin_amdgcn_sched_barrier(0);
         {
             typedef typename Pack4<TO>::type PK;
@@ -453,6 +457,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                                 s2 &= ((r >> (13 - i0)) & LOHI) * 0xFFFFu; s3 &= ((r >> (12 - i0)) & LOHI) * 0xFFFFu;
                             }
                             swap2(s0, s2); swap2(s1, s3);
+#ifdef S2T_NOTURN                                                    /* diagnostic twin: the stores in accumulator order (tools/gemm_turn_check.py) */
+                            buf_store(u32x4{s0, s1, s2, s3}, rC, vC[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES);
+#else
                             {
                                 char* slot = turn + (ms & 1) * 1024;
                                 *reinterpret_cast<u32x4*>(slot + turn_w) = u32x4{s0, s1, s2, s3};
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                                 if (ms > 0) buf_store(pend, rC, pend_v, pend_s);
                                 pend = back; pend_v = vT[pp]; pend_s = (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES;
                             }
+#endif
                             if constexpr (ACT == ACT_GELU) {
                                 if (p.aux_out) {
                                     uint32_t t0 = pa[0], t1 = pa[1], t2 = pb[0], t3 = pb[1];
@@ -471,7 +479,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 }
                 };
                 if (p.p_drop > 0.f) epi_steps(std::true_type{}); else epi_steps(std::false_type{});
+#ifndef S2T_NOTURN
                 buf_store(pend, rC, pend_v, pend_s);
+#endif
                 if constexpr (MOUT) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.aux_out) + moff) = mk;
             }
         }
