@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
     constexpr int DH = 64;
     ASTAMP_EARLY(2)
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 2 stages x (Q 8 KiB | dO 8 KiB)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
     int head;
     const int bx = head_xcd_remap(head, p.B * p.H, gridDim.x);
     const int b = head / p.H, h = head % p.H, kw = bx * 128 + wave * 32;
@@ -857,7 +857,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnArgs p) {
             // per element (their Q / dO rows repeat the last query: finite); the DMA writes nothing for the lanes that are off
             float* dst = sStat + stg * 128 + wave * 64;
             if (wave == 1 || qt + lane < p.Tq) {
-                const float* src = (wave == 0 ? lse : dlt) + min(qt + lane, p.Tq - 1);
+                // a wave-uniform base + a 32-bit lane offset: a 64-bit per-lane pointer here was spilled, and its reload -- issued right
+                // behind the tile's DMAs -- made the compiler's wait a vmcnt(0): the whole prefetch latency, exposed, every tile
+                const char* sb = reinterpret_cast<const char*>(wave == 0 ? lse : dlt);
+                const char* src = sb + (uint32_t)(min(qt + lane, p.Tq - 1) * 4);
                 __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
             } else dst[lane] = INFINITY;
