@@ -345,9 +345,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         for (int t = 1; t < nk; ++t) ktile(t, std::false_type{});
         // ---- this tile's epilogue (no barrier inside: the other group is one interval away in its own stream).  Running the two groups'
         // epilogues in the SAME interval (group 0 idling through group 1's last cluster, group 1 closing an extra interval after its own)
-        // was tried: 7,800 -> 7,000 cycles per boundary, but the masked epilogue then stored corrupted values through the lane turn
-        // (not understood; it does not happen with one epilogue per SIMD at a time, which tools/gemm_turn_check.py holds to a twin built
-        // with -DS2T_NOTURN bit for bit)
+        // was tried: 7,800 -> 7,000 cycles per boundary, but the masked (per-quad) epilogue then stored a few wrong values per launch --
+        // with AND without the lane turn below, non-deterministically, in the same lanes (rows 4 a + 3 of a 16-row block, first dword of
+        // a 16-byte chunk); not understood.  With one epilogue per SIMD at a time it does not happen: tools/gemm_turn_check.py holds
+        // this arrangement to a twin built with -DS2T_NOTURN bit for bit
         __builtin_amdgcn_sched_barrier(0);
         {
             typedef typename Pack4<TO>::type PK;
