@@ -85,6 +85,21 @@ def reference_slot(name):
 
 
 # ------------------------------------------------------------------ autograd bridges
+def anchor_zero_grad(anchor):
+    z = getattr(anchor, "_s2t_zero", None)
+    if z is None or z.device != anchor.device:
+        z = anchor._s2t_zero = torch.zeros_like(anchor.data)
+    return z
+
+
+def unwrap_model(model):
+    """the arena-homed model behind a data-parallel wrapper (fairseq/models/distributed_fairseq_model.py:88-100 forwards attribute
+    READS to the wrapped module; attribute writes would land on the wrapper)"""
+    while not hasattr(type(model), "_ensure_engine") and isinstance(getattr(model, "module", None), nn.Module):
+        model = model.module
+    return model
+
+
 class _EncoderFn(torch.autograd.Function):
     """Connects the engine's encoder to torch autograd: outputs (encoder_out, ctc_out, state_k)."""
 
@@ -92,7 +107,7 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, anchor, enc, src_tokens, src_lengths, training, seed, want_state, keep=None):
         out, ectx = enc.engine.encoder_forward(src_tokens, src_lengths, training, seed, return_all_hiddens=want_state is not None,
                                                keep=keep)
-        ctx.enc, ctx.ectx, ctx.want_state = enc, ectx, want_state
+        ctx.enc, ctx.ectx, ctx.want_state, ctx.anchor = enc, ectx, want_state, anchor
         enc._last = out
         eo = out["out"]
         co = out["ctc_out"] if out["ctc_out"] is not None else eo.new_zeros(1)
@@ -108,7 +123,13 @@ class _EncoderFn(torch.autograd.Function):
         ds = ({ctx.ectx["state_layers"][ctx.want_state]: d_state.contiguous()}
               if (ctx.want_state is not None and d_state is not None) else None)
         eng.encoder_backward(ctx.ectx, d_out, d_ctc if (has_ctc and d_ctc is not None) else None, ds)
-        return (None,) * 8
+        # The encoder's backward is the LAST piece of a backward pass and ends with the flush of the deferred weight gradients: every
+        # gradient of the arena is final here.  A data-parallel wrapper that reduces `p.grad` in place from a parameter hook -- the
+        # reference's LegacyDistributedDataParallel (`--ddp-backend no_c10d`, legacy_distributed_data_parallel.py:173-180) -- never
+        # sees an autograd gradient on this path (the kernels write the arena), so the anchor, the one parameter autograd does know,
+        # is handed a zero gradient when somebody hooked it: the hook queues the wrapper's reduction for the end of this pass.
+        ga = anchor_zero_grad(ctx.anchor) if ctx.anchor._backward_hooks else None
+        return (ga,) + (None,) * 7
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -585,10 +606,39 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
         a("--ctc-compress-out", action="store_true", default=False)
         a("--ctc-compress-strategy", type=str, default="avg", choices=["avg", "weighted", "softmax"])
         a("--freeze-pretrained", action="store_true")
+        a("--init-variance", type=float, default=1.0)                  # conv_transformer.py:66-67 (only read by the gauss penalty)
+        # The rest of TransformerModel.add_args (fairseq/models/transformer.py:95-175), which the reference's model inherits: a
+        # command line written for the reference must PARSE here; what this path does not implement is refused at build time,
+        # by name (`_refuse_unbuilt_options`), instead of being dropped silently.
+        a("--encoder-embed-path", type=str, metavar="STR"); a("--decoder-embed-path", type=str, metavar="STR")
+        a("--encoder-learned-pos", action="store_true"); a("--decoder-learned-pos", action="store_true")
+        a("--decoder-output-dim", type=int, metavar="N")
+        a("--share-all-embeddings", action="store_true")
+        a("--no-token-positional-embeddings", default=False, action="store_true")
+        a("--adaptive-softmax-cutoff", metavar="EXPR"); a("--adaptive-softmax-dropout", type=float, metavar="D")
+        a("--layernorm-embedding", action="store_true")
+        a("--no-cross-attention", default=False, action="store_true"); a("--cross-self-attention", default=False, action="store_true")
+        a("--encoder-layers-to-keep", default=None); a("--decoder-layers-to-keep", default=None)
+        a("--quant-noise-pq", type=float, metavar="D", default=0); a("--quant-noise-pq-block-size", type=int, metavar="D", default=8)
+        a("--quant-noise-scalar", type=float, metavar="D", default=0)
+
+    @staticmethod
+    def _refuse_unbuilt_options(args):
+        g = lambda k: getattr(args, k, None)
+        bad = [k for k in ("encoder_embed_path", "decoder_embed_path", "encoder_learned_pos", "decoder_learned_pos", "share_all_embeddings",
+                           "no_token_positional_embeddings", "adaptive_softmax_cutoff", "layernorm_embedding", "no_cross_attention",
+                           "cross_self_attention", "encoder_layers_to_keep", "decoder_layers_to_keep", "quant_noise_pq",
+                           "quant_noise_scalar") if g(k)]
+        if g("decoder_output_dim") not in (None, g("decoder_embed_dim")):
+            bad.append("decoder_output_dim != decoder_embed_dim")
+        if bad:
+            raise NotImplementedError("TransformerModel options outside the S2T hot path (SURVEY.md 2.2): " +
+                                      ", ".join("--" + k.replace("_", "-") for k in bad))
 
     @classmethod
     def build_model(cls, args, task):
         base_architecture(args)
+        cls._refuse_unbuilt_options(args)
         if not hasattr(args, "max_source_positions"):
             args.max_source_positions = 100000
         if not hasattr(args, "max_target_positions"):

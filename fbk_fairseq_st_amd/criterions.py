@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import kernels as K
+from .conv_transformer import anchor_zero_grad, unwrap_model
 from .registry import CRITERION_REGISTRY, FairseqCriterion, register_criterion
 
 
@@ -67,14 +68,25 @@ class _Deferred:
         return repr(float(self))
 
 
-def _publish(stats):
-    """inside a fairseq process the reduced statistics also go where its trainer and progress bar read them
-    (fairseq/logging/metrics.py: the reference's criteria call metrics.log_scalar from reduce_metrics)"""
+def _publish(stats, weights=None, derived=None):
+    """Inside a fairseq process the reduced statistics also go where its trainer and progress bar read them, with the weights the
+    reference's criteria give them (fairseq/logging/metrics.py: `log_scalar(key, value, weight, round=3)` -- an epoch's or a
+    validation run's figure is the WEIGHTED mean over its updates: loss by sample size, nll_loss by tokens) and perplexities as
+    derived meters of the averaged nll (label_smoothed_cross_entropy.py:85-87, ctc_multi_loss.py:189-194)."""
     from .registry import inside_fairseq
     if inside_fairseq():
+        from fairseq import utils
         from fairseq.logging import metrics
         for k, v in stats.items():
-            metrics.log_scalar(k, float(v), round=3)
+            if derived and k in derived:
+                continue
+            w = (weights or {}).get(k)
+            if w is None:
+                metrics.log_scalar(k, float(v))
+            else:
+                metrics.log_scalar(k, float(v), w, round=3)
+        for k, src in (derived or {}).items():
+            metrics.log_derived(k, lambda meters, src=src: utils.get_perplexity(meters[src].avg))
     return stats
 
 
@@ -166,13 +178,13 @@ class _LinearFn(torch.autograd.Function):
     """y = x W^T + b on the HIP GEMM, for heads owned by a criterion (ctc_aware_model.fc_out)."""
 
     @staticmethod
-    def forward(ctx, x, model, wname, bname):
+    def forward(ctx, x, model, wname, bname, anchor=None):
         eng = model.engine
         T, B, D = x.shape
         x2 = x.contiguous().view(T * B, D)
         w = eng.W(wname)
         y = K.gemm(x2, w, bias=eng.P(bname), out=K.alloc_rows((T * B,), w.shape[0], x2.dtype, x2.device))
-        ctx.model, ctx.x2, ctx.names, ctx.shape = model, x2, (wname, bname), (T, B, D)
+        ctx.model, ctx.x2, ctx.names, ctx.shape, ctx.anchor = model, x2, (wname, bname), (T, B, D), anchor
         return y.view(T, B, -1)
 
     @staticmethod
@@ -182,7 +194,9 @@ class _LinearFn(torch.autograd.Function):
         wname, bname = ctx.names
         dy2 = dy.reshape(T * B, -1)
         dx = eng.linear_bwd(dy2 if dy2.stride(1) == 1 else dy2.contiguous(), ctx.x2, wname[: -len(".weight")])
-        return dx.view(T, B, D), None, None, None
+        # the owner's anchor gets a zero gradient when a data-parallel wrapper hooked it (see conv_transformer._EncoderFn.backward)
+        a = ctx.anchor
+        return dx.view(T, B, D), None, None, None, (anchor_zero_grad(a) if a is not None and a._backward_hooks else None)
 
 
 @register_criterion("label_smoothed_cross_entropy")
@@ -220,8 +234,9 @@ class LabelSmoothedCrossEntropyCriterion(FairseqCriterion):
         ntokens = sum(_item(l.get("ntokens", 0)) for l in logging_outputs)
         sample_size = sum(_item(l.get("sample_size", 0)) for l in logging_outputs)
         nll = nll_sum / ntokens / math.log(2)
-        return _publish({"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
-                         "ntokens": ntokens, "sample_size": sample_size})
+        _publish({"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll},
+                 {"loss": sample_size, "nll_loss": ntokens}, {"ppl": "nll_loss"})
+        return {"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll, "ntokens": ntokens, "sample_size": sample_size}
 
     @staticmethod
     def logging_outputs_can_be_summed():
@@ -246,6 +261,12 @@ class CTCMultiLoss(FairseqCriterion):
         self.ctc_aware_model = CTCEncoderWrapperModel(args, task.source_dictionary)
         for n, p in self.arena_params().items():            # see conv_transformer._register: arena name of a criterion-owned parameter
             p._s2t_extra_name = n
+        # The reference's trainer wraps a criterion that owns parameters in its data-parallel class too (fairseq/trainer.py:100-114),
+        # and LegacyDistributedDataParallel reduces from a parameter hook: fc_out's gradients are written by the kernels, never by
+        # autograd, so this one-element parameter is what the hook can fire on (absent from state_dict(): checkpoints keep the
+        # reference's keys).
+        self._anchor = nn.Parameter(torch.zeros(1))
+        self._anchor._s2t_anchor = True
         self.blank_idx = task.source_dictionary.index("<ctc_blank>")          # ctc_multi_loss.py:103
         self.pad_idx = task.source_dictionary.pad()
         saved = args.criterion
@@ -269,9 +290,17 @@ class CTCMultiLoss(FairseqCriterion):
         return {"criterion.ctc_aware_model.fc_out.weight": self.ctc_aware_model.fc_out.weight,
                 "criterion.ctc_aware_model.fc_out.bias": self.ctc_aware_model.fc_out.bias}
 
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        for k in [k for k in sd if k.endswith("_anchor")]:
+            del sd[k]
+        return sd
+
     def load_state_dict(self, state_dict, strict=True):
         """fairseq/trainer.py:215-218 loads the criterion's own parameters; once they live in a model's arena the bf16 copy the
         GEMMs read has to follow"""
+        state_dict = dict(state_dict)
+        state_dict.setdefault("_anchor", self._anchor.data)
         out = super().load_state_dict(state_dict, strict=strict)
         owner = getattr(self.ctc_aware_model.fc_out.weight, "_s2t_owner", None)
         model = owner() if owner is not None else None
@@ -281,6 +310,7 @@ class CTCMultiLoss(FairseqCriterion):
 
     def forward(self, model, sample, reduce=True, log_probs=True):
         ni = {k: v for k, v in sample["net_input"].items() if k != "transcript_prev_output_tokens"}
+        model = unwrap_model(model)          # `_ctc_state_layer` below must land on the model, not on a data-parallel wrapper
         enc = model.encoder
         k = self.ctc_aware_model.ctc_encoder_layer
         model._ctc_state_layer = k - 1
@@ -291,7 +321,7 @@ class CTCMultiLoss(FairseqCriterion):
             ctc_lse = last.get("ctc_lse")                # row log-sum-exps of ctc_out, by-product of the compression's arg-max pass
         else:
             ctc_feat = _LinearFn.apply(encoder_out.encoder_states[k - 1], model,
-                                       "criterion.ctc_aware_model.fc_out.weight", "criterion.ctc_aware_model.fc_out.bias")
+                                       "criterion.ctc_aware_model.fc_out.weight", "criterion.ctc_aware_model.fc_out.bias", self._anchor)
             in_len, in_len_host, pred, ctc_lse = last["lengths"], last["lengths_host"], None, None
         tr, tr_len = sample["transcript_target"], sample["transcript_target_lengths"]
         ctc_loss = _CTCFn.apply(ctc_feat, tr, tr_len, in_len.to(torch.int32), self.blank_idx, ctc_lse)      # side stream
@@ -337,7 +367,8 @@ class CTCMultiLoss(FairseqCriterion):
         nll = nll_sum / ntokens / math.log(2)
         return _publish({"loss": loss_sum / sample_size / math.log(2), "nll_loss": nll, "ppl": 2 ** nll,
                          "ctc_loss": ctc_sum / sample_size / math.log(2),
-                         "ctc_acc": 100.0 - min(errors * 100.0 / max(total, 1), 100.0), "nframes": nframes})
+                         "ctc_acc": 100.0 - min(errors * 100.0 / max(total, 1), 100.0), "nframes": nframes},
+                        {"loss": sample_size, "nll_loss": ntokens, "ctc_loss": sample_size}, {"ppl": "nll_loss"})
 
 
 class _KDFn(torch.autograd.Function):
@@ -400,7 +431,11 @@ class CrossEntropyKnowledgeDistillationCriterion(FairseqCriterion):
         out = {"loss": loss_sum / sample_size / math.log(2)}
         nll = loss_sum / ntokens / math.log(2) if sample_size != ntokens else out["loss"]
         out.update(nll_loss=nll, ppl=2 ** nll)
-        return _publish(out)
+        if sample_size != ntokens:                       # fairseq/criterions/knowledge_distillation.py:114-119
+            _publish(out, {"loss": sample_size, "nll_loss": ntokens}, {"ppl": "nll_loss"})
+        else:
+            _publish({"loss": out["loss"], "ppl": out["ppl"]}, {"loss": sample_size}, {"ppl": "loss"})
+        return out
 
 
 @register_criterion("cross_entropy_dualdecoder")
@@ -444,6 +479,10 @@ class CrossEntropyDualDecoder(FairseqCriterion):
         s = lambda k: sum(_item(l.get(k, 0)) for l in logging_outputs)
         ss, nt, ant = s("sample_size"), s("ntokens"), s("auxiliary_ntokens")
         ln2 = math.log(2)
-        return _publish({"loss": s("loss") / ss / ln2, "primary_loss": s("primary_loss") / ss / ln2,
-                         "auxiliary_loss": s("auxiliary_loss") / ss / ln2, "primary_nll_loss": s("primary_nll_loss") / nt / ln2,
-                         "auxiliary_nll_loss": s("auxiliary_nll_loss") / max(ant, 1) / ln2})
+        out = {"loss": s("loss") / ss / ln2, "primary_loss": s("primary_loss") / ss / ln2,
+               "auxiliary_loss": s("auxiliary_loss") / ss / ln2, "primary_nll_loss": s("primary_nll_loss") / nt / ln2,
+               "auxiliary_nll_loss": s("auxiliary_nll_loss") / max(ant, 1) / ln2}
+        _publish(dict(out, primary_ppl=0.0, auxiliary_ppl=0.0),                 # cross_entropy_dualdecoder.py:77-83
+                 {"loss": ss, "primary_loss": ss, "auxiliary_loss": ss, "primary_nll_loss": nt, "auxiliary_nll_loss": ant},
+                 {"primary_ppl": "primary_nll_loss", "auxiliary_ppl": "auxiliary_nll_loss"})
+        return out

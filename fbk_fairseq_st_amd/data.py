@@ -63,6 +63,44 @@ class Dictionary:
             d.add_symbol("w%d" % i)
         return d
 
+    def unk_string(self, escape=False):
+        return "<%s>" % self.symbols[self.unk_index] if escape else self.symbols[self.unk_index]
+
+    def string(self, tensor, bpe_symbol=None, escape_unk=False, extra_symbols_to_ignore=None):
+        """fairseq/data/dictionary.py:59-94: token ids -> text, EOS (and BOS) dropped, optional BPE continuation marker removed"""
+        if torch.is_tensor(tensor) and tensor.dim() == 2:
+            return "\n".join(self.string(t, bpe_symbol, escape_unk, extra_symbols_to_ignore) for t in tensor)
+        skip = set(extra_symbols_to_ignore or ())
+        skip.add(self.eos_index)
+        words = [self.unk_string(escape_unk) if int(i) == self.unk_index else self[int(i)]
+                 for i in tensor if int(i) not in skip and int(i) != self.bos_index]
+        sent = " ".join(words)
+        if bpe_symbol == "sentencepiece":
+            sent = sent.replace(" ", "").replace("\u2581", " ").strip()
+        elif bpe_symbol is not None:
+            sent = (sent + " ").replace(bpe_symbol, "").rstrip()
+        return sent
+
+
+_StandaloneDictionary = Dictionary
+try:
+    from .registry import inside_fairseq as _inside_fairseq
+    if _inside_fairseq():
+        # Inside a fairseq process the dictionaries are fairseq's own class: `generate.main` post-processes hypotheses through
+        # `tgt_dict.string / encode_line / unk_string` and the BLEU scorer (fairseq_cli/generate.py:160-230), checkpoints pickle
+        # nothing of it, and nothing on the hot path reads more than pad / eos / len / index.
+        from fairseq.data import Dictionary as _FairseqDictionary
+
+        class Dictionary(_FairseqDictionary):                                    # noqa: F811
+            @classmethod
+            def synthetic(cls, n_words):
+                d = cls()
+                for i in range(n_words):
+                    d.add_symbol("w%d" % i)
+                return d
+except ImportError:                                                              # pragma: no cover
+    pass
+
 
 def collate_tokens(values, pad_idx, eos_idx, move_eos_to_beginning=False):
     """fairseq/data/data_utils.py:collate_tokens with left_pad=False."""

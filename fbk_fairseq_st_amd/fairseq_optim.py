@@ -53,6 +53,13 @@ class FairseqAdam(FairseqOptimizer):
                              "and %d foreign parameters -- use the reference's models with the reference's optimizer"
                              % (len(owners), len(foreign)))
         model = self.model = owners[0]
+        if getattr(args, "distributed_world_size", 1) > 1 and not getattr(args, "use_bmuf", False) and \
+                (getattr(args, "ddp_backend", "c10d") != "no_c10d" or getattr(args, "distributed_wrapper", "DDP") != "DDP"):
+            # c10d's reducer counts autograd gradients per parameter and SlowMo averages module parameters its own way: the arena's
+            # gradients are written by the kernels, which only the in-place reduction of LegacyDistributedDataParallel picks up
+            raise ValueError("data-parallel training of the arena-homed S2T model under fairseq's trainer needs --ddp-backend no_c10d "
+                             "(what the reference's paper script uses, README.md:142); got --ddp-backend %s --distributed-wrapper %s"
+                             % (getattr(args, "ddp_backend", None), getattr(args, "distributed_wrapper", None)))
         if model.arena is None:
             # fairseq's trainer has already moved the module to its device (trainer.py:51-52); re-home the parameters in one flat
             # arena there.  --compute-dtype bf16 (model flag) selects bf16 storage with f32 accumulation and f32 masters.

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import lib as L
+from .registry import FairseqDataset
 
 _MAGIC = b"TNTIDX\x00\x00"
 _DTYPES = {1: np.uint8, 2: np.int8, 3: np.int16, 4: np.int32, 5: np.int64, 6: np.float64, 7: np.float64, 8: np.float32}
@@ -193,7 +194,7 @@ def apply_mv_norm(features):
     return (features - mean) * inv
 
 
-class FilterBankToTextDataset:
+class FilterBankToTextDataset(FairseqDataset):
     """fbank_dataset.py:17-95: filterbank item + target token item -> {"id", "data": [frames, tokens]}"""
 
     def __init__(self, src_dataset, tgt_dataset, tgt_dict, skip_normalization=False):
@@ -230,7 +231,7 @@ class FilterBankToTextDataset:
         return np.arange(len(self))                      # the reference does not sort filterbanks by length (fbank_dataset.py:78-81)
 
 
-class TranscriptionWrapperDataset:
+class TranscriptionWrapperDataset(FairseqDataset):
     """transcription_dataset.py:7-86: adds the source-language transcript of every utterance"""
 
     def __init__(self, tgt_dataset, transcription_dataset, transcription_dict):
@@ -295,7 +296,7 @@ class TeacherOutputDataset(IndexedDataset):
         return item.long() if self.dtype.kind in "iu" else item.float()
 
 
-class DatasetWithTeacherOutput:
+class DatasetWithTeacherOutput(FairseqDataset):
     """knowledge_distillation.py:58-153: adds `teacher_output` = [columns, logits] to every item and batch"""
 
     def __init__(self, src, teacher_probs, teacher_idxs, tgt_dict, distill_k):

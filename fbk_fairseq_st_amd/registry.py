@@ -258,6 +258,22 @@ else:
         def logging_outputs_can_be_summed(self, criterion):
             return criterion.logging_outputs_can_be_summed()
 
+        def reduce_metrics(self, logging_outputs, criterion):
+            # (inside fairseq the inherited method also logs wpb / wps / bsz before it calls the criterion's: fairseq_task.py:370-404)
+            return criterion.__class__.reduce_metrics(logging_outputs)
+
+
+if _FS:
+    from fairseq.data import FairseqDataset      # fairseq_task.py:100-105 type-checks what `task.dataset(split)` hands out
+else:
+    class FairseqDataset:                          # fairseq/data/fairseq_dataset.py:19-85 (map-style dataset + collater / sizes)
+        def set_epoch(self, epoch):
+            pass
+
+        @property
+        def supports_prefetch(self):
+            return False
+
 
 # ---- what this path adds on top of the bases, identical in both modes
 class FairseqEncoder(_EncoderBase):
@@ -349,8 +365,6 @@ class FairseqTask(_TaskBase):
         with torch.no_grad():
             return generator.generate(models, sample, prefix_tokens=prefix_tokens)
 
-    def reduce_metrics(self, logging_outputs, criterion):
-        return criterion.__class__.reduce_metrics(logging_outputs)
 
 
 def build_model(args, task):

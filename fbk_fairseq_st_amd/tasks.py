@@ -76,7 +76,17 @@ class SpeechTranslationCTCTask(FairseqTask):
 
     def get_batch_iterator(self, dataset, max_tokens=None, max_sentences=None, max_positions=None, ignore_invalid_inputs=False,
                            required_batch_size_multiple=1, seed=1, num_shards=1, shard_id=0, num_workers=0, epoch=1):
-        """fairseq_task.py:107-199 on the native batcher + pinned-memory prefetch thread (iterators.py)"""
+        """fairseq_task.py:107-199 on the native batcher + pinned-memory prefetch thread (iterators.py).  Inside a fairseq process
+        the reference's own `train.main` drives the result (next_epoch_idx, GroupedIterator over a CountingIterator, state_dict /
+        load_state_dict in checkpoints: fairseq/data/iterators.py:170-340), so there it IS fairseq's EpochBatchIterator, built by
+        the inherited method from this package's datasets (same indices, same filter, same frame-budget batches: golden
+        `iterator.npz`)."""
+        from .registry import inside_fairseq
+        if inside_fairseq():
+            return super().get_batch_iterator(dataset, max_tokens=max_tokens, max_sentences=max_sentences, max_positions=max_positions,
+                                              ignore_invalid_inputs=ignore_invalid_inputs,
+                                              required_batch_size_multiple=required_batch_size_multiple, seed=seed,
+                                              num_shards=num_shards, shard_id=shard_id, num_workers=num_workers, epoch=epoch)
         from .iterators import get_batch_iterator
         return get_batch_iterator(dataset, max_tokens, max_sentences, max_positions, ignore_invalid_inputs, required_batch_size_multiple,
                                   seed, num_shards, shard_id, epoch, bucket_by_length=getattr(self.args, "bucket_by_length", False))

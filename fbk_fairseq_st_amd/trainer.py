@@ -169,7 +169,7 @@ class Trainer:
         from .conv_transformer import reference_slot
         frozen = set(getattr(self.model, "_frozen_names", ()) or ())
         names = [n for n in self.model.reference_parameter_names() if reference_slot(n)[0] not in frozen]
-        return names + [n for n, _ in self.criterion.named_parameters()]
+        return names + [n for n, p in self.criterion.named_parameters() if not getattr(p, "_s2t_anchor", False)]
 
     def save_checkpoint(self, filename, extra_state=None):
         if D.get_rank() != 0:                                       # only the data-parallel master writes (trainer.py:175)

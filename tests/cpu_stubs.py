@@ -184,3 +184,213 @@ class OracleEngine:
         logits = s2t_ref.decoder_forward(self.W, self.cfg, st["toks"], enc, mask, pfx=st["pfx"])
         st["steps"] += 1
         return logits[:, -1, :].detach()
+
+
+# ------------------------------------------------------------------ the oracle as a TRAINING engine (whole-CLI plumbing)
+def cfg_of(hp):
+    """oracle cfg dict of an engine.HParams"""
+    return s2t_ref.default_cfg(D=hp.D, heads=hp.heads, ffn=hp.ffn, enc_layers=hp.enc_layers, dec_layers=hp.dec_layers,
+                               ctc_layer=hp.ctc_layer, act=hp.act, pad=hp.pad, strategy=("avg", "weighted", "softmax")[hp.ctc_strategy],
+                               conv_ch=hp.conv_ch, feat=hp.feat, no_scale_embedding=hp.no_scale_embedding, ln_eps=hp.ln_eps,
+                               bn_eps=hp.bn_eps, bn_momentum=hp.bn_momentum, attn_2d=hp.attn_2d,
+                               distance_penalty=bool(hp.distance_penalty))
+
+
+class OracleTrainEngine(OracleEngine):
+    """engine.S2TEngine's training AND generation entry points answered by oracle/s2t_ref.py under torch autograd on the host,
+    reading the weights from the arena and adding the gradients into it: with it the reference's unchanged `train.main` /
+    `generate.main` run end to end over the plug-in where there is no GPU (tests/golden/make_cli_fixture.py).  Dropout is the
+    identity, as everywhere in the oracle; the constructor has S2TEngine's signature so that
+    `conv_transformer.S2TEngine = OracleTrainEngine` is the whole installation."""
+
+    def __init__(self, hp, arena):
+        self.hp, self.A, self.cfg = hp, arena, cfg_of(hp)
+        self.on_grads_ready = None
+        self.bn_buffers = {}
+        self.wgrad_flush_layers = None
+        self.calls = []
+
+    # -- weights: one autograd leaf per arena tensor, handed to the oracle under the reference's names (views of the leaves)
+    def _weights(self, prefixes):
+        from fbk_fairseq_st_amd.conv_transformer import fused_to_reference
+        leaves = {n: self.A.p(n).detach().clone().requires_grad_(True) for n in self.A.slices if n.startswith(prefixes)}
+        W = {}
+        for k, v in leaves.items():
+            if ".self_attn.qkv." in k:
+                D = v.shape[0] // 3
+                for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                    W[k.replace("qkv", n)] = v[i * D:(i + 1) * D]
+            elif ".encoder_attn.kv." in k:
+                D = v.shape[0] // 2
+                for i, n in enumerate(("k_proj", "v_proj")):
+                    W[k.replace("kv", n)] = v[i * D:(i + 1) * D]
+            else:
+                W[k] = v
+        for k, b in self.bn_buffers.items():
+            if k.startswith(prefixes) and not k.endswith("num_batches_tracked"):
+                W[k] = b.detach().clone()
+        assert fused_to_reference is not None
+        return leaves, W
+
+    def _harvest(self, leaves, prefix):
+        for n, v in leaves.items():
+            if v.grad is not None:
+                self.A.g(n).add_(v.grad)
+        self._ready(prefix)
+
+    def _ready(self, prefix):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(prefix)
+
+    def reset_wgrad(self):
+        pass
+
+    def flush_wgrad(self):
+        pass
+
+    def W(self, name):
+        return self.A.p(name)
+
+    P = W
+
+    # -- encoder
+    def encoder_forward(self, src_tokens, src_lengths, training, seed=0, return_all_hiddens=False, keep=None):
+        self.calls.append(("encoder_forward", bool(training), int(seed)))
+        lens = src_lengths if torch.is_tensor(src_lengths) else torch.tensor(src_lengths)
+        cfg = dict(self.cfg, enc_keep=keep)
+        with torch.enable_grad():
+            leaves, W = self._weights(("encoder.",))
+            enc, stats = s2t_ref.encoder_forward(W, cfg, src_tokens.float(), lens.long(), training=training)
+        if training:                                   # BatchNorm running statistics (nn.BatchNorm2d, momentum 0.1)
+            for k, v in stats.items():
+                self.bn_buffers[k].copy_(v.detach())
+            for k, b in self.bn_buffers.items():
+                if k.startswith("encoder.") and k.endswith("num_batches_tracked"):
+                    b.add_(1)
+        L = [int(v) for v in enc.src_lengths]
+        T = enc.encoder_out.shape[0]
+        res = dict(out=enc.encoder_out.detach(), ctc_out=None, ctc_lengths=None, ctc_lengths_host=None, pred=None,
+                   states=[s.detach() for s in enc.encoder_states] if return_all_hiddens else None,
+                   lengths=torch.tensor(L, dtype=torch.int64), lengths_host=L,
+                   klen=torch.tensor(L, dtype=torch.int32) if min(L) < T else None, ctc_klen=None)
+        if enc.ctc_out is not None:
+            T4 = enc.ctc_out.shape[0]
+            L4 = [((int(l) + 1) // 2 + 1) // 2 for l in lens.tolist()]
+            res.update(ctc_out=enc.ctc_out.detach(), ctc_lengths=torch.tensor(L4, dtype=torch.int64), ctc_lengths_host=L4,
+                       ctc_klen=torch.tensor(L4, dtype=torch.int32) if min(L4) < T4 else None, pred=enc.ctc_pred.to(torch.int32),
+                       pred_host=enc.ctc_pred.to(torch.int32))
+        layers = [l for l in range(self.hp.enc_layers) if keep is None or keep[l]]
+        return res, dict(graph=(enc, leaves), ctc=enc.ctc_out is not None or None, state_layers=layers)
+
+    def encoder_backward(self, ctx, d_out, d_ctc_out=None, d_states=None):
+        enc, leaves = ctx["graph"]
+        outs, grads = [enc.encoder_out], [d_out.reshape(enc.encoder_out.shape)]
+        if d_ctc_out is not None:
+            outs.append(enc.ctc_out)
+            grads.append(d_ctc_out.reshape(enc.ctc_out.shape))
+        for l, g in (d_states or {}).items():
+            s = enc.encoder_states[ctx["state_layers"].index(l)]
+            outs.append(s)
+            grads.append(g.reshape(s.shape))
+        torch.autograd.backward(outs, grads)
+        self._harvest(leaves, "encoder.")
+
+    # -- decoder
+    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None):
+        self.calls.append(("decoder_forward", bool(training), int(seed)))
+        B, L = prev_tokens.shape
+        mask = None
+        if enc_klen32 is not None:
+            mask = torch.arange(enc_out.shape[0])[None, :] >= enc_klen32[:, None].long()
+        with torch.enable_grad():
+            leaves, W = self._weights((pfx,))
+            eo = enc_out.detach().clone().requires_grad_(True)
+            logits = s2t_ref.decoder_forward(W, dict(self.cfg, dec_keep=keep), prev_tokens, eo, mask, pfx=pfx)   # (B, L, V)
+            tm = logits.transpose(0, 1).reshape(L * B, -1)
+        return tm.detach(), dict(graph=(tm, leaves, eo), Ts=enc_out.shape[0], B=B, pfx=pfx)
+
+    def decoder_backward(self, ctx, dlogits, denc=None):
+        tm, leaves, eo = ctx["graph"]
+        tm.backward(dlogits.reshape(tm.shape))
+        self._harvest(leaves, ctx["pfx"])
+        g = eo.grad.reshape(ctx["Ts"] * ctx["B"], -1)
+        return g if denc is None else denc.add_(g)
+
+    def linear_bwd(self, dy2, x2, stem):
+        """criterion-owned head (criterions._LinearFn.backward): dW, db into the arena, returns dx"""
+        self.A.g(stem + ".weight").add_(dy2.float().t() @ x2.float())
+        self.A.g(stem + ".bias").add_(dy2.float().sum(0))
+        return dy2.float() @ self.A.p(stem + ".weight")
+
+    # -- generation: the weights are read from the arena at decoder_begin
+    def decoder_begin(self, enc_out, enc_klen32, max_steps, pfx="decoder."):
+        with torch.no_grad():
+            _, self.W_gen = self._weights((pfx,))
+        return dict(pfx=pfx, enc=enc_out, klen=enc_klen32, toks=None, steps=0, max_steps=max_steps, N=enc_out.shape[1])
+
+    def decoder_step(self, st, last_tokens):
+        t = last_tokens.view(-1, 1)
+        st["toks"] = t if st["toks"] is None else torch.cat([st["toks"], t], 1)
+        enc = st["enc"]
+        mask = None
+        if st["klen"] is not None:
+            mask = torch.arange(enc.shape[0])[None, :] >= st["klen"][:, None].long()
+        with torch.no_grad():
+            logits = s2t_ref.decoder_forward(self.W_gen, self.cfg, st["toks"], enc, mask, pfx=st["pfx"])
+        st["steps"] += 1
+        return logits[:, -1, :].detach()
+
+
+class _CTCFnCPU(torch.autograd.Function):
+    """criterions._CTCFn without its streams: the oracle's CTC loss (float64 recursion) and its gradient"""
+
+    @staticmethod
+    def forward(ctx, logits, targets, tgt_len, in_len32, blank, lse=None):
+        with torch.enable_grad():
+            x = logits.detach().float().clone().requires_grad_(True)
+            loss = s2t_ref.ctc_loss_sum(x, targets, in_len32.long(), tgt_len, blank)
+            (g,) = torch.autograd.grad(loss, x)
+        ctx.g = g
+        return loss.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.g * g, None, None, None, None, None
+
+    @staticmethod
+    def join():
+        pass
+
+
+def _ctc_argmax(x_ctc, want_lse=False):
+    from oracle import int_ref
+    import numpy as np
+    lp = torch.log_softmax(x_ctc.float(), dim=-1).transpose(0, 1)
+    pred = torch.from_numpy(int_ref.argmax_first_np(lp.detach().numpy()).astype(np.int32))
+    return (pred, None, None) if want_lse else (pred, None)
+
+
+def _matmul_linear(x2, w, bias=None, out=None, **kw):
+    y = x2.float() @ w.float().t()
+    return y + bias if bias is not None else y
+
+
+@contextlib.contextmanager
+def oracle_engine():
+    """everything the reference's CLI needs to run over the plug-in on the host: the kernels.* stand-ins, the oracle as the
+    engine class the model instantiates, the stream-free CTC bridge, and no `cuda only` refusal"""
+    from fbk_fairseq_st_amd import conv_transformer as CT, criterions as CR, kernels as K
+    saved = (CT.S2TEngine, CR._CTCFn, CT.ConvolutionalTransformerModel._ensure_engine, K.ctc_argmax, K.gemm, K.alloc_rows)
+
+    def ensure(self, device):
+        if self.engine is None:
+            self.materialize(device, self.compute_dtype)
+
+    CT.S2TEngine, CR._CTCFn, CT.ConvolutionalTransformerModel._ensure_engine = OracleTrainEngine, _CTCFnCPU, ensure
+    K.ctc_argmax, K.gemm = _ctc_argmax, _matmul_linear
+    K.alloc_rows = lambda lead, n, dtype, device: None
+    try:
+        with cpu_kernels():
+            yield
+    finally:
+        CT.S2TEngine, CR._CTCFn, CT.ConvolutionalTransformerModel._ensure_engine, K.ctc_argmax, K.gemm, K.alloc_rows = saved

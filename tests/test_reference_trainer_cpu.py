@@ -57,7 +57,9 @@ def _build(variant, D=32, H=2, Ff=64, EL=2, DL=1):
 def test_reference_parameter_order(variant):
     a, task, model, crit = _build(variant)
     assert model.reference_parameter_names() == ORDER["orders"][variant]["model"]
-    assert [n for n, _ in crit.named_parameters()] == ORDER["orders"][variant]["criterion"]
+    # (a criterion that owns parameters also carries the one-element anchor its data-parallel wrapper hooks: not a reference name)
+    assert [n for n, p in crit.named_parameters() if not getattr(p, "_s2t_anchor", False)] == ORDER["orders"][variant]["criterion"]
+    assert not any(k.endswith("_anchor") for k in crit.state_dict())
     # every reference name has a home in the fused arena layout
     from fbk_fairseq_st_amd.conv_transformer import reference_slot
     shapes = model.hp.param_shapes()
@@ -159,8 +161,84 @@ def test_bench_launches_its_own_ranks():
     assert r.stderr.count("bench.py needs an MI355X") == 2, r.stderr[-2000:]
 
 
+def test_a_hook_on_the_anchor_fires_once_per_backward_when_the_arena_is_final():
+    """The protocol the reference's LegacyDistributedDataParallel relies on (legacy_distributed_data_parallel.py:173-180): a hook on a
+    parameter queues the reduction for the end of the backward pass.  Autograd never computes a gradient of an arena-homed parameter,
+    so the model's anchor is handed a zero gradient by the LAST bridge of the pass -- when, and only when, somebody hooked it."""
+    from torch.autograd import Variable
+    a, task, model, crit = _build("plain")
+    a.criterion = "label_smoothed_cross_entropy"
+    crit = task.build_criterion(a)
+    model.materialize("cpu", torch.float32)
+    model.engine = cpu_stubs.ToyEngine(model)
+    g = torch.Generator().manual_seed(2)
+    B, T, L, V = 2, 21, 5, len(task.target_dictionary)
+    tgt = torch.randint(4, V, (B, L), generator=g)
+    prev = torch.cat([torch.full((B, 1), 2, dtype=torch.long), tgt[:, :-1]], 1)
+    sample = {"ntokens": B * L, "target": tgt, "net_input": {"src_tokens": torch.randn(B, T, 80, generator=g),
+                                                            "src_lengths": torch.full((B,), T, dtype=torch.long), "prev_output_tokens": prev}}
+    with cpu_stubs.cpu_kernels():
+        model.train()
+        crit(model, sample)[0].backward()
+        assert model.anchor.grad is None                            # nobody listening: the bridges return nothing for the anchor
+        model.arena.grad.zero_()
+        seen, fired = [], []
+
+        def hook(*unused):
+            fired.append(1)
+            Variable._execution_engine.queue_callback(lambda: seen.append(model.arena.grad.clone()))
+
+        model.anchor.register_hook(hook)
+        crit(model, sample)[0].backward()
+    assert len(fired) == 1 and len(seen) == 1
+    assert float(seen[0].abs().sum()) > 0 and torch.equal(seen[0], model.arena.grad)     # every gradient was in place when it ran
+    assert float(model.anchor.grad.abs().sum()) == 0.0
+    # behind a wrapper that forwards attribute reads only (distributed_fairseq_model.py:88-100) the criterion still reaches the model
+    from fbk_fairseq_st_amd.conv_transformer import unwrap_model
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, module):
+            super().__init__()
+            self.module = module
+
+        def forward(self, *a, **k):
+            return self.module(*a, **k)
+
+    assert unwrap_model(Wrapper(Wrapper(model))) is model and unwrap_model(model) is model
+
+
+def test_fixture_the_reference_cli_runs_over_the_plugin():
+    """tests/golden/cli_trajectory.json (make_cli_fixture.py): the reference's unchanged train.main and generate.main, once over its own
+    user directory and once over this package, same initial checkpoint: every update's logged numbers, the validation losses, the files
+    written and the beam-5 hypotheses agree (the script asserts it before it writes; here: what it recorded)"""
+    c = json.load(open(os.path.join(HERE, "golden", "cli_trajectory.json")))
+    assert c["n_updates"] == len(c["reference_updates"]) == 6 and c["updates_agree_rel"] == "< 2e-4"
+    assert [u["num_updates"] for u in c["reference_updates"]] == [1, 2, 3, 4, 5, 6]
+    assert {"loss", "nll_loss", "ctc_loss", "gnorm", "ctc_acc", "nframes"} <= set(c["reference_updates"][0])
+    assert c["reference_updates"][-1]["loss"] < c["reference_updates"][0]["loss"]
+    assert c["checkpoints"] == ["checkpoint_best.pt", "checkpoint_last.pt"] and c["optimizer_name"] == "FairseqAdam"
+    assert len(c["valid_losses"]) == 2 and len(c["hypotheses"]) == 13 and c["bleu"].startswith("BLEU4")
+
+
+def test_fixture_no_c10d_data_parallel_under_the_reference_trainer():
+    """tests/golden/reference_ddp.json (make_ddp_fixture.py): two gloo ranks of the reference's Trainer + LegacyDistributedDataParallel
+    over the plug-in land on the single-process parameters for a plain update, an --update-freq 2 update and an empty shard"""
+    d = json.load(open(os.path.join(HERE, "golden", "reference_ddp.json")))
+    for cfg, head in (("criterion_head", True), ("ctc_compress_out", False)):
+        c = d[cfg]
+        assert c["model_wrapper"] == c["criterion_wrapper"] == "LegacyDistributedDataParallel" and c["criterion_head_in_use"] is head
+        assert [u["num_updates"] for u in c["updates"]] == [1, 2, 3] and all(u["ranks_identical"] for u in c["updates"])
+        assert c["plan"][2][1] is None and len(c["plan"][1]) == 4
+
+
+def test_the_arena_adam_refuses_wrappers_that_cannot_see_the_arena():
+    """--ddp-backend c10d counts autograd gradients per parameter: it would never reduce; refused by name at optimizer construction"""
+    src = open(os.path.join(REPO, "fbk_fairseq_st_amd", "fairseq_optim.py")).read()
+    assert "needs --ddp-backend no_c10d" in src
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
-@pytest.mark.parametrize("script", ["make_trainer_fixture.py", "make_param_order_fixture.py"])
+@pytest.mark.parametrize("script", ["make_trainer_fixture.py", "make_param_order_fixture.py", "make_cli_fixture.py", "make_ddp_fixture.py"])
 def test_fixtures_regenerate_identically_through_the_reference(script):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, os.path.join(HERE, "golden", script), "--check"], env=env, stdout=subprocess.PIPE,
