@@ -143,7 +143,7 @@ __device__ __forceinline__ void buf_store(u32x4 v, __amdgpu_buffer_rsrc_t r, uin
 // Persistent: gridDim.x workgroups (one per CU) walk the output tiles; the operand stream never stops at a tile boundary (the
 // half-tiles staged in the last two K-tiles of a tile are the first ones of the next tile), and the stores of a tile drain under
 // the next tile's K-loop.
-template <typename TO, bool TB, int MT, int ACT, int EXT>
+template <typename TO, bool TB, int MT, int ACT, int EXT, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int QM = MT / 2;                       // row tiles of one phase's quadrant (4 / 3)
@@ -203,26 +203,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // stream position u = t + 1 or t + 2 of the CURRENT tile: past its last K-tile it is K-tile u - nk of the next tile (nk >= 2);
     // with no next tile the source is clamped to the last K-tile (in bounds) and the destination stays the half-tile the schedule
     // says is free: the DMA count per phase is a constant and nothing reads those bytes afterwards
+    // The DMA instructions are buffer-addressed (buffer_load_dwordx4 ... offen lds): the lane's byte offset inside the operand is the
+    // 32-bit voffset as it stands in `cur` / `nxt`, the K-tile's advance is the scalar soffset -- no 64-bit per-lane address to form
+    // and to hand to the memory pipeline per instruction (a global_load_lds costs ~60 cycles of the wave's issue time, and issue slots
+    // are what bounds this loop: tools/gemm_x_time.py on the -DS2T_X twins).  -DS2T_DMA_FLAT: the global_load_lds form, for A/B runs.
+#ifndef S2T_DMA_FLAT
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)((size_t)p.M * p.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0,
+                                                                         (int)((size_t)(TB ? p.K : p.N) * p.ldb * 2), 0x00020000);
+#define S2T_DMA(RS_, BASE_, VO_, SO_, DST_) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS_, (lds_void*)(DST_), 16, VO_, SO_, 0, 0)
+#else
+#define S2T_DMA(RS_, BASE_, VO_, SO_, DST_) glds16((BASE_) + (VO_) + (SO_), DST_)
+#endif
     auto stageA = [&](int h, int u) {
         char* dst = smem + __builtin_amdgcn_readfirstlane(((sbase + u) & 1) * BUF + h * HALF + a_dst);
         const bool roll = u >= nk && has_next;
         const uint32_t ko = (uint32_t)(roll ? u - nk : min(u, nk - 1)) * kstepA;
         const uint32_t o0 = roll ? nxt.a[h][0] : cur.a[h][0], o1 = roll ? nxt.a[h][1] : cur.a[h][1];
-        glds16(Ab + o0 + ko, dst);
-        if (a_two) glds16(Ab + o1 + ko, dst + 1024);
+        S2T_DMA(rA, Ab, o0, ko, dst);
+        if (a_two) S2T_DMA(rA, Ab, o1, ko, dst + 1024);
     };
     auto stageB = [&](int h, int u) {
         char* dst = smem + __builtin_amdgcn_readfirstlane(((sbase + u) & 1) * BUF + 2 * HALF + h * HALF + wave * 2048);
         const bool roll = u >= nk && has_next;
         const uint32_t ko = (uint32_t)(roll ? u - nk : min(u, nk - 1)) * kstepB;
         const uint32_t o0 = roll ? nxt.b[h][0] : cur.b[h][0], o1 = roll ? nxt.b[h][1] : cur.b[h][1];
-        glds16(Bb + o0 + ko, dst);
-        glds16(Bb + o1 + ko, dst + 1024);
+        S2T_DMA(rB, Bb, o0, ko, dst);
+        S2T_DMA(rB, Bb, o1, ko, dst + 1024);
     };
     // ONE counted wait per K-tile (never 0 in the loop), at the end of SPb's memory segment: only the half-tiles issued in that
     // segment (A-h0, B-h0 of K-tile t+2: 4 DMA instructions, 3 for a wave that stages one A piece) may still be in flight, so all of
     // K-tile t+1 has landed
 #define S2T_WAIT_TILE() do { if (a_two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } while (0)
+    // SCHED 1: per K-tile a wave issues G1 = A-h0, B-h0, B-h1 (6 DMA instructions, 5 for a wave with one A piece) and G2 = A-h1 (2 / 1);
+    // both of its waits leave exactly one G1 and one G2 in flight (see the schedule below)
+#define S2T_WAIT_PIPE() do { if (a_two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
     // reads of a half-tile that is re-staged in the very next super-phase must have RETURNED before this wave passes the barrier
 #define S2T_READS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
@@ -240,6 +255,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         const char* base = buf + h * HALF + a_off + (s_ ? swz1 : swz0);
 #pragma unroll
         for (int i = 0; i < QM; ++i) fa[i][s_] = *reinterpret_cast<const u32x4*>(base + i * 2048);
+    };
+    u32x4 fa0[QM], fa1[QM];                                             // SCHED 1: the two A fragment sets (this stage's / the next one's)
+    auto readA1 = [&](const char* buf, int h, int s_, u32x4 (&dst)[QM]) {
+        const char* base = buf + h * HALF + a_off + (s_ ? swz1 : swz0);
+#pragma unroll
+        for (int i = 0; i < QM; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * 2048);
     };
     auto readBs = [&](const char* buf, int h, int s_) {
         const char* base = buf + 2 * HALF + h * HALF;
@@ -294,12 +315,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         S2T_STAMP(1)                                                                                         \
     } while (0)
 
+    if constexpr (SCHED == 0) {
     // ---- prologue: K-tile 0 and what the steady state stages in SPb of "K-tile -1" (A-h0, B-h0 of K-tile 1)
     stageA(0, 0); stageB(0, 0); stageB(1, 0); stageA(1, 0);
     stageA(0, 1); stageB(0, 1);
     S2T_WAIT_TILE();
     S2T_BAR();
     if (grp == 1) S2T_BAR();                                            // group 1 runs one barrier behind from here on
+    } else {
+    // ---- SCHED 1 prologue: both K-tile buffers, each as the steady state issues them (G1 = A-h0, B-h0, B-h1; G2 = A-h1)
+    stageA(0, 0); stageB(0, 0); stageB(1, 0); stageA(1, 0);
+    stageA(0, 1); stageB(0, 1); stageB(1, 1); stageA(1, 1);
+    S2T_WAIT_PIPE();                                                    // all but the youngest G1 + G2: K-tile 0 has landed
+    S2T_BAR();
+    }
 
     const uint32_t drop_th = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f);
     const float drop_inv = 1.f / (1.f - p.p_drop);
@@ -341,8 +370,97 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             S2T_MMA2(1, 1, 0);
             S2T_BAR();
         };
+        // ---- SCHED 1: the same LDS image and the same staging, another schedule.  All eight waves run ONE program, software-pipelined
+        // at 16-MFMA stages, with the fragments of the next stage in flight under the MFMAs of the current one (two A fragment sets,
+        // both k-halves of the B fragments kept: the same 64 fragment registers as the phases above) -- no wave group waits for the
+        // other, the two waves of a SIMD fall into step by themselves, and a barrier only separates "every wave has read half-tile
+        // X" from "X is re-staged" (twice per K-tile):
+        //     st0  MFMA A-h0.s0 x B.s0   | reads A-h0.s1, B.s1
+        //     st1  MFMA A-h0.s1 x B.s1   | B1; reads A-h1.s0; DMA G1(t+2) = A-h0, B-h0 (B-h1 in st2)      A-h0(t), B(t): all read
+        //     st2  MFMA A-h1.s0 x B.s0   | reads A-h1.s1; DMA B-h1(t+2)
+        //     st3  MFMA A-h1.s1 x B.s1   | B2; reads A-h0.s0, B.s0 of K-tile t+1; DMA G2(t+2) = A-h1  A-h1(t): all read
+        // Read-after-write: a wave's wait before B2(t) leaves one G1 and one G2 of its own in flight, i.e. G1 of K-tile t+1 has landed
+        // (its first reader is st3(t), behind B2(t)); the wait before B1(t+1) does the same for G2 of K-tile t+1 (A-h1(t+1), first read
+        // in st1(t+1) behind B1(t+1)).  Every DMA has six to eight stages (1.5 - 2 K-tiles) to land.
+        // diagnostic twins only (make x X=<mask>; tools/gemm_x_time.py): -DS2T_X bit 0 drops the loop's barriers, bit 1 its DMA, bit 2 its
+        // fragment reads -- WRONG results, timing only: what each of them costs the schedule
+#ifndef S2T_X
+#define S2T_X 0
+#endif
+#define S2T_XBAR() do { if (!(S2T_X & 1)) { S2T_BAR(); } } while (0)
+#define S2T_XDMA(...) if (!(S2T_X & 2)) { __VA_ARGS__ }
+#define S2T_XRD(...) if (!(S2T_X & 4)) { __VA_ARGS__ }
+        auto ktile1 = [&](int t, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const char* buf = smem + ((sbase + t) & 1) * BUF;
+            const char* nbuf = smem + ((sbase + t + 1) & 1) * BUF;
+#define S2T_STAGE(MI, S_, FA)                                                                                 \
+            _Pragma("unroll") for (int NI = 0; NI < 2; ++NI)                                                 \
+                _Pragma("unroll") for (int i = 0; i < QM; ++i)                                               \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
+                        acc[QM * (MI) + i][2 * NI + j] = mma16<bf16>(fb[NI][j][S_], FA[i],                   \
+                            (FIRST && (S_) == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[QM * (MI) + i][2 * NI + j]);
+            // sched_barrier(0) pins the order the stages are written in: hipcc otherwise sinks a stage's MFMAs below the hand-placed
+            // waits of the next one (register-only instructions are not ordered by an asm "memory" clobber: rule 18) and issues the
+            // fragment reads late, right in front of the wait for them.  Inside a stage the DMA instructions go between MFMA groups.
+#define S2T_SB() __builtin_amdgcn_sched_barrier(0)
+#define S2T_MIX(NMFMA, NDMA)                                                                                  \
+            _Pragma("unroll") for (int g_ = 0; g_ < (NDMA); ++g_) {                                          \
+                __builtin_amdgcn_sched_group_barrier(0x008, (NMFMA), 0);                                     \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                           \
+            }
+            // st0 (its fragments -- fa0 = A-h0.s0, fb[.][.][0] -- were requested in st3 of the K-tile before, or at the tile's start: a
+            // stage ago.  The explicit wait is a builtin, not asm: hipcc's own counter model then knows they have landed and does not
+            // wait for the reads issued right below before the first MFMA)
+            S2T_SB();
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0)
+            S2T_XRD(readA1(buf, 0, 1, fa1); readBs(buf, 0, 1); readBs(buf, 1, 1);)
+            S2T_SB();
+            S2T_STAGE(0, 0, fa0)
+            S2T_SB();
+            // st1
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // A-h0(t) and B(t) are in this wave's registers
+            S2T_WAIT_PIPE();
+            S2T_XBAR();                                         // B1
+            S2T_XRD(readA1(buf, 1, 0, fa0);)
+            S2T_SB();
+            S2T_XDMA(stageA(0, t + 2); stageB(0, t + 2);)
+            S2T_STAGE(0, 1, fa1)
+            S2T_MIX(QM, 4)
+            S2T_SB();
+            // st2
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            S2T_XRD(readA1(buf, 1, 1, fa1);)
+            S2T_SB();
+            S2T_XDMA(stageB(1, t + 2);)
+            S2T_STAGE(1, 0, fa0)
+            S2T_MIX(2 * QM, 2)
+            S2T_SB();
+            // st3
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // A-h1(t) too
+            S2T_WAIT_PIPE();
+            S2T_XBAR();                                         // B2
+            S2T_XRD(if (t + 1 < nk) { readA1(nbuf, 0, 0, fa0); readBs(nbuf, 0, 0); readBs(nbuf, 1, 0); })
+            S2T_SB();
+            S2T_XDMA(stageA(1, t + 2);)
+            S2T_STAGE(1, 1, fa1)
+            S2T_MIX(2 * QM, 2)
+            S2T_SB();
+#undef S2T_MIX
+#undef S2T_SB
+#undef S2T_STAGE
+        };
+        if constexpr (SCHED == 0) {
         ktile(0, std::true_type{});
         for (int t = 1; t < nk; ++t) ktile(t, std::false_type{});
+        } else {
+        {   // the tile's first fragments: K-tile 0 is visible (prologue barrier, or B2 of the tile before)
+            const char* buf = smem + (sbase & 1) * BUF;
+            readA1(buf, 0, 0, fa0); readBs(buf, 0, 0); readBs(buf, 1, 0);
+        }
+        ktile1(0, std::true_type{});
+        for (int t = 1; t < nk; ++t) ktile1(t, std::false_type{});
+        }
         // ---- this tile's epilogue (no barrier inside: the other group is one interval away in its own stream).  Running the two groups'
         // epilogues in the SAME interval (group 0 idling through group 1's last cluster, group 1 closing an extra interval after its own)
         // was tried: 7,800 -> 7,000 cycles per boundary, but the masked (per-quad) epilogue then stored a few wrong values per launch --
@@ -397,7 +515,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                     const int row = row0 + wr * (2 * HR) + (lane >> 2);
                     vT[pp] = col < p.N ? (uint32_t)(((size_t)row * p.ldc + col) * ES) : 0xFFFFFFF0u;
                 }
-                u32x4 pend = {0u, 0u, 0u, 0u};
+                // The read-back of step ms lands in quad ms & 3 of a four-deep ring and is stored one step later; a quad is NOT touched
+                // again before its next read-back, three steps on (the empty asm in front of that read-back consumes its old value, with a
+                // memory clobber that keeps it behind the store issued from it).  Why: hipcc re-used a 16-byte store's data registers
+                // two instructions after the store -- the wait states the ISA asks for -- which holds while ONE wave of a SIMD runs an
+                // epilogue; with both waves of a SIMD storing at once, the younger wave's stores left with the next step's f32
+                // intermediates in their first dwords, in lanes 12-15 of every 16-lane row (the part of the data that is read out last):
+                // the store's data read queues behind the partner wave's stores.  That was round 3's "wrong values when the two groups'
+                // epilogues overlap, with and without the lane turn"; tools/gemm_sched_diff.py decodes it, tests/test_kernels_gpu.py
+                // holds the -DS2T_G256_SCHED=1 twin (all eight waves in the epilogue together) to this library bit for bit.
+                // -DS2T_NO_HOLD: the ring without the hold (the reproducer's failing arm).
+                u32x4 ring[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
                 uint32_t pend_v = 0xFFFFFFF0u, pend_s = 0u;
                 auto swap2 = [](uint32_t& x, uint32_t& y) {
                     const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
@@ -464,9 +592,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             {
                                 char* slot = turn + (ms & 1) * 1024;
                                 *reinterpret_cast<u32x4*>(slot + turn_w) = u32x4{s0, s1, s2, s3};
-                                const u32x4 back = *reinterpret_cast<const u32x4*>(slot + turn_r);
-                                if (ms > 0) buf_store(pend, rC, pend_v, pend_s);
-                                pend = back; pend_v = vT[pp]; pend_s = (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES;
+                                // lanes read what OTHER lanes of the wave wrote: the pair must stay in this order (LDS operations of a
+                                // wave execute in issue order; the fence keeps the compiler from moving the read above the write)
+                                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef S2T_TURN_WAIT                                                  /* experiment: the write has COMPLETED before the read-back issues */
+                                __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+                                u32x4& rq = ring[ms & 3];
+#ifndef S2T_NO_HOLD
+                                asm volatile("" : "+v"(rq[0]), "+v"(rq[1]), "+v"(rq[2]), "+v"(rq[3]) :: "memory");
+#endif
+                                rq = *reinterpret_cast<const u32x4*>(slot + turn_r);
+#ifdef S2T_STORE_NOP                                                  /* experiment: distance between the read-back's return and the store */
+                                if (ms > 0) { __builtin_amdgcn_s_waitcnt(0xC07F); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+#endif
+                                if (ms > 0) buf_store(ring[(ms - 1) & 3], rC, pend_v, pend_s);
+                                pend_v = vT[pp]; pend_s = (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES;
                             }
 #endif
                             if constexpr (ACT == ACT_GELU) {
@@ -481,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 };
                 if (p.p_drop > 0.f) epi_steps(std::true_type{}); else epi_steps(std::false_type{});
 #ifndef S2T_NOTURN
-                buf_store(pend, rC, pend_v, pend_s);
+                buf_store(ring[(4 * QM - 1) & 3], rC, pend_v, pend_s);
 #endif
                 if constexpr (MOUT) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.aux_out) + moff) = mk;
             }
@@ -492,12 +633,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         tile += G;
         cur = nxt;
     }
-    if (grp == 0) S2T_BAR();                              // group 0 waits for group 1's last phase
+    if (SCHED == 0 && grp == 0) S2T_BAR();                // group 0 waits for group 1's last phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail DMAs land in LDS nobody reads; retire them before the wave ends
 #undef S2T_MMA2
 #undef S2T_QUAD
 #undef S2T_BAR
 #undef S2T_WAIT_TILE
+#undef S2T_WAIT_PIPE
+#undef S2T_DMA
 #undef S2T_READS_DONE
 }
 
@@ -563,16 +706,26 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     const int grid = tiles < 256 ? tiles : 256;
     const size_t lds = 2 * BUF + 16384;            // two K-tile buffers + the epilogue's lane-turn slots (8 waves x 2 KiB)
     bool done = false;
-#define S2T_G256(TO_, TB_, MT_, ACT_, EXT_)                                                                                  \
+    const int sched = g_s2t_opt_gemm256_sched;
+#define S2T_G256(TO_, TB_, MT_, ACT_, EXT_, SC_)                                                                             \
     if (!done && (out_dtype == S2T_BF16) == (sizeof(TO_) == 2) && (trans_b != 0) == TB_ && use192 == (MT_ == 6) &&          \
-        a.act == ACT_ && ext == EXT_) {                                                                                      \
+        a.act == ACT_ && ext == EXT_ && sched == SC_) {                                                                      \
         static bool attr = false;                                                                                            \
-        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO_, TB_, MT_, ACT_, EXT_>),    \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<TO_, TB_, MT_, ACT_, EXT_, SC_>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }         \
-        hipLaunchKernelGGL((gemm256_kernel<TO_, TB_, MT_, ACT_, EXT_>), dim3(grid), dim3(512), lds, st, a);                                     \
+        hipLaunchKernelGGL((gemm256_kernel<TO_, TB_, MT_, ACT_, EXT_, SC_>), dim3(grid), dim3(512), lds, st, a);             \
         done = true;                                                                                                         \
     }
-#define S2T_G256_MT(TO_, TB_, ACT_, EXT_) S2T_G256(TO_, TB_, 8, ACT_, EXT_) S2T_G256(TO_, TB_, 6, ACT_, EXT_)
+    // SCHED 1 (all eight waves software-pipelined at 16-MFMA stages, every wave in the epilogue at once) measured 0.92 - 1.04 x the
+    // shipped schedule and is not in the product library: -DS2T_G256_SCHED1 builds it into the twins of `make twins`, where it is the
+    // vehicle of the store-data hazard test (two waves of a SIMD issuing 16-byte stores together)
+#ifdef S2T_G256_SCHED1
+#define S2T_G256_MT(TO_, TB_, ACT_, EXT_) S2T_G256(TO_, TB_, 8, ACT_, EXT_, 0) S2T_G256(TO_, TB_, 6, ACT_, EXT_, 0) \
+                                          S2T_G256(TO_, TB_, 8, ACT_, EXT_, 1) S2T_G256(TO_, TB_, 6, ACT_, EXT_, 1)
+#else
+    if (sched != 0) return S2T_ENOTSUP;
+#define S2T_G256_MT(TO_, TB_, ACT_, EXT_) S2T_G256(TO_, TB_, 8, ACT_, EXT_, 0) S2T_G256(TO_, TB_, 6, ACT_, EXT_, 0)
+#endif
     S2T_G256_MT(bf16, false, ACT_NONE, EXT_NONE) S2T_G256_MT(bf16, false, ACT_RELU, EXT_NONE) S2T_G256_MT(bf16, false, ACT_GELU, EXT_NONE)
     S2T_G256_MT(bf16, false, ACT_NONE, EXT_RES) S2T_G256_MT(bf16, false, ACT_RELU_MASK, EXT_NONE)
     S2T_G256_MT(bf16, true, ACT_NONE, EXT_NONE) S2T_G256_MT(bf16, true, ACT_RELU_BWD, EXT_AUX) S2T_G256_MT(bf16, true, ACT_GELU_BWD, EXT_AUX)

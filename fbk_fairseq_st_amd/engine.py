@@ -196,7 +196,9 @@ class S2TEngine:
         # launch): from Python a launch costs 6-12 us of host time, from C ~2.5 us, and with 8 utterances per GPU the host's launch
         # rate is what bounds the update.  bf16 path with deferred weight gradients; the per-kernel schedules below remain the
         # reference the tests hold it to (bit for bit) and the path of f32 mode.
-        self.composite = self.defer_wgrad
+        # (shapes csrc/layer.hip refuses -- D or ffn not a multiple of 8, D not divisible by heads: its `bad()` -- stay on the per-kernel
+        # schedule, whose products fall back to the linear_wgrad / 128-wide routes)
+        self.composite = self.defer_wgrad and hp.D % 8 == 0 and hp.ffn % 8 == 0 and hp.D % hp.heads == 0
         self._descs = {}
         self._call = L.LayerCall()
         self._items = (L.WgradProblem * K.WGRAD_GROUP_MAX)()     # weight-gradient products appended by the layer calls
@@ -648,8 +650,11 @@ class S2TEngine:
 
     # ------------------------------------------------------------------ one layer per C call (csrc/layer.hip)
     def _layer_desc(self, pfx, decoder, T, B, Ts, causal, dist_penalty):
-        key = (pfx, T, B, Ts, causal, dist_penalty)
-        e = self._descs.get(key)
+        """ONE descriptor per layer: the shape-independent part (weight / gradient / LayerNorm pointers, rates) is filled once, the
+        data-dependent part (T after CTC compression, target length, source length, mask flags) is patched in place per call --
+        real batches have a new (T, B, Ts) almost every update, and a descriptor per shape would grow without bound and rebuild ~60
+        pointer fields per miss.  Workspace sizes are remembered per shape in a small bounded table."""
+        e = self._descs.get(pfx)
         if e is None:
             hp = self.hp
             d = L.LayerDesc(dtype=L.BF16, decoder=int(decoder), T=T, B=B, D=hp.D, heads=hp.heads, ffn=hp.ffn, Ts=Ts, gelu=int(hp.act == "gelu"),
@@ -666,17 +671,29 @@ class S2TEngine:
             for k, n in lns.items():
                 setattr(d, k + "_g", self.P(pfx + n + ".weight").data_ptr()); setattr(d, k + "_b", self.P(pfx + n + ".bias").data_ptr())
                 setattr(d, "g_" + k + "_g", self.G(pfx + n + ".weight").data_ptr()); setattr(d, "g_" + k + "_b", self.G(pfx + n + ".bias").data_ptr())
-            e = self._descs[key] = dict(desc=d, addr=ctypes.addressof(d), ws={}, tmp=K.layer_tmp_bytes(d))
+            e = self._descs[pfx] = dict(desc=d, addr=ctypes.addressof(d), sizes={})
+        d = e["desc"]
+        d.T, d.B, d.Ts, d.causal, d.dist_penalty = T, B, Ts, int(causal), int(bool(dist_penalty))
         return e
+
+    def _layer_sizes(self, e, key, training):
+        """(workspace bytes for this mode, backward scratch bytes) of the descriptor's CURRENT shape"""
+        sz = e["sizes"].get(key + (training,))
+        if sz is None:
+            if len(e["sizes"]) >= 64:
+                e["sizes"].clear()
+            sz = e["sizes"][key + (training,)] = (K.layer_ws_bytes(e["desc"], training), K.layer_tmp_bytes(e["desc"]))
+        return sz
 
     def layer_fwd(self, pfx, x, training, seeds, self_klen=None, causal=False, dist_penalty=False, enc2d=None, Ts=0, enc_klen=None):
         """x [T,B,D] -> the layer's output; seeds = (sa_attn, sa_out, xa_attn, xa_out, ffn_act, ffn_out)"""
         T, B, D = x.shape
         decoder = enc2d is not None
-        e = self._layer_desc(pfx, decoder, T, B, Ts, causal, dist_penalty)
-        nws = e["ws"].get(training)
-        if nws is None:
-            nws = e["ws"][training] = K.layer_ws_bytes(e["desc"], training)
+        shape = (T, B, Ts, bool(causal), bool(dist_penalty))
+        e = self._layer_desc(pfx, decoder, *shape)
+        nws, ntmp = self._layer_sizes(e, shape, bool(training))
+        if nws == 0:
+            raise RuntimeError("s2t_layer_ws_bytes refused the layer shape %r (D %d, ffn %d, heads %d)" % (shape, self.hp.D, self.hp.ffn, self.hp.heads))
         ws = torch.empty((nws,), dtype=torch.uint8, device=self.dev)
         y = torch.empty((T, B, D), dtype=self.dtype, device=self.dev)
         c = self._call
@@ -687,15 +704,15 @@ class S2TEngine:
         c.x = x.data_ptr(); c.enc = enc2d.data_ptr() if decoder else None; c.y = y.data_ptr(); c.ws = ws.data_ptr()
         K.layer_fwd(e["addr"], ctypes.addressof(c))
         p = self.hp.dropout if training else 0.0
-        return y, dict(composite=True, e=e, ws=ws, x=x, enc2d=enc2d, self_klen=self_klen, enc_klen=enc_klen, seeds=seeds, training=training,
-                       p=p, T=T, B=B, Ts=Ts)
+        return y, dict(composite=True, pfx=pfx, decoder=decoder, shape=shape, ntmp=ntmp, ws=ws, x=x, enc2d=enc2d, self_klen=self_klen,
+                       enc_klen=enc_klen, seeds=seeds, training=training, p=p, T=T, B=B, Ts=Ts)
 
     def layer_bwd(self, cl, dy, dyd, nxt, denc=None, denc_accumulate=False):
         """dy [T*B, D] gradient w.r.t. the layer output (dyd: its dropout with the FFN's output mask, or None); nxt = (p, seed) of the
         dropout that consumes the result next.  Returns (dx, dropout(dx) or None); the weight-gradient products are appended to the
         engine's list for the grouped launch."""
-        e = cl["e"]
-        tmp = torch.empty((e["tmp"],), dtype=torch.uint8, device=self.dev)
+        e = self._layer_desc(cl["pfx"], cl["decoder"], *cl["shape"])       # the layer's one descriptor, set back to this call's shape
+        tmp = torch.empty((cl["ntmp"],), dtype=torch.uint8, device=self.dev)
         dx = torch.empty_like(dy)
         dxd = torch.empty_like(dy) if nxt is not None else None
         c = self._call
@@ -711,6 +728,9 @@ class S2TEngine:
         c.denc = denc.data_ptr() if denc is not None else None
         c.denc_accumulate = int(denc_accumulate)
         c.tmp = tmp.data_ptr()
+        if self._n_items + 8 > K.WGRAD_GROUP_MAX:            # a decoder layer appends 7 products: never run out of room mid-layer
+            K.wgrad_group_raw(self._n_items, ctypes.addressof(self._items))
+            self._n_items = 0                                 # (their operands stay in _keep until the flush, which is harmless)
         c.items = ctypes.addressof(self._items); c.max_items = K.WGRAD_GROUP_MAX; c.n_items = self._n_items
         K.layer_bwd(e["addr"], ctypes.addressof(c))
         self._n_items = c.n_items

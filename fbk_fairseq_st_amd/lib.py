@@ -127,7 +127,9 @@ _lib = None
 
 def build(verbose=False):
     """Compile csrc/*.hip for gfx950 into libs2t_hip.so (hipcc cross-compiles without a GPU), then the CPython binding of its C ABI."""
-    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 4))]
+    # `twins`: the two diagnostic builds of gemm256 the store-data hazard test loads (tests/test_kernels_gpu.py); they travel to the
+    # GPU box with the tree like the library itself
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 4)), "all", "twins"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("building libs2t_hip.so failed:\n" + res.stdout[-4000:])
@@ -147,6 +149,15 @@ def build(verbose=False):
 FAST_PATH = os.path.join(_HERE, "_s2t_fastcall.so")
 _HOST_SIDE = ("s2t_host_batch_by_size", "s2t_host_ctc_uer")          # CPU work: release the GIL around the call, as ctypes does
 _SIZE_T_RESULT = ("s2t_gemm_relu_mask_bytes", "s2t_layer_ws_bytes", "s2t_layer_bwd_tmp_bytes")
+
+
+def signature_hash():
+    """hash of the table the binding is generated from (names, argument types, result kinds): baked into the generated module, so a
+    module built from an older table is never used (its wrappers erase types through a function-pointer cast: a changed argument
+    type with the same count would be mis-marshalled without any error)"""
+    import hashlib
+    text = ";".join("%s(%s)%s" % (n, ",".join(t.__name__ for t in SIGNATURES[n]), "z" if n in _SIZE_T_RESULT else "i") for n in sorted(SIGNATURES))
+    return int(hashlib.sha256(text.encode()).hexdigest()[:15], 16)
 
 
 def _fastcall_source():
@@ -192,8 +203,9 @@ def _fastcall_source():
         out.append("    return %s;" % ("PyLong_FromSize_t(r)" if ret == "size_t" else "PyLong_FromLong((long)r)"))
         out.append("}")
     out.append("static PyObject* w_s2t_build_info(PyObject* self, PyObject* const* args, Py_ssize_t nargs) { return PyBytes_FromString(s2t_build_info()); }")
+    out.append("static PyObject* w_s2t_signature_hash(PyObject* self, PyObject* const* args, Py_ssize_t nargs) { return PyLong_FromLongLong(%dLL); }" % signature_hash())
     out.append("static PyMethodDef methods[] = {")
-    for name in names + ["s2t_build_info"]:
+    for name in names + ["s2t_build_info", "s2t_signature_hash"]:
         out.append('    {"%s", (PyCFunction)(void (*)(void))w_%s, METH_FASTCALL, ""},' % (name, name))
     out.append("    {NULL, NULL, 0, NULL}};")
     out.append('static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_s2t_fastcall", "generated binding of include/s2t_hip.h", -1, methods};')
@@ -240,6 +252,8 @@ def load():
     if lib.s2t_abi_version() != ABI_VERSION:
         raise ImportError("libs2t_hip.so at %s has ABI version %d, this package binds version %d -- rebuild it (make -C %s)"
                           % (LIB_PATH, lib.s2t_abi_version(), ABI_VERSION, CSRC))
+    global _ctypes_lib
+    _ctypes_lib = lib
     _lib = _load_fastcall(lib) or lib
     return _lib
 
@@ -257,7 +271,18 @@ def _load_fastcall(ctypes_lib):
         return None
     if any(not hasattr(mod, n) for n in SIGNATURES) or mod.s2t_abi_version() != ABI_VERSION:
         return None
+    if getattr(mod, "s2t_signature_hash", lambda: None)() != signature_hash():
+        return None                       # generated from another table (SIGNATURES edited, or `make` without build()): ctypes instead
     return mod
+
+
+_ctypes_lib = None
+
+
+def load_ctypes():
+    """the ctypes handle of the library (diagnostic symbols outside the table, tools/); load() may hand out the generated module"""
+    load()
+    return _ctypes_lib
 
 
 class S2THipError(RuntimeError):

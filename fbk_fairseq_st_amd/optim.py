@@ -117,8 +117,14 @@ class ArenaAdam:
                 m.copy_(st["exp_avg"].to(dtype=m.dtype)); v.copy_(st["exp_avg_sq"].to(dtype=v.dtype))
                 steps.add(int(st["step"]))
         if len(steps) > 1:
-            raise ValueError("per-parameter step counts differ (%s): one fused Adam launch keeps ONE step count" % sorted(steps))
-        self.step_count = steps.pop() if steps else 0
+            # The reference's Adam skips a parameter whose gradient is None -- a layer LayerDrop removed from an update: no moment decay,
+            # no weight decay, its own `step` does not advance (fairseq/optim/adam.py:160-165) -- so a checkpoint trained with
+            # --encoder/--decoder-layerdrop holds different step counts per layer.  The fused arena Adam keeps ONE count (and steps
+            # dropped layers with zero gradients: a documented deviation); the largest count is the global update
+            # count, which is what the bias corrections of every parameter use from here on.
+            import warnings
+            warnings.warn("optimizer state with per-parameter step counts %s (LayerDrop): continuing with the largest" % sorted(steps))
+        self.step_count = max(steps) if steps else 0
         # hyper-parameters: the running optimizer's win over the file's (fairseq_optimizer.py:62-77, optimizer_overrides)
 
 

@@ -18,6 +18,9 @@ runs at full model size on the host.  Tolerances, stated per test:
              with the oracle GIVEN the engine's integer path (s2t_ref.ctc_compress(pred_override=...)): an arg-max over
              bf16-rounded logits may legitimately differ from the f32 one at near-ties; the number of such frames is reported.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -127,7 +130,35 @@ def compare_grads(mine, ref, tol, cos_min=None, what=""):
                 wcos = (c, k)
             assert c >= cos_min, "%s gradient direction of %s: cosine %.6f < %.6f" % (what, k, c, cos_min)
     print("MEASURED %s: worst gradient-norm error %.3e (%s), worst cosine %.6f (%s)" % (what, worst[0], worst[1], wcos[0], wcos[1]))
+    tripwire(what, grad=worst[0], one_minus_cos=1.0 - wcos[0])
     return worst
+
+
+# ---- tripwire: the bf16 bounds below are ~2x the measured worst case, so a regression of less than 2x would pass them silently.
+# tests/golden/parity_measured.json holds what a known-good build measured on an MI355X, per test case; a bf16 figure more than 1.3x
+# (plus a floor for run-to-run noise: atomics order) above its committed value fails here.  S2T_WRITE_MEASURED=<file> records a run.
+_MEASURED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_measured.json")
+_MEASURED = json.load(open(_MEASURED_PATH)) if os.path.exists(_MEASURED_PATH) else {}
+_FLOOR = dict(grad=2e-3, one_minus_cos=1e-3, loss=3e-4, flips=0.005, gen=1e-2)
+
+
+def tripwire(what, **figures):
+    if "bfloat16" not in what and "bf16" not in what:
+        return
+    case = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+    key = "%s | %s" % (case, what)
+    out = os.environ.get("S2T_WRITE_MEASURED")
+    if out:
+        rec = json.load(open(out)) if os.path.exists(out) else {}
+        rec.setdefault(key, {}).update({k: float(v) for k, v in figures.items()})
+        json.dump(rec, open(out, "w"), indent=1, sort_keys=True)
+        return
+    base = _MEASURED.get(key)
+    if base is None:
+        return
+    for k, v in figures.items():
+        if k in base:
+            assert float(v) <= 1.3 * base[k] + _FLOOR[k], "%s: %s %.3e against %.3e measured by the committed build (tripwire 1.3x)" % (key, k, v, base[k])
 
 
 def rel(a, b):
@@ -194,6 +225,7 @@ def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
         flips = sum(int((pred_ref[b, :len4[b]] != int_ref.argmax_first_np(
             torch.softmax(enc.ctc_out.detach()[:, b], -1).numpy())[:len4[b]]).sum()) for b in range(len(len4)))
         print("MEASURED bf16: %d of %d frames pick another unit than the f32 oracle's logits would" % (flips, int(len4.sum())))
+        tripwire("%s bf16 arg-max flips" % arch, flips=flips / float(len4.sum()))
         assert flips <= BF16_MAX_FLIP_FRACTION * int(len4.sum()), (flips, int(len4.sum()))
     t = TOL[dtype]
     assert ss == oss
@@ -324,6 +356,7 @@ def test_cfg5_m_dual_decoder_loss(dtype):
     for k in ("primary_loss", "auxiliary_loss", "primary_nll_loss", "auxiliary_nll_loss"):
         assert rel(log[k], olog[k]) <= t["loss"], k
     print("MEASURED dual %s: loss error %.3e" % (dtype, rel(loss, oloss)))
+    tripwire("dual %s loss" % dtype, loss=rel(loss, oloss))
     compare_grads(engine_grads(model), ograds, t["grad"], t["cos"], what="dual %s" % dtype)
 
 
@@ -385,6 +418,7 @@ def test_cfg5_m_beam5_generation_bf16():
             worst_best = max(worst_best, abs(rescored[0] - os_[0][1]))
     print("MEASURED bf16 beam-5: %d of %d (sentence, rank) slots identical to the f32 oracle; positional scores within %.3e of the "
           "oracle's re-scoring; best-hypothesis near-tie gap %.3e" % (same, total, worst_pos, worst_best))
+    tripwire("bf16 beam-5", gen=worst_pos)
     assert worst_pos <= BF16_GEN_ATOL and worst_best <= BF16_GEN_ATOL
 
 

@@ -3,6 +3,8 @@ fp32 path: 1e-4 (north_star); bf16 path: tolerance stated per test (bf16 has 8 b
 Integer outputs (CTC compression) are compared bit-exactly."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -350,6 +352,61 @@ def test_ctc_argmax_random_matches_oracle(dtype):
     assert [len(r) for r in runs] == new_len.cpu().tolist()
 
 
+def _near_tie_rows(V, mags, gaps, seed):
+    """f32 logit rows whose two largest entries are `gap` ulp apart (gap 0: equal), the larger one at the LATER index in half of
+    the rows and at the earlier one in the other half; everything else at least 1.5 below.  Returns x [R, V], meta rows
+    (magnitude, gap, later_is_larger)."""
+    rs = np.random.RandomState(seed)
+    rows, meta = [], []
+    for mag in mags:
+        for gap in gaps:
+            for later in (False, True):
+                for rep in range(24):
+                    x = (rs.randn(V) * 0.7 - 4.0).astype(np.float32)
+                    top = np.float32(mag * (0.75 + 0.5 * rs.rand()))
+                    lo = top
+                    for _ in range(gap):
+                        lo = np.nextafter(lo, np.float32(-np.inf), dtype=np.float32)
+                    x = np.minimum(x, lo - np.float32(1.5))
+                    i, j = sorted(rs.choice(V, 2, replace=False))
+                    x[i], x[j] = (lo, top) if later else (top, lo)
+                    rows.append(x); meta.append((mag, gap, later))
+    return np.stack(rows), meta
+
+
+def test_ctc_argmax_near_ties_of_a_5001_wide_row():
+    """The reference takes arg-max of the f32 softmax OUTPUT (conv_transformer.py:282-284): two distinct logits whose probabilities
+    round to the same float are a tie there, and the FIRST index wins.  The kernel evaluates the same formula, exp(x - max) / sum in
+    f32 with first-index ties, in its own arithmetic: its sum (and exp) differ from torch's in the last bits, so whether two
+    probabilities one ulp apart collapse into one float can come out differently -- on either side (the reference's own answer for
+    such a row changes with the platform's exp and summation order).  Pinned here: exact logit ties give the first index; a
+    disagreement is only ever between the SAME two candidates, and only where the reference's two probabilities are at most one
+    ulp apart (its decision is at rounding level); how often that happens on rows built to provoke it is measured and bounded."""
+    V = 5001
+    x, meta = _near_tie_rows(V, mags=(0.05, 0.3, 1.5, 6.0, 20.0), gaps=(0, 1, 2, 4), seed=5)
+    R = x.shape[0]
+    xt = torch.from_numpy(x)
+    prob = torch.softmax(xt, -1)
+    ref = prob.argmax(-1).numpy()                                    # first index among equal maxima
+    pred, _ = K.ctc_argmax(xt.view(R, 1, V).to(DEV))                 # [B = 1, T = R]
+    got = pred.view(-1).cpu().numpy().astype(np.int64)
+    top2 = torch.topk(prob, 2, dim=-1).values.numpy()
+    ulps = np.abs(top2[:, 0].view(np.int32).astype(np.int64) - top2[:, 1].view(np.int32).astype(np.int64))   # distance of the reference's two probabilities
+    gap = np.array([m[1] for m in meta]); mag = np.array([m[0] for m in meta])
+    bad = got != ref
+    assert not bad[gap == 0].any(), "exact logit ties must give the first index"
+    order = np.argsort(-x, axis=1)[:, :2]
+    assert all(got[r] in order[r] for r in np.nonzero(bad)[0]), "a disagreement must stay between the two near-tied candidates"
+    assert not bad[ulps > 1].any(), "rows whose reference probabilities are more than one ulp apart must agree"
+    near = (gap > 0) & (ulps <= 1)
+    rate = float(bad[near].mean()) if near.any() else 0.0
+    print("MEASURED near-tie arg-max: %d rows with unequal top logits, %d of them with reference probabilities <= 1 ulp apart, "
+          "%d disagreements (%.1f %% of those; by top-logit magnitude: %s)" % (
+              int((gap > 0).sum()), int(near.sum()), int(bad.sum()), 100 * rate,
+              ", ".join("%g: %d/%d" % (m, int(bad[near & (mag == m)].sum()), int((near & (mag == m)).sum())) for m in sorted(set(mag)))))
+    assert rate <= 0.35, rate
+
+
 @pytest.mark.parametrize("V", [37, 2048, 5001, 5120, 8000, 9001])
 def test_ctc_argmax_padded_rows_single_pass_and_three_pass(V):
     """rows with a padded stride (what the CTC head writes) take the single-pass kernel up to 8192 units, the three-pass kernel
@@ -629,6 +686,84 @@ def test_wgrad_group_mixed_reduction_lengths(t_long, t_short, n_long):
         assert rel_err(dw, rw) < 2e-5 * max(1.0, dy.shape[0] ** 0.5 / 8), (tuple(dw.shape), dy.shape[0], rel_err(dw, rw))
         if db is not None:
             assert rel_err(db, rb) < 1e-4
+
+
+TURN_SHAPES = [(24000, 384, 192), (24000, 512, 512), (24000, 1536, 512), (24000, 2048, 512), (24000, 512, 2048), (23000, 640, 1280),
+               (6211, 1536, 512), (36800, 256, 512), (24000, 2048, 128), (12000, 1024, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K_", TURN_SHAPES)
+def test_gemm256_epilogues_against_the_128_wide_route_and_themselves(M, N, K_):
+    """tools/gemm_turn_check.py as a test: every epilogue variant of gemm256 (stores leave in a lane order turned through wave-private
+    LDS slots, masked epilogue per quad, unmasked one straight-line) on ten shapes, six launches each.  The 128-wide route (gemm.hip)
+    runs the same MFMA instruction over K in the same order and the same epilogue arithmetic (gemm_epilogue.hpp), so the two routes
+    must agree BIT FOR BIT, and every repeated launch must reproduce the first one (a store path that races shows up as a few
+    wrong values in some launches)."""
+    dt = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(M + N + K_)
+    a = torch.randn(M, K_, device=DEV, generator=g).to(dt); w = (torch.randn(N, K_, device=DEV, generator=g) * K_ ** -0.5).to(dt)
+    b = torch.randn(N, device=DEV, generator=g); r = torch.randn(M, N, device=DEV, generator=g).to(dt)
+    dy = torch.randn(M, N, device=DEV, generator=g).to(dt); aux = torch.randn(M, K_, device=DEV, generator=g).to(dt)
+    calls = [lambda s: K.gemm(a, w, bias=b), lambda s: K.gemm(a, w, bias=b, p_drop=0.25, seed=9 + s),
+             lambda s: K.gemm(a, w, bias=b, residual=r, p_drop=0.1, seed=3), lambda s: K.gemm(a, w, bias=b, act=K.ACT_RELU, p_drop=0.1, seed=5),
+             lambda s: K.gemm(a, w, bias=b, act=K.ACT_RELU, residual=r), lambda s: K.gemm(dy, w, trans_b=True),
+             lambda s: K.gemm(dy, w, trans_b=True, act=K.ACT_RELU_BWD, aux=aux, alpha=1.25)]
+    old = K.set_option("gemm256", 0)
+    try:
+        want = [[fn(rep) for fn in calls] for rep in range(2)]           # the seed of the second variant changes with the launch index
+        K.set_option("gemm256", 1)
+        for rep in range(6):
+            for i, fn in enumerate(calls):
+                got = fn(rep % 2)
+                assert torch.equal(got, want[rep % 2][i]), "epilogue %d, launch %d: %d of %d values differ from the 128-wide route" % (
+                    i, rep, int((got != want[rep % 2][i]).sum()), got.numel())
+    finally:
+        K.set_option("gemm256", old)
+
+
+def test_gemm256_store_data_hazard_twins():
+    """Round 3 left "wrong values when the two wave groups' epilogues overlap" unexplained; this is its reproducer.  `make twins` builds
+    gemm256 with a second K-loop schedule in which all eight waves -- both waves of every SIMD -- run their epilogues at the same
+    time (s2t_set_option "gemm256_sched" 1; not in the product library, whose schedule keeps one epilogue per SIMD at a time):
+      libs2t_hip_sched1_nohold.so   the epilogue as round 3 had it: hipcc re-uses a 16-byte store's data registers two instructions
+                                    after the store (the wait states the ISA asks for).  With the SIMD partner storing too, the
+                                    younger wave's stores leave with the NEXT step's f32 intermediates in their first dwords, lanes
+                                    12-15 of every 16-lane row (the data beats read last; tools/gemm_sched_diff.py decodes it):
+                                    thousands of wrong values in nearly every launch of a masked or operand-reading epilogue.
+      libs2t_hip_sched1.so          stores from a four-deep register ring that is untouched for three steps (the product's epilogue):
+                                    the raw-f32 garbage is gone; a residue of stale-but-valid values (same lanes, ~1e-5 of the
+                                    elements, a few launches in a hundred) remains in the operand-reading variants, i.e. a second
+                                    mechanism is still open -- which is why concurrent epilogues stay out of the product.
+    Asserted: the product library is bit-exact against the 128-wide route (test above); without the hold the hazard shows; the hold
+    removes at least three quarters of the differing launches.  Counts are printed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "fbk_fairseq_st_amd")
+
+    def sums(lib, sched):
+        env = dict(os.environ)
+        if lib:
+            env["S2T_HIP_LIB"] = os.path.join(pkg, lib)
+            assert os.path.exists(env["S2T_HIP_LIB"]), "run __graft_entry__.build(): it also builds the twins"
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_epilogue_sums.py"), str(sched)], env=env,
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if l.startswith("SUM ")]
+
+    want = sums(None, 0)
+    assert len(want) == 4 * 6 * 4
+    raw = sums("libs2t_hip_sched1_nohold.so", 1)
+    held = sums("libs2t_hip_sched1.so", 1)
+    n_raw = sum(a != b for a, b in zip(want, raw))
+    n_held = sum(a != b for a, b in zip(want, held))
+    plain = [k for k, (a, b) in enumerate(zip(want, held)) if a != b and a.split()[4] in ("0", "4")]
+    print("MEASURED store-data hazard (both waves of a SIMD in their epilogues): %d of %d launches differ from the product library "
+          "without the register hold, %d with it" % (n_raw, len(want), n_held))
+    assert not plain, "the plain epilogues (no mask, no operand stream) must be exact under either arrangement"
+    if n_raw == 0:
+        pytest.xfail("the hazard did not show on this box")
+    assert n_held * 4 <= n_raw, (n_held, n_raw)
 
 
 def test_gemm256_is_deterministic_under_load():

@@ -40,6 +40,7 @@ else:
         fn = lambda: K.gemm(dy, w, trans_b=True, act=K.ACT_RELU_BWD_MASK, aux=rec, alpha=1.0 / 0.85)
     else:
         fn = lambda: K.gemm(dy, w, trans_b=True)
+K.set_option("gemm256_sched", int(os.environ.get("GEMM256_SCHED", 0)))
 for _ in range(reps):
     fn()
 torch.cuda.synchronize()
