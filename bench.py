@@ -185,7 +185,7 @@ def cpu_baseline(args, a, ref_sd, task):
                 W[k].data.copy_(p)
         times.append(time.perf_counter() - t0)
     t = sum(times[1:]) / len(times[1:])
-    return {"value": Bc * args.frames / t, "unit": "audio-frames/s", "cores": ncores, "kind": "port",
+    return {"value": Bc * args.frames / t, "unit": "audio-frames/s", "cores": ncores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "oracle/s2t_ref.py full update (ctc_multi_loss fwd+bwd, clip, Adam), fp32, %d x %d frames, mean of %d updates after 1 warm-up"
                       % (Bc, args.frames, args.cpu_updates)}
 
@@ -385,6 +385,19 @@ def main():
             "allreduce_buckets": len(red.plan), "bucket_bytes": red.bucket_elems * red.flat.element_size(),
             "allreduce_launched_in_backward_frac": round(red.early_elems / max(red.n, 1), 4) if world > 1 else None}
         if roof is not None:
+            # north_star's "MFMA utilisation on the encoder": SURVEY.md 8-d's algorithmic FLOP of the ENCODER side per input frame
+            # (subsampler + encoder layers with the context length each layer actually sees + the CTC head; x3 for forward + backward)
+            # times the frames per second ONE GPU sustains over the WHOLE update, over the dense bf16 peak -- decoder, losses,
+            # optimizer and every memory-bound kernel count as time but not as work
+            a_ = a
+            D, Ff, T4 = a_.encoder_embed_dim, a_.encoder_ffn_embed_dim, (args.frames + 3) // 4
+            Tc = enc_mean if args.ctc_layer else T4
+            per_tok = lambda ctx: 8 * D * D + 4 * D * Ff + 4 * ctx * D
+            fwd = args.frames * (23040 + 368640 + 640 * D) + T4 * args.ctc_layer * per_tok(T4) \
+                + Tc * (a_.encoder_layers - args.ctc_layer) * per_tok(Tc) + (T4 * 2 * D * len(task.src_dict) if args.ctc_layer else 0)
+            flop_per_frame = 3.0 * fwd / args.frames
+            roof["encoder_flop_per_frame_fwd_bwd"] = round(flop_per_frame / 1e6, 2)
+            roof["encoder_mfma_util"] = round(frames_done / dt * flop_per_frame / (PEAK_BF16_TFLOPS * 1e12), 4)
             out["roofline"] = roof
         if args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, a, ref_sd, task)

@@ -209,6 +209,9 @@ class S2TEngine:
         # launches of six layers pack as well as one of twelve (576 / 2 tiles each over 256 CUs, tail cut), and half of the encoder's
         # gradient bytes then travel over xGMI underneath the lower layers' backward instead of after it.
         self.wgrad_flush_layers = None
+        # diagnostic: a dict here collects the ReLU decisions of the next forward passes of the per-kernel (f32) schedule, site ->
+        # bool tensor (tests/test_configs_gpu.py hands them to the oracle, so that the fp32 comparison holds no discrete decision)
+        self.relu_record = None
         # True: the decoder's queued weight gradients go out at the end of ITS backward (data-parallel runs: ~130 MB of gradients
         # then travel under the encoder's backward).  False: they wait for the encoder's flush and share its launch; measured on one GPU
         # (tools/ab_engine_flag.py flush_decoder_wgrad): 15.63 ms per update against 15.48 with the separate launch -- the one work
@@ -373,6 +376,10 @@ class S2TEngine:
         p = hp.dropout if training else 0.0
         xe = K.add_pos(h3.view(T4, B, hp.D), self.table(T4 + 1, 0), len4_32, out=torch.empty((T4, B, hp.D), dtype=self.dtype, device=self.dev),
                        p_drop=p, seed=seed + 3)
+        if self.relu_record is not None and not gelu:           # reference layouts: (B,C,T2,F2), (B,C,T4,F4), (T4,B,D)
+            self.relu_record["encoder.conv0"] = (y1.view(B, T2, F2, C) > 0).permute(0, 3, 1, 2)
+            self.relu_record["encoder.conv1"] = (z2.view(T4, B, F4, C) > 0).permute(1, 3, 0, 2)
+            self.relu_record["encoder.fc3"] = (h3 > 0).view(T4, B, hp.D)
         c.update(y1=y1, y1n=y1n, z2=z2, z2n=z2n, h3=h3, w2p=w2p, w3p=w3p, mean1=mean1, rstd1=rstd1, mean2=mean2,
                  rstd2=rstd2, cnt1=cnt1, P2=P2, p=p, pre1=pre1, pre2=pre2, pre3=pre3)
         return xe, c
@@ -628,6 +635,8 @@ class S2TEngine:
                         p_drop=pact, seed=seed + 3)
         p = hp.dropout if training else 0.0
         y = self.linear(a, pfx + "fc2", residual=x2, p_drop=p, seed=seed + 4)
+        if self.relu_record is not None and hp.act == "relu" and pact == 0.0:
+            self.relu_record[pfx + "ffn"] = (a > 0).view(T, B, hp.ffn)
         c = dict(x=x2, h=h, mean=mean, rstd=rstd, a=a, pre=pre, pact=pact, p=p, seed=seed, amask=amask)
         return y.view(T, B, D), c
 

@@ -28,6 +28,18 @@ def default_cfg(**kw):
     return cfg
 
 
+def site_act(cfg, site, act):
+    """The activation of one site, or -- checker-only -- that site's ReLU with the ACTIVE SET taken from the caller
+    (cfg["relu_masks"][site], a bool tensor in this function's layout): y = x * mask, gradient routed by the same mask.
+    The fp32 parity tests feed it the decisions the product made on its own pre-activations, the way `pred_override` feeds the
+    CTC arg-max: a pre-activation within f32 rounding of zero is then active on both sides or on neither, and what is left
+    of the comparison is floating-point arithmetic only."""
+    m = (cfg.get("relu_masks") or {}).get(site)
+    if m is None or cfg["act"] != "relu":
+        return act
+    return lambda x: x * m.reshape(x.shape).to(x.dtype)
+
+
 def act_fn(name):
     # fairseq/utils.py:390-408 ; fairseq/modules/gelu.py:24-25 (gelu in fp32)
     if name == "relu":
@@ -137,7 +149,7 @@ def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
     for i in range(2):
         p = "encoder.convolutions.%d." % i
         x = F.conv2d(x, W[p + "weight"], W[p + "bias"], stride=2, padding=1)
-        x = act(x)
+        x = site_act(cfg, "encoder.conv%d" % i, act)(x)
         q = "encoder.bn.%d." % i
         x, rm, rv = batch_norm2d(x, W[q + "weight"], W[q + "bias"], W[q + "running_mean"],
                                  W[q + "running_var"], training, cfg["bn_momentum"], cfg["bn_eps"])
@@ -152,7 +164,7 @@ def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
                 trace["attn2d%d" % i] = x
     B, C, T4, F4 = x.shape
     x = x.transpose(1, 2).contiguous().view(B, T4, C * F4).transpose(0, 1)   # :225-226
-    x = act(F.linear(x, W["encoder.fc3.weight"], W["encoder.fc3.bias"]))    # :227
+    x = site_act(cfg, "encoder.fc3", act)(F.linear(x, W["encoder.fc3.weight"], W["encoder.fc3.bias"]))    # :227
     if trace is not None:
         trace["fc3"] = x
     table = sinusoid_table(T4 + 1, cfg["D"], 0)
@@ -216,7 +228,7 @@ def encoder_layer(W, cfg, pfx, x, pad_mask):
     r = x
     if pre:
         x = layer_norm(W, pfx + "final_layer_norm.", x)
-    x = r + ffn(W, pfx, x, act)
+    x = r + ffn(W, pfx, x, site_act(cfg, pfx + "ffn", act))
     if not pre:
         x = layer_norm(W, pfx + "final_layer_norm.", x)
     return x
@@ -301,7 +313,7 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
         r = x
         if pre:
             x = layer_norm(W, p + "final_layer_norm.", x)
-        x = r + ffn(W, p, x, act)
+        x = r + ffn(W, p, x, site_act(cfg, p + "ffn", act))
         if not pre:
             x = layer_norm(W, p + "final_layer_norm.", x)
     if pre:

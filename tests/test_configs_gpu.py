@@ -183,6 +183,7 @@ def rel(a, b):
 #   gradient direction    cosine on EVERY tensor whose norm is above 1e-3 of the largest: worst 0.9972 ctc_multi_loss, 0.9951 shared
 #                         embedding, 0.9968 dual decoder, 0.9915 KD (decoder.layers.5.encoder_attn.q_proj.weight)   -> 0.99 (KD: 0.983)
 TOL = {torch.float32: dict(loss=1e-4, grad=1e-3, cos=0.9999), torch.bfloat16: dict(loss=6e-3, grad=5e-2, cos=0.99)}
+FP32_NORTH_STAR = 1e-4          # BASELINE.json north_star: "within fp32 1e-4"; held by the comparison with shared ReLU decisions
 TOL_BF16_KD = dict(loss=6e-3, grad=5e-2, cos=0.983)
 TOL_BF16_DUAL = dict(loss=6e-3, grad=9e-2, cos=0.99)
 
@@ -198,6 +199,9 @@ def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
     sample = batch(task, B, T, L, L, seed, lengths)
     model.train(); crit.train()
     model.arena.zero_grad()
+    if dtype == torch.float32:
+        model._ensure_engine(DEV)
+        model.engine.relu_record = {}                   # the ReLU decisions of this pass, for the second oracle run below
     loss, ss, log = crit(model, to_dev(sample))
     loss.backward()
     torch.cuda.synchronize()
@@ -238,6 +242,20 @@ def check_ctc_multi_loss(arch, dtype, B, T, L, lengths, seed, **over):
     worst = compare_grads(engine_grads(model), ograds, t["grad"], t["cos"], what="%s %s" % (arch, dtype))
     print("%s %s: loss %.6f (oracle %.6f), worst gradient-norm error %.2e at %s, frames %s -> %s" %
           (arch, dtype, float(loss), float(oloss), worst[0], worst[1], list(len4), last["lengths_host"]))
+    if dtype == torch.float32 and cfg["act"] == "relu":
+        # ---- north_star's fp32 bound (1e-4) with the DISCRETE decisions taken out of the comparison: the oracle runs again with the
+        # engine's own ReLU active sets (as `pred_override` does for the arg-max in bf16 mode), so a pre-activation within f32 rounding
+        # of zero cannot be active on one side only; what remains is floating-point arithmetic in another summation order.  The
+        # free-running comparison above stays, at 1e-3.
+        masks = {k: v.cpu() for k, v in model.engine.relu_record.items()}
+        model.engine.relu_record = None
+        n_sites = 3 + cfg["enc_layers"] + cfg["dec_layers"]
+        assert len(masks) == n_sites, (sorted(masks), n_sites)
+        cfg_m = dict(cfg, relu_masks=masks)
+        (mloss, _, _, _, _, _), mgrads = oracle_grads(W, lambda Wg: s2t_ref.ctc_multi_loss(Wg, cfg_m, sample, 0.1, 1.0, blank, training=True))
+        assert rel(loss, mloss) <= 1e-4
+        wm = compare_grads(engine_grads(model), mgrads, FP32_NORTH_STAR, t["cos"], what="%s %s, ReLU decisions shared" % (arch, dtype))
+        print("%s fp32 with shared ReLU decisions: worst gradient-norm error %.2e at %s" % (arch, wm[0], wm[1]))
 
 
 # ------------------------------------------------------------------------------------------------ Cfg2

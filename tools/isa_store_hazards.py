@@ -1,0 +1,60 @@
+"""Static check of a gfx950 .s file (hipcc -S --cuda-device-only): for every wide LDS write (ds_write_b96 / b128) and wide vector store
+(buffer_ / global_ / scratch_store_dwordx3 / x4), how soon after it a VALU instruction writes one of its DATA registers.  The data of such
+an instruction is read out over several cycles after issue; a VALU write inside that window ends up in the stored data (gemm256.hip, the
+epilogue's HAZARD note; hipcc pads two wait states after wide buffer stores and none after wide LDS writes).  `s_nop N` counts as N + 1
+states, everything else as one.
+    python tools/isa_store_hazards.py file.s [min_states]   ->   one line per kernel with the closest distance found (and its count)"""
+import re
+import sys
+
+
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+WIDE = re.compile(r"^(ds_write_b96|ds_write_b128|ds_write2_b64|(buffer|global|scratch)_store_dwordx[34])\b")
+
+
+def scan(text, horizon=8):
+    """{kernel: (closest distance in states or None, number of stores at that distance, example)}"""
+    out = {}
+    for fn in re.findall(r"^(\w+):\s*;? ?@?\1", text, re.M) or re.findall(r"^(_Z\w+|\w+_kernel\w*):", text, re.M):
+        i = text.index(fn + ":")
+        j = text.find(".Lfunc_end", i)
+        body = [l.strip() for l in text[i:j].splitlines()]
+        body = [l for l in body if l and not l.startswith(";") and not l.startswith(".")]
+        best, n, ex = None, 0, None
+        for k, l in enumerate(body):
+            if not WIDE.match(l):
+                continue
+            ops = [t.strip(",") for t in l.split()[1:]]
+            data = regs(ops[1]) if l.startswith(("ds_write", "global_store")) else regs(ops[0])     # buffer_ / scratch_: data first
+            if l.startswith("ds_write2") and len(ops) > 2:
+                data |= regs(ops[2])
+            dist = 0
+            for nx in body[k + 1:k + 1 + horizon]:
+                dist += (int(nx.split()[1], 0) + 1) if nx.startswith("s_nop") else 1
+                if nx.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier")):
+                    break
+                if nx.startswith("v_") and not nx.startswith("v_cmp") and regs(nx.split()[1].strip(",")) & data:
+                    if best is None or dist < best:
+                        best, n, ex = dist, 1, l[:44] + "  ->  " + nx[:44]
+                    elif dist == best:
+                        n += 1
+                    break
+        out[fn] = (best, n, ex)
+    return out
+
+
+if __name__ == "__main__":
+    res = scan(open(sys.argv[1]).read())
+    lim = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    for fn, (d, n, ex) in sorted(res.items(), key=lambda kv: (kv[1][0] is None, kv[1][0] or 0)):
+        if d is not None and (not lim or d < lim):
+            print("%-70s closest VALU overwrite of wide store data: %d states (%d times)  %s" % (fn[:70], d, n, ex))
+    worst = min([d for d, _, _ in res.values() if d is not None], default=None)
+    print("kernels: %d, closest distance: %s" % (len(res), worst))
