@@ -808,9 +808,9 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     // form transposes in registers): they switch to 64x64 tiles much later (tools/small_gemm.py: NN 2560 x 512 x 8000 93 -> 67 us,
     // TN 512 x 512 18 -> 14.6 us with the 128-wide kernels; NT is better off with 64x64 below ~192 tiles)
     const bool small = t128 < ((trans_a || trans_b) ? 40 : 192);
-    // conv2 implicit GEMM (64 output channels) -- and products whose 128 x 128 tiles would leave most of the 256 CUs idle
-    // (s2t_set_option "gemm_mid_tiles": below that many tiles 128 x 64 ones are used: twice the workgroups)
-    const bool narrow = !small && (N <= 64 || (t128 < g_s2t_opt_gemm_mid_tiles && !mapA && !mapB && !mapC && splitk == 1));
+    // (128 x 64 tiles for products with 40-160 tiles of 128 x 128 -- twice the workgroups on the idle CUs -- measured 2-3 % SLOWER on
+    // the decoder's M = 2,560 / 3,000 products, tools/dec_gemm_time.py: not used)
+    const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
     // families for the roofline report (one kernel template each): dW-shaped (TN), forward (NT), dX-shaped (NN) products on
     // 128x128 tiles, their small-problem 64x64 forms, and the implicit-GEMM convolution
     // ONE KERNEL TEMPLATE per family: the 256 x 256 x 64 LDS-DMA kernel in its forward (NT) and data-gradient (NN) forms, and the

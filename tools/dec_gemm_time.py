@@ -4,7 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fbk_fairseq_st_amd import kernels as K
 dev = "cuda"; dt = torch.bfloat16; M = int(os.environ.get("M", 2560))
-K.set_option("gemm_mid_tiles", int(os.environ.get("MID", 0)))
 def timeit(fn, n=200, w=10):
     for _ in range(w): fn()
     torch.cuda.synchronize()

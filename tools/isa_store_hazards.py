@@ -22,7 +22,7 @@ WIDE = re.compile(r"^(ds_write_b96|ds_write_b128|ds_write2_b64|(buffer|global|sc
 def scan(text, horizon=8):
     """{kernel: (closest distance in states or None, number of stores at that distance, example)}"""
     out = {}
-    for fn in re.findall(r"^(\w+):\s*;? ?@?\1", text, re.M) or re.findall(r"^(_Z\w+|\w+_kernel\w*):", text, re.M):
+    for fn in re.findall(r"^(\w+):\s*;? ?@?\1", text, re.M) or re.findall(r"^([A-Za-z_]\w*):", text, re.M):
         i = text.index(fn + ":")
         j = text.find(".Lfunc_end", i)
         body = [l.strip() for l in text[i:j].splitlines()]

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pf/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extra > /dev/null 2>&1
 python3 $R/tools/hbm_traffic.py /tmp/pf/fetch /tmp/pf/write $R/gpurun_out/ref/hbm_traffic.json
-cp $R/gpurun_out/ref/hbm_traffic.json $R/profiles/r03_hbm_traffic.json
+cp $R/gpurun_out/ref/hbm_traffic.json $R/profiles/r04_hbm_traffic.json
 cd $R
 python bench.py > $R/gpurun_out/ref/bench.json 2> $R/gpurun_out/ref/bench.err
 cd /tmp
