@@ -284,157 +284,210 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const T* __restrict__ logi
     if (lane == 0) lse[row] = m + logf(s);
 }
 
-__device__ __forceinline__ float lae(float a, float b) {          // log(exp a + exp b), -inf safe
-    if (a == -INFINITY) return b;
-    if (b == -INFINITY) return a;
-    const float m = fmaxf(a, b);
-    return m + log1pf(expf(-fabsf(a - b)));
+// The alpha / beta recursion runs in LOG2 units with a finite "never" (CTC_NEVER) instead of -inf: a dependent chain of 375 steps
+// per utterance whose latency IS the kernel's duration (a lone wave issues one instruction per ~8 cycles), so every instruction
+// in the step counts.  log2(2^a + 2^b [+ 2^c]) on the hardware exp2 / log2 units takes no scaling multiplies; with CTC_NEVER the
+// all-unreachable case needs no test (2^0 three times, log2 3 added to -1e30 is absorbed: one ulp there is 7.6e22) and no inf - inf
+// can arise.  Absolute error ~1e-6 per step on values of magnitude 1e2: far inside the 1e-4 relative budget of the loss.
+#define CTC_NEVER (-1.0e30f)
+#define CTC_NEVER_TEST (-1.0e29f)          // "reachable" = above this (unreachable values only move further down)
+__device__ __forceinline__ float l2ae2(float a, float b) {
+    return fmaxf(a, b) + __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
 }
-// log(exp a + exp b [+ exp c]) on the hardware exp2 / log2 units: the alpha / beta recursion is a 375-step dependent chain per
-// utterance, its latency IS the kernel's duration (libm expf + log1pf twice per step cost ~4x this form).  Absolute error ~1e-6
-// per step on values of magnitude 1e2: far inside the 1e-4 relative budget of the loss.
-__device__ __forceinline__ float lae3(float a, float b, float c, bool use_c) {
-    if (!use_c) c = -INFINITY;
+__device__ __forceinline__ float l2ae3(float a, float b, float c) {
     const float m = fmaxf(fmaxf(a, b), c);
-    if (m == -INFINITY) return -INFINITY;
-    const float L2E = 1.44269504088896f;
-    const float sum = __builtin_amdgcn_exp2f((a - m) * L2E) + __builtin_amdgcn_exp2f((b - m) * L2E) + __builtin_amdgcn_exp2f((c - m) * L2E);
-    return m + __builtin_amdgcn_logf(sum) * 0.693147180559945f;
+    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m));
 }
 
-// Pass 2: alpha (wave 0) and beta (wave 1) recursions of one utterance in log space.
-// Extended target ext[s], s < S = 2L+1 <= 64*SPL; lane owns SPL consecutive s; the two neighbours
-// needed from the previous lane travel by shuffle.  Emissions lp[t][ext[s]] = logit - lse are
-// gathered CH time steps at a time into LDS by the whole workgroup.
-// Outputs: la/lb [B][T][Smax] (f32 log alpha/beta), nll[b] (0 if infeasible: zero_infinity).
+// Lane i <- lane i-1 (lane 0 <- never) and lane i <- lane i+1 (lane 63 <- never) as DPP wave shifts: ~2 VALU issues where a
+// ds_bpermute shuffle is an LDS round trip, and the neighbour's value sits on the recursion's dependent chain at every step.
+__device__ __forceinline__ float lane_before(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(CTC_NEVER), __float_as_int(v), 0x138, 0xf, 0xf, false));   // wave_shr:1
+}
+__device__ __forceinline__ float lane_after(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(CTC_NEVER), __float_as_int(v), 0x130, 0xf, 0xf, false));   // wave_shl:1
+}
+// wave maximum, wave-uniform: an inclusive row scan (row_shr 1, 2, 4, 8), the rows' last lanes carried across (row_bcast 15, 31)
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    // in place: lanes whose source lies outside the row / wave keep their value (bound_ctrl off disables the write).  A VALU write
+    // followed by a DPP read of the same register needs two wait states, which hipcc cannot see inside an asm: the s_nop 1's.
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1" : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Pass 2: alpha (wave 0) and beta (wave 1) recursions of one utterance in log2 space.
+// Extended target ext[s], s < S = 2L+1 <= 64*SPL; lane owns SPL consecutive s; the neighbours needed from the adjacent lane travel
+// by DPP wave shift.  Emissions lp[t][ext[s]] = (logit - lse) log2 e are gathered CH time steps at a time into LDS by the whole
+// workgroup (CTC_NEVER for s >= S and frames outside the utterance: such positions then stay "never" by themselves, no per-step
+// test); with one position per thread (SPL <= 2) the NEXT chunk's gather is in flight in registers while this chunk's steps run.
+// Outputs: la/lb [B][T][64 SPL] (f32 log2 alpha/beta, each step's vector shifted by a per-step offset; rows are padded to the
+// lanes' positions so that a step is one unconditional aligned store per lane), nll[b] in nats (+inf if infeasible).
 // CTC_SPL extended-target positions per lane (1 .. 16: transcripts of up to 511 units), CTC_CH time steps of emissions per LDS chunk
 // (the chunk buffer is 2 x CTC_CH x 64 x CTC_SPL floats: CTC_CH shrinks as CTC_SPL grows to stay inside 64 KB of static LDS)
+//
+// Round 4 took the step from ~2,900 cycles to ~?: (1) DPP shifts instead of shuffles; (2) the normalisation no longer sits on the
+// chain: every fourth step is shifted by the wave maximum of the vector it STARTS from (a DPP reduction beside that step's sums),
+// not every step by its own; (3) t = 0 / t = Tb-1 are the ordinary step applied to a virtual state delta(s = 0) / delta(s = S-1);
+// (4) the chunk gather is prefetched; (5) log2 units, a finite "never", two-term sums at the blanks (even s never skip).
 template <typename T, int CTC_SPL, int CTC_CH = (CTC_SPL <= 4 ? 16 : (CTC_SPL == 8 ? 8 : 4))>
 __global__ __launch_bounds__(128) void ctc_alphabeta_kernel(const T* __restrict__ logits, const float* __restrict__ lse,
                                                             const long long* __restrict__ targets, const long long* __restrict__ tgt_len,
                                                             const int* __restrict__ in_len, float* __restrict__ la,
                                                             float* __restrict__ lb, float* __restrict__ nll, int Tn, int B,
-                                                            int V, int ld, int Lmax, int Smax, int blank) {
-    __shared__ float em[2][CTC_CH][64 * CTC_SPL];
-    __shared__ int ext_s[64 * CTC_SPL];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, dir = threadIdx.x >> 6;
+                                                            int V, int ld, int Lmax, int blank) {
+    constexpr int P = 64 * CTC_SPL;                         // positions of the wave = row stride of la / lb
+    constexpr float L2E = 1.44269504088896f;
+    __shared__ float em[2][CTC_CH][P];
+    __shared__ int ext_s[P];
+    constexpr bool PF = CTC_SPL <= 2;                       // S <= 128: thread = position, one gather per thread and chunk
+    const int b = blockIdx.x, lane = threadIdx.x & 63, dir = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int L = (int)tgt_len[b], S = 2 * L + 1, Tb = min(in_len[b], Tn);
-    for (int s = threadIdx.x; s < 64 * CTC_SPL; s += 128)
+    for (int s = threadIdx.x; s < P; s += 128)
         ext_s[s] = (s < S) ? ((s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : blank) : -1;
     __syncthreads();
     float a[CTC_SPL];
-    bool skip2[CTC_SPL];          // alpha: may come from s-2 ; beta: may go to s+2
-    int es[CTC_SPL];
+    bool skip2[CTC_SPL];          // alpha: may come from s-2 ; beta: may go to s+2 (odd positions only: blanks never skip)
 #pragma unroll
     for (int i = 0; i < CTC_SPL; ++i) {
         const int s = lane * CTC_SPL + i;
-        es[i] = ext_s[s];
-        a[i] = -INFINITY;
-        if (dir == 0) skip2[i] = (s >= 2 && s < S && es[i] != blank && es[i] != ext_s[s - 2]);
-        else skip2[i] = (s + 2 < S && ext_s[s + 2] != blank && ext_s[s + 2] != es[i]);
+        const int e = ext_s[s];
+        // the state "before" the first step: alpha_{-1} = delta(s = 0), beta_{Tb} = delta(s = S-1).  One ordinary step from it gives
+        // alpha_0 = {lp(blank), lp(l_1), never ...} and beta_{Tb-1} likewise (l2ae(0, never[, never]) = 0 exactly).
+        a[i] = (s == (dir == 0 ? 0 : S - 1)) ? 0.f : CTC_NEVER;
+        if (dir == 0) skip2[i] = (s >= 2 && s < S && e != blank && e != ext_s[s - 2]);
+        else skip2[i] = (s + 2 < S && ext_s[s + 2] != blank && ext_s[s + 2] != e);
     }
-    float* out = (dir == 0 ? la : lb) + (long)b * Tn * Smax;
-    // Every step's vector is stored RELATIVE to its own maximum (one wave reduction per step, ~5 % of the step's latency) and the
-    // maxima are summed in double.  In plain log space alpha and beta reach -3,000 over 375 frames x 5,001 units, where one f32 ulp
-    // is 2.4e-4: alpha + beta - log P then carries ~1e-3 of relative error into every posterior (measured against float64: 8e-4 in
-    // |dg|/|g|, torch's own f32 ctc_loss 6e-4).  Relative vectors stay within a few tens of their maximum, and the gradient kernel
-    // normalises alpha + beta - emission per frame, so the offsets never enter the posteriors; only the loss needs their sum.
+    // Every step's vector is stored RELATIVE to a per-step offset and the offsets are summed in double.  In plain log space alpha and
+    // beta reach -3,000 over 375 frames x 5,001 units, where one f32 ulp is 2.4e-4: alpha + beta - log P then carries ~1e-3 of
+    // relative error into every posterior (measured against float64: 8e-4 in |dg|/|g|, torch's own f32 ctc_loss 6e-4).  The offset
+    // of step t is the sum of the wave maxima taken every fourth step before it: the vector's maximum then stays within four steps'
+    // change (each at most +log 3, at least the largest emission) of zero, and the gradient kernel normalises alpha + beta -
+    // emission per frame, so the offsets never enter the posteriors; only the loss needs their sum.
     double offsum = 0.0;
     const int nch = (Tb + CTC_CH - 1) / CTC_CH;
-    for (int ch = 0; ch < nch; ++ch) {
-        // chunk of time steps handled in this iteration: alpha walks forward, beta backward
+    float xv[2 * CTC_CH], lv[2 * CTC_CH];
+    // all 32 gathered loads of a position are issued from clamped (always valid) rows before any is used: guarded loads get sunk
+    // under their bounds test and waited for one by one (seen in the ISA of conv1: one memory latency each)
+    auto fetch = [&](int ch, int s) {
+        const int col = max(ext_s[s], 0);
         const int ta0 = ch * CTC_CH, tb0 = Tb - 1 - ch * CTC_CH;
+#pragma unroll
+        for (int dk = 0; dk < 2 * CTC_CH; ++dk) {
+            const int d = dk / CTC_CH, k = dk % CTC_CH;
+            const int t = min(max(d == 0 ? ta0 + k : tb0 - k, 0), max(Tb - 1, 0));
+            xv[dk] = to_f32(logits[((long)t * B + b) * ld + col]);
+            lv[dk] = lse[(long)t * B + b];
+        }
+    };
+    auto deposit = [&](int ch, int s) {
+        const int ta0 = ch * CTC_CH, tb0 = Tb - 1 - ch * CTC_CH;
+#pragma unroll
+        for (int dk = 0; dk < 2 * CTC_CH; ++dk) {
+            const int d = dk / CTC_CH, k = dk % CTC_CH;
+            const int t = d == 0 ? ta0 + k : tb0 - k;
+            em[d][k][s] = (s < S && t >= 0 && t < Tb) ? (xv[dk] - lv[dk]) * L2E : CTC_NEVER;
+        }
+    };
+    if (PF && nch > 0 && (int)threadIdx.x < P) fetch(0, threadIdx.x);
+    // this wave's output row of the first step and its stride (alpha walks forward, beta backward)
+    float* out = (dir == 0 ? la : lb) + ((long)b * Tn + (dir == 0 ? 0 : max(Tb - 1, 0))) * P + lane * CTC_SPL;
+    const long ostep = dir == 0 ? P : -P;
+    for (int ch = 0; ch < nch; ++ch) {
         __syncthreads();
-        for (int s = threadIdx.x; s < S; s += 128) {          // no index divisions: (direction, step) pairs outside, position = thread
-            const int col = ext_s[s];
-            // all 32 gathered loads of this position are issued from clamped (always valid) rows before any is used: guarded loads
-            // get sunk under their bounds test and waited for one by one (seen in the ISA of conv1: one memory latency each)
-            float xv[2 * CTC_CH], lv[2 * CTC_CH];
+        if (PF) { if ((int)threadIdx.x < P) deposit(ch, threadIdx.x); }
+        else {
+            for (int s = threadIdx.x; s < P; s += 128) {      // no index divisions: (direction, step) pairs outside, position = thread
+                fetch(ch, s);
 #pragma unroll
-            for (int dk = 0; dk < 2 * CTC_CH; ++dk) {
-                const int d = dk / CTC_CH, k = dk % CTC_CH;
-                const int t = min(max(d == 0 ? ta0 + k : tb0 - k, 0), max(Tb - 1, 0));
-                xv[dk] = to_f32(logits[((long)t * B + b) * ld + col]);
-                lv[dk] = lse[(long)t * B + b];
-            }
-#pragma unroll
-            for (int dk = 0; dk < 2 * CTC_CH; ++dk) asm volatile("" : "+v"(xv[dk]), "+v"(lv[dk]));
-#pragma unroll
-            for (int dk = 0; dk < 2 * CTC_CH; ++dk) {
-                const int d = dk / CTC_CH, k = dk % CTC_CH;
-                const int t = d == 0 ? ta0 + k : tb0 - k;
-                em[d][k][s] = (t >= 0 && t < Tb) ? xv[dk] - lv[dk] : -INFINITY;
+                for (int dk = 0; dk < 2 * CTC_CH; ++dk) asm volatile("" : "+v"(xv[dk]), "+v"(lv[dk]));
+                deposit(ch, s);
             }
         }
         __syncthreads();
-        for (int k = 0; k < CTC_CH; ++k) {
-            const int t = dir == 0 ? ta0 + k : tb0 - k;
-            if (t < 0 || t >= Tb) break;
+        if (PF && ch + 1 < nch && (int)threadIdx.x < P) fetch(ch + 1, threadIdx.x);
+        // emissions travel one step ahead of their use (an LDS read issued at the top of a step is ~100 cycles on the chain)
+        float e_next[CTC_SPL];
+#pragma unroll
+        for (int i = 0; i < CTC_SPL; ++i) e_next[i] = em[dir][0][lane * CTC_SPL + i];
+        const int nk = min(CTC_CH, Tb - ch * CTC_CH);
+        for (int k = 0; k < nk; ++k) {
+            float e[CTC_SPL];
+#pragma unroll
+            for (int i = 0; i < CTC_SPL; ++i) e[i] = e_next[i];
+            {
+                const int kn = min(k + 1, CTC_CH - 1);
+#pragma unroll
+                for (int i = 0; i < CTC_SPL; ++i) e_next[i] = em[dir][kn][lane * CTC_SPL + i];
+            }
+            if ((k & 3) == 0) {
+                float loc = a[0];
+#pragma unroll
+                for (int i = 1; i < CTC_SPL; ++i) loc = fmaxf(loc, a[i]);
+                float sh = wave_max_dpp(loc);
+                sh = sh > CTC_NEVER_TEST ? sh : 0.f;                      // (nothing reachable: an infeasible alignment, nothing to shift)
+                offsum += (double)sh;
+#pragma unroll
+                for (int i = 0; i < CTC_SPL; ++i) e[i] -= sh;
+            }
             float n[CTC_SPL];
             if (dir == 0) {
-                // alpha[s-1], alpha[s-2] of the previous lane(s): with one position per lane they sit 1 and 2 lanes back
-                const float p1 = __shfl_up(a[CTC_SPL - 1], 1);
-                const float p2 = CTC_SPL >= 2 ? __shfl_up(a[CTC_SPL >= 2 ? CTC_SPL - 2 : 0], 1) : __shfl_up(a[0], 2);
-                const bool has2 = CTC_SPL >= 2 ? lane > 0 : lane > 1;
+                // alpha[s-1], alpha[s-2] of the previous lane: lanes own whole (blank, unit) pairs when SPL is even, and then only
+                // s-1 of the lane's first position (a blank: no skip) crosses lanes
+                const float p1 = lane_before(a[CTC_SPL - 1]);
+                const float p2 = CTC_SPL >= 2 ? CTC_NEVER : lane_before(p1);
 #pragma unroll
                 for (int i = 0; i < CTC_SPL; ++i) {
-                    const int s = lane * CTC_SPL + i;
-                    float v;
-                    if (t == 0) v = (s <= 1 && s < S) ? 0.f : -INFINITY;
-                    else {
-                        const float m1 = (i >= 1) ? a[i - 1] : (lane > 0 ? p1 : -INFINITY);
-                        const float m2 = (i >= 2) ? a[i - 2] : (i == 1 ? (lane > 0 ? p1 : -INFINITY) : (has2 ? p2 : -INFINITY));
-                        v = lae3(a[i], m1, m2, skip2[i]);
-                    }
-                    n[i] = (s < S) ? v + em[0][k][s] : -INFINITY;
+                    const float m1 = (i >= 1) ? a[i - 1] : p1;
+                    const float m2 = (i >= 2) ? a[i - 2] : (i == 1 ? p1 : p2);
+                    if (CTC_SPL >= 2 && (i & 1) == 0) n[i] = l2ae2(a[i], m1) + e[i];
+                    else n[i] = l2ae3(a[i], m1, skip2[i] ? m2 : CTC_NEVER) + e[i];
                 }
             } else {
-                const float p1 = __shfl_down(a[0], 1);
-                const float p2 = CTC_SPL >= 2 ? __shfl_down(a[CTC_SPL >= 2 ? 1 : 0], 1) : __shfl_down(a[0], 2);
-                const bool has2 = CTC_SPL >= 2 ? lane < 63 : lane < 62;
+                // beta[s+1], beta[s+2] of the next lane: its first position is a blank (s+1 of this lane's last, a unit) and its
+                // second a unit (s+2 of it: the skip)
+                const float p1 = lane_after(a[0]);
+                const float p2 = CTC_SPL >= 2 ? lane_after(a[CTC_SPL >= 2 ? 1 : 0]) : lane_after(p1);
 #pragma unroll
                 for (int i = 0; i < CTC_SPL; ++i) {
-                    const int s = lane * CTC_SPL + i;
-                    float v;
-                    if (t == Tb - 1) v = (s < S && s >= S - 2) ? 0.f : -INFINITY;
-                    else {
-                        const float m1 = (i + 1 < CTC_SPL) ? a[i + 1] : (lane < 63 ? p1 : -INFINITY);
-                        const float m2 = (i + 2 < CTC_SPL) ? a[i + 2] : (i + 2 == CTC_SPL ? (lane < 63 ? p1 : -INFINITY) : (has2 ? p2 : -INFINITY));
-                        v = lae3(a[i], m1, m2, skip2[i]);
-                    }
-                    n[i] = (s < S) ? v + em[1][k][s] : -INFINITY;
+                    const float m1 = (i + 1 < CTC_SPL) ? a[i + 1] : p1;
+                    const float m2 = (i + 2 < CTC_SPL) ? a[i + 2] : (i + 2 == CTC_SPL ? p1 : p2);
+                    if (CTC_SPL >= 2 && (i & 1) == 0) n[i] = l2ae2(a[i], m1) + e[i];
+                    else n[i] = l2ae3(a[i], m1, skip2[i] ? m2 : CTC_NEVER) + e[i];
                 }
             }
-            float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < CTC_SPL; ++i) mx = fmaxf(mx, n[i]);
+            for (int i = 0; i < CTC_SPL; ++i) a[i] = n[i];
+            if constexpr (CTC_SPL == 1) out[0] = a[0];
+            else if constexpr (CTC_SPL == 2) *reinterpret_cast<float2*>(out) = float2{a[0], a[1]};
+            else {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            if (mx > -INFINITY) offsum += (double)mx; else mx = 0.f;      // (all -inf: an infeasible alignment, nothing to shift)
-#pragma unroll
-            for (int i = 0; i < CTC_SPL; ++i) {
-                a[i] = n[i] - mx;                                         // -inf stays -inf
-                const int s = lane * CTC_SPL + i;
-                if (s < S) out[(long)t * Smax + s] = a[i];
+                for (int i = 0; i < CTC_SPL; i += 4) *reinterpret_cast<float4*>(out + i) = float4{a[i], a[i + 1], a[i + 2], a[i + 3]};
             }
+            out += ostep;
         }
     }
     if (dir == 0) {
         // log-likelihood = logaddexp(alpha[Tb-1][S-1], alpha[Tb-1][S-2])
-        float v = -INFINITY;
+        float v = CTC_NEVER;
 #pragma unroll
         for (int i = 0; i < CTC_SPL; ++i) {
             const int s = lane * CTC_SPL + i;
-            if (s < S && s >= S - 2) v = lae(v, a[i]);
+            if (s < S && s >= S - 2) v = l2ae2(v, a[i]);
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = lae(v, __shfl_xor(v, o));
-        if (lane == 0) nll[b] = (Tb > 0 && v > -INFINITY) ? (float)-((double)v + offsum) : INFINITY;
+        for (int o = 32; o > 0; o >>= 1) v = l2ae2(v, __shfl_xor(v, o));
+        if (lane == 0) nll[b] = (Tb > 0 && v > CTC_NEVER_TEST) ? (float)(-((double)v + offsum) * 0.693147180559945309) : INFINITY;
     }
 }
 
 // Pass 3: gradient w.r.t. the logits, one workgroup per (t,b) row:
-//   g[c] = softmax[c] - sum_{s: ext[s]=c} post[s],   post[s] = exp(la + lb - lp[ext s]) / sum_s' exp(la + lb - lp[ext s'])
+//   g[c] = softmax[c] - sum_{s: ext[s]=c} post[s],   post[s] = 2^(la + lb - lp2[ext s]) / sum_s' 2^(la + lb - lp2[ext s'])   (log2 units)
 // for t < in_len[b] and finite nll, else 0.  (sum_s alpha_t(s) beta_t(s) / y_t(ext s) = P for every t: normalising per frame is
 // the same posterior as exp(la + lb - lp + nll) and is indifferent to the per-step offsets the recursion subtracts.)
 // Also the summed loss (atomic add of the finite nll's, done by the t = 0 rows).
@@ -444,7 +497,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
                                                        const int* __restrict__ in_len, const float* __restrict__ la,
                                                        const float* __restrict__ lb, const float* __restrict__ nll,
                                                        T* __restrict__ grad, float* __restrict__ loss_sum, int Tn, int B,
-                                                       int V, int ld, int Lmax, int Smax, int blank, float gscale,
+                                                       int V, int ld, int Lmax, int Srow, int blank, float gscale,
                                                        const float* __restrict__ gscale_dev) {
     extern __shared__ float occ[];                      // [V]
     if (gscale_dev) gscale *= gscale_dev[0];            // upstream gradient of the loss (a device scalar produced by autograd)
@@ -470,8 +523,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
         wv[k] = -INFINITY; wc[k] = 0;
         if (s < S) {
             wc[k] = (s & 1) ? (int)targets[(long)b * Lmax + (s >> 1)] : blank;
-            const float lab = la[((long)b * Tn + t) * Smax + s] + lb[((long)b * Tn + t) * Smax + s];
-            if (lab > -INFINITY) wv[k] = lab - (to_f32(x[wc[k]]) - ls);
+            const float lab = la[((long)b * Tn + t) * Srow + s] + lb[((long)b * Tn + t) * Srow + s];      // log2 units
+            if (lab > CTC_NEVER_TEST) wv[k] = lab - (to_f32(x[wc[k]]) - ls) * 1.44269504088896f;
         }
         mx = fmaxf(mx, wv[k]);
     }
@@ -481,7 +534,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const T* __restrict__ log
     mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
     float ev[4], sm = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { ev[k] = wv[k] > -INFINITY ? expf(wv[k] - mx) : 0.f; sm += ev[k]; }
+    for (int k = 0; k < 4; ++k) { ev[k] = wv[k] > -INFINITY ? __builtin_amdgcn_exp2f(wv[k] - mx) : 0.f; sm += ev[k]; }
     sm = wave_sum(sm);
     if ((threadIdx.x & 63) == 0) reds[threadIdx.x >> 6] = sm;
     __syncthreads();
@@ -568,7 +621,7 @@ extern "C" int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w,
 // Fused log-softmax + CTC loss (sum, zero_infinity) + gradient w.r.t. the logits.
 //   logits / grad rows have stride ld >= V elements (pad ld to a multiple of 8 so GEMMs can vector-load them)
 //   logits [T][B][V]; targets [B][Lmax] int64 (first tgt_len[b] entries); in_len [B] int32
-//   workspaces: lse [T*B] f32, la/lb [B*T*Smax] f32 with Smax = 2*Lmax+1, nll [B] f32
+//   workspaces: lse [T*B] f32, la/lb [B*T*S2T_CTC_ROW(Lmax)] f32 (rows padded to the recursion wave's positions), nll [B] f32
 //   outputs: grad [T][B][V] (dtype), loss_sum[0] += sum of finite nll  (caller zeroes it)
 // forward-only calls: loss_sum[0] += sum of the finite nll's (the gradient pass does it when both run in one call)
 __global__ void ctc_loss_sum_kernel(const float* __restrict__ nll, int B, float* __restrict__ loss_sum) {
@@ -600,29 +653,29 @@ extern "C" int s2t_ctc_loss(int dtype, const void* logits, const long long* targ
     if (dtype == S2T_BF16) {
         if (fwd) {
         if (!lse_given) hipLaunchKernelGGL(row_lse_kernel<bf16>, g1, dim3(256), 0, st, (const bf16*)logits, lse, rows, V, ld);
-        if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 1>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 2>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else if (spl == 4) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 4>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else if (spl == 8) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 8>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 16>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 1>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 2>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else if (spl == 4) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 4>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else if (spl == 8) hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 8>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else hipLaunchKernelGGL((ctc_alphabeta_kernel<bf16, 16>), dim3(B), dim3(128), 0, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
         if (phase == 1) hipLaunchKernelGGL(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, st, nll, B, loss_sum);
         }
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
-        if (bwd) hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, lsum_grad, T, B, V, ld, Lmax, Smax, blank, grad_scale, grad_scale_dev);
+        if (bwd) hipLaunchKernelGGL(ctc_grad_kernel<bf16>, g3, dim3(256), lds, st, (const bf16*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (bf16*)grad, lsum_grad, T, B, V, ld, Lmax, 64 * spl, blank, grad_scale, grad_scale_dev);
     } else if (dtype == S2T_F32) {
         if (fwd) {
         if (!lse_given) hipLaunchKernelGGL(row_lse_kernel<float>, g1, dim3(256), 0, st, (const float*)logits, lse, rows, V, ld);
-        if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 1>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 2>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else if (spl == 4) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 4>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else if (spl == 8) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 8>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
-        else hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 16>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, Smax, blank);
+        if (spl == 1) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 1>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else if (spl == 2) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 2>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else if (spl == 4) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 4>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else if (spl == 8) hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 8>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
+        else hipLaunchKernelGGL((ctc_alphabeta_kernel<float, 16>), dim3(B), dim3(128), 0, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, T, B, V, ld, Lmax, blank);
         if (phase == 1) hipLaunchKernelGGL(ctc_loss_sum_kernel, dim3(1), dim3(64), 0, st, nll, B, loss_sum);
         }
         static bool attr = false;
         if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_grad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); attr = true; }
-        if (bwd) hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, lsum_grad, T, B, V, ld, Lmax, Smax, blank, grad_scale, grad_scale_dev);
+        if (bwd) hipLaunchKernelGGL(ctc_grad_kernel<float>, g3, dim3(256), lds, st, (const float*)logits, lse, targets, tgt_len, in_len, la, lb, nll, (float*)grad, lsum_grad, T, B, V, ld, Lmax, 64 * spl, blank, grad_scale, grad_scale_dev);
     } else return S2T_ENOTSUP;
     S2T_LAUNCH_CHECK();
     return S2T_OK;

@@ -395,7 +395,7 @@ def ctc_loss(logits, targets, tgt_len, in_len32, blank, grad_scale=1.0, defer_gr
                             "(S2T_CTC_MAX_TARGET / S2T_CTC_MAX_VOCAB, include/s2t_hip.h); this batch has %d / %d: filter the data "
                             "with --max-target-positions or shorten the transcripts" % (CTC_MAX_TARGET, CTC_MAX_VOCAB, Lmax, V))
     dev = logits.device
-    S = 2 * Lmax + 1
+    S = next(r for r in (64, 128, 256, 512, 1024) if 2 * Lmax + 1 <= r)      # S2T_CTC_ROW(Lmax), include/s2t_hip.h
     lse_given = lse is not None                     # row log-sum-exps of THESE logits from ctc_argmax(want_lse=True)
     if lse is None:
         lse = torch.empty((T * B,), dtype=torch.float32, device=dev)

@@ -260,7 +260,8 @@ int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int*
 
 /* ---- losses ------------------------------------------------------------------------------------
  * F.log_softmax + F.ctc_loss(reduction="sum", zero_infinity=True) (CTC_loss.py:143-151) and its gradient
- * w.r.t. the logits [T][B][V].  Workspaces: lse [T*B], la/lb [B*T*(2*Lmax+1)], nll [B] (all f32).
+ * w.r.t. the logits [T][B][V].  Workspaces: lse [T*B], la/lb [B*T*S2T_CTC_ROW(Lmax)], nll [B] (all f32; la/lb rows are padded
+ * to the positions of the recursion's wave and hold log2 values shifted per frame: private to the two passes).
  * loss_sum[0] += sum_b nll_b (caller zeroes). grad is multiplied by grad_scale and, if given, by the device scalar
  * grad_scale_dev[0] (the upstream gradient autograd hands to backward).  phase 0: loss and gradient in one call;
  * phase 1: loss only (workspaces kept by the caller); phase 2: the gradient from the workspaces of a phase-1 call;
@@ -270,6 +271,8 @@ int s2t_ctc_compress_bwd(int dtype, const void* dout, const float* w, const int*
  * (criterions.py) refuses the batch with the limit in the message. */
 #define S2T_CTC_MAX_TARGET 511
 #define S2T_CTC_MAX_VOCAB 40704
+/* row stride of the la / lb workspaces: the 2*Lmax+1 extended-target positions rounded up to 64 x {1, 2, 4, 8, 16} */
+#define S2T_CTC_ROW(Lmax) (2 * (Lmax) + 1 <= 64 ? 64 : 2 * (Lmax) + 1 <= 128 ? 128 : 2 * (Lmax) + 1 <= 256 ? 256 : 2 * (Lmax) + 1 <= 512 ? 512 : 1024)
 int s2t_ctc_loss(int dtype, const void* logits, const long long* targets, const long long* tgt_len, const int* in_len,
                  float* lse, float* la, float* lb, float* nll, void* grad, float* loss_sum,
                  int T, int B, int V, int ld, int Lmax, int blank, float grad_scale, int phase, const float* grad_scale_dev,
