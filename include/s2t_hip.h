@@ -372,6 +372,9 @@ int s2t_prof_enable(int on);
  *       "attn_v2_min_tq": shortest query block taken by the second-generation attention kernels (default 16);
  *       "gemm256_min_tiles": fewest 192 / 256-row output tiles a product must have for the 256-wide kernel (0 = default = 160;
  *                  tools/gemm_gate_probe.py measures both sides of it);
+ *       "gemm256_sched": 1 selects gemm256's second K-loop schedule (diagnostic twins only: -95 in the product library);
+ *       "gemm4w": 1 sends gemm256's NT products to the four-wave partition of the same tile (gemm4w.hip: an experiment,
+ *                  bit-identical results, default 0);
  * returns the previous value, or S2T_EINVAL (-22) for an unknown key. */
 int s2t_set_option(const char* key, int value);
 int s2t_prof_read(const char* family, double* ms, long long* launches, double* flops, double* bytes);

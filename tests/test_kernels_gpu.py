@@ -721,6 +721,35 @@ def test_gemm256_epilogues_against_the_128_wide_route_and_themselves(M, N, K_):
         K.set_option("gemm256", old)
 
 
+@pytest.mark.parametrize("M,N,K_", [(24000, 512, 2048), (6211, 1536, 512), (23000, 640, 1280)])
+def test_gemm4w_experiment_equals_gemm256_bit_for_bit(M, N, K_):
+    """gemm4w.hip (the same 256 x 256 x 64 tile as four waves of 128 x 128: an experiment behind s2t_set_option("gemm4w"), off by default,
+    profiles/r04_gemm4w.txt) runs the same MFMA instruction over K in the same order and the same epilogue arithmetic as gemm256: its
+    NT variants must reproduce gemm256's output bit for bit, launch after launch."""
+    dt = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(M + N + K_)
+    a = torch.randn(M, K_, device=DEV, generator=g).to(dt); w = (torch.randn(N, K_, device=DEV, generator=g) * K_ ** -0.5).to(dt)
+    b = torch.randn(N, device=DEV, generator=g); r = torch.randn(M, N, device=DEV, generator=g).to(dt)
+    pre = torch.empty(M, N, device=DEV, dtype=dt)
+
+    def gelu(s):
+        y = K.gemm(a, w, bias=b, act=K.ACT_GELU, aux_out=pre, p_drop=0.1, seed=4)
+        return torch.cat([y.reshape(-1), pre.reshape(-1)])
+    calls = [lambda s: K.gemm(a, w, bias=b), lambda s: K.gemm(a, w, bias=b, p_drop=0.25, seed=9 + s),
+             lambda s: K.gemm(a, w, bias=b, residual=r, p_drop=0.1, seed=3), lambda s: K.gemm(a, w, bias=b, act=K.ACT_RELU, p_drop=0.1, seed=5), gelu]
+    old = K.set_option("gemm4w", 0)
+    try:
+        want = [[fn(rep) for fn in calls] for rep in range(2)]
+        K.set_option("gemm4w", 1)
+        for rep in range(4):
+            for i, fn in enumerate(calls):
+                got = fn(rep % 2)
+                assert torch.equal(got, want[rep % 2][i]), "variant %d, launch %d: %d of %d values differ from gemm256" % (
+                    i, rep, int((got != want[rep % 2][i]).sum()), got.numel())
+    finally:
+        K.set_option("gemm4w", old)
+
+
 def test_gemm256_store_data_hazard_twins():
     """Round 3 left "wrong values when the two wave groups' epilogues overlap" unexplained; this is its reproducer.  `make twins` builds
     gemm256 with a second K-loop schedule in which all eight waves -- both waves of every SIMD -- run their epilogues at the same

@@ -1,0 +1,194 @@
+// Probe (not product code): the 256 x 256 x 64 tile of gemm256 partitioned as FOUR waves of 128 x 128 (one per SIMD, 256 accumulator
+// registers each) instead of eight of 128 x 64 -- does the main loop get closer to the MFMA rate when every fragment read from LDS
+// feeds eight MFMAs instead of four and no second wave competes for the SIMD's issue slot?  NT form, bf16, plain stores.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I fbk_fairseq_st_amd/csrc -I include -o tools/_bin/gemm4w_probe tools/gemm4w_probe.hip
+//   tools/_bin/gemm4w_probe [M N K reps]
+// LDS: two K-tile buffers of 64 KiB = A-h0 | A-h1 | B-h0 | B-h1, a half = 128 rows x 128 B (64 k), chunks XOR-swizzled with row & 7 on
+// the DMA's source side; wave (wr, wc) reads A-h[wr] and B-h[wc].  Per K-tile and wave: 128 MFMAs in two k-halves of 64 (8 x 8
+// tiles), 32 ds_read_b128, 16 LDS-DMA instructions, ONE barrier:
+//     P0  MFMA k-half 0 | reads k-half 1 of this K-tile                       ; wait reads + DMA(t+1) ; barrier
+//     P1  MFMA k-half 1 | DMA K-tile t+2 into this buffer ; reads k-half 0 of K-tile t+1 from the other buffer
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include "common.hpp"
+
+typedef __attribute__((address_space(3))) void lds_void;
+#ifndef X_MASK
+#define X_MASK 0        // bit 0: no barriers, bit 1: no DMA in the loop, bit 2: no fragment reads in the loop (timing only, wrong results)
+#endif
+
+constexpr int HALF = 16384, BUFB = 65536, BK = 64;
+
+__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C,
+                                                        int M, int N, int K, int lda, int ldb, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = N / 256;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (tile / tiles_n) * 256, col0 = (tile % tiles_n) * 256;
+    const int nk = K / BK;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1, r16 = lane & 15, q = lane >> 4;
+
+    // staging: wave w fills pieces 4w .. 4w+3 (1 KiB = 8 rows) of each of the four halves
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, (int)((size_t)M * lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B), 0, (int)((size_t)N * ldb * 2), 0x00020000);
+    const int prow = lane >> 3, pos = lane & 7;
+    uint32_t voA[2], voB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        voA[h] = (uint32_t)(((size_t)(row0 + 128 * h + 32 * wave + prow) * lda + ((pos ^ prow) << 3)) * 2);
+        voB[h] = (uint32_t)(((size_t)(col0 + 128 * h + 32 * wave + prow) * ldb + ((pos ^ prow) << 3)) * 2);
+    }
+    const uint32_t pstepA = 8u * lda * 2u, pstepB = 8u * ldb * 2u;
+    auto stage = [&](int t, int which) {      // which: 0..15 = (half-kind, piece); one DMA instruction
+        char* base = smem + (t & 1) * BUFB + wave * 4096;
+        const uint32_t ko = (uint32_t)t * (BK * 2);
+        const int kind = which >> 2, i = which & 3;           // kind 0 A-h0, 1 A-h1, 2 B-h0, 3 B-h1
+        char* dst = base + kind * HALF + i * 1024;
+        if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)dst, 16, voA[kind], ko + i * pstepA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)dst, 16, voB[kind - 2], ko + i * pstepB, 0, 0);
+    };
+
+    f32x4 acc[8][8];
+    u32x4 fa[2][8], fb[2][8];                    // [k-half set][tile]
+    const int fr_off = r16 * 128;
+    const int swz[2] = {((0 + q) ^ (r16 & 7)) << 4, ((4 + q) ^ (r16 & 7)) << 4};
+    auto readA = [&](int t, int s, int i) {
+        fa[s][i] = *reinterpret_cast<const u32x4*>(smem + (t & 1) * BUFB + wr * HALF + i * 2048 + fr_off + swz[s]);
+    };
+    auto readB = [&](int t, int s, int j) {
+        fb[s][j] = *reinterpret_cast<const u32x4*>(smem + (t & 1) * BUFB + 2 * HALF + wc * HALF + j * 2048 + fr_off + swz[s]);
+    };
+#define BAR() do { __builtin_amdgcn_sched_barrier(0); if (!(X_MASK & 1)) __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+    // prologue
+#pragma unroll
+    for (int w = 0; w < 16; ++w) stage(0, w);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) stage(1, w);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { readA(0, 0, i); readB(0, 0, i); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+
+    auto ktile = [&](int t, auto first_tag, auto last_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // ---- P0: k-half 0 (set 0) | reads of k-half 1 into set 1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!(X_MASK & 4)) { readA(t, 1, i); readB(t, 1, i); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i][j] = mma16<bf16>(fb[0][j], fa[0][i], FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 DS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0), in the form hipcc's counter model sees
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // K-tile t+1 (issued in P1 of K-tile t-1) has landed
+        BAR();
+        // ---- P1: k-half 1 (set 1) | DMA of K-tile t+2 into this buffer, reads of K-tile t+1's k-half 0 into set 0
+        // past the last K-tile the DMA re-stages K-tile nk-1 into the buffer just read and the reads take the other buffer as it is:
+        // in bounds, never used (a persistent version stages the next tile's first K-tiles there) -- P1 stays one basic block
+        const int t2 = min(t + 2, nk - 1);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {                               // source order = the order asked of the scheduler: DMA, read, 4 MFMAs
+            const int i = g >> 1, j0 = 4 * (g & 1);
+            if (!(X_MASK & 2)) {
+                char* base = smem + (t & 1) * BUFB + wave * 4096;
+                const uint32_t ko = (uint32_t)t2 * (BK * 2);
+                const int kind = g >> 2, pi = g & 3;
+                char* dst = base + kind * HALF + pi * 1024;
+                if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)dst, 16, voA[kind], ko + pi * pstepA, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)dst, 16, voB[kind - 2], ko + pi * pstepB, 0, 0);
+            }
+            if (!(X_MASK & 4)) { if (g & 1) readB(t + 1, 0, i); else readA(t + 1, 0, i); }
+#pragma unroll
+            for (int j = j0; j < j0 + 4; ++j) acc[i][j] = mma16<bf16>(fb[1][j], fa[1][i], acc[i][j]);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // 1 VMEM read (the DMA)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // 1 DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);       // 4 MFMA
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    };
+    ktile(0, std::true_type{}, std::false_type{});
+    for (int t = 1; t < nk; ++t) ktile(t, std::false_type{}, std::false_type{});
+
+    // plain epilogue: lane holds C[row0 + 128 wr + 16 i + r16][col0 + 128 wc + 16 j + 4 q .. + 3]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bf16 o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = from_f32<bf16>(acc[i][j][e]);
+            *reinterpret_cast<u32x2*>(C + (size_t)(row0 + 128 * wr + 16 * i + r16) * ldc + col0 + 128 * wc + 16 * j + 4 * q) = *reinterpret_cast<const u32x2*>(o);
+        }
+}
+
+__global__ void ref_kernel(const bf16* A, const bf16* B, float* R, int N, int K, int lda, int ldb, const int* rows, int nrows) {
+    const int r = rows[blockIdx.x];
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += to_f32(A[(size_t)r * lda + k]) * to_f32(B[(size_t)n * ldb + k]);
+        R[(size_t)blockIdx.x * N + n] = s;
+    }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 24064, N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 2048;
+    const int reps = argc > 4 ? atoi(argv[4]) : 20;
+    if (M % 256 || N % 256 || K % 64 || K < 128) { printf("M, N multiples of 256, K of 64\n"); return 1; }
+    std::vector<uint16_t> ha((size_t)M * K), hb((size_t)N * K);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; const float f = ((s >> 8) & 0xffff) / 65536.f - 0.5f; uint32_t u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); };
+    for (auto& v : ha) v = rnd();
+    for (auto& v : hb) v = rnd();
+    bf16 *A, *B, *C; float* R; int* rows;
+    CK(hipMalloc(&A, ha.size() * 2)); CK(hipMalloc(&B, hb.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 2));
+    CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(C, 0, (size_t)M * N * 2));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUFB));
+    const int tiles = (M / 256) * (N / 256);
+    hipLaunchKernelGGL(gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
+    CK(hipDeviceSynchronize());
+    // check 64 rows spread over the tiles
+    const int nr = 64; std::vector<int> hr(nr);
+    for (int i = 0; i < nr; ++i) hr[i] = (int)(((long)i * 7919 * 131) % M);
+    CK(hipMalloc(&rows, nr * 4)); CK(hipMalloc(&R, (size_t)nr * N * 4));
+    CK(hipMemcpy(rows, hr.data(), nr * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_kernel, dim3(nr), dim3(256), 0, 0, A, B, R, N, K, K, K, rows, nr);
+    std::vector<float> href((size_t)nr * N); std::vector<uint16_t> hc((size_t)M * N);
+    CK(hipMemcpy(href.data(), R, href.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost));
+    double worst = 0, scale = 0;
+    for (int i = 0; i < nr; ++i)
+        for (int n = 0; n < N; ++n) {
+            uint32_t u = (uint32_t)hc[(size_t)hr[i] * N + n] << 16; float c; memcpy(&c, &u, 4);
+            worst = fmax(worst, fabs(c - href[(size_t)i * N + n])); scale = fmax(scale, fabs(href[(size_t)i * N + n]));
+        }
+    printf("check: worst |C - ref| = %.4g on values up to %.4g (%s)\n", worst, scale, worst <= scale * 0.01 + 1e-3 ? "ok" : (X_MASK ? "expected: X_MASK" : "WRONG"));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / us * 1e-6;
+    printf("gemm4w X=%d  %d x %d x %d: %.1f us  %.0f TFLOP/s  (%d tiles; per tile at that duration: %.0f%% of one CU's MFMA peak)\n", X_MASK, M, N, K, us, tf, tiles,
+           100.0 * (2.0 * 256 * 256 * K / (us * 1e-6)) / (2.5e15 / 256));
+    return 0;
+}
