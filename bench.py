@@ -398,6 +398,10 @@ def main():
             flop_per_frame = 3.0 * fwd / args.frames
             roof["encoder_flop_per_frame_fwd_bwd"] = round(flop_per_frame / 1e6, 2)
             roof["encoder_mfma_util"] = round(frames_done / dt * flop_per_frame / (PEAK_BF16_TFLOPS * 1e12), 4)
+            # what a loop of nothing but v_mfma_f32_16x16x32_bf16 sustains on all 256 CUs of this pool's boxes (tools/gemm4w_probe.hip with
+            # X_MASK=7, 16384 x 1024 x 8192: profiles/r04_gemm4w.txt) -- not re-measured by this run; `peak` stays the guide's dense figure
+            roof["mfma_only_ceiling_tflops"] = 1620.0
+            roof["frac_of_mfma_only_ceiling"] = round(roof["achieved"] / 1620.0, 4) if roof.get("unit") == "TFLOP/s" else None
             out["roofline"] = roof
         if args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, a, ref_sd, task)
