@@ -138,6 +138,180 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__
         }
 }
 
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- the same tile, LDS image, DMA and barrier structure with v_mfma_f32_32x32x16_bf16: 4 x 4 tiles of 32 x 32 per wave, four k-steps of
+// 16 per K-tile (16 MFMAs each), the fragments of the next k-step in flight under the MFMAs of the current one.
+//     steps 0-2  MFMA k-step s | reads k-step s+1 of this K-tile          ; after step 2: own reads returned, own DMA(t+1) landed ; barrier
+//     step 3     MFMA k-step 3 | DMA K-tile t+2 into this buffer ; reads k-step 0 of K-tile t+1 from the other buffer
+__global__ __launch_bounds__(256, 1) void gemm4w32_kernel(const bf16* __restrict__ A, const bf16* __restrict__ B, bf16* __restrict__ C,
+                                                          int M, int N, int K, int lda, int ldb, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = N / 256;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int row0 = (tile / tiles_n) * 256, col0 = (tile % tiles_n) * 256;
+    const int nk = K / BK;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1, r32 = lane & 31, hi = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, (int)((size_t)M * lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B), 0, (int)((size_t)N * ldb * 2), 0x00020000);
+    const int prow = lane >> 3, pos = lane & 7;
+    uint32_t voA[2], voB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        voA[h] = (uint32_t)(((size_t)(row0 + 128 * h + 32 * wave + prow) * lda + ((pos ^ prow) << 3)) * 2);
+        voB[h] = (uint32_t)(((size_t)(col0 + 128 * h + 32 * wave + prow) * ldb + ((pos ^ prow) << 3)) * 2);
+    }
+    const uint32_t pstepA = 8u * lda * 2u, pstepB = 8u * ldb * 2u;
+    auto stage = [&](int t, int which) {
+        char* base = smem + (t & 1) * BUFB + wave * 4096;
+        const uint32_t ko = (uint32_t)t * (BK * 2);
+        const int kind = which >> 2, i = which & 3;
+        char* dst = base + kind * HALF + i * 1024;
+        if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)dst, 16, voA[kind], ko + i * pstepA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)dst, 16, voB[kind - 2], ko + i * pstepB, 0, 0);
+    };
+    f32x16 acc[4][4];
+    u32x4 fa[2][4], fb[2][4];                    // [set][tile]: k-step s uses set s & 1
+    const int fr_off = r32 * 128;
+    int swz[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) swz[s] = ((2 * s + hi) ^ (r32 & 7)) << 4;
+    auto readA = [&](int t, int s, int i) { fa[s & 1][i] = *reinterpret_cast<const u32x4*>(smem + (t & 1) * BUFB + wr * HALF + i * 4096 + fr_off + swz[s]); };
+    auto readB = [&](int t, int s, int j) { fb[s & 1][j] = *reinterpret_cast<const u32x4*>(smem + (t & 1) * BUFB + 2 * HALF + wc * HALF + j * 4096 + fr_off + swz[s]); };
+#pragma unroll
+    for (int w = 0; w < 16; ++w) stage(0, w);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) stage(1, w);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { readA(0, 0, i); readB(0, 0, i); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int t = 0; t < nk; ++t) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {                                // group g: one read, two MFMAs
+                if (!(X_MASK & 4)) { if (g & 1) readB(t, s + 1, g >> 1); else readA(t, s + 1, g >> 1); }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int i = g >> 1, j = 2 * (g & 1) + m;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[s & 1][j]), __builtin_bit_cast(bf16x8, fa[s & 1][i]), acc[i][j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BAR();
+        const int t2 = min(t + 2, nk - 1);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                                    // step 3: two DMAs, one read, two MFMAs per group
+            if (!(X_MASK & 2)) {
+                char* base = smem + (t & 1) * BUFB + wave * 4096;
+                const uint32_t ko = (uint32_t)t2 * (BK * 2);
+#pragma unroll
+                for (int w = 2 * g; w < 2 * g + 2; ++w) {
+                    const int kind = w >> 2, pi = w & 3;
+                    char* dst = base + kind * HALF + pi * 1024;
+                    if (kind < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void*)dst, 16, voA[kind], ko + pi * pstepA, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)dst, 16, voB[kind - 2], ko + pi * pstepB, 0, 0);
+                }
+            }
+            if (!(X_MASK & 4)) { if (g & 1) readB(t + 1, 0, g >> 1); else readA(t + 1, 0, g >> 1); }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int i = g >> 1, j = 2 * (g & 1) + m;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[1][j]), __builtin_bit_cast(bf16x8, fa[1][i]), acc[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    // lane holds, for tile (i, j): output row 32 i + r32, columns 32 j + 8 g + 4 hi + 0..3 (g = 0..3) as acc[i][j][4 g + 0..3]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16 o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = from_f32<bf16>(acc[i][j][4 * g + e]);
+                *reinterpret_cast<u32x2*>(C + (size_t)(row0 + 128 * wr + 32 * i + r32) * ldc + col0 + 128 * wc + 32 * j + 8 * g + 4 * hi) = *reinterpret_cast<const u32x2*>(o);
+            }
+}
+
+// MFMA-only loops of the two bf16 shapes with the same flops per wave and K-tile (128 x 128 x 64): which one does the chip clock higher?
+template <int SHAPE>
+__global__ __launch_bounds__(256, 1) void mfma_only_kernel(float* out, int nk) {
+    const int lane = threadIdx.x & 63;
+    u32x4 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = u32x4{0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + i}; b[i] = u32x4{0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u + i, 0x3f803f80u}; }
+    float sum = 0.f;
+    if constexpr (SHAPE == 16) {
+        f32x4 acc[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nk; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[i][j] = mma16<bf16>(b[j], a[i], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][3];
+    } else {
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int t = 0; t < nk; ++t) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b[j + 4 * (s & 1)]), __builtin_bit_cast(bf16x8, a[i + 4 * (s >> 1)]), acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][15];
+    }
+    if (sum == 123.456f) out[threadIdx.x] = sum;
+}
+
 __global__ void ref_kernel(const bf16* A, const bf16* B, float* R, int N, int K, int lda, int ldb, const int* rows, int nrows) {
     const int r = rows[blockIdx.x];
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -163,8 +337,10 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemset(C, 0, (size_t)M * N * 2));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUFB));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUFB));
+    const bool k32 = getenv("SHAPE32") != nullptr;
     const int tiles = (M / 256) * (N / 256);
-    hipLaunchKernelGGL(gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
+    hipLaunchKernelGGL(k32 ? gemm4w32_kernel : gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
     CK(hipDeviceSynchronize());
     // check 64 rows spread over the tiles
     const int nr = 64; std::vector<int> hr(nr);
@@ -182,13 +358,30 @@ int main(int argc, char** argv) {
         }
     printf("check: worst |C - ref| = %.4g on values up to %.4g (%s)\n", worst, scale, worst <= scale * 0.01 + 1e-3 ? "ok" : (X_MASK ? "expected: X_MASK" : "WRONG"));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k32 ? gemm4w32_kernel : gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k32 ? gemm4w32_kernel : gemm4w_kernel, dim3(tiles), dim3(256), 2 * BUFB, 0, A, B, C, M, N, K, K, K, N);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / us * 1e-6;
-    printf("gemm4w X=%d  %d x %d x %d: %.1f us  %.0f TFLOP/s  (%d tiles; per tile at that duration: %.0f%% of one CU's MFMA peak)\n", X_MASK, M, N, K, us, tf, tiles,
+    printf("gemm4w %s X=%d  %d x %d x %d: %.1f us  %.0f TFLOP/s  (%d tiles; per tile at that duration: %.0f%% of one CU's MFMA peak)\n", k32 ? "32x32x16" : "16x16x32", X_MASK, M, N, K, us, tf, tiles,
            100.0 * (2.0 * 256 * 256 * K / (us * 1e-6)) / (2.5e15 / 256));
+    {   // MFMA-only shape comparison: 256 workgroups x 4 waves, nk K-tiles of 128 x 128 x 64 per wave
+        const int nkk = K / 64 * ((M / 256) * (N / 256) + 255) / 256;          // the K-tiles one CU would run for this product
+        float* dummy; CK(hipMalloc(&dummy, 4096));
+        for (int shape = 16; shape <= 32; shape += 16) {
+            auto launch = [&]() {
+                if (shape == 16) hipLaunchKernelGGL(mfma_only_kernel<16>, dim3(256), dim3(256), 0, 0, dummy, nkk);
+                else hipLaunchKernelGGL(mfma_only_kernel<32>, dim3(256), dim3(256), 0, 0, dummy, nkk);
+            };
+            for (int i = 0; i < 3; ++i) launch();
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) launch();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us2 = ms * 1e3 / reps, tf2 = 2.0 * 256 * 256 * 64 * (double)nkk * 256 / us2 * 1e-6;
+            printf("MFMA only, %s, 256 CUs x %d K-tiles: %.1f us  %.0f TFLOP/s = %.3f of 2,500\n", shape == 16 ? "16x16x32" : "32x32x16", nkk, us2, tf2, tf2 / 2500.0);
+        }
+    }
     return 0;
 }
