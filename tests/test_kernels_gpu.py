@@ -472,6 +472,33 @@ def test_ctc_loss(dtype):
     assert abs(float(loss3) - float(loss)) <= 1e-6 * abs(float(loss)) and torch.equal(grad3, grad)
 
 
+@pytest.mark.parametrize("Lm,T", [(20, 70), (40, 130), (100, 330), (200, 520), (400, 900), (511, 1100)])
+def test_ctc_loss_transcript_lengths_of_every_lane_width(Lm, T):
+    """The alpha / beta recursion keeps 1, 2, 4, 8 or 16 extended-target positions per lane (transcripts of up to 31 / 63 / 127 / 255 /
+    511 units): every width against torch's float64 F.ctc_loss (the reference's call, CTC_loss.py:143-151) -- ragged frame counts,
+    repeated units (no skip across equal labels), one empty and one infeasible transcript."""
+    B, V = 6, 50
+    blank = V - 1
+    g = torch.Generator().manual_seed(Lm)
+    logits = torch.randn(T, B, V, generator=g) * 2.0
+    tgt = torch.randint(0, blank, (B, Lm), generator=g)
+    tgt[1, : Lm // 2] = 7                                             # a long run of one unit: needs a blank between every two
+    tl = torch.tensor([Lm, Lm // 2, max(Lm // 3, 1), 0, Lm, 1])
+    il = torch.tensor([T, T, T - 7, T // 2, Lm // 2, 3])                # utterance 4: fewer frames than units -> infeasible
+    lp = torch.log_softmax(logits.double(), -1).requires_grad_(True)
+    ref = torch.nn.functional.ctc_loss(lp, tgt, il, tl, blank=blank, reduction="sum", zero_infinity=True)
+    ref.backward()
+    ref = ref.detach()
+    gl = lp.grad - lp.detach().exp() * lp.grad.sum(-1, keepdim=True)   # d/dlogits from d/dlog-probs
+    loss, grad, nll = K.ctc_loss(logits.to(DEV), tgt.to(DEV), tl.to(DEV), il.to(torch.int32).to(DEV), blank)
+    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    assert rel_err(grad, gl.float()) < 1e-4
+    assert not math.isfinite(float(nll[4])) and math.isfinite(float(nll[3]))
+    per = torch.nn.functional.ctc_loss(lp.detach(), tgt, il, tl, blank=blank, reduction="none", zero_infinity=False)
+    ok = torch.isfinite(per)
+    assert torch.allclose(nll.cpu()[ok].double(), per[ok], rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("V", [100, 8000])
 def test_lsce(dtype, V):
