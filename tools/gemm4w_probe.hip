@@ -55,6 +55,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__
 
     f32x4 acc[8][8];
     u32x4 fa[2][8], fb[2][8];                    // [k-half set][tile]
+#ifdef VALU_PER_ROW
+    float dummy[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) dummy[v] = (float)(lane + v);
+#endif
     const int fr_off = r16 * 128;
     const int swz[2] = {((0 + q) ^ (r16 & 7)) << 4, ((4 + q) ^ (r16 & 7)) << 4};
     auto readA = [&](int t, int s, int i) {
@@ -85,6 +90,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 acc[i][j] = mma16<bf16>(fb[0][j], fa[0][i], FIRST ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j]);
+#ifdef VALU_PER_ROW
+            // stand-in for an epilogue step hidden under the MFMAs: VALU_PER_ROW fmas on 8 independent chains per 8-MFMA row
+#pragma unroll
+            for (int v = 0; v < VALU_PER_ROW; ++v) dummy[v & 7] = __builtin_fmaf(dummy[v & 7], 1.0001f, 0.5f);
+#endif
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -113,6 +123,10 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__
             if (!(X_MASK & 4)) { if (g & 1) readB(t + 1, 0, i); else readA(t + 1, 0, i); }
 #pragma unroll
             for (int j = j0; j < j0 + 4; ++j) acc[i][j] = mma16<bf16>(fb[1][j], fa[1][i], acc[i][j]);
+#ifdef VALU_PER_ROW
+#pragma unroll
+            for (int v = 0; v < VALU_PER_ROW / 2; ++v) dummy[v & 7] = __builtin_fmaf(dummy[v & 7], 1.0001f, 0.5f);
+#endif
         }
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -126,6 +140,12 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const bf16* __restrict__
     ktile(0, std::true_type{}, std::false_type{});
     for (int t = 1; t < nk; ++t) ktile(t, std::false_type{}, std::false_type{});
 
+#ifdef VALU_PER_ROW
+    { float sd = 0.f;
+#pragma unroll
+      for (int v = 0; v < 8; ++v) sd += dummy[v];
+      if (sd == 123.456f) C[0] = from_f32<bf16>(sd); }
+#endif
     // plain epilogue: lane holds C[row0 + 128 wr + 16 i + r16][col0 + 128 wc + 16 j + 4 q .. + 3]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
