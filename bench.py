@@ -126,6 +126,55 @@ def timed_updates(trainer, next_batch, steps, warmup, world, device):
     return dt, frames, enc_mean, stats
 
 
+# RCCL all-reduce bus bandwidth ASSUMED by the projection below (8 MI355X, xGMI: 7 links x ~153 GB/s per GPU; a ring / tree over all
+# links sustains a fraction of the 1,075 GB/s aggregate).  Not measured: no multi-GPU node was available to this build.
+ASSUMED_BUS_GBPS = 300.0
+
+
+def dp_dry_run(trainer, next_batch, ms_single, steps=6):
+    """With ONE rank there is no collective, but the data-parallel machinery above the collective can still be exercised and
+    observed: the update runs on the data-parallel SCHEDULE (mid-backward weight-gradient flush), the engine's
+    readiness reports reach the static bucket plan, and a device event marks where on the compute stream each bucket would have been
+    handed to RCCL.  Reported: the schedule's cost, the share of gradient bytes launched from inside backward, the bytes left after
+    it, and -- clearly labelled -- a PROJECTION of the exposed all-reduce time at 8 ranks under an assumed bus bandwidth."""
+    from fbk_fairseq_st_amd import distributed as D
+    trainer.set_dp_dry_run(True)
+    red = trainer.reducer
+    try:
+        for _ in range(2):
+            trainer.train_step([next_batch()])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.train_step([next_batch()])
+        torch.cuda.synchronize()
+        ms_sched = (time.perf_counter() - t0) / steps * 1e3
+        red.record_events = True
+        trainer.train_step([next_batch()])
+        torch.cuda.synchronize()
+        ev0 = red.events[0][3]
+        launches = [(e - s_, ev0.elapsed_time(ev)) for s_, e, early, ev in red.events]
+        finish_ms = ev0.elapsed_time(red.finish_event)
+        early_elems, n = red.early_elems, red.n
+        proj = {}
+        for nr in (2, 4, 8):
+            exposed, total = D.project_exposed_allreduce(launches, finish_ms, nr, ASSUMED_BUS_GBPS, red.flat.element_size())
+            proj["n%d" % nr] = {"allreduce_ms_total": round(total, 3), "exposed_ms_after_backward": round(exposed, 3),
+                                "projected_scaling": round(nr * ms_single / (ms_sched + exposed), 3)}
+        return {"what": "one rank, no collective: reducer bookkeeping on the data-parallel schedule; `projection` is NOT a measurement",
+                "ms_per_step_dp_schedule": round(ms_sched, 3), "ms_per_step_single": round(ms_single, 3),
+                "allreduce_bytes_per_step": n * red.flat.element_size(), "allreduce_buckets": len(red.plan),
+                "allreduce_launched_in_backward_frac": round(early_elems / max(n, 1), 4),
+                "exposed_bytes_after_last_flush": (n - early_elems) * red.flat.element_size(),
+                "bucket_launch_ms_before_backward_end": [round(finish_ms - t, 3) for _, t in launches],
+                "projection": dict(proj, assumed_bus_GBps=ASSUMED_BUS_GBPS,
+                                   formula="bucket all-reduce = 2 (N-1)/N x bytes / bus, buckets back to back from their launch times; "
+                                           "scaling = N x single-rank ms / (dp-schedule ms + exposed ms)")}
+    finally:
+        red.record_events = False
+        trainer.set_dp_dry_run(False)
+
+
 def loader_batches(task, trainer, lengths, max_tokens, max_sentences, seed=1):
     """endless stream of batches from the product iterator (frame-budget batcher, per-epoch shuffle, pinned prefetch thread)"""
     task.load_dataset("train", lengths=lengths, seed=seed)
@@ -268,7 +317,9 @@ def self_launch(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # HSA_ENABLE_IPC_MODE_LEGACY is inherited from the caller's environment as it stands (the pool exports 0: dmabuf IPC, which
+        # RCCL's intra-node transport needs there); this launcher neither sets nor overrides it
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     try:
@@ -356,6 +407,9 @@ def main():
         # EVERY rank runs them (an update contains the gradient all-reduce: rank 0 alone would wait for the others forever); only
         # rank 0 instruments and reports.
         roof = roofline_of(trainer, next_batch, args.prof_steps, dtype, instrument=rank == 0)
+    dry = None
+    if world == 1 and rank == 0 and not args.loader:
+        dry = dp_dry_run(trainer, next_batch, dt / args.steps * 1e3)
     if world > 1:
         torch.distributed.barrier()
 
@@ -384,6 +438,8 @@ def main():
             "allreduce_bytes_per_step": red.n * red.flat.element_size() if world > 1 else 0,
             "allreduce_buckets": len(red.plan), "bucket_bytes": red.bucket_elems * red.flat.element_size(),
             "allreduce_launched_in_backward_frac": round(red.early_elems / max(red.n, 1), 4) if world > 1 else None}
+        if dry is not None:
+            out["data_parallel"]["dry_run"] = dry              # N = 1: the reducer's bookkeeping on the data-parallel schedule + a PROJECTION
         if roof is not None:
             # north_star's "MFMA utilisation on the encoder": SURVEY.md 8-d's algorithmic FLOP of the ENCODER side per input frame
             # (subsampler + encoder layers with the context length each layer actually sees + the CTC head; x3 for forward + backward)
@@ -398,10 +454,9 @@ def main():
             flop_per_frame = 3.0 * fwd / args.frames
             roof["encoder_flop_per_frame_fwd_bwd"] = round(flop_per_frame / 1e6, 2)
             roof["encoder_mfma_util"] = round(frames_done / dt * flop_per_frame / (PEAK_BF16_TFLOPS * 1e12), 4)
-            # what a loop of nothing but v_mfma_f32_16x16x32_bf16 sustains on all 256 CUs of this pool's boxes (tools/gemm4w_probe.hip with
-            # X_MASK=7, 16384 x 1024 x 8192: profiles/r04_gemm4w.txt) -- not re-measured by this run; `peak` stays the guide's dense figure
-            roof["mfma_only_ceiling_tflops"] = 1620.0
-            roof["frac_of_mfma_only_ceiling"] = round(roof["achieved"] / 1620.0, 4) if roof.get("unit") == "TFLOP/s" else None
+            # (rounds 3-4 carried `mfma_only_ceiling_tflops` = 1,620 beside `frac`: the rate of a bare v_mfma_f32_16x16x32_bf16 loop at the
+            # clock the chip holds under it.  Removed in round 5: it is the ceiling of one MFMA shape on this pool's boxes, not of the
+            # chip, and flattered the figure -- `frac` is priced against the guide's 2.5 PFLOP/s dense bf16 peak and nothing else.)
             out["roofline"] = roof
         if args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, a, ref_sd, task)

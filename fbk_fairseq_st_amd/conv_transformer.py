@@ -134,16 +134,21 @@ class _EncoderFn(torch.autograd.Function):
 
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, dec, prev_tokens, enc_out, enc_klen, training, seed, keep=None):
-        logits, dctx = dec.engine.decoder_forward(prev_tokens, enc_out.contiguous(), enc_klen, training, seed, pfx=dec.pfx, keep=keep)
+    def forward(ctx, anchor, dec, prev_tokens, enc_out, enc_klen, training, seed, keep=None, attn_layer=None, attn_heads=None):
+        kw = {} if attn_layer is None else dict(attn_layer=attn_layer, attn_heads=attn_heads)
+        logits, dctx = dec.engine.decoder_forward(prev_tokens, enc_out.contiguous(), enc_klen, training, seed, pfx=dec.pfx, keep=keep, **kw)
         ctx.dec, ctx.dctx = dec, dctx
-        return logits
+        attn = dctx.pop("attn", None)
+        if attn is None:
+            attn = logits.new_zeros((0,), dtype=torch.float32)
+        ctx.mark_non_differentiable(attn)              # the reference's attention weights are never differentiated on this path
+        return logits, attn
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, _dattn=None):
         denc = ctx.dec.engine.decoder_backward(ctx.dctx, dlogits if dlogits.stride(-1) == 1 else dlogits.contiguous())
         c = ctx.dctx
-        return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None, None
+        return None, None, None, denc.view(c["Ts"], c["B"], -1), None, None, None, None, None, None
 
 
 class _DualDecoderFn(torch.autograd.Function):
@@ -260,9 +265,24 @@ class TransformerDecoder(FairseqIncrementalDecoder):
     def engine(self):
         return self.owner.engine
 
-    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, **unused):
+    def _alignment_request(self, alignment_layer, alignment_heads, need_attn):
+        """fairseq/models/transformer.py:700-703,756-782: the reference returns the encoder-attention weights of `alignment_layer` (default:
+        the last layer), averaged over its first `alignment_heads` heads (default: all), on EVERY forward.  Here they cost an extra
+        kernel (the fused attention never materialises P), so they are computed in eval mode -- generation, generate.py
+        --print-alignment, ensemble attention averaging -- and in training only when asked for (need_attn=True or an explicit
+        alignment_layer); `need_attn=False` switches them off."""
+        m = self.owner
+        want = need_attn if need_attn is not None else (alignment_layer is not None or not self.training)
+        if not want or getattr(m.hp, "dec_layers", 0) == 0:
+            return None, None
+        layer = m.hp.dec_layers - 1 if alignment_layer is None else int(alignment_layer)
+        return layer, alignment_heads
+
+    def forward(self, prev_output_tokens, encoder_out=None, incremental_state=None, features_only=False, alignment_layer=None,
+                alignment_heads=None, need_attn=None, **unused):
         m = self.owner
         m._ensure_engine(prev_output_tokens.device)
+        a_layer, a_heads = self._alignment_request(alignment_layer, alignment_heads, need_attn)
         if incremental_state is not None:
             # transformer.py:690-760 with incremental_state: only the last token is embedded, K/V come from the cache.
             key = "s2t_hip_state.%s" % self.pfx
@@ -270,8 +290,9 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             if st is None:
                 st = incremental_state[key] = self.begin_incremental(encoder_out, min(self.max_positions(), 1024))
             assert st["steps"] == prev_output_tokens.shape[1] - 1, "incremental decoding must advance one token at a time"
+            st["attn_layer"], st["attn_heads"], st["attn"] = a_layer, a_heads, None
             logits = self.step_incremental(st, prev_output_tokens[:, -1])
-            return logits.unsqueeze(1), {"attn": [None], "inner_states": None}
+            return logits.unsqueeze(1), {"attn": [st["attn"]], "inner_states": None}       # attn [N, 1, Ts] (transformer.py:782)
         eo = encoder_out.encoder_out
         klen = None
         if encoder_out.encoder_padding_mask is not None:
@@ -281,19 +302,22 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             draws = torch.empty(m.hp.dec_layers).uniform_().tolist()
             if self.training:
                 keep = [d > m.hp.decoder_layerdrop for d in draws]
-        logits_tm = _DecoderFn.apply(m.anchor, self, prev_output_tokens, eo, klen, self.training, m._next_seed(), keep)
+        if keep is not None and a_layer is not None and not keep[a_layer]:
+            a_layer = None                                        # LayerDrop removed the alignment layer: no attention this pass
+        logits_tm, attn = _DecoderFn.apply(m.anchor, self, prev_output_tokens, eo, klen, self.training, m._next_seed(), keep, a_layer, a_heads)
         B, L = prev_output_tokens.shape
         logits = logits_tm.view(L, B, -1).transpose(0, 1)         # view, no copy: (B, L, V)
-        return logits, {"attn": [None], "inner_states": None}
+        return logits, {"attn": [attn if attn.numel() else None], "inner_states": None}     # attn (B, L, Ts), heads averaged
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
-        if self.training:
-            raise NotImplementedError("use the fused label-smoothed CE kernel (criterions.py); lprobs are never materialised")
+        """fairseq/models/fairseq_decoder.py:58-79: f32 (log-)probabilities of the decoder's logits, differentiable -- what a criterion
+        of the reference other than the three re-registered here consumes (those use the fused loss + gradient kernels and never
+        materialise this tensor).  Both directions are kernels (s2t_log_softmax / s2t_softmax_probs, s2t_softmax_bwd)."""
         logits = net_output[0]
-        lp = K.log_softmax(logits.reshape(-1, logits.shape[-1]).contiguous()).view(logits.shape)
-        if not log_probs:
-            raise NotImplementedError("probabilities are only needed in log space on this path")
-        return lp
+        flat = logits.reshape(-1, logits.shape[-1]).contiguous()
+        if torch.is_grad_enabled() and flat.requires_grad:
+            return K.NormalizedProbs.apply(flat, bool(log_probs)).view(logits.shape)
+        return (K.log_softmax(flat) if log_probs else K.softmax_probs(flat)).view(logits.shape)
 
     # ---- incremental decoding (SURVEY 8-a a22): state = per-hypothesis K/V rows owned by the engine
     def begin_incremental(self, encoder_out, max_steps):
@@ -639,6 +663,16 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
     def build_model(cls, args, task):
         base_architecture(args)
         cls._refuse_unbuilt_options(args)
+        if getattr(args, "distributed_world_size", 1) > 1 and getattr(args, "ddp_backend", None) == "c10d" and not getattr(args, "use_bmuf", False):
+            # fairseq's DEFAULT wrapper (fairseq/options.py:387, fairseq/models/distributed_fairseq_model.py:31-45) is torch's c10d
+            # DistributedDataParallel, whose reducer counts autograd gradients per parameter -- the kernels write the arena's
+            # gradients directly, so it would wait forever.  The model is built before fairseq's trainer wraps it
+            # (fairseq_cli/train.py:60-80, fairseq/trainer.py:100-112), so the run is moved to the wrapper that reduces `p.grad` in
+            # place after backward (legacy_distributed_data_parallel.py:96-170: the reference paper script's --ddp-backend no_c10d).
+            import warnings
+            warnings.warn("--ddp-backend c10d cannot see gradients written by the HIP kernels; using --ddp-backend no_c10d "
+                          "(LegacyDistributedDataParallel: one flat all-reduce after backward, as the reference's S2T recipes run)")
+            args.ddp_backend = "no_c10d"
         if not hasattr(args, "max_source_positions"):
             args.max_source_positions = 100000
         if not hasattr(args, "max_target_positions"):

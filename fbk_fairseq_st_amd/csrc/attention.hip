@@ -1303,3 +1303,74 @@ extern "C" int s2t_attn_bwd(int dtype, int head_dim, int B, int H, int Tq, int T
     if (dtype == S2T_BF16) return head_dim == 64 ? bwd_launch<bf16, 64>(a, st) : bwd_launch<bf16, 32>(a, st);
     return head_dim == 64 ? bwd_launch<float, 64>(a, st) : bwd_launch<float, 32>(a, st);
 }
+
+// ------------------------------------------------------------------------------------ head-averaged attention probabilities
+// fairseq/models/transformer.py:756-782 (TransformerDecoder.extract_features): the decoder returns, for `alignment_layer` (the last
+// layer by default), the encoder-attention probabilities averaged over the heads -- what generate.py --print-alignment and the
+// ensemble's attention averaging consume (fairseq_cli/generate.py:82,219; sequence_generator.py:757-768).  The fused attention kernels
+// never materialise P, so this recomputes it for the ONE layer that is asked for: out[b][tq][tk] = mean_h softmax_tk(scale q_h . k_h),
+// keys past klen[b] get probability 0 (key padding: -inf scores).  Eval-mode semantics (no dropout on P), as the reference's
+// need_weights path returns the softmax output after dropout only in training -- alignment is an inference feature.
+// One workgroup per (query, batch); plain f32 VALU dot products: a decoding step has Tq = 1 and a few hundred keys.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_probs_avg_kernel(const T* __restrict__ Q, long q_st, long q_sb, const T* __restrict__ Kp, long k_st,
+                                                             long k_sb, const int* __restrict__ klen, float* __restrict__ out, int H, int dh,
+                                                             int Tq, int Tk, int heads_used, float scale) {
+    __shared__ float sh[16];
+    __shared__ float qs[128];
+    const int tq = blockIdx.x, b = blockIdx.y;
+    const int kl = klen ? min(klen[b], Tk) : Tk;
+    constexpr int NK = 8;                                     // keys per thread: Tk <= 2048 (host check)
+    float acc[NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) acc[i] = 0.f;
+    for (int h = 0; h < heads_used; ++h) {
+        __syncthreads();
+        if ((int)threadIdx.x < dh) qs[threadIdx.x] = to_f32(Q[tq * q_st + b * q_sb + h * dh + threadIdx.x]) * scale;
+        __syncthreads();
+        float s[NK];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int tk = threadIdx.x + 256 * i;
+            s[i] = -INFINITY;
+            if (tk < kl) {
+                const T* kr = Kp + (long)tk * k_st + b * k_sb + h * dh;
+                float d = 0.f;
+                for (int j = 0; j < dh; ++j) d += qs[j] * to_f32(kr[j]);
+                s[i] = d;
+            }
+            m = fmaxf(m, s[i]);
+        }
+        m = block_max(m, sh);
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) { s[i] = (s[i] == -INFINITY) ? 0.f : expf(s[i] - m); l += s[i]; }
+        l = block_sum(l, sh);
+        const float inv = l > 0.f ? 1.f / (l * heads_used) : 0.f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) acc[i] += s[i] * inv;
+    }
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int tk = threadIdx.x + 256 * i;
+        if (tk < Tk) out[((long)b * Tq + tq) * Tk + tk] = acc[i];
+    }
+}
+
+extern "C" int s2t_attn_probs_avg(int dtype, int head_dim, int B, int H, int Tq, int Tk, const void* Q, long q_st, long q_sb,
+                                  const void* K, long k_st, long k_sb, const int* klen, int heads_used, float scale, float* out,
+                                  void* stream) {
+    if (B == 0 || Tq == 0 || Tk == 0) return S2T_OK;
+    if (!Q || !K || !out || head_dim <= 0 || head_dim > 128 || H <= 0 || heads_used <= 0 || heads_used > H) return S2T_EINVAL;
+    if (Tk > 2048) return S2T_ENOTSUP;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)Tq, (unsigned)B);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(attn_probs_avg_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)Q, q_st, q_sb, (const bf16*)K, k_st, k_sb,
+                                               klen, out, H, head_dim, Tq, Tk, heads_used, scale);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(attn_probs_avg_kernel<float>, grid, dim3(256), 0, st, (const float*)Q, q_st, q_sb, (const float*)K, k_st,
+                                                  k_sb, klen, out, H, head_dim, Tq, Tk, heads_used, scale);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}

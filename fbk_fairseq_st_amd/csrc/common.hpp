@@ -26,7 +26,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     } while (0)
 
 // kernel-route options (runtime.hip, s2t_set_option)
-extern int g_s2t_opt_gemm256, g_s2t_opt_attn_v1, g_s2t_opt_attn_v2_min_tq, g_s2t_opt_gemm256_min_tiles, g_s2t_opt_gemm256_sched, g_s2t_opt_gemm4w;
+extern int g_s2t_opt_gemm256, g_s2t_opt_attn_v1, g_s2t_opt_attn_v2_min_tq, g_s2t_opt_gemm256_min_tiles, g_s2t_opt_gemm256_sched;
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int PER16 = 4; };

@@ -1,4 +1,4 @@
-// Pieces shared by the two big-tile bf16 GEMM kernels (gemm256.hip: eight waves of 128 x 64; gemm4w.hip: four waves of 128 x 128):
+// Pieces of the big-tile bf16 GEMM kernel (gemm256.hip: eight waves of 128 x 64; the archived four-wave experiment tools/lab/gemm4w.hip used them too):
 // the LDS image constants, the transposed fragment read, the epilogue arithmetic of one output quad and the buffer-addressed accesses.
 #pragma once
 #include "common.hpp"

@@ -396,7 +396,7 @@ extern "C" int s2t_kd_loss(int dtype, const void* logits, const long long* targe
 // ------------------------------------------------------------------ log-softmax rows (generation)
 // out[row][v] = log_softmax(logits[row][:] * inv_temperature)[v] in f32
 // (sequence_generator.py:711-768 EnsembleModel.forward_decoder -> get_normalized_probs(log_probs=True))
-template <typename T>
+template <typename T, bool LOG = true>
 __global__ __launch_bounds__(256) void log_softmax_kernel(const T* __restrict__ logits, float* __restrict__ out, int V, int ld, float it) {
     __shared__ float sh[16];
     const long row = blockIdx.x;
@@ -408,7 +408,26 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const T* __restrict__ 
     for (int v = threadIdx.x; v < V; v += 256) s += expf(to_f32(x[v]) * it - m);
     s = block_sum(s, sh);
     const float lse = m + logf(s);
-    for (int v = threadIdx.x; v < V; v += 256) out[row * V + v] = to_f32(x[v]) * it - lse;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float lp = to_f32(x[v]) * it - lse;
+        out[row * V + v] = LOG ? lp : expf(lp);
+    }
+}
+// gradient of log_softmax / softmax rows w.r.t. the logits from the saved output (include/s2t_hip.h: s2t_softmax_bwd)
+template <typename T, bool LOG>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout, T* __restrict__ dx,
+                                                          int V, int ld, float it) {
+    __shared__ float sh[16];
+    const long row = blockIdx.x;
+    const float* y = out + row * V;
+    const float* g = dout + row * V;
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) s += LOG ? g[v] : g[v] * y[v];
+    s = block_sum(s, sh);
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float pv = LOG ? expf(y[v]) : y[v];
+        dx[row * ld + v] = from_f32<T>(it * (LOG ? g[v] - pv * s : pv * (g[v] - s)));
+    }
 }
 extern "C" int s2t_log_softmax(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream) {
     if (rows <= 0) return S2T_OK;
@@ -417,6 +436,30 @@ extern "C" int s2t_log_softmax(int dtype, const void* logits, float* out, long r
     if (dtype == S2T_BF16) hipLaunchKernelGGL(log_softmax_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, out, V, ld, inv_temperature);
     else if (dtype == S2T_F32) hipLaunchKernelGGL(log_softmax_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, out, V, ld, inv_temperature);
     else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_softmax_probs(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream) {
+    if (rows <= 0) return S2T_OK;
+    if (!logits || !out || V <= 0 || ld < V) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL((log_softmax_kernel<bf16, false>), dim3((unsigned)rows), dim3(256), 0, st, (const bf16*)logits, out, V, ld, inv_temperature);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL((log_softmax_kernel<float, false>), dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, out, V, ld, inv_temperature);
+    else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+extern "C" int s2t_softmax_bwd(int dtype, const float* out, const float* dout, void* dlogits, long rows, int V, int ld, float inv_temperature,
+                               int log_probs, void* stream) {
+    if (rows <= 0) return S2T_OK;
+    if (!out || !dout || !dlogits || V <= 0 || ld < V) return S2T_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define S2T_SMB(T_, LOG_) hipLaunchKernelGGL((softmax_bwd_kernel<T_, LOG_>), dim3((unsigned)rows), dim3(256), 0, st, out, dout, (T_*)dlogits, V, ld, inv_temperature)
+    if (dtype == S2T_BF16) { if (log_probs) S2T_SMB(bf16, true); else S2T_SMB(bf16, false); }
+    else if (dtype == S2T_F32) { if (log_probs) S2T_SMB(float, true); else S2T_SMB(float, false); }
+    else return S2T_ENOTSUP;
+#undef S2T_SMB
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

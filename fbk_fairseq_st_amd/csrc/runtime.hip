@@ -9,7 +9,7 @@
 #include <cstring>
 
 int g_s2t_prof_on = 0;
-int g_s2t_opt_gemm256 = 1, g_s2t_opt_attn_v1 = 0, g_s2t_opt_attn_v2_min_tq = 16, g_s2t_opt_gemm256_min_tiles = 0, g_s2t_opt_gemm256_sched = 0, g_s2t_opt_gemm4w = 0;
+int g_s2t_opt_gemm256 = 1, g_s2t_opt_attn_v1 = 0, g_s2t_opt_attn_v2_min_tq = 16, g_s2t_opt_gemm256_min_tiles = 0, g_s2t_opt_gemm256_sched = 0;
 namespace {
 struct Rec { hipEvent_t a, b; double flops, bytes; };
 struct Fam { std::vector<Rec> recs; double ms = 0, flops = 0, bytes = 0; long long launches = 0; };
@@ -61,13 +61,13 @@ void* s2t_scratch(int slot, hipStream_t st, size_t bytes, hipError_t* err) {
     return b.p;
 }
 
-extern "C" int s2t_abi_version(void) { return 7; }
+extern "C" int s2t_abi_version(void) { return 8; }
 extern "C" const char* s2t_build_info(void) { return "libs2t_hip gfx950 (CDNA4, wave64, MFMA) built " __DATE__ " " __TIME__; }
 extern "C" int s2t_set_option(const char* key, int value) {
     if (!key) return S2T_EINVAL;
     int* slot = !strcmp(key, "gemm256") ? &g_s2t_opt_gemm256 : !strcmp(key, "attn_v1") ? &g_s2t_opt_attn_v1
               : !strcmp(key, "attn_v2_min_tq") ? &g_s2t_opt_attn_v2_min_tq : !strcmp(key, "gemm256_min_tiles") ? &g_s2t_opt_gemm256_min_tiles
-              : !strcmp(key, "gemm256_sched") ? &g_s2t_opt_gemm256_sched : !strcmp(key, "gemm4w") ? &g_s2t_opt_gemm4w : nullptr;
+              : !strcmp(key, "gemm256_sched") ? &g_s2t_opt_gemm256_sched : nullptr;
     if (!slot) return S2T_EINVAL;
     const int old = *slot;
     *slot = value;

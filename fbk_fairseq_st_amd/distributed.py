@@ -74,6 +74,7 @@ class BucketedGradReducer:
         self.bucket_elems = max(1, bucket_bytes // flat_grad.element_size())
         self.plan = bucket_plan(self.n, self.bucket_elems)
         self.group = group
+        self.record_events = False     # bench.py: a device event per bucket launch (where on the compute stream's timeline it left)
         self.reset()
 
     def reset(self):
@@ -82,6 +83,8 @@ class BucketedGradReducer:
         self.handles = []
         self.launched = []
         self.early_elems = 0       # elements whose bucket left from inside backward (notify), not from finish()
+        self.events = []           # record_events: (start, end, early, event recorded on the current stream at launch)
+        self.finish_event = None
 
     def _launch_next(self, early=False):
         start, end = self.plan[self.next]
@@ -89,6 +92,10 @@ class BucketedGradReducer:
         self.launched.append((start, end))
         if early:
             self.early_elems += end - start
+        if self.record_events:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.events.append((start, end, early, ev))
         if get_world_size() > 1:
             self.handles.append(dist.all_reduce(self.flat[start:end], group=self.group, async_op=True))
 
@@ -100,12 +107,28 @@ class BucketedGradReducer:
             self._launch_next(early=True)
 
     def finish(self):
+        if self.record_events:
+            self.finish_event = torch.cuda.Event(enable_timing=True)
+            self.finish_event.record()
         while self.next < len(self.plan):
             self._launch_next()
         self.ready_low = 0
         for h in self.handles:
             h.wait()
         self.handles = []
+
+
+def project_exposed_allreduce(launches, finish_ms, n_ranks, bus_gbps, elem_bytes=4):
+    """PROJECTION, not a measurement: given when each bucket became launchable on one rank's timeline (launches = [(elements,
+    ms since the first launch)], finish_ms = when backward ended on the same clock), how long after backward would the last bucket
+    of an N-rank ring all-reduce finish if the buckets run back to back on one RCCL stream at `bus_gbps` GB/s of bus bandwidth
+    (an all-reduce of S bytes takes 2 (N - 1) / N * S / bus)?  -> (exposed ms, total all-reduce ms)"""
+    t_free, total = 0.0, 0.0
+    for elems, t_ms in launches:
+        dur = 2.0 * (n_ranks - 1) / n_ranks * elems * elem_bytes / (bus_gbps * 1e9) * 1e3
+        t_free = max(t_free, t_ms) + dur
+        total += dur
+    return max(0.0, t_free - finish_ms), total
 
 
 def all_reduce_stats(values, device=None):

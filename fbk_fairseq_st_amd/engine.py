@@ -880,8 +880,11 @@ class S2TEngine:
         self.flush_wgrad()
 
     # ------------------------------------------------------------------ decoder
-    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None):
-        """keep: LayerDrop decisions (--decoder-layerdrop, fairseq/modules/layer_drop.py:11-44), one bool per layer, drawn by the caller"""
+    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None, attn_layer=None, attn_heads=None):
+        """keep: LayerDrop decisions (--decoder-layerdrop, fairseq/modules/layer_drop.py:11-44), one bool per layer, drawn by the caller.
+        attn_layer: also return (ctx["attn"], f32 [B, L, Ts]) the encoder-attention probabilities of that layer averaged over its first
+        attn_heads heads (fairseq/models/transformer.py:756-782: alignment_layer / alignment_heads); that layer then runs on the per-kernel
+        schedule, whose q and k are at hand (bit-identical to the layer call: tests/test_engine_gpu.py)."""
         hp = self.hp
         B, L = prev_tokens.shape
         D = hp.D
@@ -901,13 +904,15 @@ class S2TEngine:
                 continue
             lp = pfx + "layers.%d." % l
             s = seed * 1000 + 510 + 10 * l
-            if self.composite and self.defer_wgrad:
+            if self.composite and self.defer_wgrad and l != attn_layer:
                 x, cl = self.layer_fwd(lp, x, training, (s + 1, s + 2, s + 4, s + 5, s + 7, s + 8), self_klen=tlen, causal=True,
                                        enc2d=enc2d, Ts=Ts, enc_klen=enc_klen32)
                 ctx["layers"].append(cl)
                 continue
             x, c1 = self.self_attn_block_fwd(lp, x, tlen, True, training, s)
             x, c2 = self.cross_attn_block_fwd(lp, x, enc2d, Ts, enc_klen32, training, s + 3)
+            if l == attn_layer:
+                ctx["attn"] = K.attn_probs_avg(c2["q"], c2["kv"][:, :, :D], hp.heads, klen=enc_klen32, heads_used=attn_heads)
             x, c3 = self.ffn_block_fwd(lp, x, training, s + 4)
             ctx["layers"].append((c1, c2, c3))
         xn, mean, rstd = K.layernorm_fwd(x.view(L * B, D), self.P(pfx + "layer_norm.weight"), self.P(pfx + "layer_norm.bias"), hp.ln_eps)
@@ -923,7 +928,8 @@ class S2TEngine:
         hp = self.hp
         Ts, N, D = enc_out.shape
         enc2d = enc_out.reshape(Ts * N, D)
-        st = dict(pfx=pfx, N=N, Ts=Ts, klen=enc_klen32, kv_enc=[], cache=[], spare=[], steps=0, max_steps=max_steps)
+        st = dict(pfx=pfx, N=N, Ts=Ts, klen=enc_klen32, kv_enc=[], cache=[], spare=[], steps=0, max_steps=max_steps,
+                  attn_layer=None, attn_heads=None, attn=None)     # attn_layer set by the caller: decoder_step leaves st["attn"] [N, 1, Ts]
         for l in range(hp.dec_layers):
             lp = pfx + "layers.%d." % l
             st["kv_enc"].append(self.linear(enc2d, lp + "encoder_attn.kv").view(Ts, N, 2 * D))
@@ -980,6 +986,8 @@ class S2TEngine:
             q = self.linear(h, lp + "encoder_attn.q_proj").view(1, N, D)
             kv = st["kv_enc"][l]
             ctx, _ = K.attn_fwd(q, kv[:, :, :D], kv[:, :, D:], hp.heads, klen=st["klen"])
+            if l == st.get("attn_layer"):
+                st["attn"] = K.attn_probs_avg(q, kv[:, :, :D], hp.heads, klen=st["klen"], heads_used=st.get("attn_heads"))
             x = self.linear(ctx.view(N, D), lp + "encoder_attn.out_proj", residual=x)
             h, _, _ = K.layernorm_fwd(x, self.P(lp + "final_layer_norm.weight"), self.P(lp + "final_layer_norm.bias"), hp.ln_eps)
             a = self.linear(h, lp + "fc1", act=self.act_fwd)

@@ -176,6 +176,19 @@ def attn_fwd(q, k, v, heads, klen=None, causal=False, scale=None, p_drop=0.0, se
     return out, lse
 
 
+def attn_probs_avg(q, k, heads, klen=None, scale=None, heads_used=None):
+    """head-averaged attention probabilities of one layer, recomputed from q [Tq,B,D'] and k [Tk,B,D'] -> f32 [B, Tq, Tk]
+    (transformer.py:756-782: what the decoder returns as `attn` for its alignment layer)"""
+    Tq, B, D = q.shape
+    Tk = k.shape[0]
+    d = D // heads
+    out = torch.empty((B, Tq, Tk), dtype=torch.float32, device=q.device)
+    L.check(_lib().s2t_attn_probs_avg(L.dt(q), d, B, heads, Tq, Tk, L.ptr(q), *_tb(q), L.ptr(k), *_tb(k), L.ptr(klen),
+                                      int(heads_used or heads), float(d ** -0.5 if scale is None else scale), L.ptr(out), L.stream()),
+            "s2t_attn_probs_avg")
+    return out
+
+
 def attn_bwd(q, k, v, o, do, lse, heads, dq, dk, dv, klen=None, causal=False, scale=None, p_drop=0.0, seed=0, dist_penalty=False):
     Tq, B, D = q.shape
     Tk = k.shape[0]
@@ -508,6 +521,42 @@ def log_softmax(logits, temperature=1.0):
     L.check(_lib().s2t_log_softmax(L.dt(logits), L.ptr(logits), L.ptr(out), rows, V, _row_ld(logits), 1.0 / float(temperature),
                                    L.stream()), "s2t_log_softmax")
     return out
+
+
+def softmax_probs(logits, temperature=1.0):
+    """[rows,V] (row stride may be padded) -> f32 [rows,V] probabilities"""
+    rows, V = logits.shape
+    out = torch.empty((rows, V), dtype=torch.float32, device=logits.device)
+    L.check(_lib().s2t_softmax_probs(L.dt(logits), L.ptr(logits), L.ptr(out), rows, V, _row_ld(logits), 1.0 / float(temperature),
+                                     L.stream()), "s2t_softmax_probs")
+    return out
+
+
+def softmax_bwd(out, dout, dtype, log_probs, temperature=1.0):
+    """gradient of log_softmax / softmax_probs w.r.t. the logits from the saved f32 output and its gradient -> [rows,V] of `dtype`"""
+    rows, V = out.shape
+    assert out.dtype == torch.float32 and dout.dtype == torch.float32 and out.is_contiguous() and dout.is_contiguous()
+    dx = torch.empty((rows, V), dtype=dtype, device=out.device)
+    L.check(_lib().s2t_softmax_bwd(L.dt(dx), L.ptr(out), L.ptr(dout), L.ptr(dx), rows, V, V, 1.0 / float(temperature), int(bool(log_probs)),
+                                   L.stream()), "s2t_softmax_bwd")
+    return dx
+
+
+class NormalizedProbs(torch.autograd.Function):
+    """log_softmax / softmax of logit rows with a gradient (get_normalized_probs for criteria that consume the (log-)probabilities:
+    fairseq/models/fairseq_decoder.py:58-79); both directions are kernels of csrc/loss_embed.hip"""
+
+    @staticmethod
+    def forward(ctx, logits2d, log_probs):
+        out = log_softmax(logits2d) if log_probs else softmax_probs(logits2d)
+        ctx.save_for_backward(out)
+        ctx.log_probs, ctx.dtype = bool(log_probs), logits2d.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        return softmax_bwd(out, dout.contiguous().float(), ctx.dtype, ctx.log_probs), None
 
 
 def ensemble_lse(lprobs):

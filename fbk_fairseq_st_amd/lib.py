@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7              # s2t_abi_version() of the library this binding was written against
+ABI_VERSION = 8              # s2t_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD, ACT_RELU_MASK, ACT_RELU_BWD_MASK = 0, 1, 2, 3, 4, 5, 6
 
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
@@ -37,6 +37,7 @@ SIGNATURES = {
     "s2t_attn_fwd": [c_int] * 6 + [P, c_long, c_long] * 4 + [P, P, c_int, c_int, c_float, c_float, c_ull, P],
     "s2t_attn_bwd": [c_int] * 6 + [P, c_long, c_long] * 5 + [P, P] + [P, c_long, c_long] * 3 +
                     [P, c_int, c_int, c_float, c_float, c_ull, P],
+    "s2t_attn_probs_avg": [c_int] * 6 + [P, c_long, c_long] * 2 + [P, c_int, c_float, P, P],
     "s2t_layernorm_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_float, P],
     "s2t_layernorm_bwd": [c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P, c_float, c_ull, P],
     "s2t_conv1_fwd": [c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
@@ -58,6 +59,8 @@ SIGNATURES = {
     "s2t_kd_loss": [c_int, P, P, P, P, P, P, c_long, c_int, c_int, c_int, c_float, c_float, c_int, c_float, P],
     "s2t_embed_fwd": [c_int, P, P, P, P, c_int, c_int, c_int, c_float, c_int, c_int, P],
     "s2t_log_softmax": [c_int, P, P, c_long, c_int, c_int, c_float, P],
+    "s2t_softmax_probs": [c_int, P, P, c_long, c_int, c_int, c_float, P],
+    "s2t_softmax_bwd": [c_int, P, P, P, c_long, c_int, c_int, c_float, c_int, P],
     "s2t_ensemble_lse": [c_int, P, P, c_size_t, P],
     "s2t_embed_bwd": [c_int, P, P, P, c_int, c_int, c_int, c_float, c_int, P],
     "s2t_act_bwd": [c_int, P, P, P, c_size_t, c_int, c_float, c_ull, P],
@@ -125,11 +128,11 @@ class LayerCall(ctypes.Structure):
 _lib = None
 
 
-def build(verbose=False):
-    """Compile csrc/*.hip for gfx950 into libs2t_hip.so (hipcc cross-compiles without a GPU), then the CPython binding of its C ABI."""
-    # `twins`: the two diagnostic builds of gemm256 the store-data hazard test loads (tests/test_kernels_gpu.py); they travel to the
-    # GPU box with the tree like the library itself
-    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 4)), "all", "twins"]
+def build(verbose=False, twins=False):
+    """Compile csrc/*.hip for gfx950 into libs2t_hip.so (hipcc cross-compiles without a GPU), then the CPython binding of its C ABI.
+    twins=True also builds the two diagnostic libraries of the store-data hazard reproducer (tests/test_kernels_gpu.py, marked slow:
+    S2T_SLOW=1); the product build does not depend on them."""
+    cmd = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 4)), "all"] + (["twins"] if twins else [])
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("building libs2t_hip.so failed:\n" + res.stdout[-4000:])
@@ -272,7 +275,10 @@ def _load_fastcall(ctypes_lib):
     if any(not hasattr(mod, n) for n in SIGNATURES) or mod.s2t_abi_version() != ABI_VERSION:
         return None
     if getattr(mod, "s2t_signature_hash", lambda: None)() != signature_hash():
-        return None                       # generated from another table (SIGNATURES edited, or `make` without build()): ctypes instead
+        import warnings                   # generated from another table (SIGNATURES edited, or `make` without build()): ctypes instead
+        warnings.warn("fbk_fairseq_st_amd: the generated binding %s was built from another signature table; falling back to ctypes "
+                      "(~4 us per launch instead of 0.3) -- run __graft_entry__.build()" % FAST_PATH)
+        return None
     return mod
 
 

@@ -349,7 +349,7 @@ class FairseqTask(_TaskBase):
     def build_generator(self, models, args):
         """fairseq_task.py:230-313 (beam search only: sampling / diverse search / scoring are outside the S2T path)."""
         from .sequence_generator import SequenceGenerator
-        for flag in ("score_reference", "sampling", "match_source_len", "print_alignment"):
+        for flag in ("score_reference", "sampling", "match_source_len"):
             if getattr(args, flag, False):
                 raise NotImplementedError("--%s is outside the S2T hot path" % flag.replace("_", "-"))
         if getattr(args, "diverse_beam_groups", -1) > 0 or getattr(args, "diversity_rate", -1) > 0:
@@ -359,7 +359,8 @@ class FairseqTask(_TaskBase):
                                  min_len=getattr(args, "min_len", 1), normalize_scores=(not getattr(args, "unnormalized", False)),
                                  len_penalty=getattr(args, "lenpen", 1), unk_penalty=getattr(args, "unkpen", 0),
                                  temperature=getattr(args, "temperature", 1.0),
-                                 no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0))
+                                 no_repeat_ngram_size=getattr(args, "no_repeat_ngram_size", 0),
+                                 print_alignment=getattr(args, "print_alignment", False))     # fairseq_task.py:300-303
 
     def inference_step(self, generator, models, sample, prefix_tokens=None):      # fairseq_task.py:392-394
         with torch.no_grad():

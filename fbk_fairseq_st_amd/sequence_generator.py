@@ -14,7 +14,9 @@ in-place K/V rows, output projection, log-softmax) is a libs2t_hip.so kernel; to
 integer selection bookkeeping (top-k, gathers of token/score rows) exactly as the reference does.
 Ensembles (EnsembleModel.forward_decoder :711-770: every member runs its own encoder and incremental decoder, the
 log-probabilities meet in one logsumexp kernel), prefix tokens (:270-280,449-476) and n-gram blocking (:617-650) follow the
-reference; sampling and attention / alignment output are not part of this path (they raise).  `TwoPhaseSequenceGenerator` runs the same loop twice for dual-decoder
+reference; with `retain_attention=True` every hypothesis carries its `attention` (src_len x tgt_len, the last decoder layer's
+encoder-attention averaged over heads and ensemble members: sequence_generator.py:286-292,510-560,757-768) and, with `print_alignment`, the
+hard `alignment` generate.py prints (utils.extract_hard_alignment, fairseq/utils.py); sampling is not part of this path.  `TwoPhaseSequenceGenerator` runs the same loop twice for dual-decoder
 models: transcripts with the auxiliary decoder, then translations seeded by the transcript scores.
 """
 import math
@@ -60,7 +62,7 @@ class HierarchicalBeamSearch(BeamSearch):
 class SequenceGenerator:
     def __init__(self, models, tgt_dict, beam_size=1, max_len_a=0, max_len_b=200, min_len=1, normalize_scores=True, len_penalty=1.0,
                  unk_penalty=0.0, retain_dropout=False, temperature=1.0, match_source_len=False, no_repeat_ngram_size=0,
-                 search_strategy=None, eos=None):
+                 search_strategy=None, eos=None, retain_attention=False, print_alignment=False):
         self.models = list(models) if isinstance(models, (list, tuple)) else [models]
         if not 1 <= len(self.models) <= 8:
             raise ValueError("an ensemble of 1..8 models (s2t_ensemble_lse), got %d" % len(self.models))
@@ -75,6 +77,11 @@ class SequenceGenerator:
         if match_source_len or retain_dropout:
             raise NotImplementedError("match_source_len / retain_dropout are outside the S2T hot path")
         self.no_repeat_ngram_size = int(no_repeat_ngram_size)
+        # the reference records the averaged encoder attention of every step whenever the decoder returns one (:286-292); here it costs
+        # a kernel per step (the fused attention never materialises P), so it is on request -- task.build_generator sets it for
+        # generate.py --print-alignment
+        self.print_alignment = bool(print_alignment)
+        self.retain_attention = bool(retain_attention) or self.print_alignment
         self.search = BeamSearch(tgt_dict) if search_strategy is None else search_strategy
 
     # ------------------------------------------------------------------ API of the reference
@@ -98,10 +105,24 @@ class SequenceGenerator:
         encs = [self._encode(m, net_input) for m in self.models]
         hyps = self._beam_search([m.decoder for m in self.models], encs, B, src_tokens.device, max_len, self.search, bos_token,
                                  self.pad, self.unk, self.eos, self.vocab_size, prefix_tokens=prefix_tokens)
-        for hs in hyps:
+        for b, hs in enumerate(hyps):
             for h in hs:
                 h.pop("origin")
+                if self.print_alignment and h["attention"] is not None:
+                    h["alignment"] = self._hard_alignment(h["attention"], net_input["src_lengths"][b], h["tokens"])
         return hyps
+
+    def _hard_alignment(self, attn, src_len, tgt_tokens):
+        """SequenceGeneratorWithAlignment.generate for a model without full-context alignment (sequence_generator.py:830-841) +
+        fairseq/utils.py:486-503 extract_hard_alignment: for every target position that is neither pad nor EOS, the source position
+        with the largest attention weight, as (source, target) pairs.  The source side of this model is filterbank frames, so the
+        reference's token-to-word mapping has nothing to map: the pair holds the 0-based index on the axis the attention is over (the
+        encoder's output frames, after subsampling and CTC compression) and the 0-based target position.  Index work only."""
+        valid = (tgt_tokens.ne(self.pad) & tgt_tokens.ne(self.eos)).nonzero(as_tuple=False).view(-1)
+        if attn.numel() == 0 or valid.numel() == 0:
+            return []
+        _, src_idx = attn.t()[valid.to(attn.device)].max(dim=1)
+        return list(zip(src_idx.tolist(), valid.tolist()))
 
     def _encode(self, model, net_input):
         """encoder output with one copy per hypothesis slot (sequence_generator.py:176-196)"""
@@ -119,6 +140,10 @@ class SequenceGenerator:
         decoders = list(decoder) if isinstance(decoder, (list, tuple)) else [decoder]
         encs = list(enc) if isinstance(decoder, (list, tuple)) else [enc]
         states = [d.begin_incremental(e, max_len + 1) for d, e in zip(decoders, encs)]
+        attn = None                                                        # [N, Ts, max_len + 2], column step + 1 = the attention of step `step` (:286-292)
+        if self.retain_attention:
+            for d, st in zip(decoders, states):
+                st["attn_layer"] = d.owner.hp.dec_layers - 1                # alignment_layer's default: the last layer (transformer.py:700-703)
         if prefix_tokens is not None:
             prefix_tokens = prefix_tokens.to(dev)
 
@@ -143,6 +168,13 @@ class SequenceGenerator:
                     d.reorder_incremental(st, reorder)
                 member.append(K.log_softmax(d.step_incremental(st, tokens[:, step]), self.temperature))      # f32 [N, V]
             lprobs = member[0] if len(member) == 1 else K.ensemble_lse(member)       # log of the members' mean probability
+            if self.retain_attention and all(st["attn"] is not None and st["attn"].shape[-1] == states[0]["attn"].shape[-1] for st in states):
+                avg = states[0]["attn"][:, 0, :]
+                for st in states[1:]:
+                    avg = avg + st["attn"][:, 0, :]                        # index-free sum of a handful of [N, Ts] rows (:757-768)
+                if attn is None:
+                    attn = torch.zeros((avg.shape[0], avg.shape[1], max_len + 2), dtype=torch.float32, device=dev)
+                attn[:, :, step + 1] = avg / len(states) if len(states) > 1 else avg
             lprobs[lprobs != lprobs] = -math.inf
             lprobs[:, pad] = -math.inf
             lprobs[:, unk] -= self.unk_penalty
@@ -167,7 +199,7 @@ class SequenceGenerator:
             eos_mask[:, :beam] &= ~blacklist
             top_eos = eos_mask[:, :beam] & ~done.unsqueeze(1)
             if bool(top_eos.any()):                                        # the step's only host sync
-                self._finalize(step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len, eos, origin)
+                self._finalize(step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len, eos, origin, attn)
                 done = torch.tensor(finished, device=dev)
                 if all(finished):
                     break
@@ -186,6 +218,8 @@ class SequenceGenerator:
                 scores[:, :step] = scores.index_select(0, parent)[:, :step]
             scores[:, step] = torch.gather(cand_scores, 1, pick).view(-1)
             origin = origin.index_select(0, parent)
+            if attn is not None:
+                attn[:, :, :step + 2] = attn.index_select(0, parent)[:, :, :step + 2]      # :427-430
             reorder = parent
 
         out = []
@@ -233,7 +267,7 @@ class SequenceGenerator:
         if ban_r:
             lprobs[torch.tensor(ban_r, device=lprobs.device), torch.tensor(ban_c, device=lprobs.device)] = -math.inf
 
-    def _finalize(self, step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len, eos, origin):
+    def _finalize(self, step, top_eos, cand_row, cand_scores, tokens, scores, finalized, finished, max_len, eos, origin, attn=None):
         """sequence_generator.py:502-600 finalize_hypos: hypotheses ending in EOS among the top `beam` candidates."""
         beam = self.beam_size
         sent, rank = top_eos.nonzero(as_tuple=True)                       # row-major: sentence ascending, rank ascending
@@ -245,11 +279,13 @@ class SequenceGenerator:
         pos = scores.index_select(0, rows)[:, :step + 1].clone()
         pos[:, step] = eos_s
         pos[:, 1:] = pos[:, 1:] - pos[:, :-1]
+        attn_clone = attn.index_select(0, rows)[:, :, 1:step + 2] if attn is not None else None     # :510-514: src_len x tgt_len
         if self.normalize_scores:
             eos_s = eos_s / (step + 1) ** self.len_penalty
         for i, s in enumerate(sent.tolist()):
             if len(finalized[s]) < beam:
-                finalized[s].append({"tokens": toks[i], "score": eos_s[i], "attention": None, "alignment": None,
+                finalized[s].append({"tokens": toks[i], "score": eos_s[i], "attention": None if attn_clone is None else attn_clone[i],
+                                     "alignment": None,
                                      "positional_scores": pos[i], "origin": org[i]})
         for s in set(sent.tolist()):
             if not finished[s] and (len(finalized[s]) == beam or step == max_len):

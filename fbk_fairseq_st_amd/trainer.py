@@ -51,6 +51,7 @@ class Trainer:
         if self.world > 1 and getattr(model.engine, "defer_wgrad", False):
             model.engine.wgrad_flush_layers = max(1, model.hp.enc_layers // 2)     # see S2TEngine.wgrad_flush_layers
         self._ranges = {}
+        self.dp_dry_run = False         # world 1 only: run the reducer's bookkeeping as a data-parallel rank would (set_dp_dry_run)
         self._sync_grads = True         # False while a non-final micro-batch accumulates locally (the reference's no_sync)
         self._dummy_batch = None
         self.last_stats = {}
@@ -66,7 +67,7 @@ class Trainer:
     def _grads_ready(self, prefix):
         """Called by the engine as backward finishes a parameter group (last layer first): hand the finished,
         contiguous tail of the flat gradient buffer to the reducer, which launches RCCL on it asynchronously."""
-        if self.world <= 1 or not self._sync_grads:
+        if (self.world <= 1 and not self.dp_dry_run) or not self._sync_grads:
             return
         r = self._ranges.get(prefix)
         if r is None:
@@ -75,6 +76,18 @@ class Trainer:
             self._ranges[prefix] = r
         if r[1] > r[0]:
             self.reducer.notify(*r)
+
+    def set_dp_dry_run(self, on):
+        """One process, no collective: make the update take the DATA-PARALLEL schedule (the mid-backward weight-gradient flush of a
+        world > 1 trainer) and let the engine's readiness reports reach the reducer, whose plan / early_elems / launched list then say
+        what a rank of an N-GPU job would hand to RCCL from inside backward and what is left after it.  Bookkeeping only: with one
+        rank BucketedGradReducer issues nothing.  bench.py reports it at N = 1 (`data_parallel.dry_run`)."""
+        assert self.world == 1
+        self.dp_dry_run = bool(on)
+        eng = self.model.engine
+        if getattr(eng, "defer_wgrad", False):
+            eng.wgrad_flush_layers = max(1, self.model.hp.enc_layers // 2) if on else None
+        self._ranges = {}
 
     def _prepare_sample(self, sample):
         """trainer.py:631-653 + host-side statistics taken BEFORE the copy (no device round trip later)."""

@@ -73,7 +73,10 @@ int s2t_augment(const float* x, float* out, const int* row_map, const int* fmask
 int s2t_host_batch_by_size(const long long* indices, long long n, const long long* lens, long long max_tokens,
                            long long max_sentences, int bsz_mult, long long* out_flat, long long* out_offsets,
                            long long* n_batches);
-int s2t_abi_version(void);                       /* bumps when a signature changes */
+int s2t_abi_version(void);                       /* bumps when a signature OR a workspace contract changes.  8 (round 5): s2t_ctc_loss's la / lb
+                                                  * workspaces are B*T*S2T_CTC_ROW(Lmax) floats holding log2 values with per-step offsets
+                                                  * (a phase-1 workspace of a version-7 library is unusable by a version-8 phase 2);
+                                                  * the "gemm4w" option of s2t_set_option is gone */
 const char* s2t_build_info(void);                /* "gfx950 <date> ..." */
 
 /* ---- GEMM with fused epilogue (MFMA) --------------------------------------------------------
@@ -142,7 +145,13 @@ int s2t_attn_fwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
                  const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
                  const void* V, long v_st, long v_sb, void* O, long o_st, long o_sb, float* LSE,
                  const int* klen, int causal, int dist_penalty, float scale, float p_drop, unsigned long long seed, void* stream);
-/* Backward of the above (flash-style recomputation; Delta [B][H][Tq] f32 is workspace). */
+/* Head-averaged attention probabilities of ONE layer, recomputed from its q and k (the fused kernels never materialise P):
+ * out[b][tq][tk] = mean over the first heads_used heads of softmax_tk(scale * q . k), 0 past klen[b]; f32 [B][Tq][Tk], Tk <= 2048.
+ * Replaces the need_attn / need_head_weights return of fairseq/modules/multihead_attention.py:342-355 as consumed by
+ * fairseq/models/transformer.py:756-782 (alignment_layer / alignment_heads; generate.py --print-alignment, ensemble averaging). */
+int s2t_attn_probs_avg(int dtype, int head_dim, int B, int H, int Tq, int Tk, const void* Q, long q_st, long q_sb,
+                       const void* K, long k_st, long k_sb, const int* klen, int heads_used, float scale, float* out, void* stream);
+/* Backward of s2t_attn_fwd (flash-style recomputation; Delta [B][H][Tq] f32 is workspace). */
 int s2t_attn_bwd(int dtype, int head_dim, int B, int H, int Tq, int Tk,
                  const void* Q, long q_st, long q_sb, const void* K, long k_st, long k_sb,
                  const void* V, long v_st, long v_sb, const void* O, long o_st, long o_sb,
@@ -293,6 +302,15 @@ int s2t_embed_fwd(int dtype, const long long* tokens, const void* W, const float
                   int B, int L, int D, float scale, int pad, int pos_offset, void* stream);
 /* f32 log-probabilities of one decoding step (fairseq/sequence_generator.py:711-768) */
 int s2t_log_softmax(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream);
+/* The model's get_normalized_probs for criteria that work on (log-)probabilities themselves (fairseq/models/fairseq_decoder.py:58-79,
+ * fairseq/models/fairseq_model.py:46-74: utils.log_softmax / utils.softmax of logits.float(); the three criteria of the S2T recipes use
+ * the fused loss kernels instead).  s2t_softmax_probs: out = softmax(logits * inv_temperature) in f32.  s2t_softmax_bwd: the gradient of
+ * either form w.r.t. the logits, from the saved OUTPUT `out` and its gradient `dout` (both f32 [rows][V], dense):
+ *   log_probs = 1:  dlogits = it * (dout - exp(out) * sum_v dout)        log_probs = 0:  dlogits = it * out * (dout - sum_v dout * out)
+ * written in `dtype` with row stride ld. */
+int s2t_softmax_probs(int dtype, const void* logits, float* out, long rows, int V, int ld, float inv_temperature, void* stream);
+int s2t_softmax_bwd(int dtype, const float* out, const float* dout, void* dlogits, long rows, int V, int ld, float inv_temperature,
+                    int log_probs, void* stream);
 /* ensemble of n <= 8 models (fairseq/sequence_generator.py:757-768 EnsembleModel.forward_decoder): out = logsumexp_j lprobs[j] - log n,
  * element-wise over numel f32 values; `lprobs` is a HOST array of n device pointers */
 int s2t_ensemble_lse(int n, const float* const* lprobs, float* out, size_t numel, void* stream);

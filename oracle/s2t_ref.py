@@ -176,7 +176,7 @@ def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
 
 
 # ------------------------------------------------------------------ attention (a7, a13)
-def mha(W, pfx, heads, query, key, key_padding_mask=None, causal=False, dist_penalty=False):
+def mha(W, pfx, heads, query, key, key_padding_mask=None, causal=False, dist_penalty=False, probs_out=None):
     """fairseq/modules/multihead_attention.py:108-366 / F.multi_head_attention_forward
     (Appendix B1): q,k,v projections with bias, q * d^-1/2, -inf on padded keys and
     above the diagonal (causal), softmax in fp32, P.V, out-projection.
@@ -202,6 +202,10 @@ def mha(W, pfx, heads, query, key, key_padding_mask=None, causal=False, dist_pen
         dist = (torch.arange(Tq).unsqueeze(1) - torch.arange(Tk).unsqueeze(0)).abs().float()
         s = s - torch.max(torch.zeros_like(dist), torch.log(dist)).unsqueeze(0)
     p = F.softmax(s.float(), dim=-1)
+    if probs_out is not None:
+        # need_weights / need_head_weights (multihead_attention.py:342-355): the softmax output (before dropout) as
+        # (heads, B, Tq, Tk); the decoder averages the first `alignment_heads` of them (transformer.py:772-777)
+        probs_out.append(p.view(B, heads, Tq, Tk).transpose(0, 1))
     o = torch.bmm(p, v).transpose(0, 1).contiguous().view(Tq, B, D)
     return F.linear(o, W[pfx + "out_proj.weight"], W[pfx + "out_proj.bias"])
 
@@ -279,8 +283,9 @@ def encoder_forward(W, cfg, src_tokens, src_lengths, training=False, trace=None,
 
 
 # ------------------------------------------------------------------ decoder (a12, a13)
-def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="decoder."):
-    """TransformerDecoder.forward, fairseq/models/transformer.py:636-790 (training path)."""
+def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="decoder.", attn_layer=None, attn_heads=None):
+    """TransformerDecoder.forward, fairseq/models/transformer.py:636-790 (training path).  attn_layer: also return the
+    encoder-attention weights of that layer averaged over its first attn_heads heads, (B, L, Ts) (:756-782) -> (logits, attn)."""
     act = act_fn(cfg["act"])
     D = cfg["D"]
     pad = cfg["pad"]
@@ -293,6 +298,7 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
     self_pad = prev_output_tokens.eq(pad)
     self_pad = self_pad if bool(self_pad.any()) else None                     # :739-741
     pre = cfg["dec_pre_ln"]
+    attn = None
     dkeep = cfg.get("dec_keep")           # --decoder-layerdrop (fairseq/modules/layer_drop.py:39-44)
     for l in range(cfg["dec_layers"]):
         if dkeep is not None and not dkeep[l]:
@@ -307,7 +313,10 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
         r = x
         if pre:
             x = layer_norm(W, p + "encoder_attn_layer_norm.", x)
-        x = r + mha(W, p + "encoder_attn.", cfg["heads"], x, enc_out, enc_pad_mask)
+        probs = [] if l == attn_layer else None
+        x = r + mha(W, p + "encoder_attn.", cfg["heads"], x, enc_out, enc_pad_mask, probs_out=probs)
+        if probs:
+            attn = probs[0][:attn_heads].mean(dim=0) if attn_heads is not None else probs[0].mean(dim=0)
         if not pre:
             x = layer_norm(W, p + "encoder_attn_layer_norm.", x)
         r = x
@@ -322,7 +331,8 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
     # :784-788; --share-decoder-input-output-embed: the projection's weight is the embedding table itself
     # (fairseq/models/transformer.py:618-624), so its state dict need not carry a second copy
     w_out = W.get(pfx + "output_projection.weight")
-    return F.linear(x, w_out if w_out is not None else W[pfx + "embed_tokens.weight"])
+    logits = F.linear(x, w_out if w_out is not None else W[pfx + "embed_tokens.weight"])
+    return logits if attn_layer is None else (logits, attn)
 
 
 # ------------------------------------------------------------------ generation (a22)

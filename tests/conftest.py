@@ -10,6 +10,7 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: diagnostic reproducers that need extra builds (run with S2T_SLOW=1; tools/ runs them)")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -19,6 +20,11 @@ def pytest_collection_modifyitems(config, items):
         has_gpu = torch.cuda.is_available()
     except Exception:
         has_gpu = False
+    if not os.environ.get("S2T_SLOW"):
+        slow = pytest.mark.skip(reason="slow diagnostic (S2T_SLOW=1 runs it)")
+        for it in items:
+            if "slow" in it.keywords:
+                it.add_marker(slow)
     if has_gpu:
         return
     skip = pytest.mark.skip(reason="no GPU visible")

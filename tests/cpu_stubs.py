@@ -121,7 +121,7 @@ class ToyEngine:
         self.A.g("encoder.fc3.weight").add_(w.grad)
         self._ready("encoder.")
 
-    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None):
+    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None, attn_layer=None, attn_heads=None):
         self.calls.append(("decoder_forward", bool(training), int(seed)))
         B, L = prev_tokens.shape
         with torch.enable_grad():
@@ -296,7 +296,7 @@ class OracleTrainEngine(OracleEngine):
         self._harvest(leaves, "encoder.")
 
     # -- decoder
-    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None):
+    def decoder_forward(self, prev_tokens, enc_out, enc_klen32, training, seed=0, pfx="decoder.", keep=None, attn_layer=None, attn_heads=None):
         self.calls.append(("decoder_forward", bool(training), int(seed)))
         B, L = prev_tokens.shape
         mask = None
@@ -305,9 +305,16 @@ class OracleTrainEngine(OracleEngine):
         with torch.enable_grad():
             leaves, W = self._weights((pfx,))
             eo = enc_out.detach().clone().requires_grad_(True)
-            logits = s2t_ref.decoder_forward(W, dict(self.cfg, dec_keep=keep), prev_tokens, eo, mask, pfx=pfx)   # (B, L, V)
+            logits = s2t_ref.decoder_forward(W, dict(self.cfg, dec_keep=keep), prev_tokens, eo, mask, pfx=pfx, attn_layer=attn_layer,
+                                             attn_heads=attn_heads)   # (B, L, V)
+            attn = None
+            if attn_layer is not None:
+                logits, attn = logits
             tm = logits.transpose(0, 1).reshape(L * B, -1)
-        return tm.detach(), dict(graph=(tm, leaves, eo), Ts=enc_out.shape[0], B=B, pfx=pfx)
+        ctx = dict(graph=(tm, leaves, eo), Ts=enc_out.shape[0], B=B, pfx=pfx)
+        if attn is not None:
+            ctx["attn"] = attn.detach().float()
+        return tm.detach(), ctx
 
     def decoder_backward(self, ctx, dlogits, denc=None):
         tm, leaves, eo = ctx["graph"]
@@ -336,7 +343,11 @@ class OracleTrainEngine(OracleEngine):
         if st["klen"] is not None:
             mask = torch.arange(enc.shape[0])[None, :] >= st["klen"][:, None].long()
         with torch.no_grad():
-            logits = s2t_ref.decoder_forward(self.W_gen, self.cfg, st["toks"], enc, mask, pfx=st["pfx"])
+            logits = s2t_ref.decoder_forward(self.W_gen, self.cfg, st["toks"], enc, mask, pfx=st["pfx"], attn_layer=st.get("attn_layer"),
+                                             attn_heads=st.get("attn_heads"))
+            if st.get("attn_layer") is not None:
+                logits, attn = logits
+                st["attn"] = attn[:, -1:, :].float()
         st["steps"] += 1
         return logits[:, -1, :].detach()
 

@@ -961,7 +961,51 @@ def run_layerdrop_case():
     np.savez_compressed(os.path.join(OUT, "layerdrop.npz"), **out)
 
 
+def run_attn_case():
+    """Round 5: the decoder's returned attention (fairseq/models/transformer.py:756-782: head-averaged encoder-attention weights of
+    `alignment_layer`, default the last layer) on the model_a / model_b inputs in eval mode, and the `attention` the reference's
+    SequenceGenerator attaches to its hypotheses (sequence_generator.py:286-292,510-560) on generate.npz case a."""
+    from fairseq.sequence_generator import SequenceGenerator
+    out = {}
+    for name, (D, H, Ff, EL, DL, ctc_layer, compress, lens, tgt_lens, tr_lens, seed) in {
+            "model_a": (64, 2, 128, 3, 2, 2, True, [61, 50, 37], [7, 5, 6], [6, 4, 5], 100),
+            "model_b": (128, 2, 256, 2, 1, 1, True, [45, 45], [6, 6], [5, 5], 200)}.items():
+        args, task, model, crit, V_src, V_tgt = build(name, D, H, Ff, EL, DL, ctc_layer, compress)
+        blank = task.source_dictionary.index("<ctc_blank>")
+        cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer if compress else 0)
+        W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+        load_weights(model, crit, W)
+        sample = to_ref_sample(make_sample(seed + 1, lens, tgt_lens, tr_lens, V_src, V_tgt, blank))
+        model.eval()
+        with torch.no_grad():
+            eo = model.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+            _, extra = model.decoder(sample["net_input"]["prev_output_tokens"], encoder_out=eo)
+            _, extra0 = model.decoder(sample["net_input"]["prev_output_tokens"], encoder_out=eo, alignment_layer=0, alignment_heads=1)
+        out[name + "_attn_last"] = extra["attn"][0].float().numpy()
+        out[name + "_attn_l0h1"] = extra0["attn"][0].float().numpy()
+        print(name, "attn", out[name + "_attn_last"].shape, float(out[name + "_attn_last"].sum(-1).mean()))
+    # the generator's attention (generate.npz case a: same build, seed and sample as run_generate_case)
+    m = dict(D=64, H=2, Ff=128, EL=3, DL=2, ctc_layer=2, compress=True, seed=600, lens=[61, 50, 37])
+    g = dict(beam_size=5, max_len_a=0, max_len_b=12, min_len=1)
+    args, task, model, criterion, V_src, V_tgt = build("gena", m["D"], m["H"], m["Ff"], m["EL"], m["DL"], m["ctc_layer"], m["compress"],
+                                                       criterion=("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy"))
+    cfg = s2t_ref.default_cfg(D=m["D"], heads=m["H"], ffn=m["Ff"], enc_layers=m["EL"], dec_layers=m["DL"], ctc_layer=m["ctc_layer"])
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), m["seed"])
+    W["decoder.output_projection.weight"][2] *= 4.0
+    load_weights(model, criterion, W)
+    sample = to_ref_sample(make_sample(m["seed"] + 1, m["lens"], [4] * 3, [3] * 3, V_src, V_tgt, V_src - 1))
+    model.eval()
+    hyps = SequenceGenerator([model], task.target_dictionary, **g).generate([model], sample)
+    for b, hs in enumerate(hyps):
+        for i, h in enumerate(hs[:2]):
+            out["gen_a_attn_%d_%d" % (b, i)] = h["attention"].float().numpy()          # src_len x tgt_len
+            out["gen_a_tokens_%d_%d" % (b, i)] = h["tokens"].numpy()
+    np.savez_compressed(os.path.join(OUT, "attn.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "attn":
+        run_attn_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "generate_ext":
         run_generate_ext_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "layerdrop":

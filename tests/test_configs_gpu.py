@@ -47,8 +47,10 @@ def build(arch, dtype, criterion="ctc_multi_loss", seed=11, dual=False, ctc_laye
     from fbk_fairseq_st_amd.data import Dictionary
     from fbk_fairseq_st_amd.registry import apply_arch, namespace
     is_ctc = criterion == "ctc_multi_loss"
-    a = namespace(arch=arch, criterion=criterion, label_smoothing=0.1, input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0,
-                  activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False, no_attn_2d=True, max_target_positions=1000, **over)
+    kw = dict(arch=arch, criterion=criterion, label_smoothing=0.1, input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0,
+              activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False, no_attn_2d=True, max_target_positions=1000)
+    kw.update(over)
+    a = namespace(**kw)
     if is_ctc:
         a.underlying_criterion, a.ctc_compress_out, a.ctc_encoder_layer, a.ctc_weight = "label_smoothed_cross_entropy", True, ctc_layer, 1.0
     apply_arch(a)
@@ -280,6 +282,59 @@ def test_cfg3_m_ctc_compression_T1500(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_cfg3_m_ctc_compression_ragged(dtype):
     check_ctc_multi_loss("s2t_transformer_m", dtype, B=3, T=1500, L=40, lengths=[1500, 1210, 777], seed=4)
+
+
+def test_cfg3_m_bf16_gemm256_route():
+    """The route the bench is timed on, against the oracle (parity 1): s2t_transformer_m at 16 x 1500 frames = 6,000 encoder
+    tokens in bf16, with the 256-wide kernel's tile threshold lowered ("gemm256_min_tiles": the measurement option of the library) so
+    that EVERY encoder product of the layer calls -- csrc/layer.hip -> gemm256 with its 1-bit ReLU record (fc1) and the record-reading
+    data gradient (fc2), the residual / accumulate epilogues -- and the grouped weight-gradient launch run as they do at 64 x 1500.
+    Same tolerances and tripwire as the small bf16 cases; the launch counts of the profiling families prove the route."""
+    from fbk_fairseq_st_amd import kernels as K
+    old = K.set_option("gemm256_min_tiles", 32)
+    try:
+        assert K.relu_mask_bytes(16 * 375, 2048, 512) > 0
+        K.prof_reset(); K.prof_enable(1)
+        check_ctc_multi_loss("s2t_transformer_m", torch.bfloat16, B=16, T=1500, L=40, lengths=None, seed=21)
+        torch.cuda.synchronize()
+        fam = {f: K.prof_read(f)["launches"] for f in ("gemm256_nt", "gemm256_nn", "wgrad_group")}
+    finally:
+        K.prof_enable(0)
+        K.set_option("gemm256_min_tiles", old)
+    print("MEASURED gemm256 route launches:", fam)
+    # 12 encoder layers x (qkv, out, fc1, fc2) forward (the layers behind the compression see fewer tokens, still above the lowered
+    # threshold) + fc3 / CTC head; their data gradients; two grouped weight-gradient launches
+    assert fam["gemm256_nt"] >= 40 and fam["gemm256_nn"] >= 40 and fam["wgrad_group"] >= 2, fam
+
+
+def test_cfg3_m_bf16_gemm256_route_equals_the_128_wide_route_with_dropout():
+    """the same 16 x 1500 batch with the preset's dropout ON, once through gemm256 (masked epilogues, 1-bit record) and once with the
+    256-wide kernel switched off: both routes run the same MFMA instruction over K in the same order and draw the same dropout masks,
+    so loss, CTC lengths and encoder output are IDENTICAL and the parameter gradients agree to the order of f32 atomics"""
+    from fbk_fairseq_st_amd import kernels as K
+
+    def run(g256):
+        old = (K.set_option("gemm256_min_tiles", 32), K.set_option("gemm256", g256))
+        try:
+            a, task, model, crit, cfg, W = build("s2t_transformer_m", torch.bfloat16, dropout=0.1, attention_dropout=0.1, activation_dropout=0.1)
+            sample = batch(task, 16, 1500, 40, 40, 22, None)
+            model.train(); crit.train()
+            model.set_num_updates(3) if hasattr(model, "set_num_updates") else None
+            model.arena.zero_grad()
+            loss, ss, log = crit(model, to_dev(sample))
+            loss.backward()
+            torch.cuda.synchronize()
+            last = model.encoder._last
+            return (float(loss), [int(v) for v in last["lengths_host"]], float(log["ctc_loss"]), float(log["nll_loss"]),
+                    {n: model.arena.g(n).detach().float().cpu().clone() for n in model.arena.slices})
+        finally:
+            K.set_option("gemm256_min_tiles", old[0]); K.set_option("gemm256", old[1])
+    l1, len1, c1, n1, g1 = run(1)
+    l0, len0, c0, n0, g0 = run(0)
+    assert len1 == len0 and l1 == l0 and c1 == c0 and n1 == n0, (l1, l0, c1, c0, n1, n0)
+    worst = max((float((g1[k] - g0[k]).norm()) / max(float(g0[k].norm()), 1e-12), k) for k in g0 if float(g0[k].norm()) > 0)
+    print("MEASURED gemm256 vs 128-wide route with dropout: identical loss %.6f, worst gradient difference %.2e (%s)" % (l1, worst[0], worst[1]))
+    assert worst[0] < 1e-3, worst          # f32 atomics order in the grouped weight gradients / LayerNorm parameter sums only
 
 
 def test_cfg3_m_gelu_model_level():

@@ -59,3 +59,16 @@ def test_world2_gloo_bucketed_allreduce_and_stats():
         assert launched_early >= 2, "buckets must be launched before backward ends (overlap)"
         assert stats == {"nframes": 300.0, "sample_size": 7.0}
         assert same and bad
+
+
+def test_projected_exposed_allreduce_is_plain_queueing_arithmetic():
+    """bench.py's N = 1 `data_parallel.dry_run.projection` (a labelled projection, not a measurement): buckets run back to back on one
+    RCCL stream from the moment each became launchable; what sticks out past the end of backward is exposed"""
+    from fbk_fairseq_st_amd.distributed import project_exposed_allreduce
+    # 8 ranks, 100 GB/s bus: a bucket of 25e6 f32 elements = 100 MB takes 2 * 7/8 * 1e8 / 1e11 s = 1.75 ms
+    exposed, total = project_exposed_allreduce([(25_000_000, 0.0)], finish_ms=5.0, n_ranks=8, bus_gbps=100.0)
+    assert abs(total - 1.75) < 1e-9 and exposed == 0.0                       # fully under the remaining backward
+    exposed, total = project_exposed_allreduce([(25_000_000, 0.0), (25_000_000, 1.0), (25_000_000, 4.0)], 4.0, 8, 100.0)
+    assert abs(total - 5.25) < 1e-9 and abs(exposed - (5.75 - 4.0)) < 1e-9   # 0 -> 1.75 -> 3.5, third starts at 4.0 -> 5.75
+    exposed, _ = project_exposed_allreduce([(25_000_000, 3.0)], 3.0, 2, 100.0)  # launched by finish(): all of it exposed (2 ranks: 1.0 ms)
+    assert abs(exposed - 1.0) < 1e-9

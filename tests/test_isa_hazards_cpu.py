@@ -35,19 +35,3 @@ def test_gemm256_epilogue_keeps_wide_store_data_untouched(tmp_path):
     # the checker itself: a planted hazard is found
     planted = "k:\n\tds_write_b128 v1, v[4:7]\n\tv_mov_b32_e32 v5, 0\n.Lfunc_end0:\n"
     assert isa_store_hazards.scan(planted)["k"][0] == 1
-
-
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-def test_gemm4w_epilogue_keeps_wide_store_data_untouched(tmp_path):
-    """the experimental four-wave partition (gemm4w.hip, off by default) carries the same epilogue and the same hold"""
-    import isa_store_hazards
-    out = str(tmp_path / "gemm4w.s")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I" + os.path.join(REPO, "include"),
-           "-S", "--cuda-device-only", os.path.join(REPO, "fbk_fairseq_st_amd", "csrc", "gemm4w.hip"), "-o", out]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:]
-    res = isa_store_hazards.scan(open(out).read())
-    kernels = {k: v for k, v in res.items() if "gemm4w_kernel" in k}
-    assert len(kernels) == 8, sorted(kernels)                       # 4 NT epilogue variants x 2 tile heights
-    close = {k: v for k, v in kernels.items() if v[0] is not None and v[0] < MIN_STATES}
-    assert not close, "VALU writes to wide-store data within %d states: %s" % (MIN_STATES, close)

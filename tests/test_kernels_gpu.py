@@ -4,6 +4,7 @@ Integer outputs (CTC compression) are compared bit-exactly."""
 import math
 
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -748,38 +749,36 @@ def test_gemm256_epilogues_against_the_128_wide_route_and_themselves(M, N, K_):
         K.set_option("gemm256", old)
 
 
-@pytest.mark.parametrize("M,N,K_", [(24000, 512, 2048), (6211, 1536, 512), (23000, 640, 1280), (12000, 5001, 512)])
-def test_gemm4w_experiment_equals_gemm256_bit_for_bit(M, N, K_):
-    """gemm4w.hip (the same 256 x 256 x 64 tile as four waves of 128 x 128: an experiment behind s2t_set_option("gemm4w"), off by default,
-    profiles/r04_gemm4w.txt) runs the same MFMA instruction over K in the same order and the same epilogue arithmetic as gemm256: its
-    NT variants must reproduce gemm256's output bit for bit, launch after launch."""
-    dt = torch.bfloat16
-    g = torch.Generator(device=DEV).manual_seed(M + N + K_)
-    a = torch.randn(M, K_, device=DEV, generator=g).to(dt); w = (torch.randn(N, K_, device=DEV, generator=g) * K_ ** -0.5).to(dt)
-    b = torch.randn(N, device=DEV, generator=g); r = torch.randn(M, N, device=DEV, generator=g).to(dt)
-    pre = torch.empty(M, N, device=DEV, dtype=dt)
-
-    def gelu(s):
-        y = K.gemm(a, w, bias=b, act=K.ACT_GELU, aux_out=pre, p_drop=0.1, seed=4)
-        return torch.cat([y.reshape(-1), pre.reshape(-1)])
-    if N % 8:                                           # the CTC head's 5,001 logits per row: rows padded to a multiple of 8, plain bias epilogue only
-        calls = [lambda s: K.gemm(a, w, bias=b, out=K.alloc_rows((M,), N, dt, DEV))]
-    else:
-        calls = [lambda s: K.gemm(a, w, bias=b), lambda s: K.gemm(a, w, bias=b, p_drop=0.25, seed=9 + s),
-                 lambda s: K.gemm(a, w, bias=b, residual=r, p_drop=0.1, seed=3), lambda s: K.gemm(a, w, bias=b, act=K.ACT_RELU, p_drop=0.1, seed=5), gelu]
-    old = K.set_option("gemm4w", 0)
-    try:
-        want = [[fn(rep) for fn in calls] for rep in range(2)]
-        K.set_option("gemm4w", 1)
-        for rep in range(4):
-            for i, fn in enumerate(calls):
-                got = fn(rep % 2)
-                assert torch.equal(got, want[rep % 2][i]), "variant %d, launch %d: %d of %d values differ from gemm256" % (
-                    i, rep, int((got != want[rep % 2][i]).sum()), got.numel())
-    finally:
-        K.set_option("gemm4w", old)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("log_probs", [True, False])
+def test_softmax_rows_forward_and_backward(dtype, log_probs):
+    """s2t_log_softmax / s2t_softmax_probs / s2t_softmax_bwd (get_normalized_probs with a gradient) against float64 autograd; padded rows"""
+    rows, V = 37, 1003
+    x = K.alloc_rows((rows,), V, dtype, DEV)
+    x.copy_((torch.randn(rows, V, generator=torch.Generator().manual_seed(3)) * 3).to(dtype))
+    xr = x.detach().double().cpu().requires_grad_(True)
+    ref = torch.log_softmax(xr, -1) if log_probs else torch.softmax(xr, -1)
+    gout = torch.randn(rows, V, generator=torch.Generator().manual_seed(4))
+    ref.backward(gout.double())
+    xd = x.detach().requires_grad_(True)
+    out = K.NormalizedProbs.apply(xd, log_probs)
+    assert rel_err(out, ref.detach()) < 1e-5
+    out.backward(gout.to(DEV))
+    assert rel_err(xd.grad, xr.grad) < tol(dtype)
 
 
+def test_gemm256_product_epilogues_soak_against_the_128_wide_route():
+    """tools/gemm_soak.py as a test: 200 launches of every masked / operand-reading / accumulating / 1-bit-record epilogue of the
+    SHIPPED gemm256 per shape, half of them beside a store-only kernel on a second stream (the CTC side stream of a training step),
+    each compared bit for bit with the 128-wide route -- zero differing launches (the product route's sample had been 6).
+    The 2,000-launch run of the same function is committed as profiles/r05_gemm_soak.txt"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gemm_soak
+    bad, total = gemm_soak.soak(200, shapes=[(24000, 2048, 512), (24000, 512, 512)], verbose=False)
+    assert total == 2 * 6 * 200 and bad == 0, "%d of %d launches differ from the 128-wide route" % (bad, total)
+
+
+@pytest.mark.slow
 def test_gemm256_store_data_hazard_twins():
     """Round 3 left "wrong values when the two wave groups' epilogues overlap" unexplained; this is its reproducer.  `make twins` builds
     gemm256 with a second K-loop schedule in which all eight waves -- both waves of every SIMD -- run their epilogues at the same
@@ -804,7 +803,8 @@ def test_gemm256_store_data_hazard_twins():
         env = dict(os.environ)
         if lib:
             env["S2T_HIP_LIB"] = os.path.join(pkg, lib)
-            assert os.path.exists(env["S2T_HIP_LIB"]), "run __graft_entry__.build(): it also builds the twins"
+            if not os.path.exists(env["S2T_HIP_LIB"]):
+                pytest.skip("diagnostic twins not built (make -C fbk_fairseq_st_amd/csrc twins; lib.build(twins=True))")
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_epilogue_sums.py"), str(sched)], env=env,
                              capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]

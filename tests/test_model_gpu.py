@@ -800,3 +800,88 @@ def test_beam_search_ensemble_prefix_ngram_match_reference_generator(tag):
             assert h["tokens"].tolist() == et.tolist()
             assert abs(float(h["score"]) - esc) < 1e-4
             np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), eps, atol=1e-4)
+
+
+@pytest.mark.parametrize("log_probs", [True, False], ids=["log_probs", "probs"])
+def test_get_normalized_probs_in_training_mode_is_differentiable(log_probs):
+    """fairseq/models/fairseq_decoder.py:58-79 / fairseq_model.py:46-74: a criterion of the reference other than the re-registered ones takes
+    (log-)probabilities from the model and differentiates through them.  The golden model in TRAINING mode: a plain NLL (or expected-
+    probability) objective built on get_normalized_probs, its gradients against the same objective on the CPU oracle's logits."""
+    g, cfg, W, sample, meta, model, crit = build("model_a")
+    model.train()
+    s = to_dev(sample)
+    ni = s["net_input"]
+    model.arena.zero_grad()
+    eo = model.encoder(ni["src_tokens"], ni["src_lengths"], return_all_hiddens=True)
+    net = model.decoder(ni["prev_output_tokens"], encoder_out=eo)
+    out = model.get_normalized_probs(net, log_probs=log_probs)
+    assert out.dtype == torch.float32 and out.shape == net[0].shape and out.requires_grad
+    tgt = s["target"]
+    picked = out.gather(-1, tgt.unsqueeze(-1)).squeeze(-1)
+    loss = -picked.sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle: the same objective through torch autograd on the CPU restatement
+    Wg = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in W.items()}
+    enc, _ = s2t_ref.encoder_forward(Wg, cfg, sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"], training=True)
+    logits = s2t_ref.decoder_forward(Wg, cfg, sample["net_input"]["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+    ref = torch.log_softmax(logits.float(), -1) if log_probs else torch.softmax(logits.float(), -1)
+    close(out, ref.detach().numpy(), 1e-4, "normalized probs")
+    oloss = -ref.gather(-1, sample["target"].unsqueeze(-1)).sum()
+    oloss.backward()
+    assert abs(float(loss) - float(oloss)) <= 1e-4 * max(1.0, abs(float(oloss)))
+    from fbk_fairseq_st_amd.conv_transformer import fused_to_reference
+    mine = fused_to_reference({n: model.arena.g(n).detach().float().cpu().clone() for n in model.arena.slices})
+    for k in ("decoder.output_projection.weight", "decoder.layers.0.fc1.weight", "encoder.layers.0.self_attn.q_proj.weight", "encoder.fc3.weight"):
+        a, b = mine[k], Wg[k].grad
+        assert float((a - b).norm()) <= 5e-4 * max(float(b.norm()), 1e-6), (k, float((a - b).norm()), float(b.norm()))
+
+
+@pytest.mark.parametrize("name", ["model_a", "model_b"])
+def test_decoder_returns_the_reference_attention(name):
+    """fairseq/models/transformer.py:756-782: in eval mode the decoder returns the head-averaged encoder-attention weights of its
+    last layer (B, L, Ts); with alignment_layer / alignment_heads those of another layer over its first heads.  Against the fixture
+    captured from the real reference (attn.npz).  In training mode they are computed only on request."""
+    from helpers import load_golden
+    g, cfg, W, sample, meta, model, crit = build(name)
+    ga = load_golden("attn")
+    s = to_dev(sample)
+    ni = s["net_input"]
+    model.eval()
+    with torch.no_grad():
+        eo = model.encoder(ni["src_tokens"], ni["src_lengths"])
+        logits, extra = model.decoder(ni["prev_output_tokens"], encoder_out=eo)
+        _, extra0 = model.decoder(ni["prev_output_tokens"], encoder_out=eo, alignment_layer=0, alignment_heads=1)
+        _, off = model.decoder(ni["prev_output_tokens"], encoder_out=eo, need_attn=False)
+    close(logits, g["eval_logits"], 1e-4, "logits (the alignment layer runs on the per-kernel schedule)")
+    close(extra["attn"][0], ga[name + "_attn_last"], 1e-4, "attention, last layer")
+    close(extra0["attn"][0], ga[name + "_attn_l0h1"], 1e-4, "attention, layer 0 head 0")
+    assert off["attn"][0] is None
+    model.train()
+    with torch.no_grad():
+        eo = model.encoder(ni["src_tokens"], ni["src_lengths"])
+        _, tr = model.decoder(ni["prev_output_tokens"], encoder_out=eo)
+        _, tr1 = model.decoder(ni["prev_output_tokens"], encoder_out=eo, need_attn=True)
+    assert tr["attn"][0] is None and tuple(tr1["attn"][0].shape) == ga[name + "_attn_last"].shape
+
+
+def test_generator_attention_and_alignment_match_the_reference_generator():
+    """sequence_generator.py:286-292,510-560: the `attention` (src_len x tgt_len) the reference's SequenceGenerator attaches to its
+    hypotheses, from the incremental HIP decoder with retain_attention; print_alignment adds the hard alignment (arg-max source
+    position per target token, utils.extract_hard_alignment).  Fixture attn.npz (generate.npz case a, first two hypotheses)."""
+    from helpers import load_golden
+    from fbk_fairseq_st_amd.sequence_generator import SequenceGenerator
+    ga = load_golden("attn")
+    task, model, src, lens, opts, exp, _ = build_gen("a")
+    gen = SequenceGenerator([model], task.target_dictionary, print_alignment=True, **opts)
+    hyps = gen.generate([model], dict(net_input=dict(src_tokens=src, src_lengths=lens)))
+    for b, hs in enumerate(hyps):
+        for i, h in enumerate(hs[:2]):
+            assert h["tokens"].tolist() == ga["gen_a_tokens_%d_%d" % (b, i)].tolist()
+            ref = ga["gen_a_attn_%d_%d" % (b, i)]
+            close(h["attention"], ref, 1e-4, "hypothesis attention")
+            n = h["tokens"].numel() - 1                                   # every position but EOS
+            assert [t for _, t in h["alignment"]] == list(range(n))
+            assert [s_ for s_, _ in h["alignment"]] == np.argmax(h["attention"].cpu().numpy()[:, :n], axis=0).tolist()
+    plain = SequenceGenerator([model], task.target_dictionary, **opts).generate([model], dict(net_input=dict(src_tokens=src, src_lengths=lens)))
+    assert all(h["attention"] is None for hs in plain for h in hs)

@@ -345,3 +345,22 @@ def test_beam_search_ensemble_prefix_ngram_match_reference_generator(tag):
             assert t.tolist() == et.tolist()
             assert abs(s - es_) < 1e-4
             np.testing.assert_allclose(ps.numpy(), eps, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["model_a", "model_b"])
+def test_decoder_attention_return_matches_reference(name):
+    """fairseq/models/transformer.py:756-782: the head-averaged encoder-attention weights the decoder returns (default: last layer, all
+    heads; alignment_layer = 0 with alignment_heads = 1), eval mode, against the fixture captured from the real reference (attn.npz)"""
+    from helpers import load_golden, model_case
+    g, cfg, W, sample, meta = model_case(name)
+    ga = load_golden("attn")
+    ni = sample["net_input"]
+    with torch.no_grad():
+        enc, _ = s2t_ref.encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training=False)
+        _, a_last = s2t_ref.decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask,
+                                            attn_layer=cfg["dec_layers"] - 1)
+        _, a_0 = s2t_ref.decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask, attn_layer=0, attn_heads=1)
+    for mine, key in ((a_last, "_attn_last"), (a_0, "_attn_l0h1")):
+        ref = ga[name + key]
+        assert tuple(mine.shape) == ref.shape
+        assert float((mine.float() - torch.from_numpy(ref)).abs().max()) < 1e-5, key

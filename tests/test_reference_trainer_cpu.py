@@ -231,10 +231,46 @@ def test_fixture_no_c10d_data_parallel_under_the_reference_trainer():
         assert c["plan"][2][1] is None and len(c["plan"][1]) == 4
 
 
-def test_the_arena_adam_refuses_wrappers_that_cannot_see_the_arena():
-    """--ddp-backend c10d counts autograd gradients per parameter: it would never reduce; refused by name at optimizer construction"""
-    src = open(os.path.join(REPO, "fbk_fairseq_st_amd", "fairseq_optim.py")).read()
-    assert "needs --ddp-backend no_c10d" in src
+_C10D_SCRIPT = r"""
+import sys, warnings
+sys.path.insert(0, %r)
+import make_cli_fixture as CLI
+CLI.shims()
+import cpu_stubs
+from fairseq import optim, options, tasks
+with cpu_stubs.oracle_engine():
+    a = CLI.train_argv("plugin", "/tmp/unused", "unused")
+    i = a.index("--distributed-world-size"); a[i + 1] = "2"
+    a += ["--ddp-backend", "c10d"]
+    args = options.parse_args_and_arch(options.get_training_parser(), input_args=a)
+    assert args.ddp_backend == "c10d"
+    task = tasks.setup_task(args)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        model = task.build_model(args)
+    assert args.ddp_backend == "no_c10d", args.ddp_backend                  # degraded before fairseq's trainer wraps the model
+    assert any("no_c10d" in str(x.message) for x in w), [str(x.message) for x in w]
+    crit = task.build_criterion(args)
+    params = [p for p in list(model.parameters()) + list(crit.parameters()) if p.requires_grad]
+    args.ddp_backend = "c10d"                                               # somebody forces it back: the optimizer refuses by name
+    try:
+        optim.build_optimizer(args, params)
+    except ValueError as e:
+        assert "no_c10d" in str(e)
+        print("C10D-OK")
+    else:
+        raise SystemExit("FairseqAdam accepted --ddp-backend c10d")
+"""
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+def test_c10d_is_degraded_at_model_build_and_refused_by_the_arena_adam():
+    """--ddp-backend c10d (fairseq's default) counts autograd gradients per parameter and would never reduce the arena: building the
+    plug-in model under the reference's parser moves the run to no_c10d with a warning; an optimizer built with c10d forced back
+    raises (the refusal is now exercised, not grepped for)"""
+    r = subprocess.run([sys.executable, "-c", _C10D_SCRIPT % os.path.join(HERE, "golden")], env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, cwd=HERE)
+    assert r.returncode == 0 and "C10D-OK" in r.stdout, r.stdout[-3000:]
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")

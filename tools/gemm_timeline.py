@@ -9,10 +9,11 @@ g = torch.Generator(device="cuda").manual_seed(0)
 a = torch.randn(24000, Kd, device="cuda", generator=g).to(torch.bfloat16)
 w = (torch.randn(N, Kd, device="cuda", generator=g) * Kd ** -0.5).to(torch.bfloat16)
 dbg = torch.zeros(24000, N, dtype=torch.bfloat16, device="cuda")          # aux_out-shaped; the first 8 KiB receive the stamps
+bias = torch.randn(N, device="cuda", generator=g) if len(sys.argv) > 3 else None      # third argument: with a bias vector
 for _ in range(3):
-    K.gemm(a, w)
+    K.gemm(a, w, bias=bias)
 dbg.zero_()
-K.gemm(a, w, aux_out=dbg)
+K.gemm(a, w, bias=bias, aux_out=dbg)
 torch.cuda.synchronize()
 st = dbg.view(-1)[:16384].view(torch.int64).cpu()
 for grp in (0, 1):
@@ -39,3 +40,14 @@ for grp in (0, 1):
     print("  dma:  ", (m[:n, 2] - m[:n, 1]).tolist()[:16])
     print("  mem start -> mfma start:", (c[:n, 0] - m[:n, 0]).tolist()[:16])
     print("  prev mfma end -> mem start:", (m[1:n + 1, 0] - c[:n, 1]).tolist()[:16])
+
+# epilogue stamps (round 5): e0 K-loop end, e1 early staging issued, e2 addressing / bias done, (e3 unused),
+# e4 all steps issued, e5 drain stores issued, e6 next tile's offsets computed (loop top)
+names = ["early-stage", "setup", "all steps", "drain", "next offsets"]
+for grp in (0, 1):
+    e = st[2048 + grp * 256: 2048 + grp * 256 + 64].view(-1, 8)[:, :7]
+    e = e[(e[:, 0] > 0) & (e[:, 5] > 0)]
+    for row in e.tolist()[:3]:
+        row = row[:3] + row[4:]
+        d = [row[i + 1] - row[i] for i in range(5)]
+        print("group %d epilogue: total %d cycles | " % (grp, row[5] - row[0]) + ", ".join("%s %d" % (n, v) for n, v in zip(names, d)))

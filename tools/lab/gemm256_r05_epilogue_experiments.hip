@@ -1,3 +1,11 @@
+// ARCHIVED lab code (round 5), not built and not part of libs2t_hip.so: gemm256.hip with the round's epilogue experiments compiled
+// in behind macros.  What each one measured is in DESIGN.md section 6 ("gemm256, round 5") and profiles/r05_gemm256_epilogue.txt:
+//   S2T_EARLY        the h1 halves of the next tile's K-tile 1 staged BEFORE the epilogue + a relaxed first counted wait       = (356 vs 356 us)
+//   S2T_TURN_DEPTH   lane-turn pipeline 2 / 3 / 4 steps deep (ring of read-back quads)                                         = / -1..-3 %
+//   S2T_BIAS_LDS     the tile's bias / 1-bit record by LDS-DMA under the last K-tile (no vmcnt(0) at the epilogue's head)      MT = 8 spills: -10..-30 %
+//   S2T_EPX          timing-only twins: no global stores (-11 %), no LDS turn (-4 %), neither (-18 %), no hold nops (-2 %)
+//   S2T_ST_AUX       sc1 / nt / sc0 sc1 cache policy on the C stores (gemm_tile.hpp)                                           -1 % / +1 % / -1 %
+// Kept for the record; the product kernel is round 4's (its device code is byte-identical to round 4's build).
 // 256 x 256 x 64 MFMA GEMM for the big bf16 products of the Transformer blocks (M = tokens of the batch):
 //   NT  Y  = epi(X  . W^T)   X [M][K], W [N][K]      forward projections / FFN      (F.linear, multihead_attention.py:190-208,
 //   NN  dX = epi(dY . W)     dY [M][K], W [K][N]      their data gradients            transformer_layer.py:132-134 + autograd)
@@ -49,6 +57,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     constexpr int QM = MT / 2;                       // row tiles of one phase's quadrant (4 / 3)
     constexpr int HR = 16 * QM;                      // rows a wave group owns in one A half-tile (64 / 48)
     constexpr int BM = 4 * HR, BN = 256;
+#ifndef S2T_EARLY
+#define S2T_EARLY 1
+#endif
+#ifndef S2T_BIAS_LDS
+#define S2T_BIAS_LDS 1              /* the tile's bias values (and the 1-bit record a data gradient reads) arrive by LDS-DMA under the last K-tile */
+#endif
+#ifndef S2T_EPX
+#define S2T_EPX 0                   /* timing-only twins of the epilogue: bit 0 no global stores, bit 1 no LDS turn, bit 2 no hold nops */
+#endif
+#ifndef S2T_TURN_DEPTH
+#define S2T_TURN_DEPTH 4            /* LDS slots (1 KiB each) of a wave's lane turn = epilogue steps in flight between write and store */
+#endif
+    constexpr int NST = 4 * QM + (ACT == ACT_RELU_MASK ? 1 : 0);       // vector stores of one epilogue (S2T_WAIT_ROLLED)
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, tiles = tiles_m * tiles_n;
     const int G = gridDim.x;
     int tile = xcd_remap(blockIdx.x, G);             // then tile += G: every round is a contiguous run of tiles, an XCD's share contiguous inside it
@@ -135,6 +156,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // segment (A-h0, B-h0 of K-tile t+2: 4 DMA instructions, 3 for a wave that stages one A piece) may still be in flight, so all of
     // K-tile t+1 has landed
 #define S2T_WAIT_TILE() do { if (a_two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); } while (0)
+    // K-tile 0 of a tile that follows another one in this workgroup (S2T_EARLY): its h1 halves of K-tile 1 were staged BEFORE the
+    // previous tile's epilogue, so the wait that retires K-tile 1 may leave the epilogue's stores in flight as well: everything
+    // issued after that early staging = NST stores (the C quads, the 1-bit record; the GELU pre-activation stores, present only with
+    // aux_out, are not counted: an under-count waits for more, never for less) + this segment's DMA instructions.  vmcnt retires
+    // in issue order, so without this the first counted wait of a tile waited for the acknowledgement of the whole store burst.
+#define S2T_WAIT_ROLLED() do { if (a_two) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST + 4) : "memory"); \
+                               else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST + 3) : "memory"); } while (0)
     // SCHED 1: per K-tile a wave issues G1 = A-h0, B-h0, B-h1 (6 DMA instructions, 5 for a wave with one A piece) and G2 = A-h1 (2 / 1);
     // both of its waits leave exactly one G1 and one G2 in flight (see the schedule below)
 #define S2T_WAIT_PIPE() do { if (a_two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } while (0)
@@ -192,8 +220,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         if (lane == 0) { DBG[1024 + (wave >> 2) * 512 + 3 * dbg_n] = tm0_; DBG[1024 + (wave >> 2) * 512 + 3 * dbg_n + 1] = tm1_;  \
                          DBG[1024 + (wave >> 2) * 512 + 3 * dbg_n + 2] = tm2_; }                             \
     }
-    // epilogue stamps (round 5): six s_memtime values per tile boundary, collected in SGPRs and written at the next loop top (the
-    // counted lgkmcnt waits hipcc places in the epilogue do not know about them: TIMING ONLY, a stamped build's results are not valid)
+    // epilogue stamps: seven s_memtime values per tile boundary, collected in SGPRs and written at the next loop top (the counted
+    // lgkmcnt waits hipcc places in the epilogue do not know about them: TIMING ONLY, the results of a stamped build are not valid)
     unsigned long long es_[7] = {0, 0, 0, 0, 0, 0, 0};
     int ep_n = 0;
 #define S2T_ES(I_) if (dbg_on) asm volatile("s_memtime %0" : "=s"(es_[I_]) :: "memory");
@@ -257,7 +285,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     // the data registers of a tile's last two 16-byte stores (the last C quad, the 1-bit record): held over the loop's back edge until
     // the next tile's offset arithmetic is done -- they are dead after the epilogue and would otherwise be the first registers that
     // arithmetic writes, within a few cycles of the stores (store-data hazard: see the epilogue's ring)
+    // bias / 1-bit record of a tile through this wave's (idle) lane-turn slots: see the LAST K-tile and the epilogue
+    constexpr bool MOUT = ACT == ACT_RELU_MASK, MIN = ACT == ACT_RELU_BWD_MASK;
+    const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(p.bias ? const_cast<float*>(p.bias) : reinterpret_cast<float*>(p.C), 0,
+                                                                            p.bias ? p.N * 4 : 0, 0x00020000);
+    const void* recp = MIN ? p.aux : MOUT ? (const void*)p.aux_out : (const void*)p.C;
+    const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(recp), 0, (MIN || MOUT) ? tiles * 8192 : 0, 0x00020000);
     u32x4 tail_c = {0u, 0u, 0u, 0u}, tail_m = {0u, 0u, 0u, 0u};
+    bool rolled = false;                                                // this tile's K-tile 1 h1 halves were staged before the previous epilogue
     for (;;) {
         has_next = tile + G < tiles;
         if (has_next) offsets(tile + G, nxt);
@@ -266,15 +301,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         asm volatile("" :: "v"(tail_c[0]), "v"(tail_c[1]), "v"(tail_c[2]), "v"(tail_c[3]),
                            "v"(tail_m[0]), "v"(tail_m[1]), "v"(tail_m[2]), "v"(tail_m[3]) : "memory");
 #endif
-        auto ktile = [&](int t, auto first_tag) {
+        auto ktile = [&](int t, auto first_tag, auto rolled_tag, auto last_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;           // the tile's last K-tile also fetches what its epilogue reads first
+            constexpr bool ROLLED = decltype(rolled_tag)::value;       // K-tile 0 behind another tile: SPa's half-tiles are already on their way
             const char* buf = smem + ((sbase + t) & 1) * BUF;
             // SPa: quadrants (A-h0 x B-h0), (A-h0 x B-h1).  The B-h1 fragments are read at the head of the MFMA cluster (their latency
             // hides under the first quadrant's MFMAs).  Re-stage, in the OTHER buffer: A-h1 (last read in SPb of K-tile t-1, reads
             // returned before that segment's barrier) and B-h1 (last read in the MFMA cluster of SPa of K-tile t-1) with K-tile t+1.
             S2T_MT(tm0_) readBs(buf, 0, 0); readAs(buf, 0, 0); readBs(buf, 0, 1); readAs(buf, 0, 1);
             if constexpr (TB) { readBs(buf, 1, 0); readBs(buf, 1, 1); }    // transposed reads: two instructions per fragment, kept out of the MFMA cluster
-            S2T_MT(tm1_) stageA(1, t + 1); stageB(1, t + 1);
+            S2T_MT(tm1_) if constexpr (!ROLLED) { stageA(1, t + 1); stageB(1, t + 1); }
             S2T_MT(tm2_) S2T_MEM_END()
             S2T_READS_DONE();
             S2T_BAR();
@@ -284,10 +321,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             // SPb: quadrants (A-h1 x B-h1), (A-h1 x B-h0) on the B fragments still in registers.  Re-stage, in THIS buffer: A-h0 and B-h0
             // (read in SPa's memory segment just before: returned before its barrier) with K-tile t+2.
             S2T_MT(tm0_) readAs(buf, 1, 0); readAs(buf, 1, 1);
+            if constexpr (LAST && S2T_BIAS_LDS) {
+                // The epilogue's first operands by LDS-DMA into this wave's own lane-turn slots (idle until the epilogue): the 64 bias
+                // values of the wave's columns (one dword per lane: [pair][32 columns]) and, for the data gradient through the 1-bit
+                // ReLU record, the wave's 1 KiB of it.  Issued BEFORE this segment's half-tiles, so the counted wait below retires
+                // them (vmcnt retires in issue order) and the wave's own wait is all a read of its own DMA needs.  As register loads
+                // at the top of the epilogue they cost it a vmcnt(0) -- hipcc cannot count past the LDS-DMA builtins -- i.e. the full
+                // latency of the next tile's prefetch, with the matrix cores idle.
+                char* tb = smem + __builtin_amdgcn_readfirstlane(2 * BUF + wave * (S2T_TURN_DEPTH * 1024));
+                if (p.bias) {
+                    const int colb = min((tile % tiles_n) * BN + wc * 32 + (lane >> 5) * 128 + (lane & 31), p.N - 1);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, (lds_void*)tb, 4, (uint32_t)colb * 4u, 0, 0, 0);
+                }
+                if constexpr (MIN)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rRec, (lds_void*)(tb + 1024), 16, ((uint32_t)tile * 512u + threadIdx.x) * 16u, 0, 0, 0);
+            }
             S2T_MT(tm1_) stageA(0, t + 2); stageB(0, t + 2);
             S2T_MT(tm2_) S2T_MEM_END()
             S2T_READS_DONE();
-            S2T_WAIT_TILE();
+            if constexpr (ROLLED) S2T_WAIT_ROLLED(); else S2T_WAIT_TILE();
             S2T_BAR();
             S2T_MMA2(1, 1, 0);
             S2T_BAR();
@@ -373,8 +425,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #undef S2T_STAGE
         };
         if constexpr (SCHED == 0) {
-        ktile(0, std::true_type{});
-        for (int t = 1; t < nk; ++t) ktile(t, std::false_type{});
+        if (rolled) ktile(0, std::true_type{}, std::true_type{}, std::false_type{}); else ktile(0, std::true_type{}, std::false_type{}, std::false_type{});
+        for (int t = 1; t < nk - 1; ++t) ktile(t, std::false_type{}, std::false_type{}, std::false_type{});
+        ktile(nk - 1, std::false_type{}, std::false_type{}, std::true_type{});               // nk >= 2 (host check)
         } else {
         {   // the tile's first fragments: K-tile 0 is visible (prologue barrier, or B2 of the tile before)
             const char* buf = smem + (sbase & 1) * BUF;
@@ -390,7 +443,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         // a 16-byte chunk); not understood.  With one epilogue per SIMD at a time it does not happen: tools/gemm_turn_check.py holds
         // this arrangement to a twin built with -DS2T_NOTURN bit for bit
         __builtin_amdgcn_sched_barrier(0);
-        S2T_ES(0) S2T_ES(1)
+        S2T_ES(0)
+        bool early = false;
+        if constexpr (SCHED == 0 && S2T_EARLY) {
+            // The h1 halves of the buffer the tile's last K-tile lived in are free from here on: A-h1 was last read in the memory
+            // segment of this K-tile's SPb (every wave's reads returned before the barrier that ended it; this wave has since run
+            // its MFMA cluster behind another barrier), B-h1 at the head of SPa's cluster.  Stage K-tile 1 of the next tile there
+            // NOW -- SPa of its K-tile 0 would do it, but only behind this epilogue's stores in the in-order vmcnt queue.
+            if (has_next) { stageA(1, nk + 1); stageB(1, nk + 1); early = true; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        S2T_ES(1)
         {
             typedef typename Pack4<TO>::type PK;
             constexpr uint32_t ES = sizeof(TO);
@@ -398,6 +461,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
             const int colw = col0 + wc * 32 + 4 * q;                      // column of this lane's quad in tile j: + 128 (j >> 1) + 16 (j & 1)
             const int roww = row0 + wr * (2 * HR) + r16;                  // + HR hm + 16 ii
             f32x4 b4[4];
+            char* const turn0 = smem + 2 * BUF + wave * (S2T_TURN_DEPTH * 1024);
+#if S2T_BIAS_LDS
+            // the wave's 64 bias values sit in its first lane-turn slot as [pair][32 columns] (LAST K-tile; columns past N repeat the
+            // last one: their outputs are never stored, or land in the row padding of an odd vocabulary)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                b4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.bias) b4[j] = *reinterpret_cast<const f32x4*>(turn0 + ((j >> 1) * 32 + 16 * (j & 1) + 4 * q) * 4);
+            }
+#else
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int col = colw + (j >> 1) * 128 + 16 * (j & 1);
@@ -408,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                     for (int e = 0; e < 4; ++e) b4[j][e] = col + e < p.N ? p.bias[col + e] : 0.f;
                 }
             }
+#endif
             static_assert(sizeof(TO) == 2, "bf16 outputs");
             {
                 // bf16: a store of one quad is 8 bytes per lane = sixteen 32-byte row segments per wave-instruction, and the store tail
@@ -429,7 +503,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 // a wave-private 1 KiB LDS slot (ds_write_b128 at the turned position, ds_read_b128 at the own one: LDS operations of a
                 // wave execute in order, no barrier), on the LDS pipe, which is idle in the epilogue; the store of a step is issued one step
                 // later so that its read-back has returned.
-                char* const turn = smem + 2 * BUF + wave * 2048;
+                constexpr int TD = S2T_TURN_DEPTH;
+                char* const turn = turn0;
                 const int turn_w = (4 * r16 + 2 * (q & 1) + (q >> 1)) * 16, turn_r = lane * 16;
                 uint32_t vT[2];                                           // byte offsets in the turned order: row lane / 4, chunk lane % 4
 #pragma unroll
@@ -448,9 +523,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 // PREVIOUS step stored from (inputs only: nothing is redefined, hipcc merely cannot touch those registers earlier)
                 // and waits five states: a ds_write's data survives the read-back and store issue that follow it, a store's data one
                 // whole step.  -DS2T_NO_HOLD drops it (the reproducer's failing arm).
+                // The turn is a software pipeline TD steps deep (round 5): one LDS write + read-back is ~200-250 cycles of latency, a
+                // step's own work ~50 (plain epilogue), and with ONE step in flight (round 3-4: the store of a step issued one step
+                // later) every step waited that latency out: ~250 cycles x 16 steps = the ~4,000-cycle epilogue of a wave group that
+                // the s_memtime stamps showed, twice per tile boundary.  With TD slots per wave the store of step s leaves at step
+                // s + TD - 1; the read-backs live in a ring of TD + 1 register quads, so a quad is rewritten (by a ds_read's return)
+                // two steps after the store that read it.
+                u32x4 ring[TD + 1];
+                uint32_t ring_v[TD + 1], ring_s[TD + 1];
+#pragma unroll
+                for (int i = 0; i <= TD; ++i) { ring[i] = u32x4{0u, 0u, 0u, 0u}; ring_v[i] = 0xFFFFFFF0u; ring_s[i] = 0u; }
+                constexpr int NSTEP = 4 * QM;
                 u32x4 pend = {0u, 0u, 0u, 0u}, pend2 = {0u, 0u, 0u, 0u};
                 u32x4 xhold[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};          // GELU pre-activation stores (aux_out), see there
-                uint32_t pend_v = 0xFFFFFFF0u, pend_s = 0u;
                 auto swap2 = [](uint32_t& x, uint32_t& y) {
                     const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
                     x = r[0]; y = r[1];
@@ -461,10 +546,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 // the steps 4k .. 4k+3 = 16 packed bf16 pairs; pair i of them owns bit 15 - i (low element) and bit 31 - i (high
                 // element): written as rec = rec << 1 | min(pair & 0x7FFF7FFF, 0x00010001) (3 VALU per pair), applied as
                 // pair &= ((rec >> (15 - i)) & 0x00010001) * 0xFFFF (4 VALU per pair; the stored activation is never negative).
-                constexpr bool MOUT = ACT == ACT_RELU_MASK, MIN = ACT == ACT_RELU_BWD_MASK;
                 u32x4 mk = {0u, 0u, 0u, 0u};
-                const size_t moff = ((size_t)tile * 512 + threadIdx.x) * 16;
-                if constexpr (MIN) mk = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.aux) + moff);
+                const uint32_t moff = ((uint32_t)tile * 512u + threadIdx.x) * 16u;                 // < tiles * 8 KiB
+#if S2T_BIAS_LDS
+                if constexpr (MIN) mk = *reinterpret_cast<const u32x4*>(turn0 + 1024 + lane * 16);   // LAST K-tile's DMA
+#else
+                if constexpr (MIN) mk = buf_load<u32x4>(rRec, moff, 0u);
+#endif
                 auto pos_pair = [](uint32_t w) -> uint32_t {   // (hipcc scalarises __builtin_elementwise_min on u16x2 into compares and selects)
                     uint32_t r;
                     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w & 0x7FFF7FFFu), "v"(0x00010001u));
@@ -514,18 +602,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                             buf_store(u32x4{s0, s1, s2, s3}, rC, vC[pp], (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES);
 #else
                             {
-                                char* slot = turn + (ms & 1) * 1024;
+                                char* slot = turn + (ms % TD) * 1024;       // last read at step ms - TD: LDS operations of a wave execute in order
+#if S2T_EPX & 2                                                          /* timing-only twin: no LDS turn (WRONG results) */
+                                ring[ms % (TD + 1)] = u32x4{s0, s1, s2, s3};
+#else
                                 *reinterpret_cast<u32x4*>(slot + turn_w) = u32x4{s0, s1, s2, s3};
                                 // lanes read what OTHER lanes of the wave wrote: the pair must stay in this order (LDS operations of a
                                 // wave execute in issue order; the fence keeps the compiler from moving the read above the write)
                                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                                const u32x4 back = *reinterpret_cast<const u32x4*>(slot + turn_r);
-                                if (ms > 0) buf_store(pend, rC, pend_v, pend_s);
-#ifndef S2T_NO_HOLD
+                                ring[ms % (TD + 1)] = *reinterpret_cast<const u32x4*>(slot + turn_r);
+#endif
+                                ring_v[ms % (TD + 1)] = vT[pp]; ring_s[ms % (TD + 1)] = (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES;
+                                if (ms >= TD - 1) {
+                                    const int k = (ms - (TD - 1)) % (TD + 1);
+#if S2T_EPX & 1                                                          /* timing-only twin: no global stores (WRONG results) */
+                                    asm volatile("" :: "v"(ring[k][0]), "v"(ring[k][1]), "v"(ring[k][2]), "v"(ring[k][3]));
+#else
+                                    buf_store(ring[k], rC, ring_v[k], ring_s[k]);
+#endif
+                                    pend2 = pend; pend = ring[k];
+                                }
+#if !defined(S2T_NO_HOLD) && !(S2T_EPX & 4)
                                 asm volatile("s_nop 4" :: "v"(s0), "v"(s1), "v"(s2), "v"(s3),
                                              "v"(pend2[0]), "v"(pend2[1]), "v"(pend2[2]), "v"(pend2[3]) : "memory");
 #endif
-                                pend2 = pend; pend = back; pend_v = vT[pp]; pend_s = (uint32_t)((hm * HR + 16 * ii) * p.ldc) * ES;
                             }
 #endif
                             if constexpr (ACT == ACT_GELU) {
@@ -549,10 +649,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
                 if (p.p_drop > 0.f) epi_steps(std::true_type{}); else epi_steps(std::false_type{});
                 S2T_ES(4)
 #ifndef S2T_NOTURN
-                buf_store(pend, rC, pend_v, pend_s);
-                tail_c = pend;
+#pragma unroll
+                for (int ms = NSTEP; ms < NSTEP + TD - 1; ++ms) {          // drain: the last TD - 1 steps' stores
+                    const int k = (ms - (TD - 1)) % (TD + 1);
+#if S2T_EPX & 1
+                    asm volatile("" :: "v"(ring[k][0]), "v"(ring[k][1]), "v"(ring[k][2]), "v"(ring[k][3]));
+#else
+                    buf_store(ring[k], rC, ring_v[k], ring_s[k]);
 #endif
-                if constexpr (MOUT) { *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.aux_out) + moff) = mk; tail_m = mk; }
+                    tail_c = ring[k];
+                }
+#endif
+                if constexpr (MOUT) { buf_store(mk, rRec, moff, 0u); tail_m = mk; }
                 S2T_ES(5)
             }
         }
@@ -561,6 +669,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
         sbase += nk;
         tile += G;
         cur = nxt;
+        rolled = early;
     }
     if (SCHED == 0 && grp == 0) S2T_BAR();                // group 0 waits for group 1's last phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the tail DMAs land in LDS nobody reads; retire them before the wave ends
@@ -633,7 +742,7 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     if (!tiles) return 0;
     if (dry_run) return 1;                         // every gate passed: the caller names the launch (profiling family) before it happens
     const int grid = tiles < 256 ? tiles : 256;
-    const size_t lds = 2 * BUF + 16384;            // two K-tile buffers + the epilogue's lane-turn slots (8 waves x 2 KiB)
+    const size_t lds = 2 * BUF + 8 * S2T_TURN_DEPTH * 1024;   // two K-tile buffers + the epilogue's lane-turn slots (8 waves x TD KiB): 160 KiB at TD = 4
     bool done = false;
     const int sched = g_s2t_opt_gemm256_sched;
 #define S2T_G256(TO_, TB_, MT_, ACT_, EXT_, SC_)                                                                             \

@@ -2,7 +2,8 @@
 //   NT  Y  = epi(X  . W^T)   X [M][K], W [N][K]      forward projections / FFN      (F.linear, multihead_attention.py:190-208,
 //   NN  dX = epi(dY . W)     dY [M][K], W [K][N]      their data gradients            transformer_layer.py:132-134 + autograd)
 //
-// STATUS: an experiment kept behind s2t_set_option("gemm4w", 1), OFF by default (profiles/r04_gemm4w.txt): bit-identical to gemm256 on
+// STATUS (round 5): ARCHIVED lab code, not built and not part of libs2t_hip.so.  Round 4 shipped it behind s2t_set_option("gemm4w", 1)
+// (removed with it); to revive it, move it back into fbk_fairseq_st_amd/csrc and restore the hook in s2t_gemm256_try.  Bit-identical to gemm256 on
 // every variant, +0..8 % on K = 2,048 products, -5..-20 % on K = 512 ones -- see "What it measured" below.
 //
 // Why (round 4, profiles/r04_gemm256_experiments.txt): the eight-wave loop is bound by what feeds the matrix cores -- taking its

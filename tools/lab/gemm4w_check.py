@@ -1,4 +1,5 @@
-"""gemm4w (four waves of 128 x 128) against gemm256 (eight of 128 x 64): every epilogue variant bit for bit, and the time of each:
+"""ARCHIVED with tools/lab/gemm4w.hip (round 5: the "gemm4w" option no longer exists in the product library).
+gemm4w (four waves of 128 x 128) against gemm256 (eight of 128 x 64): every epilogue variant bit for bit, and the time of each:
     python tools/gemm4w_check.py [M]          (default 24000 and 6211)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
