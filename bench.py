@@ -55,7 +55,7 @@ KERNEL_OF = {"wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward p
              "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (implicit-GEMM convolutions)",
              "conv2_fwd": "conv2_fwd_kernel (3x3 stride-2 convolution, input rows staged once in LDS, weights in registers)",
              "conv2_dgrad": "conv2_dgrad_kernel (its data gradient, four pixel-parity classes in one launch)"}
-TRAFFIC_FILE = os.path.join("profiles", "r04_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_F32_TFLOPS = 157.3
 

@@ -162,12 +162,34 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < QM; ++i) dst[i] = *reinterpret_cast<const u32x4*>(base + i * 2048);
     };
+#ifndef S2T_G256_TR_ASM
+#define S2T_G256_TR_ASM 1
+#endif
+    // TB: per-lane LDS addresses of the k-strided operand's fragments in buffer 0 ([column tile][inner half]); buffer parity toggles
+    // bit 16, half-tile and k-half are the instruction's immediate offset (gemm_tile.hpp tr_read_asm)
+    uint32_t aB[2][2] = {{0u, 0u}, {0u, 0u}};
+    if constexpr (TB && S2T_G256_TR_ASM) {
+        const uint32_t s0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) aB[j][hh] = tr_lane_addr(s0, wc * 32 + 16 * j, hh, r16, q);
+    }
     auto readBs = [&](const char* buf, int h, int s_) {
         const char* base = buf + 2 * HALF + h * HALF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if constexpr (!TB) fb[h][j][s_] = *reinterpret_cast<const u32x4*>(base + b_off + j * 2048 + (s_ ? swz1 : swz0));
-            else fb[h][j][s_] = tr_frag(base, wc * 32 + 16 * j, s_, r16, q);
+            else if constexpr (!S2T_G256_TR_ASM) fb[h][j][s_] = tr_frag(base, wc * 32 + 16 * j, s_, r16, q);
+            else {
+                const uint32_t bb = (uint32_t)(buf - smem);                 // 0 or BUF: wave-uniform
+                u32x2 w0, w1;
+                if (h == 0 && s_ == 0) { w0 = tr_read_asm<2 * HALF>(aB[j][0] ^ bb); w1 = tr_read_asm<2 * HALF>(aB[j][1] ^ bb); }
+                else if (h == 0) { w0 = tr_read_asm<2 * HALF + 8192>(aB[j][0] ^ bb); w1 = tr_read_asm<2 * HALF + 8192>(aB[j][1] ^ bb); }
+                else if (s_ == 0) { w0 = tr_read_asm<3 * HALF>(aB[j][0] ^ bb); w1 = tr_read_asm<3 * HALF>(aB[j][1] ^ bb); }
+                else { w0 = tr_read_asm<3 * HALF + 8192>(aB[j][0] ^ bb); w1 = tr_read_asm<3 * HALF + 8192>(aB[j][1] ^ bb); }
+                fb[h][j][s_] = u32x4{w0[0], w0[1], w1[0], w1[1]};
+            }
         }
     };
 #define S2T_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)

@@ -34,6 +34,22 @@ __device__ __forceinline__ u32x4 tr_frag(const char* img, int col, int s, int r1
     return f;
 }
 
+// The same read as inline assembly (round 5; wgrad_group.hip has the twin and the reasoning): through the builtin hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the first transposed read of a memory segment -- the intrinsic has no memory operand, so the
+// wait-count pass assumes it reads what any LDS-DMA in flight writes -- which drained the NN kernels' prefetch once per K-tile.
+// addr = LDS byte address of the lane's 8 bytes in buffer 0 / half 0 / k-half 0, OFF = the compile-time rest (16-bit offset field).
+template <int OFF>
+__device__ __forceinline__ u32x2 tr_read_asm(uint32_t addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint32_t tr_lane_addr(uint32_t img, int col, int hh, int r16, int q) {
+    const int row = 8 * q + 4 * hh + (r16 >> 2);
+    const int ch = (col >> 3) + ((r16 & 3) >> 1);
+    return img + row * 256 + ((ch ^ trswz(row)) << 4) + ((r16 & 1) << 3);        // trswz(row + 32 s) == trswz(row)
+}
+
 // ---- epilogue straight from the accumulators (the LDS ring keeps filling for the next tile meanwhile): the MFMAs ran as
 // (W rows x X rows), so a lane holds 4 consecutive columns of one row: C[row][col .. col + 3] -> one 8-byte (bf16) or 16-byte (f32)
 // access per operand.  Same arithmetic, in the same order, as gemm_finish (gemm_epilogue.hpp): alpha, bias, activation, dropout

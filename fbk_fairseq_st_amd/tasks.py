@@ -83,6 +83,10 @@ class SpeechTranslationCTCTask(FairseqTask):
         `iterator.npz`)."""
         from .registry import inside_fairseq
         if inside_fairseq():
+            if getattr(self.args, "bucket_by_length", False):
+                import warnings                 # ADVICE r4: say so instead of dropping the flag silently
+                warnings.warn("--bucket-by-length (and the pinned-memory prefetch thread) belong to this package's own batch iterator; inside a "
+                              "fairseq process the reference's EpochBatchIterator is used and the flag has no effect")
             return super().get_batch_iterator(dataset, max_tokens=max_tokens, max_sentences=max_sentences, max_positions=max_positions,
                                               ignore_invalid_inputs=ignore_invalid_inputs,
                                               required_batch_size_multiple=required_batch_size_multiple, seed=seed,
