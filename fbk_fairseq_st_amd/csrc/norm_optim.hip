@@ -333,22 +333,39 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float mult = mult_ptr ? mult_ptr[1] : 1.f;
     size_t done = 0;
     if constexpr (VEC) {
-        const size_t nv = n / 4;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
-            f32x4 pi = reinterpret_cast<const f32x4*>(p)[i], mi = reinterpret_cast<const f32x4*>(m)[i], vi = reinterpret_cast<const f32x4*>(v)[i];
-            const f32x4 gi = reinterpret_cast<const f32x4*>(g)[i];
+        // two 16-byte groups per lane and step, every access non-temporal: each of the seven streams is touched once per update and
+        // 2 GB of them go by, so nothing here is worth a cache line (tools/lab/adam_probe.hip, 74 M parameters back to back:
+        // 441 us = 5.0 TB/s as one cached group per step, 376-400 us = 5.6-5.9 TB/s in this form)
+        const size_t nv = n / 4, stride = (size_t)gridDim.x * 256;
+        f32x4* P4 = reinterpret_cast<f32x4*>(p); const f32x4* G4 = reinterpret_cast<const f32x4*>(g);
+        f32x4* M4 = reinterpret_cast<f32x4*>(m); f32x4* V4 = reinterpret_cast<f32x4*>(v);
+        for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += 2 * stride) {
+            f32x4 pi[2], mi[2], vi[2], gi[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float pe = pi[e], me = mi[e], ve = vi[e];
-                adam_one(pe, gi[e], me, ve, mult, lr, beta1, beta2, eps, wd, step_size);
-                pi[e] = pe; mi[e] = me; vi[e] = ve;
+            for (int u = 0; u < 2; ++u) {
+                const size_t i = i0 + u * stride;
+                if (i < nv) {
+                    pi[u] = __builtin_nontemporal_load(P4 + i); gi[u] = __builtin_nontemporal_load(G4 + i);
+                    mi[u] = __builtin_nontemporal_load(M4 + i); vi[u] = __builtin_nontemporal_load(V4 + i);
+                }
             }
-            reinterpret_cast<f32x4*>(m)[i] = mi; reinterpret_cast<f32x4*>(v)[i] = vi; reinterpret_cast<f32x4*>(p)[i] = pi;
-            if (shadow) {
-                bf16 sh[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sh[e] = (bf16)pi[e];
-                reinterpret_cast<u32x2*>(shadow)[i] = *reinterpret_cast<const u32x2*>(sh);
+            for (int u = 0; u < 2; ++u) {
+                const size_t i = i0 + u * stride;
+                if (i >= nv) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float pe = pi[u][e], me = mi[u][e], ve = vi[u][e];
+                    adam_one(pe, gi[u][e], me, ve, mult, lr, beta1, beta2, eps, wd, step_size);
+                    pi[u][e] = pe; mi[u][e] = me; vi[u][e] = ve;
+                }
+                __builtin_nontemporal_store(mi[u], M4 + i); __builtin_nontemporal_store(vi[u], V4 + i); __builtin_nontemporal_store(pi[u], P4 + i);
+                if (shadow) {
+                    bf16 sh[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sh[e] = (bf16)pi[u][e];
+                    __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(sh), reinterpret_cast<u32x2*>(shadow) + i);
+                }
             }
         }
         done = nv * 4;
@@ -389,7 +406,7 @@ extern "C" int s2t_adam_step(float* p, const float* g, float* m, float* v, void*
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
     const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (((uintptr_t)shadow_bf16 & 7) == 0) && n >= 4;
     int blocks = (int)(((vec ? n / 4 : n) + 255) / 256);
-    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+    blocks = blocks > (vec ? 16384 : 4096) ? (vec ? 16384 : 4096) : (blocks < 1 ? 1 : blocks);
     if (vec) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n,
                                 mult2, lr, beta1, beta2, eps, wd, step_size);
     else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow_bf16, n,
