@@ -10,7 +10,10 @@
 // One wavefront per row.  Lane l owns EPL contiguous elements [l*EPL, l*EPL+EPL) (D = 64*EPL, EPL in {4,8,16}):
 // 8/16/32-byte loads per lane, fully coalesced, the row lives in registers; statistics by wavefront
 // shuffles.  Other widths (D <= 1024) take the strided scalar variant (EPL = 0).
-template <typename T, int EPL> struct RowIO {
+#ifndef S2T_LN_NT
+#define S2T_LN_NT 2      // 1 non-temporal row loads in the backward, 2 non-temporal stores there, 4 loads in the forward, 8 stores in the forward
+#endif
+template <typename T, int EPL, bool NT = false> struct RowIO {
     static __device__ __forceinline__ void load(const T* row, int lane, int D, float (&v)[16]) {
         if constexpr (EPL == 0) {
 #pragma unroll
@@ -23,8 +26,10 @@ template <typename T, int EPL> struct RowIO {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 T tmp[VE];
-                if constexpr (EPL * sizeof(T) >= 16) *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(p + k * VE);
-                else *reinterpret_cast<u32x2*>(tmp) = *reinterpret_cast<const u32x2*>(p);
+                if constexpr (EPL * sizeof(T) >= 16) {
+                    if constexpr (NT) *reinterpret_cast<u32x4*>(tmp) = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + k * VE));
+                    else *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(p + k * VE);
+                } else *reinterpret_cast<u32x2*>(tmp) = *reinterpret_cast<const u32x2*>(p);
 #pragma unroll
                 for (int e = 0; e < PER; ++e) v[k * VE + e] = to_f32(tmp[e]);
             }
@@ -44,8 +49,10 @@ template <typename T, int EPL> struct RowIO {
                 T tmp[VE];
 #pragma unroll
                 for (int e = 0; e < PER; ++e) tmp[e] = from_f32<T>(v[k * VE + e]);
-                if constexpr (EPL * sizeof(T) >= 16) *reinterpret_cast<u32x4*>(p + k * VE) = *reinterpret_cast<const u32x4*>(tmp);
-                else *reinterpret_cast<u32x2*>(p) = *reinterpret_cast<const u32x2*>(tmp);
+                if constexpr (EPL * sizeof(T) >= 16) {
+                    if constexpr (NT) __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(tmp), reinterpret_cast<u32x4*>(p + k * VE));
+                    else *reinterpret_cast<u32x4*>(p + k * VE) = *reinterpret_cast<const u32x4*>(tmp);
+                } else *reinterpret_cast<u32x2*>(p) = *reinterpret_cast<const u32x2*>(tmp);
             }
         }
     }
@@ -60,11 +67,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      int M, int D, float eps) {
     typedef RowIO<T, EPL> IO;
+    typedef RowIO<T, EPL, (S2T_LN_NT & 4) != 0> ION;
+    typedef RowIO<T, EPL, (S2T_LN_NT & 8) != 0> IOSN;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float v[16];
-    IO::load(x + (size_t)row * D, lane, D, v);
+    ION::load(x + (size_t)row * D, lane, D, v);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < IO::N; ++i) s += v[i];
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int i = 0; i < IO::N; ++i) { const int j = IO::col(lane, i); if (j < D) v[i] = (v[i] - mu) * rs * gamma[j] + beta[j]; }
     }
-    IO::store(y + (size_t)row * D, lane, D, v);
+    IOSN::store(y + (size_t)row * D, lane, D, v);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
@@ -105,6 +114,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                                                      float* __restrict__ dbeta, int M, int D,
                                                      T* __restrict__ dx_drop, float p_drop, unsigned long long seed) {
     typedef RowIO<T, EPL> IO;
+    typedef RowIO<T, EPL, (S2T_LN_NT & 1) != 0> IOL;
+    typedef RowIO<T, EPL, (S2T_LN_NT & 2) != 0> IOS;
     extern __shared__ float sh_ln[];                       // [2][NW][D]
     const uint32_t th16 = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) >> 16;
     const float inv_keep = 1.f / (1.f - p_drop);
@@ -118,9 +129,9 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
     int row = blockIdx.x * NW + w;
     float xn[16], dn[16], rn[16], mun = 0.f, rsn = 0.f;
     if (row < M) {
-        IO::load(x + (size_t)row * D, lane, D, xn);
-        IO::load(dy + (size_t)row * D, lane, D, dn);
-        if (dres) IO::load(dres + (size_t)row * D, lane, D, rn);
+        IOL::load(x + (size_t)row * D, lane, D, xn);
+        IOL::load(dy + (size_t)row * D, lane, D, dn);
+        if (dres) IOL::load(dres + (size_t)row * D, lane, D, rn);
         mun = mean[row]; rsn = rstd[row];
     }
     for (; row < M; row += stride) {
@@ -130,9 +141,9 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
         for (int i = 0; i < IO::N; ++i) { xv[i] = xn[i]; dv[i] = dn[i]; rv[i] = rn[i]; }
         const int nrow = row + stride;
         if (nrow < M) {                                         // wave-uniform
-            IO::load(x + (size_t)nrow * D, lane, D, xn);
-            IO::load(dy + (size_t)nrow * D, lane, D, dn);
-            if (dres) IO::load(dres + (size_t)nrow * D, lane, D, rn);
+            IOL::load(x + (size_t)nrow * D, lane, D, xn);
+            IOL::load(dy + (size_t)nrow * D, lane, D, dn);
+            if (dres) IOL::load(dres + (size_t)nrow * D, lane, D, rn);
             mun = mean[nrow]; rsn = rstd[nrow];
         }
         float s1 = 0.f, s2 = 0.f;
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
             if (dres) r += rv[i];
             dv[i] = r;
         }
-        IO::store(dx + (size_t)row * D, lane, D, dv);
+        IOS::store(dx + (size_t)row * D, lane, D, dv);
         if (dx_drop) {
             // second output = dropout(dx) with the consumer block's mask (what s2t_dropout would produce from the stored,
             // rounded dx: element index row*D + col, one hash per aligned group of four)
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
                                            ? to_f32(from_f32<T>(dv[i])) * inv_keep : 0.f;
                 }
             }
-            IO::store(dx_drop + (size_t)row * D, lane, D, dv);
+            IOS::store(dx_drop + (size_t)row * D, lane, D, dv);
         }
     }
     float* sg = sh_ln;
