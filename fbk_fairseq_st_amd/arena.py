@@ -35,6 +35,12 @@ class ParamArena:
                        if compute_dtype == torch.bfloat16 else None)
         self._views = {}
         self.frozen = []               # [start, end) element ranges excluded from the optimizer (--freeze-pretrained)
+        # LayerDrop bookkeeping (--encoder-layerdrop / --decoder-layerdrop): the layer groups that CAN be dropped, and the ones that ran
+        # in a training forward since the last zero_grad.  A group that never ran has no gradient in the reference (p.grad is None
+        # after FairseqOptimizer.zero_grad, fairseq_optimizer.py:97-101) and its Adam skips it (fairseq/optim/adam.py:160-165).
+        self.drop_groups = []          # parameter-name prefixes, e.g. "encoder.layers.3."
+        self._ran = set()
+        self._noted = False
 
     # ---- frozen parameters (conv_transformer.py:114-121: loaded weights get requires_grad = False and so never reach the
     # optimizer or the gradient norm, fairseq/trainer.py:143).  Here the kernels write gradients for everything; the optimizer
@@ -101,6 +107,40 @@ class ParamArena:
 
     def zero_grad(self):
         self.grad.zero_()
+        self._ran.clear()
+        self._noted = False
+
+    def note_layers(self, prefixes, keep):
+        """a training forward drew LayerDrop decisions: prefixes[i] ran iff keep[i]"""
+        for pfx in prefixes:
+            if pfx not in self.drop_groups:
+                self.drop_groups.append(pfx)
+        self._ran.update(pfx for pfx, k in zip(prefixes, keep) if k)
+        self._noted = True
+
+    def untouched_groups(self):
+        """the droppable groups no forward of this update ran (empty when no LayerDrop forward was noted since zero_grad)"""
+        if not self._noted:
+            return []
+        return [g for g in self.drop_groups if g not in self._ran]
+
+    def group_of(self, name):
+        for g in self.drop_groups:
+            if name.startswith(g):
+                return g
+        return None
+
+    def group_runs(self):
+        """the arena as maximal runs of consecutive parameters with the same group: [(group or None, start, end)]"""
+        runs = []
+        for name, (off, n, _) in self.slices.items():
+            g = self.group_of(name)
+            end = off + (n + ALIGN - 1) // ALIGN * ALIGN
+            if runs and runs[-1][0] == g and runs[-1][2] == off:
+                runs[-1] = (g, runs[-1][1], end)
+            else:
+                runs.append((g, off, end))
+        return runs
 
     def ensure_adam_state(self):
         if self.exp_avg is None:

@@ -215,6 +215,8 @@ class ConvolutionalTransformerEncoder(FairseqEncoder):
             draws = [float(torch.empty(1).uniform_()) for _ in range(m.hp.enc_layers)]
             if self.training:
                 keep = [d > m.hp.encoder_layerdrop for d in draws]
+                if m.arena is not None:
+                    m.arena.note_layers(["encoder.layers.%d." % l for l in range(m.hp.enc_layers)], keep)
         eo, co, st = _EncoderFn.apply(m.anchor, self, src_tokens, src_lengths, self.training, seed, want_state, keep)
         o = self._last
         B = eo.shape[1]
@@ -302,6 +304,8 @@ class TransformerDecoder(FairseqIncrementalDecoder):
             draws = torch.empty(m.hp.dec_layers).uniform_().tolist()
             if self.training:
                 keep = [d > m.hp.decoder_layerdrop for d in draws]
+                if m.arena is not None:
+                    m.arena.note_layers([self.pfx + "layers.%d." % l for l in range(m.hp.dec_layers)], keep)
         if keep is not None and a_layer is not None and not keep[a_layer]:
             a_layer = None                                        # LayerDrop removed the alignment layer: no attention this pass
         logits_tm, attn = _DecoderFn.apply(m.anchor, self, prev_output_tokens, eo, klen, self.training, m._next_seed(), keep, a_layer, a_heads)
@@ -494,6 +498,11 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
             b.data = b.data.to(device)
         arena.refresh_shadow()
         arena.freeze(getattr(self, "_frozen_names", ()))
+        # the layer groups LayerDrop can remove from an update (their Adam state keeps its own step count: optim.ArenaAdam.step)
+        if self.hp.encoder_layerdrop > 0:
+            arena.drop_groups += ["encoder.layers.%d." % l for l in range(self.hp.enc_layers)]
+        if self.hp.decoder_layerdrop > 0:
+            arena.drop_groups += ["decoder.layers.%d." % l for l in range(self.hp.dec_layers)]
         self.arena, self.compute_dtype = arena, compute_dtype
         self.engine = S2TEngine(self.hp, arena)
         self.engine.bn_buffers = {

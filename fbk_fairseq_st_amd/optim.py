@@ -16,6 +16,7 @@ class ArenaAdam:
         self.arena = arena
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
         self.step_count = 0
+        self.group_steps = {}                     # LayerDrop: a droppable layer group's own step count (see step)
         self._scale = 1.0                         # pending multiply_grads factor, folded into the clip / Adam kernels
         self._ws = torch.zeros(1, dtype=torch.float64, device=arena.device)
         self._out2 = torch.ones(2, dtype=torch.float32, device=arena.device)
@@ -42,11 +43,33 @@ class ArenaAdam:
         if not self._have_mult:
             self._out2[1] = self._scale
         a = self.arena
-        # one launch over the whole arena, or one per trainable segment when parameters are frozen (no moments, no weight decay,
-        # no update for those: they are not in the reference's optimizer at all)
-        for s, e in (a.trainable_segments() if a.frozen else [(0, a.numel)]):
+        segs = a.trainable_segments() if a.frozen else [(0, a.numel)]
+        if a.drop_groups:
+            # LayerDrop: the reference's Adam skips a parameter whose gradient is None -- a layer no forward of this update ran: no
+            # moment decay, no weight decay, and its own `step` (the bias corrections) does not advance (fairseq/optim/adam.py:160-165).
+            # Here: one launch per run of consecutive parameters with the same step count, none for the groups that did not run.
+            skipped = set(a.untouched_groups())
+            for g in a.drop_groups:
+                self.group_steps.setdefault(g, self.step_count - 1)
+                if g not in skipped:
+                    self.group_steps[g] += 1
+            runs = []
+            for g, s, e in a.group_runs():
+                if g in skipped:
+                    continue
+                st = self.group_steps[g] if g is not None else self.step_count
+                if runs and runs[-1][1] == s and runs[-1][2] == st:
+                    runs[-1] = (runs[-1][0], e, st)
+                else:
+                    runs.append((s, e, st))
+            launches = [(max(s, fs), min(e, fe), st) for s, e, st in runs for fs, fe in segs if max(s, fs) < min(e, fe)]
+        else:
+            # one launch over the whole arena, or one per trainable segment when parameters are frozen (no moments, no weight decay,
+            # no update for those: they are not in the reference's optimizer at all)
+            launches = [(s, e, self.step_count) for s, e in segs]
+        for s, e, st in launches:
             K.adam_step(a.master[s:e], a.grad[s:e], a.exp_avg[s:e], a.exp_avg_sq[s:e], a.shadow[s:e] if a.shadow is not None else None,
-                        self._out2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count)
+                        self._out2, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, st)
         self._scale, self._have_mult = 1.0, False
 
     def zero_grad(self):
@@ -62,7 +85,10 @@ class ArenaAdam:
     def state_dict(self):
         """this build's own compact layout: the two moment vectors in arena order"""
         a = self.arena
-        return {"step": self.step_count, "lr": self.lr, "exp_avg": a.exp_avg.cpu(), "exp_avg_sq": a.exp_avg_sq.cpu()}
+        sd = {"step": self.step_count, "lr": self.lr, "exp_avg": a.exp_avg.cpu(), "exp_avg_sq": a.exp_avg_sq.cpu()}
+        if self.group_steps:
+            sd["group_steps"] = dict(self.group_steps)
+        return sd
 
     def load_state_dict(self, sd, reference_names=None):
         """takes either layout: the compact one above, or the reference's (a torch.optim state dict, see reference_state_dict)"""
@@ -70,6 +96,7 @@ class ArenaAdam:
             return self.load_reference_state_dict(sd, reference_names)
         a = self.arena
         self.step_count, self.lr = int(sd["step"]), float(sd["lr"])
+        self.group_steps = {str(k): int(v) for k, v in sd.get("group_steps", {}).items()}
         a.exp_avg.copy_(sd["exp_avg"]); a.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
     # ---- the reference's optimizer-state layout (fairseq/checkpoint_utils.py:245-286 stores `optimizer.state_dict()` =
@@ -88,12 +115,21 @@ class ArenaAdam:
             m, v = m[blk * rows:(blk + 1) * rows], v[blk * rows:(blk + 1) * rows]
         return m, v
 
+    def _step_of(self, ref_name):
+        """a reference parameter's own step count: its LayerDrop group's when it has one, else the number of updates"""
+        from .conv_transformer import reference_slot
+        g = self.arena.group_of(reference_slot(ref_name)[0])
+        return self.group_steps.get(g, self.step_count) if g is not None else self.step_count
+
     def reference_state_dict(self, reference_names):
         state = {}
         if self.step_count > 0:                               # torch creates a parameter's state at its first step
             for i, n in enumerate(reference_names):
+                st = self._step_of(n)
+                if st <= 0:                                   # a layer that has not run in any update yet: no state in the reference either
+                    continue
                 m, v = self._moment_views(n)
-                state[i] = {"step": self.step_count, "exp_avg": m.detach().cpu().clone(), "exp_avg_sq": v.detach().cpu().clone()}
+                state[i] = {"step": st, "exp_avg": m.detach().cpu().clone(), "exp_avg_sq": v.detach().cpu().clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "params": list(range(len(reference_names)))}
         return {"state": state, "param_groups": [group]}
@@ -104,26 +140,31 @@ class ArenaAdam:
         if reference_names is None or len(ids) != len(reference_names):
             raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group "
                              "(%d parameters in the file, %d here)" % (len(ids), len(reference_names or ())))
-        steps = set()
+        from .conv_transformer import reference_slot
+        steps, per_group, plain = set(), {}, set()
         with torch.no_grad():
             for i, n in zip(ids, reference_names):
                 st = sd["state"].get(i)
                 m, v = self._moment_views(n)
+                grp = self.arena.group_of(reference_slot(n)[0])
                 if st is None:                                # never stepped in the run that wrote the file (gradient always None)
                     m.zero_(); v.zero_()
+                    if grp is not None:
+                        per_group.setdefault(grp, set()).add(0)
                     continue
+                (per_group.setdefault(grp, set()) if grp is not None else plain).add(int(st["step"]))
                 if tuple(st["exp_avg"].shape) != tuple(m.shape):
                     raise ValueError("optimizer state of %s has shape %s, the parameter %s" % (n, tuple(st["exp_avg"].shape), tuple(m.shape)))
                 m.copy_(st["exp_avg"].to(dtype=m.dtype)); v.copy_(st["exp_avg_sq"].to(dtype=v.dtype))
                 steps.add(int(st["step"]))
-        if len(steps) > 1:
-            # The reference's Adam skips a parameter whose gradient is None -- a layer LayerDrop removed from an update: no moment decay,
-            # no weight decay, its own `step` does not advance (fairseq/optim/adam.py:160-165) -- so a checkpoint trained with
-            # --encoder/--decoder-layerdrop holds different step counts per layer.  The fused arena Adam keeps ONE count (and steps
-            # dropped layers with zero gradients: a documented deviation); the largest count is the global update
-            # count, which is what the bias corrections of every parameter use from here on.
-            import warnings
-            warnings.warn("optimizer state with per-parameter step counts %s (LayerDrop): continuing with the largest" % sorted(steps))
+        # The reference's Adam skips a parameter whose gradient is None -- a layer LayerDrop removed from an update -- so a checkpoint
+        # trained with --encoder/--decoder-layerdrop holds a step count per layer (fairseq/optim/adam.py:160-165): kept per droppable
+        # group (`group_steps`, see step); everything else shares the number of updates.
+        bad = {g: sorted(v) for g, v in per_group.items() if len(v) > 1}
+        if bad or len(plain) > 1:
+            raise ValueError("optimizer state with different step counts inside one layer / outside the LayerDrop layers: %s %s"
+                             % (bad, sorted(plain)))
+        self.group_steps = {g: next(iter(v)) for g, v in per_group.items()}
         self.step_count = max(steps) if steps else 0
         # hyper-parameters: the running optimizer's win over the file's (fairseq_optimizer.py:62-77, optimizer_overrides)
 

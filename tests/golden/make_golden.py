@@ -961,6 +961,67 @@ def run_layerdrop_case():
     np.savez_compressed(os.path.join(OUT, "layerdrop.npz"), **out)
 
 
+def run_layerdrop_opt_case():
+    """Optimizer trajectory under LayerDrop (round 5): fairseq's Adam (fairseq/optim/adam.py:147-202) skips a parameter whose
+    gradient is None -- a layer LayerDrop removed from this update (fairseq_optimizer.py:97-101 sets every gradient to None before
+    the update): no moment decay, no weight decay, its own `step` does not advance.  Five updates of the `nc` LayerDrop model
+    (criterion-owned CTC head: no layer has to run), torch's CPU generator seeded before every forward; recorded: the keep / drop
+    decisions, losses, gradient norms, every parameter of the dropped-at-least-once layers plus a few others after the last update,
+    and the per-parameter step counts of the optimizer state."""
+    D, H, Ff, EL, DL = 64, 2, 128, 6, 3
+    pe, pd = 0.4, 0.3
+    steps, seed, ctc_layer = 5, 400, 1
+    args, task, model, crit, V_src, V_tgt = build("layerdrop_nc", D, H, Ff, EL, DL, ctc_layer, False,
+                                                  extra=["--encoder-layerdrop", str(pe), "--decoder-layerdrop", str(pd)])
+    blank = task.source_dictionary.index("<ctc_blank>")
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    load_weights(model, crit, W)
+    s = make_sample(seed + 1, [57, 44, 31], [6, 5, 4], [5, 4, 4], V_src, V_tgt, blank)
+    sample = to_ref_sample(s)
+    model.train(); crit.train()
+    named = list(model.named_parameters()) + [("criterion." + k, p) for k, p in crit.named_parameters()]
+    params = [p for _, p in named if p.requires_grad]
+    opt = Adam(params, lr=5e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-2)
+    out = {"rates": np.array([pe, pd]), "meta": np.array([D, H, Ff, EL, DL, ctc_layer, 0, V_src, V_tgt, blank, seed, steps], np.int64)}
+    for k, v in s.items():
+        if isinstance(v, np.ndarray):
+            out["in_" + k] = v
+    out["in_ntokens"] = np.int64(s["ntokens"])
+    losses, gnorms, enc_keeps, dec_keeps, seeds = [], [], [], [], []
+    for it in range(steps):
+        fwd_seed = 1000 + 37 * it
+        torch.manual_seed(fwd_seed)
+        enc_keeps.append([bool(float(torch.empty(1).uniform_()) > pe) for _ in range(EL)])
+        dec_keeps.append([bool(d > pd) for d in torch.empty(DL).uniform_().tolist()])
+        opt.zero_grad()
+        for p in params:
+            p.grad = None                                   # FairseqOptimizer.zero_grad
+        torch.manual_seed(fwd_seed)
+        loss, ss, _ = crit(model, sample)
+        loss.backward()
+        for p in params:
+            if p.grad is not None:
+                p.grad.data.mul_(1.0 / float(ss))
+        gnorm = utils.clip_grad_norm_(params, 0.5)
+        opt.step()
+        losses.append(float(loss)); gnorms.append(float(gnorm)); seeds.append(fwd_seed)
+    assert not all(all(k) for k in enc_keeps) and not all(all(k) for k in dec_keeps)
+    out["losses"] = np.array(losses); out["gnorms"] = np.array(gnorms); out["fwd_seeds"] = np.array(seeds, np.int64)
+    out["enc_keep"] = np.array(enc_keeps); out["dec_keep"] = np.array(dec_keeps)
+    sd = dict(model.state_dict()); sd.update({"criterion." + k: v for k, v in crit.state_dict().items()})
+    keep_keys = [k for k, _ in named if (".layers." in k and (k.endswith("fc2.weight") or k.endswith("fc1.bias") or k.endswith("self_attn.k_proj.weight")
+                                                                or k.endswith("self_attn_layer_norm.weight") or k.endswith("encoder_attn.v_proj.weight")))
+                 or k in ("encoder.layer_norm.weight", "decoder.embed_tokens.weight", "encoder.fc3.bias")]
+    for k in keep_keys:
+        out["param_" + k] = sd[k].numpy().copy()
+    st = opt.state_dict()["state"]
+    out["step_keys"] = np.array([k for k, p in named if p.requires_grad])
+    out["step_vals"] = np.array([int(st[i]["step"]) if i in st else 0 for i in range(len(params))], np.int64)
+    print("layerdrop_opt", "enc", enc_keeps, "dec", dec_keeps, "losses", losses, "steps", sorted(set(out["step_vals"].tolist())))
+    np.savez_compressed(os.path.join(OUT, "layerdrop_opt.npz"), **out)
+
+
 def run_attn_case():
     """Round 5: the decoder's returned attention (fairseq/models/transformer.py:756-782: head-averaged encoder-attention weights of
     `alignment_layer`, default the last layer) on the model_a / model_b inputs in eval mode, and the `attention` the reference's
@@ -1010,6 +1071,8 @@ if __name__ == "__main__":
         run_generate_ext_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "layerdrop":
         run_layerdrop_case(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "layerdrop_opt":
+        run_layerdrop_opt_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "twophase":
         run_twophase_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attn2d":

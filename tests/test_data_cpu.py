@@ -179,3 +179,58 @@ def test_teacher_output_files_and_kd_collater():
     assert batch["id"].tolist() == g["batch_id"].tolist() and np.array_equal(batch["target"].numpy(), g["batch_target"])
     assert np.array_equal(batch["teacher_output"][0].numpy(), g["batch_teacher_idx"])
     assert np.array_equal(batch["teacher_output"][1].numpy(), g["batch_teacher_out"])
+
+
+def test_arena_adam_skips_the_layers_layerdrop_removed():
+    """optim.ArenaAdam.step under LayerDrop, host logic on the CPU stand-ins: a droppable group that no forward of the update ran is
+    skipped (parameters, moments and its own step count untouched: fairseq/optim/adam.py:160-165 on a gradient that is None after
+    fairseq_optimizer.py:97-101), every other parameter steps with its own bias-correction count, and the per-group counts survive
+    both state-dict layouts.  Against a per-parameter torch loop that applies the reference's rule."""
+    import torch
+    from cpu_stubs import cpu_kernels
+    from fbk_fairseq_st_amd.arena import ParamArena
+    from fbk_fairseq_st_amd.optim import ArenaAdam
+    from oracle import s2t_ref
+    shapes = {"encoder.fc3.weight": (5, 7)}
+    for l in range(3):
+        shapes["encoder.layers.%d.fc1.weight" % l] = (6, 5); shapes["encoder.layers.%d.fc1.bias" % l] = (6,)
+    shapes["encoder.layer_norm.weight"] = (5,)
+    with cpu_kernels():
+        arena = ParamArena(shapes, "cpu")
+        arena.drop_groups += ["encoder.layers.%d." % l for l in range(3)]
+        g = torch.Generator().manual_seed(0)
+        for n in shapes:
+            arena.p(n).copy_(torch.randn(shapes[n], generator=g))
+        opt = ArenaAdam(arena, lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-2)
+        P = {n: arena.p(n).clone() for n in shapes}
+        M = {n: torch.zeros(shapes[n]) for n in shapes}; V = {n: torch.zeros(shapes[n]) for n in shapes}
+        steps = {n: 0 for n in shapes}
+        keeps = [[True, False, True], [False, False, True], [True, True, True], [True, False, False]]
+        for it, keep in enumerate(keeps):
+            opt.zero_grad()
+            arena.note_layers(["encoder.layers.%d." % l for l in range(3)], keep)
+            grads = {}
+            for n in shapes:
+                l = int(n.split(".")[2]) if ".layers." in n else None
+                if l is None or keep[l]:
+                    grads[n] = torch.randn(shapes[n], generator=g)
+                    arena.g(n).copy_(grads[n])
+            opt.step()
+            for n, gr in grads.items():
+                steps[n] += 1
+                P[n], M[n], V[n] = s2t_ref.adam_step(P[n], gr, M[n], V[n], steps[n], 1e-2, 0.9, 0.98, 1e-8, 1e-2)
+        for n in shapes:
+            assert torch.allclose(arena.p(n), P[n], atol=1e-6), n
+            assert torch.allclose(arena._view(arena.exp_avg, n), M[n], atol=1e-7), n
+        assert opt.group_steps == {"encoder.layers.0.": 3, "encoder.layers.1.": 1, "encoder.layers.2.": 3} and opt.step_count == 4
+        # both state-dict layouts carry the counts
+        names = list(shapes)
+        ref = opt.reference_state_dict(names)
+        assert [ref["state"][i]["step"] for i in range(len(names))] == [steps[n] for n in names]
+        o2 = ArenaAdam(arena, lr=1e-2); o2.load_reference_state_dict(ref, names)
+        assert o2.group_steps == opt.group_steps and o2.step_count == 4
+        o3 = ArenaAdam(arena, lr=1e-2); o3.load_state_dict(opt.state_dict())
+        assert o3.group_steps == opt.group_steps and o3.step_count == 4
+        # an update whose forward passes drew no LayerDrop decision (evaluation, or LayerDrop off) steps everything
+        opt.zero_grad(); opt.step()
+        assert opt.group_steps == {"encoder.layers.0.": 4, "encoder.layers.1.": 2, "encoder.layers.2.": 4}

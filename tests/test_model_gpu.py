@@ -708,6 +708,72 @@ def test_two_phase_generator_matches_reference(tag):
             np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), eps, atol=1e-4)
 
 
+def test_layerdrop_optimizer_trajectory_matches_reference():
+    """Five updates under --encoder-layerdrop 0.4 --decoder-layerdrop 0.3 with Adam (lr 5e-3, weight decay 1e-2): the reference's Adam
+    skips a parameter whose gradient is None -- a layer no forward of the update ran (fairseq/optim/adam.py:160-165 behind
+    fairseq_optimizer.py:97-101): no moment decay, no weight decay, its own bias-correction step.  Seeded like the reference run
+    (tests/golden/make_golden.py layerdrop_opt): same decisions, losses and gradient norms 2e-4, parameters of every layer 2e-4,
+    per-parameter step counts exact (through the reference's optimizer-state layout)."""
+    from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
+    from fbk_fairseq_st_amd.optim import ArenaAdam
+    from fbk_fairseq_st_amd.data import Dictionary
+    from fbk_fairseq_st_amd.registry import namespace
+    from helpers import load_golden
+    from oracle import s2t_ref
+    g = load_golden("layerdrop_opt")
+    D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed, steps = [int(v) for v in g["meta"]]
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    t = lambda k: torch.from_numpy(g["in_" + k])
+    sample = dict(id=t("id"), ntokens=int(g["in_ntokens"]), nsentences=int(g["in_src_lengths"].shape[0]),
+                  net_input=dict(src_tokens=t("src_tokens"), src_lengths=t("src_lengths"), prev_output_tokens=t("prev_output_tokens")),
+                  target=t("target"), target_lengths=t("target_lengths"), transcript_target=t("transcript_target"),
+                  transcript_target_lengths=t("transcript_target_lengths"), ctc_encoder_layer=ctc_layer)
+    args = namespace(arch="conv_transformer", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+                     label_smoothing=0.1, ctc_compress_out=False, ctc_encoder_layer=ctc_layer, ctc_weight=1.0,
+                     encoder_embed_dim=D, encoder_ffn_embed_dim=Ff, encoder_attention_heads=H, encoder_layers=EL, decoder_layers=DL, no_attn_2d=True,
+                     decoder_embed_dim=D, decoder_ffn_embed_dim=Ff, decoder_attention_heads=H,
+                     input_feat_per_channel=80, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0, relu_dropout=0.0, sentence_avg=False,
+                     encoder_layerdrop=float(g["rates"][0]), decoder_layerdrop=float(g["rates"][1]))
+    tgt, src = Dictionary.synthetic(V_tgt - 4), Dictionary.synthetic(V_src - 5)
+    src.add_symbol("<ctc_blank>")
+    task = tasks.SpeechTranslationCTCTask(args, tgt, src)
+    model, crit = task.build_model(args), task.build_criterion(args)
+    model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+    with torch.no_grad():
+        crit.ctc_aware_model.fc_out.weight.copy_(W["criterion.ctc_aware_model.fc_out.weight"])
+        crit.ctc_aware_model.fc_out.bias.copy_(W["criterion.ctc_aware_model.fc_out.bias"])
+    model.hp.sub_dropout = 0.0
+    model.materialize(DEV, torch.float32, extra=crit.arena_params())
+    model.train(); crit.train()
+    opt = ArenaAdam(model.arena, lr=5e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-2)
+    s = to_dev(sample)
+    for it in range(steps):
+        opt.zero_grad()
+        torch.manual_seed(int(g["fwd_seeds"][it]))
+        loss, ss, _ = crit(model, s)
+        opt.backward(loss)
+        opt.multiply_grads(1.0 / float(ss))
+        gn = opt.clip_grad_norm(0.5)
+        opt.step()
+        close(loss, g["losses"][it], 2e-4, "loss%d" % it)
+        close(gn, g["gnorms"][it], 2e-4, "gnorm%d" % it)
+    sd = dict(model.state_dict())
+    for k in g:
+        if k.startswith("param_"):
+            close(sd[k[6:]], g[k], 2e-4, k)
+    # the step counts, as the reference's checkpoint would hold them
+    names = [str(k) for k in g["step_keys"]]
+    ref_sd = opt.reference_state_dict(names)
+    for i, (n, st) in enumerate(zip(names, g["step_vals"])):
+        mine = int(ref_sd["state"][i]["step"]) if i in ref_sd["state"] else 0
+        assert mine == int(st), (n, mine, int(st))
+    # and back: a second optimizer picks the counts up from that layout
+    opt2 = ArenaAdam(model.arena, lr=5e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-2)
+    opt2.load_reference_state_dict(ref_sd, names)
+    assert opt2.group_steps == opt.group_steps and opt2.step_count == opt.step_count
+
+
 @pytest.mark.parametrize("tag", ["nc", "c"])
 def test_layerdrop_matches_reference(tag):
     """--encoder-layerdrop 0.4 --decoder-layerdrop 0.3 (conv_transformer.py:238-243, fairseq/modules/layer_drop.py): seeded like the
