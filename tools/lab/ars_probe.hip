@@ -56,6 +56,16 @@ template <int LO> __device__ __forceinline__ void mfma_acc(f32x16& acc, const u3
 template <int LO> __device__ __forceinline__ void mfma_first(f32x16& acc, const u32x4& w, const f32x16& c) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %4" : "=&v"(acc) : "v"(w), "n"(LO), "n"(LO + 3), "v"(c));
 }
+template <int LO> __device__ __forceinline__ void mfma16_acc(f32x4& acc, const u32x4& w) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%2:%3], %0" : "+v"(acc) : "v"(w), "n"(LO), "n"(LO + 3));
+}
+template <int LO> __device__ __forceinline__ void mfma16_first(f32x4& acc, const u32x4& w, const f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, a[%2:%3], %4" : "=&v"(acc) : "v"(w), "n"(LO), "n"(LO + 3), "v"(c));
+}
+__device__ __forceinline__ void swap16(uint32_t& x, uint32_t& y) {       // x's odd 16-lane rows <-> y's even ones
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    x = r[0]; y = r[1];
+}
 template <int OFF> __device__ __forceinline__ void lds_read16(u32x4& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
@@ -294,6 +304,227 @@ __global__ __launch_bounds__(256, 1) void gemm_ars_kernel(ArsArgs p) {
     ARS_T(13); ARS_RT(14);
 }
 
+__global__ __launch_bounds__(256, 1) void gemm_ars16_kernel(ArsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ARS_RESERVE();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 15, h = lane >> 4;          // 16x16x32: row / column index of the fragment, k-group (8 of the 32 k)
+    const uint32_t s0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.X), 0, (int)((size_t)p.M * p.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.W), 0, (int)((size_t)p.N * p.ldw * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)((size_t)p.M * p.ldc * 2), 0x00020000);
+    ARS_T(0); ARS_RT(12);
+
+    // ---- the whole bias -> LDS, once, by LDS-DMA (1 KiB = 256 floats per wave-instruction; columns past N read as zeros through the
+    // buffer's bounds check): older than every activation slab, so landed when the first activation load is, and published by
+    // the barrier that follows it.  No bias: zeros.
+    if (p.bias) {
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
+        for (int i = wave; i * 256 < p.N; i += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_void*)(smem + BIAS_OFF + i * 1024), 16, (uint32_t)(lane * 16), (uint32_t)(i * 1024), 0, 0);
+    } else {
+        for (int i = threadIdx.x; i * 4 < p.N; i += 256) *reinterpret_cast<u32x4*>(smem + BIAS_OFF + 16 * i) = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- constants of the weight stream.  Slot image: [32 columns][1,024 B], chunk c of column n at chunk c ^ (n & 15).
+    uint32_t vw[8];                                                // per-lane source offsets of this wave's eight rows of a block
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int col = 8 * wave + i;
+        vw[i] = (uint32_t)((size_t)col * p.ldw * 2 + ((lane ^ (col & 15)) << 4));
+    }
+    const uint32_t wstep = 32u * (uint32_t)p.ldw * 2u;             // bytes from one column block to the next
+    // fragment addresses in slot 0: column n = lane & 31, k-step s = 8 a + b: byte (32 b + 16 h) ^ ((n & 15) << 4) of 256-byte group a
+    uint32_t va[4];                                                // k-step s = 4 a + b, column tile c: + 16384 c + 256 a
+#pragma unroll
+    for (int b = 0; b < 4; ++b) va[b] = s0 + m * 1024 + (((4 * b + h) ^ m) << 4);
+    const uint32_t vbias = s0 + BIAS_OFF + 16 * h;                 // + 128 cb + 64 c: this lane's four floats (columns 16 c + 4 h ..)
+    uint32_t ar[2];                                                // activation staging: fragment addresses in this wave's quarter
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) ar[sp] = s0 + wave * SLOT + m * 128 + ((((4 * sp + h) ^ ((m >> 1) & 7))) << 4);
+
+    u32x4 wf[4];
+    f32x4 acc[2][2][4];                                            // [set][column tile][row tile]
+    f32x4 bv[2];                                                   // the block's bias per column tile (the chains' C operand)
+    uint32_t pk[4][4];                                             // [row tile][c0 lo, c0 hi, c1 lo, c1 hi]
+    u32x4 bt[2];
+#pragma unroll
+    for (int q_ = 0; q_ < 2; ++q_)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[q_][c][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int sg = 0; sg < MAXSEG; ++sg) {
+        const ArsSeg seg = p.segs[blockIdx.x * MAXSEG + sg];
+        const int cb0 = __builtin_amdgcn_readfirstlane(seg.cb0), nb = __builtin_amdgcn_readfirstlane(seg.cb1) - cb0;
+        if (nb <= 0) break;
+        const int R0 = __builtin_amdgcn_readfirstlane(seg.rb) * 256 + wave * 64;
+        if (sg > 0) { asm volatile("s_barrier" ::: "memory"); ARS_SB(); }     // every wave has left the ring
+
+        // ---- this wave's 64 rows of X -> a[0:255], through its own quarter of the idle ring: eight 64-k slabs, four in flight.
+        // Slab image: [64 rows][128 B], 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 of 32-row
+        // fragments); the DMA writes 1 KiB = 8 rows linearly, so the permutation sits on the source address.
+        {
+            uint32_t vx[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 8 * i + (lane >> 3), g = (row >> 1) & 7;
+                const int gr = min(R0 + row, p.M - 1);
+                vx[i] = (uint32_t)(((size_t)gr * p.ldx + 8 * ((lane & 7) ^ g)) * 2);
+            }
+            auto slab = [&](int u) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(smem + wave * SLOT + (u & 3) * 8192 + i * 1024), 16, vx[i],
+                                                             (uint32_t)(128 * u), 0, 0);
+            };
+            slab(0); slab(1); slab(2); slab(3);
+            static_for<8>([&](auto u_) {
+                constexpr int u = decltype(u_)::value;
+                ARS_SB();
+                wait_vm<8 * (u <= 4 ? 3 : 7 - u)>();               // all but the slabs behind this one have landed
+                ARS_SB();
+                static_for<4>([&](auto t_) {
+                    constexpr int t = decltype(t_)::value;
+                    static_for<2>([&](auto sp_) {
+                        constexpr int sp = decltype(sp_)::value;
+                        lds_read16_acc<64 * t + 4 * (2 * u + sp), (u & 3) * 8192 + t * 2048>(ar[sp]);
+                    });
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ARS_SB();
+                if constexpr (u + 4 < 8) slab(u + 4);
+            });
+        }
+        ARS_SB();
+        ARS_T(1 + 5 * sg);
+        asm volatile("s_barrier" ::: "memory");                   // every wave is done with its staging quarter: the ring is free
+        ARS_SB();
+
+        // output offsets of this lane's rows (tile t: row R0 + 32 t + m), its 16 bytes start at column 8 h of a 16-column half block
+        uint32_t vo[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = R0 + 16 * t + m;
+            vo[t] = row < p.M ? (uint32_t)(((size_t)row * p.ldc + 16 * (h & 1) + 8 * (h >> 1)) * 2) : 0xFFFFFFF0u;
+        }
+        auto dma = [&](int j, int i) {                             // row i of this wave's share of block j (clamped past the end)
+            const int jj = min(j, nb - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(smem + (j & 3) * SLOT + (8 * wave + i) * 1024), 16, vw[i],
+                                                     (uint32_t)(cb0 + jj) * wstep, 0, 0);
+        };
+        auto bias_issue = [&](int j) {                             // bias of block j: two ds_read_b128 (in the wave's LDS queue)
+            const uint32_t a = vbias + 128u * (uint32_t)(cb0 + j);
+            lds_read16<0>(bt[0], a); lds_read16<64>(bt[1], a);
+        };
+        auto bias_collect = [&]() {                                // once they have returned: -> bv
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const uint32_t u_ = bt[c][e]; bv[c][e] = __uint_as_float(u_); }
+        };
+        // epilogue pieces of the accumulator set Q (block jq): convert, swap halves between lanes l and l + 32, store
+        // row tile t of set Q: lane (m, h) holds columns 16 c + 4 h + 0..3 of row 16 t + m; after the exchange between the 16-lane rows
+        // h and h ^ 1 it holds 8 consecutive columns: (h & 1) * 16 + (h >> 1) * 8
+        auto cvt = [&](int Q, int t) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                pk[t][2 * c] = pack2(acc[Q][c][t][0], acc[Q][c][t][1]);
+                pk[t][2 * c + 1] = pack2(acc[Q][c][t][2], acc[Q][c][t][3]);
+            }
+        };
+        auto swp = [&](int t) { swap16(pk[t][0], pk[t][2]); swap16(pk[t][1], pk[t][3]); };
+        auto store = [&](int t, int jq, uint32_t vofs) {
+            const u32x4 d = {pk[t][0], pk[t][1], pk[t][2], pk[t][3]};
+            __builtin_amdgcn_raw_buffer_store_b128(d, rC, vofs, (uint32_t)(((cb0 + jq) * 32) * 2), 0);
+            asm volatile("s_nop 4" :: "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]) : "memory");
+        };
+
+        // ---- prologue of the stream: blocks 0, 1 and the first three rows of block 2
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma(0, i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma(1, i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma(2, i);
+        bias_issue(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ARS_SB();
+        bias_collect();
+        wait_vm<11>();
+        asm volatile("s_barrier" ::: "memory");
+        ARS_SB();
+        ARS_T(2 + 5 * sg);
+        lds_read16<0>(wf[0], va[0]); lds_read16<16384>(wf[1], va[0]); lds_read16<0>(wf[2], va[1]);      // steps 0, 1, 2 = (s, c) = (0, 0), (0, 1), (1, 0)
+        ARS_SB();
+
+        // one column block j: ring slot j & 3, accumulator set P (compile time: the loop below alternates).  Step S = 2 s + c: the W fragment
+        // of column tile c, k-step s (32 of k) feeds four MFMAs (the wave's four 16-row tiles)
+        auto block = [&](auto par_, int j) {
+            constexpr int P = decltype(par_)::value, Q = P ^ 1;
+            uint32_t vob[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vob[t] = j > 0 ? vo[t] : 0xFFFFFFF0u;
+            const uint32_t so = (uint32_t)((j & 3) * SLOT), sn = (uint32_t)(((j + 1) & 3) * SLOT);
+            uint32_t vc[4], vn[2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) vc[b] = va[b] + so;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) vn[b] = va[b] + sn;
+            static_for<32>([&](auto s_) {
+                constexpr int S = decltype(s_)::value, KS = S >> 1, C = S & 1;
+                if constexpr (S == 29) {
+                    if (!(ARS_X & 1)) { if (j == 0) wait_vm<12>(); else wait_vm<16>(); }
+                    if (!(ARS_X & 2)) asm volatile("s_barrier" ::: "memory");
+                    ARS_SB();
+                }
+                if constexpr (S == 26 && !(ARS_X & 8)) bias_issue(min(j + 1, nb - 1));
+                {   // W fragment of step S + 3 (the next block's first three from the next slot)
+                    constexpr int S3 = (S + 3) & 31, K3 = S3 >> 1, C3 = S3 & 1;
+                    if constexpr (S + 3 < 32) lds_read16<16384 * C3 + 256 * (K3 >> 2)>(wf[(S + 3) & 3], vc[K3 & 3]);
+                    else lds_read16<16384 * C3 + 256 * (K3 >> 2)>(wf[(S + 3) & 3], vn[K3 & 3]);
+                }
+                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                static_for<4>([&](auto t_) {
+                    constexpr int t = decltype(t_)::value;
+                    if constexpr (KS == 0) mfma16_first<64 * t>(acc[P][C][t], wf[S & 3], bv[C]);
+                    else mfma16_acc<64 * t + 4 * KS>(acc[P][C][t], wf[S & 3]);
+                });
+                if constexpr (S < 5 && !(ARS_X & 1)) dma(j + 2, S + 3);
+                if constexpr (S >= 29 && !(ARS_X & 1)) dma(j + 3, S - 29);
+                if constexpr (!(ARS_X & 4)) {
+                if constexpr (S == 2 || S == 6 || S == 10 || S == 14) cvt(Q, (S - 2) >> 2);
+                if constexpr (S == 4 || S == 8 || S == 12 || S == 16) swp((S - 4) >> 2);
+                if constexpr (S == 12 || S == 16 || S == 20 || S == 24) store((S - 12) >> 2, max(j - 1, 0), vob[(S - 12) >> 2]);
+                }
+                if constexpr (S == 28 && !(ARS_X & 8)) bias_collect();
+                ARS_SB();
+            });
+        };
+        int j = 0;
+        for (; j + 2 <= nb; j += 2) {
+            block(std::integral_constant<int, 0>{}, j);
+            block(std::integral_constant<int, 1>{}, j + 1);
+        }
+        if (j < nb) block(std::integral_constant<int, 0>{}, j);
+        ARS_T(3 + 5 * sg);
+        // ---- the last block's epilogue
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        const int Ql = (nb - 1) & 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (Ql) cvt(1, t); else cvt(0, t);
+            swp(t);
+            store(t, nb - 1, vo[t]);
+        }
+        ARS_T(4 + 5 * sg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ARS_T(5 + 5 * sg);
+    }
+    ARS_T(13); ARS_RT(14);
+}
+
 // host: cut the (row block, column block) space into one span per workgroup, charging `a` column blocks for every activation load
 static std::vector<ArsSeg> ars_partition(int RB, int CB, int G, double a) {
     const double T = (double)RB * CB;
@@ -356,6 +587,9 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(bias, hbias.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemset(C, 0xff, (size_t)M * N * 2));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ars_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ars16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    const bool shape16 = getenv("ARS_SHAPE16") != nullptr;
+    auto* const kern = shape16 ? gemm_ars16_kernel : gemm_ars_kernel;
     const int RB = (M + 255) / 256;
     unsigned long long* dbg; CK(hipMalloc(&dbg, 4096 * 16 * 8)); CK(hipMemset(dbg, 0, 4096 * 16 * 8));
     const int G = getenv("ARS_G") ? atoi(getenv("ARS_G")) : 256;
@@ -368,7 +602,7 @@ int main(int argc, char** argv) {
     }
     ArsSeg* dsegs; CK(hipMalloc(&dsegs, hs.size() * sizeof(ArsSeg))); CK(hipMemcpy(dsegs, hs.data(), hs.size() * sizeof(ArsSeg), hipMemcpyHostToDevice));
     ArsArgs a{A, B, C, bias, M, N, K, K, N, dsegs, dbg};
-    hipLaunchKernelGGL(gemm_ars_kernel, dim3(G), dim3(256), LDS_BYTES, 0, a);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS_BYTES, 0, a);
     CK(hipDeviceSynchronize());
     const int nr = 96; std::vector<int> hr(nr);
     for (int i = 0; i < nr; ++i) hr[i] = i < 8 ? i : (i < 16 ? M - 1 - (i - 8) : (int)(((long)i * 7919 * 131) % M));
@@ -388,9 +622,9 @@ int main(int argc, char** argv) {
         }
     printf("check: %ld bad of %ld; worst |C - ref| = %.4g on values up to %.4g (%s)\n", bad, (long)nr * N, worst, scale, bad == 0 ? "ok" : "WRONG");
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_ars_kernel, dim3(G), dim3(256), LDS_BYTES, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS_BYTES, 0, a);
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_ars_kernel, dim3(G), dim3(256), LDS_BYTES, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(G), dim3(256), LDS_BYTES, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / us * 1e-6;
@@ -413,6 +647,6 @@ int main(int argc, char** argv) {
         (void)tmin; (void)tmax;
     }
 #endif
-    printf("gemm_ars %d x %d x %d, load cost %.1f: %.1f us  %.0f TFLOP/s\n", M, N, K, acost, us, tf);
+    printf("gemm_ars %s %d x %d x %d, load cost %.1f: %.1f us  %.0f TFLOP/s\n", shape16 ? "16x16x32" : "32x32x16", M, N, K, acost, us, tf);
     return 0;
 }
