@@ -562,6 +562,26 @@ def test_gradnorm_clip_adam():
     assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
 
 
+def test_adam_at_arena_size():
+    """the vector loop of adam_kernel takes two 16-byte groups per lane and step once the grid is capped (> 16.8 M parameters): every
+    element of a 40 M-parameter arena (a size that is not a multiple of four: the element-wise tail too) against the same arithmetic in torch"""
+    n = 40_000_007
+    g0 = torch.Generator(device=DEV).manual_seed(3)
+    p = torch.randn(n, device=DEV, generator=g0); g = torch.randn(n, device=DEV, generator=g0) * 0.1
+    m = torch.randn(n, device=DEV, generator=g0) * 0.01; v = torch.rand(n, device=DEV, generator=g0) * 1e-3
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    out2 = torch.tensor([0.0, 0.5], device=DEV)
+    lr, b1, b2, eps, wd, step = 5e-4, 0.9, 0.98, 1e-8, 1e-2, 7
+    gs = g * 0.5
+    mr = b1 * m + (1 - b1) * gs; vr = b2 * v + (1 - b2) * gs * gs
+    ss = lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)
+    pr = (p - wd * lr * p) - ss * mr / (vr.sqrt() + eps)
+    K.adam_step(p, g, m, v, shadow, out2, lr, b1, b2, eps, wd, step)
+    for mine, ref in ((p, pr), (m, mr), (v, vr)):
+        assert float((mine - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
 def test_add_pos_and_permutes():
     T, B, D = 11, 3, 64
     x = rnd(T, B, D, seed=1); lens = torch.tensor([11, 7, 1])
