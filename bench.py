@@ -55,7 +55,7 @@ KERNEL_OF = {"wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward p
              "gemm_nn_small": "gemm_fast_kernel<.., 64, 64, 4 waves>", "gemm_gather": "gemm_kernel<..> with row gather (implicit-GEMM convolutions)",
              "conv2_fwd": "conv2_fwd_kernel (3x3 stride-2 convolution, input rows staged once in LDS, weights in registers)",
              "conv2_dgrad": "conv2_dgrad_kernel (its data gradient, four pixel-parity classes in one launch)"}
-TRAFFIC_FILE = os.path.join("profiles", "r05_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_hbm_traffic.json")
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, MI355X_MICROARCH.md (AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_F32_TFLOPS = 157.3
 
@@ -72,18 +72,21 @@ def hbm_traffic(family):
         return None
 
 
-def build_all(arch, batch, frames, tgt_len, ctc_layer, lr, dtype, device, attn_2d=False, want_sd=False):
+def build_all(arch, batch, frames, tgt_len, ctc_layer, lr, dtype, device, attn_2d=False, want_sd=False, criterion="ctc_multi_loss", **over):
     from fbk_fairseq_st_amd import conv_transformer, criterions, tasks  # noqa: F401
     from fbk_fairseq_st_amd.registry import apply_arch, namespace, setup_task
     from fbk_fairseq_st_amd.trainer import Trainer
-    a = namespace(arch=arch, task="dummy_s2t", criterion="ctc_multi_loss",
-                  underlying_criterion="label_smoothed_cross_entropy", label_smoothing=0.1, sentence_avg=True,
-                  ctc_compress_out=True, ctc_encoder_layer=ctc_layer, ctc_weight=1.0, ctc_compress_strategy="avg",
-                  input_feat_per_channel=80, no_attn_2d=not attn_2d, dict_size=8000 - 4, src_dict_size=5000 - 4,
-                  batch_size=batch, frames=frames, tgt_len=tgt_len, transcript_len=max(tgt_len, 40),
-                  lr=[lr], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=20.0,
-                  warmup_updates=4000, warmup_init_lr=min(lr, 3e-4), seed=1, bf16=(dtype == torch.bfloat16), bucket_cap_mb=64,
-                  bucket_by_length=True)
+    kw = dict(arch=arch, task="dummy_s2t", criterion=criterion, label_smoothing=0.1, sentence_avg=True,
+              input_feat_per_channel=80, no_attn_2d=not attn_2d, dict_size=8000 - 4, src_dict_size=5000 - 4,
+              batch_size=batch, frames=frames, tgt_len=tgt_len, transcript_len=max(tgt_len, 40),
+              lr=[lr], adam_betas="(0.9, 0.98)", adam_eps=1e-8, weight_decay=0.0, clip_norm=20.0,
+              warmup_updates=4000, warmup_init_lr=min(lr, 3e-4), seed=1, bf16=(dtype == torch.bfloat16), bucket_cap_mb=64,
+              bucket_by_length=True)
+    kw.update(over)
+    a = namespace(**kw)
+    if criterion == "ctc_multi_loss":
+        a.underlying_criterion, a.ctc_compress_out, a.ctc_encoder_layer = "label_smoothed_cross_entropy", True, ctc_layer
+        a.ctc_weight, a.ctc_compress_strategy = 1.0, "avg"
     apply_arch(a)
     task = setup_task(a)
     torch.manual_seed(1)
@@ -156,6 +159,41 @@ def dp_dry_run(trainer, next_batch, ms_single, steps=6):
         launches = [(e - s_, ev0.elapsed_time(ev)) for s_, e, early, ev in red.events]
         finish_ms = ev0.elapsed_time(red.finish_event)
         early_elems, n = red.early_elems, red.n
+        red.record_events = False
+        # (c) what sharing the chip with the collective costs, measured: at every bucket launch a stand-in for an 8-rank ring all-reduce at
+        # the ASSUMED bus bandwidth (s2t_comm_standin: 16 workgroups resident for the all-reduce's duration, moving the bucket's bytes
+        # through HBM twice) runs on a side stream; clip / Adam wait for it as they would for RCCL.  Once with the persistent kernels on all
+        # 256 CUs, once leaving 16 to it (s2t_set_option reserve_cus, the Trainer's --reserve-cus default at world > 1).
+        from fbk_fairseq_st_amd import kernels as K
+        standin = {}
+        scratch = torch.empty(red.bucket_elems, dtype=red.flat.dtype, device=red.flat.device)
+        red.standin = dict(stream=torch.cuda.Stream(), scratch=scratch, workgroups=16, ranks=8, bus_gbps=ASSUMED_BUS_GBPS)
+        try:
+            for reserve in (0, 16):
+                K.set_option("reserve_cus", reserve)
+                trainer.train_step([next_batch()])
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    trainer.train_step([next_batch()])
+                torch.cuda.synchronize()
+                standin["ms_per_step_reserve%d" % reserve] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+            K.set_option("reserve_cus", 16)
+            red.standin = None
+            trainer.train_step([next_batch()])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                trainer.train_step([next_batch()])
+            torch.cuda.synchronize()
+            standin["ms_per_step_reserve16_no_standin"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        finally:
+            red.standin = None
+            K.set_option("reserve_cus", trainer.reserve_cus)
+        standin.update(what="one GPU: the data-parallel schedule with a stand-in for the all-reduce on a side stream (16 workgroups resident for "
+                            "2 (N-1)/N x bucket bytes / bus, N = 8, moving 2 x bucket bytes through HBM each way); NOT a measurement of xGMI",
+                       workgroups=16, ranks=8, assumed_bus_GBps=ASSUMED_BUS_GBPS)
+        del scratch
         proj = {}
         for nr in (2, 4, 8):
             exposed, total = D.project_exposed_allreduce(launches, finish_ms, nr, ASSUMED_BUS_GBPS, red.flat.element_size())
@@ -167,6 +205,7 @@ def dp_dry_run(trainer, next_batch, ms_single, steps=6):
                 "allreduce_launched_in_backward_frac": round(early_elems / max(n, 1), 4),
                 "exposed_bytes_after_last_flush": (n - early_elems) * red.flat.element_size(),
                 "bucket_launch_ms_before_backward_end": [round(finish_ms - t, 3) for _, t in launches],
+                "comm_standin": standin,
                 "projection": dict(proj, assumed_bus_GBps=ASSUMED_BUS_GBPS,
                                    formula="bucket all-reduce = 2 (N-1)/N x bytes / bus, buckets back to back from their launch times; "
                                            "scaling = N x single-rank ms / (dp-schedule ms + exposed ms)")}
@@ -256,14 +295,24 @@ def roofline_of(trainer, next_batch, prof_steps, dtype, instrument=True, traffic
     if not instrument:
         return None
     fam = {f: K.prof_read(f) for f in FAMILIES}
-    gemms = {f: v for f, v in fam.items() if not f.startswith("attn") and v["launches"] > 0 and v["ms"] > 0}     # every MFMA product family
+    if fam["attn_bwd"]["flops"] > 0:
+        # the library counts every MFMA the two backward kernels issue (14 B H Tq Tk d: S and dP are recomputed in both); the figure
+        # reported is the conventional one, 2.5 x the forward = 10 B H Tq Tk d
+        fam["attn_bwd"] = dict(fam["attn_bwd"], flops=fam["attn_bwd"]["flops"] * 10.0 / 14.0)
+    mfma = {f: v for f, v in fam.items() if v["launches"] > 0 and v["ms"] > 0 and v["flops"] > 0}     # every MFMA family, attention included
+    gemms = {f: v for f, v in mfma.items() if not f.startswith("attn")}
     if not gemms:
         return None
-    dom = max(gemms, key=lambda f: gemms[f]["ms"])
+    dom = max(gemms, key=lambda f: gemms[f]["ms"])                     # the headline kernel: the product family with the most time
     gm = gemms[dom]
     ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
     tot_fl = sum(v["flops"] for v in gemms.values()); tot_ms = sum(v["ms"] for v in gemms.values())
+    tf = {k: v["flops"] / (v["ms"] * 1e-3) / 1e12 for k, v in mfma.items()}
+    # the MFMA family FURTHEST below its roofline among those that matter (>= 5 % of the MFMA time): reported beside the longest one
+    all_ms = sum(v["ms"] for v in mfma.values())
+    big = {k: v for k, v in mfma.items() if v["ms"] >= 0.05 * all_ms}
+    low = min(big, key=lambda f: tf[f]) if big else dom
     roof = {"bound": "mfma", "kernel": KERNEL_OF[dom], "family": dom,
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": hbm_traffic(dom) if traffic else None,
@@ -271,7 +320,11 @@ def roofline_of(trainer, next_batch, prof_steps, dtype, instrument=True, traffic
             "launches_per_step": gm["launches"] // prof_steps,
             "flop_per_launch": round(gm["flops"] / gm["launches"] / 1e9, 3), "flop_unit": "GFLOP",
             "all_gemm_tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "all_gemm_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
-            "tflops_by_family": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in gemms.items()},
+            "tflops_by_family": {k: round(v, 1) for k, v in tf.items()},
+            "frac_by_family": {k: round(v / peak, 4) for k, v in tf.items()},
+            "lowest_frac_family": {"family": low, "achieved": round(tf[low], 1), "frac": round(tf[low] / peak, 4),
+                                   "ms_per_step": round(mfma[low]["ms"] / prof_steps, 3),
+                                   "note": "attention is counted at 4 (forward) / 10 (backward) x B H Tq Tk d: the second recomputation of S and dP in the backward is not counted"},
             "ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in fam.items() if v["launches"] > 0}}
     if traffic:
         roof["traffic_source"] = TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured by this run)"
@@ -302,6 +355,169 @@ def extra_config(name, arch, dtype, device, steps, warmup, batch=None, frames=15
     del trainer, model, crit, task
     torch.cuda.empty_cache()
     return out
+
+
+def cfg5_train(name, arch, criterion, dtype, device, steps, warmup, cpu=True, **over):
+    """BASELINE configs[4], training legs: the m-sized model on 16 x 1000 frames, target length 40, dropout on,
+    full update (forward, loss, backward, clip, Adam).  `knowledge_distillation`: word-level KD from K = 8 stored teacher logits per
+    target position (fairseq/criterions/knowledge_distillation.py:44-96); `cross_entropy_dualdecoder`: encoder + translation decoder +
+    transcript decoder (conv_transformer_dualdecoder.py:13-81, criterions/cross_entropy_dualdecoder.py:8-83)."""
+    B, T, L, K_TEACHER = 16, 1000, 40, 8
+    a, task, model, crit, trainer, ref_sd = build_all(arch, B, T, L, 0, 1e-9, dtype, device, want_sd=cpu, criterion=criterion, **over)
+
+    def make(batch, seed):
+        from fbk_fairseq_st_amd.data import synthetic_batch
+        s = synthetic_batch(batch, T, L, L, len(task.tgt_dict), task.src_dict.index("<ctc_blank>"), seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        if criterion == "knowledge_distillation":
+            tidx = torch.randint(4, len(task.tgt_dict), (batch, L, K_TEACHER), generator=g)
+            tidx[:, :, 0] = s["target"]                                  # the teacher usually ranks the reference token first
+            s["teacher_output"] = [tidx, torch.randn(batch, L, K_TEACHER, generator=g).sort(dim=-1, descending=True)[0] * 2.0]
+        else:
+            tr = s["transcript_target"]
+            s["net_input"]["transcript_prev_output_tokens"] = torch.cat([torch.full((batch, 1), 2, dtype=torch.long), tr[:, :-1]], 1)
+        return s
+    sample = trainer.prepare(make(B, 100))
+    nxt = lambda: sample
+    dt, frames_done, _, stats = timed_updates(trainer, nxt, steps, warmup, 1, device)
+    out = {"name": name, "value": round(frames_done / dt, 1), "unit": "audio-frames/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "warmup": warmup, "dtype": "bf16" if dtype == torch.bfloat16 else "fp32",
+           "config": {"workload": "%s + %s full update, %d x %d x 80 fbank, target/transcript len %d%s, dropout on, batch resident in HBM"
+                                  % (arch, criterion, B, T, L, ", teacher top-%d" % K_TEACHER if criterion == "knowledge_distillation" else ""),
+                      "frames_per_step": frames_done // steps},
+           "loss_finite": finite(stats)}
+    out["roofline"] = roofline_of(trainer, nxt, 2, dtype, traffic=False)
+    if cpu:
+        from oracle import s2t_ref
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        cfg = s2t_ref.default_cfg(D=a.encoder_embed_dim, heads=a.encoder_attention_heads, ffn=a.encoder_ffn_embed_dim,
+                                  enc_layers=a.encoder_layers, dec_layers=a.decoder_layers, ctc_layer=0)
+        W = {k: v.clone().requires_grad_(v.dtype.is_floating_point and v.dim() > 0 and "running" not in k and "_float_tensor" not in k
+                                         and "version" not in k) for k, v in ref_sd.items()}
+        train = [k for k, v in W.items() if v.requires_grad]
+        Bc = 2
+        s = make(Bc, 7)
+        times = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            for k in train:
+                W[k].grad = None
+            ni = s["net_input"]
+            if criterion == "knowledge_distillation":
+                enc, _ = s2t_ref.encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training=True)
+                logits = s2t_ref.decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+                loss = s2t_ref.kd_loss(logits, s["target"], s["teacher_output"][0], s["teacher_output"][1], a.kd_lambda, a.kd_temperature, cfg["pad"])
+            else:
+                loss = s2t_ref.dual_decoder_loss(W, cfg, s, 0.1, a.primary_loss_weight, a.auxiliary_loss_weight, training=True)[0]
+            loss.backward()
+            with torch.no_grad():
+                grads = [W[k].grad / float(s["ntokens"]) if W[k].grad is not None else torch.zeros_like(W[k]) for k in train]
+                s2t_ref.clip_grad_norm(grads, 20.0)
+            times.append(time.perf_counter() - t0)
+        t = sum(times[1:]) / len(times[1:])
+        out["cpu_baseline"] = {"value": round(Bc * T / t, 1), "unit": "audio-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "oracle/s2t_ref.py forward + loss + backward + clip of the same model, fp32, %d x %d frames, mean of 2 after "
+                                         "1 warm-up (Adam left out: a lower bound on the reference's update time)" % (Bc, T)}
+    del trainer, model, crit, task
+    torch.cuda.empty_cache()
+    return out
+
+
+def cfg5_beam5(name, dtype, device, runs=2, cpu=True):
+    """BASELINE configs[4], inference leg: beam-5 generation (fairseq/sequence_generator.py:163-447 + fairseq/search.py:55-83 through
+    this package's SequenceGenerator) of 16 utterances x 1000 frames, max_len_b 200, on the random-init m model: no hypothesis ends
+    before the length limit, so every run is 201 decode steps of 80 live hypotheses -- the most expensive case.  `value` = target tokens
+    emitted per second over the WHOLE call (encoder + search + finalisation).  The roofline is the decode step's HBM floor: the bytes
+    one step must move (decoder weights once, the encoder-side K/V of every sentence once, the self-attention K/V rows of every live
+    hypothesis at the mean step) over the time one step takes."""
+    from fbk_fairseq_st_amd import kernels as K
+    from fbk_fairseq_st_amd.sequence_generator import SequenceGenerator
+    B, T, BEAM, MAXLEN = 16, 1000, 5, 200
+    a, task, model, crit, trainer, ref_sd = build_all("s2t_transformer_m", B, T, 40, 0, 1e-9, dtype, device, want_sd=cpu,
+                                                      criterion="label_smoothed_cross_entropy", max_target_positions=1024)
+    model.eval()
+    gen = SequenceGenerator([model], task.target_dictionary, beam_size=BEAM, max_len_a=0.0, max_len_b=MAXLEN, min_len=1)
+    gen.record_stats = True
+    sample = trainer.prepare(task.dummy_batch(seed=100))
+    net = {"net_input": {k: v for k, v in sample["net_input"].items() if k in ("src_tokens", "src_lengths")}}
+    gen.generate([model], net)                                            # warm-up (allocations, graph capture)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        hyps = gen.generate([model], net)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / runs
+    st = dict(gen.last_stats)                                             # steps, encoder / search seconds of the last call
+    tokens = sum(int(h["tokens"].numel()) for hs in hyps for h in hs)
+    D, Ff, Ld, V = a.decoder_embed_dim, a.decoder_ffn_embed_dim, a.decoder_layers, len(task.tgt_dict)
+    es = 2 if dtype == torch.bfloat16 else 4
+    Ts = int(st["src_frames"])
+    weight_b = (Ld * (6 * D * D + 2 * D * Ff) + V * D) * es
+    cross_b = B * Ts * 2 * D * Ld * es
+    self_b = B * BEAM * 2 * D * Ld * es * (st["steps"] / 2.0)
+    step_bytes = weight_b + cross_b + self_b
+    step_ms = st["search_s"] * 1e3 / st["steps"]
+    ach = step_bytes / (step_ms * 1e-3) / 1e9
+    out = {"name": name, "value": round(tokens / dt, 1), "unit": "target tokens/s (beam-5, all returned hypotheses)",
+           "ms_per_call": round(dt * 1e3, 2), "encoder_ms": round(st["encoder_s"] * 1e3, 3), "search_ms": round(st["search_s"] * 1e3, 2),
+           "decode_steps": st["steps"], "ms_per_decode_step": round(step_ms, 4), "launches_per_decode_step": st.get("launches_per_step"),
+           "best_hypothesis_tokens_per_s": round(sum(int(hs[0]["tokens"].numel()) for hs in hyps) / dt, 1),
+           "dtype": "bf16" if dtype == torch.bfloat16 else "fp32", "runs": runs,
+           "config": {"workload": "s2t_transformer_m, generate beam 5, max_len_b %d, %d utterances x %d frames (%d encoder frames), %d live "
+                                  "hypotheses, random-init weights (no early EOS: %d steps)" % (MAXLEN, B, T, Ts, B * BEAM, st["steps"])},
+           "roofline": {"bound": "hbm", "kernel": "decode step (all launches of one step of the incremental decoder + search)",
+                        "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                        "bytes_per_step": int(step_bytes), "bytes_decoder_weights": int(weight_b), "bytes_encoder_kv": int(cross_b),
+                        "bytes_self_kv_mean_step": int(self_b), "floor_us_at_peak": round(step_bytes / 8e12 * 1e6, 2)}}
+    if cpu:
+        from oracle import s2t_ref
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        cfg = s2t_ref.default_cfg(D=a.encoder_embed_dim, heads=a.encoder_attention_heads, ffn=a.encoder_ffn_embed_dim,
+                                  enc_layers=a.encoder_layers, dec_layers=a.decoder_layers, ctc_layer=0)
+        W = {k: v.float() for k, v in ref_sd.items()}
+        src = sample["net_input"]["src_tokens"][:1].float().cpu()
+        lens = torch.tensor([T])
+        CPU_LEN = 24
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            res = s2t_ref.beam_search(W, cfg, src, lens, BEAM, 0.0, CPU_LEN, 1, 1.0, 0.0, 1.0)
+        t = time.perf_counter() - t0
+        ntok = sum(int(h[0].numel()) for hs in res for h in hs)
+        out["cpu_baseline"] = {"value": round(ntok / t, 1), "unit": out["unit"], "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "oracle/s2t_ref.py beam_search (encoder + beam 5) of 1 utterance x %d frames with max_len_b %d, fp32; the "
+                                         "port re-decodes the whole prefix every step (no incremental state), which at %d steps costs about "
+                                         "what the reference's cached decoder does" % (T, CPU_LEN, CPU_LEN + 1)}
+    del trainer, model, crit, task, gen
+    torch.cuda.empty_cache()
+    return out
+
+
+EXTRA_NAMES = ("cfg3_batch8", "cfg2_s_fp32", "cfg4_l_bucketed", "cfg5_kd_train", "cfg5_dual_train", "cfg5_beam5", "cfg5_beam5_fp32")
+
+
+def extra_by_name(name, device, args):
+    import numpy as np
+    bf16, f32 = torch.bfloat16, torch.float32
+    cpu = args.cpu_baseline
+    if name == "cfg3_batch8":
+        return extra_config(name, "s2t_transformer_m", bf16, device, 20, 5, batch=8, frames=1500, roofline=args.roofline)
+    if name == "cfg2_s_fp32":
+        return extra_config(name, "s2t_transformer_s", f32, device, 10, 3, batch=32, frames=1000, tgt_len=30, roofline=args.roofline)
+    if name == "cfg4_l_bucketed":
+        rs = np.random.RandomState(4)
+        mustc = [int(x) for x in np.clip(rs.lognormal(np.log(600.0), 0.7, 512), 50, 2000)]
+        return extra_config(name, "s2t_transformer_l", bf16, device, 20, 5, tgt_len=0, lengths=mustc, max_tokens=48000, roofline=args.roofline)
+    if name == "cfg5_kd_train":
+        return cfg5_train(name, "s2t_transformer_m", "knowledge_distillation", bf16, device, 20, 5, cpu=cpu, kd_lambda=0.6, kd_temperature=2.0,
+                          sentence_avg=False)
+    if name == "cfg5_dual_train":
+        return cfg5_train(name, "conv_transformer_dualdecoder_big2", "cross_entropy_dualdecoder", bf16, device, 20, 5, cpu=cpu,
+                          encoder_layers=12, dropout=0.15, primary_loss_weight=0.7, auxiliary_loss_weight=0.3, sentence_avg=False)
+    if name == "cfg5_beam5":
+        return cfg5_beam5(name, bf16, device, cpu=cpu)
+    if name == "cfg5_beam5_fp32":
+        return cfg5_beam5(name, f32, device, cpu=False)
+    raise SystemExit("bench.py --only: unknown workload %r (one of %s)" % (name, ", ".join(EXTRA_NAMES)))
 
 
 def self_launch(n):
@@ -352,6 +568,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--no-roofline", dest="roofline", action="store_false")
     ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip the secondary workloads (extra_configs)")
+    ap.add_argument("--no-dry-run", dest="dry_run", action="store_false",
+                    help="skip data_parallel.dry_run (9 updates on the data-parallel schedule after the timed region; the profiling passes of "
+                         "tools/refresh_profiles.sh pass it so that profiles/ describe the single-GPU schedule alone)")
+    ap.add_argument("--only", default=None, help="run ONE secondary workload by name (profiling runs: tools/refresh_profiles.sh) and print its entry")
     ap.add_argument("--loader", action="store_true", help="feed the headline workload from the batch iterator (collate, pinned prefetch, H2D in the timed loop)")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-updates", type=int, default=3)
@@ -368,6 +588,11 @@ def main():
     if args.attn_2d:
         args.cpu_baseline = False
 
+    if args.only:
+        torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+        torch.cuda.set_device(0)
+        print(json.dumps(extra_by_name(args.only, torch.device("cuda", 0), args)))
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)                       # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -408,7 +633,7 @@ def main():
         # rank 0 instruments and reports.
         roof = roofline_of(trainer, next_batch, args.prof_steps, dtype, instrument=rank == 0)
     dry = None
-    if world == 1 and rank == 0 and not args.loader:
+    if world == 1 and rank == 0 and not args.loader and args.dry_run:
         dry = dp_dry_run(trainer, next_batch, dt / args.steps * 1e3)
     if world > 1:
         torch.distributed.barrier()
@@ -463,16 +688,8 @@ def main():
     if args.extra:
         del trainer, model, crit
         torch.cuda.empty_cache()
-        import numpy as np
-        rs = np.random.RandomState(4)
-        mustc = [int(x) for x in np.clip(rs.lognormal(np.log(600.0), 0.7, 512), 50, 2000)]
-        out["extra_configs"] = [
-            extra_config("cfg3_batch8", "s2t_transformer_m", torch.bfloat16, device, 20, 5, batch=8, frames=1500, roofline=args.roofline),
-            extra_config("cfg2_s_fp32", "s2t_transformer_s", torch.float32, device, 10, 3, batch=32, frames=1000, tgt_len=30, roofline=args.roofline),
-            extra_config("cfg4_l_bucketed", "s2t_transformer_l", torch.bfloat16, device, 20, 5, tgt_len=0, lengths=mustc, max_tokens=48000,
-                         roofline=args.roofline),
-        ]
-        ok = ok and all(e["loss_finite"] for e in out["extra_configs"])
+        out["extra_configs"] = [extra_by_name(n, device, args) for n in EXTRA_NAMES]
+        ok = ok and all(e.get("loss_finite", True) for e in out["extra_configs"])
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

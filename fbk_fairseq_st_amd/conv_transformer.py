@@ -267,7 +267,9 @@ class TransformerDecoder(FairseqIncrementalDecoder):
     def engine(self):
         return self.owner.engine
 
-    def _alignment_request(self, alignment_layer, alignment_heads, need_attn):
+    ATTN_PROBS_MAX_KEYS = 2048          # s2t_attn_probs_avg keeps one row of probabilities in LDS (csrc/attention.hip)
+
+    def _alignment_request(self, alignment_layer, alignment_heads, need_attn, src_frames=0):
         """fairseq/models/transformer.py:700-703,756-782: the reference returns the encoder-attention weights of `alignment_layer` (default:
         the last layer), averaged over its first `alignment_heads` heads (default: all), on EVERY forward.  Here they cost an extra
         kernel (the fused attention never materialises P), so they are computed in eval mode -- generation, generate.py
@@ -277,6 +279,10 @@ class TransformerDecoder(FairseqIncrementalDecoder):
         want = need_attn if need_attn is not None else (alignment_layer is not None or not self.training)
         if not want or getattr(m.hp, "dec_layers", 0) == 0:
             return None, None
+        if src_frames > self.ATTN_PROBS_MAX_KEYS and not need_attn and alignment_layer is None:
+            # nobody asked: validation / generation of a very long utterance (max_source_positions defaults to 100000) goes on
+            # without the attention output instead of failing in the kernel that would compute it
+            return None, None
         layer = m.hp.dec_layers - 1 if alignment_layer is None else int(alignment_layer)
         return layer, alignment_heads
 
@@ -284,7 +290,8 @@ class TransformerDecoder(FairseqIncrementalDecoder):
                 alignment_heads=None, need_attn=None, **unused):
         m = self.owner
         m._ensure_engine(prev_output_tokens.device)
-        a_layer, a_heads = self._alignment_request(alignment_layer, alignment_heads, need_attn)
+        a_layer, a_heads = self._alignment_request(alignment_layer, alignment_heads, need_attn,
+                                                   src_frames=int(encoder_out.encoder_out.shape[0]) if encoder_out is not None else 0)
         if incremental_state is not None:
             # transformer.py:690-760 with incremental_state: only the last token is embedded, K/V come from the cache.
             key = "s2t_hip_state.%s" % self.pfx

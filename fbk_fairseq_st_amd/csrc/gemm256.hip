@@ -607,7 +607,8 @@ static long g256_tiles(int M, int N, bool& use192) {
     // (the l preset's 9,000 tokens x N = 1,024) this kernel is 1.3-1.45x faster (K = 1,024 .. 4,096), at 126-128 tiles the two tie, at
     // 96 and below the small tiles win -> 160.  "gemm256_min_tiles" (s2t_set_option) overrides the threshold for such measurements.
     if (t192 < (g_s2t_opt_gemm256_min_tiles > 0 ? g_s2t_opt_gemm256_min_tiles : 160)) return 0;
-    use192 = ((t192 + 255) / 256) * 192 < ((t256 + 255) / 256) * 256;
+    const int ncu = s2t_persistent_cus();
+    use192 = ((t192 + ncu - 1) / ncu) * 192 < ((t256 + ncu - 1) / ncu) * 256;
     return use192 ? t192 : t256;
 }
 
@@ -654,7 +655,7 @@ int s2t_gemm256_try(const GemmArgs& a, int out_dtype, int trans_b, hipStream_t s
     const int tiles = (int)g256_tiles(a.M, a.N, use192);
     if (!tiles) return 0;
     if (dry_run) return 1;                         // every gate passed: the caller names the launch (profiling family) before it happens
-    const int grid = tiles < 256 ? tiles : 256;
+    const int grid = tiles < s2t_persistent_cus() ? tiles : s2t_persistent_cus();
     const size_t lds = 2 * BUF + 16384;            // two K-tile buffers + the epilogue's lane-turn slots (8 waves x 2 KiB)
     bool done = false;
     const int sched = g_s2t_opt_gemm256_sched;

@@ -304,8 +304,10 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 // acc[0] = sum of the partials; out[0] = gnorm = scale*sqrt(acc) ; out[1] = multiplier = scale * min(1, max_norm/(gnorm+1e-6))
 // (fairseq/utils.py:268-276 on gradients already multiplied by `scale`, trainer.py:426-436)
+// divisor (device, may be NULL): the gradients are additionally divided by max(*divisor, 1) -- the sample size summed over the ranks, which
+// a data-parallel update knows only after an all-reduce; reading it here keeps the host out of the update (trainer.py:426-430)
 __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ part, int nparts, double* __restrict__ acc, float scale,
-                                                        float max_norm, float* __restrict__ out) {
+                                                        float max_norm, float* __restrict__ out, const double* __restrict__ divisor) {
     __shared__ double shd[4];
     double s = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
     if (threadIdx.x != 0) return;
     const double tot = shd[0] + shd[1] + shd[2] + shd[3];
     acc[0] = tot;
+    if (divisor) scale = (float)((double)scale / fmax(divisor[0], 1.0));
     const float gn = scale * (float)sqrt(tot);
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(max_norm / (gn + 1e-6f), 1.f);
@@ -389,8 +392,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+static int grad_norm_clip_impl(const float* g, size_t n, double* acc_ws, float scale, const double* divisor, float max_norm, float* out2,
+                               void* stream);
 extern "C" int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, float scale, float max_norm,
                                   float* out2, void* stream) {
+    return grad_norm_clip_impl(g, n, acc_ws, scale, nullptr, max_norm, out2, stream);
+}
+extern "C" int s2t_grad_norm_clip_div(const float* g, size_t n, double* acc_ws, float scale, const double* divisor_dev, float max_norm,
+                                      float* out2, void* stream) {
+    if (!divisor_dev) return S2T_EINVAL;
+    return grad_norm_clip_impl(g, n, acc_ws, scale, divisor_dev, max_norm, out2, stream);
+}
+static int grad_norm_clip_impl(const float* g, size_t n, double* acc_ws, float scale, const double* divisor, float max_norm, float* out2,
+                               void* stream) {
     if (!g || !acc_ws || !out2) return S2T_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipError_t se = hipSuccess;                                          // 2,048 partial sums, per (device, stream)
@@ -403,7 +417,7 @@ extern "C" int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, floa
         hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, part);
         S2T_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, part, blocks, acc_ws, scale, max_norm, out2);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, part, blocks, acc_ws, scale, max_norm, out2, divisor);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

@@ -10,6 +10,8 @@
 
 int g_s2t_prof_on = 0;
 int g_s2t_opt_gemm256 = 1, g_s2t_opt_attn_v1 = 0, g_s2t_opt_attn_v2_min_tq = 16, g_s2t_opt_gemm256_min_tiles = 0, g_s2t_opt_gemm256_sched = 0;
+int g_s2t_opt_reserve_cus = 0;            // CUs the persistent one-workgroup-per-CU kernels (gemm256, wgrad_group) leave to a concurrent collective
+extern int g_s2t_opt_decode_stop_after;
 namespace {
 struct Rec { hipEvent_t a, b; double flops, bytes; };
 struct Fam { std::vector<Rec> recs; double ms = 0, flops = 0, bytes = 0; long long launches = 0; };
@@ -61,13 +63,47 @@ void* s2t_scratch(int slot, hipStream_t st, size_t bytes, hipError_t* err) {
     return b.p;
 }
 
-extern "C" int s2t_abi_version(void) { return 8; }
+// ---------------------------------------------------------------- stand-in for a collective (bench.py data_parallel.dry_run)
+// What an RCCL all-reduce does to the kernels it runs beside, without a second GPU: `workgroups` workgroups stay resident for the time a
+// ring all-reduce of `bytes` over `ranks` ranks takes at `bus_gbps` (2 (ranks - 1) / ranks * bytes / bus), and move 2 x bytes through HBM in
+// each direction meanwhile, evenly paced (each 64 KiB chunk waits for its slot on the 100 MHz real-time counter).  It measures the cost of
+// SHARING CUs and HBM with a collective; it moves no data between GPUs and proves nothing about xGMI.
+__global__ __launch_bounds__(256) void comm_standin_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16, int passes,
+                                                           unsigned long long ticks_total) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+    constexpr size_t CH = 4096;                                   // 16-byte pieces per chunk
+    const unsigned long long nchunks = (unsigned long long)passes * ((hi > lo ? hi - lo : 0) + CH - 1) / CH;
+    unsigned long long idx = 0;
+    for (int p = 0; p < passes; ++p) {
+        for (size_t c0 = lo; c0 < hi; c0 += CH, ++idx) {
+            const unsigned long long due = nchunks ? idx * ticks_total / nchunks : 0;
+            while (__builtin_amdgcn_s_memrealtime() - t0 < due) __builtin_amdgcn_s_sleep(32);
+            const size_t c1 = c0 + CH < hi ? c0 + CH : hi;
+            for (size_t i = c0 + threadIdx.x; i < c1; i += 256) dst[i] = src[i];
+        }
+    }
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_total) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int s2t_comm_standin(const void* src, void* dst, size_t bytes, int workgroups, int ranks, float bus_gbps, void* stream) {
+    if (!src || !dst || workgroups < 1 || workgroups > 256 || ranks < 2 || !(bus_gbps > 0.f) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return S2T_EINVAL;
+    if (bytes < 16) return S2T_OK;
+    const double seconds = 2.0 * (ranks - 1) / ranks * (double)bytes / ((double)bus_gbps * 1e9);
+    hipLaunchKernelGGL(comm_standin_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, bytes / 16, 2,
+                       (unsigned long long)(seconds * 1e8));
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_abi_version(void) { return 9; }
 extern "C" const char* s2t_build_info(void) { return "libs2t_hip gfx950 (CDNA4, wave64, MFMA) built " __DATE__ " " __TIME__; }
 extern "C" int s2t_set_option(const char* key, int value) {
     if (!key) return S2T_EINVAL;
     int* slot = !strcmp(key, "gemm256") ? &g_s2t_opt_gemm256 : !strcmp(key, "attn_v1") ? &g_s2t_opt_attn_v1
               : !strcmp(key, "attn_v2_min_tq") ? &g_s2t_opt_attn_v2_min_tq : !strcmp(key, "gemm256_min_tiles") ? &g_s2t_opt_gemm256_min_tiles
-              : !strcmp(key, "gemm256_sched") ? &g_s2t_opt_gemm256_sched : nullptr;
+              : !strcmp(key, "gemm256_sched") ? &g_s2t_opt_gemm256_sched : !strcmp(key, "decode_stop_after") ? &g_s2t_opt_decode_stop_after
+              : !strcmp(key, "reserve_cus") ? &g_s2t_opt_reserve_cus : nullptr;
+    if (slot == &g_s2t_opt_reserve_cus && (value < 0 || value > 128)) return S2T_EINVAL;
     if (!slot) return S2T_EINVAL;
     const int old = *slot;
     *slot = value;

@@ -263,7 +263,8 @@ namespace {
 // ---- work lists.  A list is a table [round][slot]: workgroup slot s runs items s, s + G, s + 2G, ... until an empty one.
 // Cost model for comparing lists: an item costs its K-tiles plus C0 (pipeline fill from cold operands + the epilogue's 256 KB
 // read-modify-write, measured ~8 K-tile times at 40-K-tile items); a launch takes as long as its most loaded slot.
-constexpr int G = 256, C0 = 8, MINP = 8;
+constexpr int C0 = 8, MINP = 8;
+int G = 256;                      // workgroups of the launch = s2t_persistent_cus() when the list is built (under the entry point's mutex)
 struct Layout { std::vector<Item> table; int used = 0; long makespan = 0; };
 
 long load_of(const Layout& L) {
@@ -426,6 +427,10 @@ extern "C" int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream
     (void)hipGetDevice(&device);
     std::lock_guard<std::mutex> lock(mu);
     ++tick;
+    if (G != s2t_persistent_cus()) {             // the option changed: every cached list was laid out for another number of workgroups
+        for (Cached& c : cache) c.key.clear();
+        G = s2t_persistent_cus();
+    }
     Cached* hit = nullptr;
     Cached* lru = &cache[0];
     for (Cached& c : cache) {

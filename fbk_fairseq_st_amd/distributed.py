@@ -75,6 +75,10 @@ class BucketedGradReducer:
         self.plan = bucket_plan(self.n, self.bucket_elems)
         self.group = group
         self.record_events = False     # bench.py: a device event per bucket launch (where on the compute stream's timeline it left)
+        # bench.py (one GPU): dict(stream, scratch, workgroups, ranks, bus_gbps) -> at every bucket launch a stand-in for the collective
+        # (s2t_comm_standin: that many workgroups resident for the all-reduce's duration, moving its bytes through HBM) runs on a side
+        # stream behind the bucket's gradients, and finish() waits for it as it would for the RCCL handles
+        self.standin = None
         self.reset()
 
     def reset(self):
@@ -96,6 +100,18 @@ class BucketedGradReducer:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.events.append((start, end, early, ev))
+        if self.standin is not None:
+            from . import lib as L
+            sd = self.standin
+            side = sd["stream"]
+            side.wait_stream(torch.cuda.current_stream())
+            src = self.flat[start:end].data_ptr()
+            skip = (-src) % 16                                    # bucket bounds are element counts from the tail: 16-byte align the copy
+            nbytes = (end - start) * self.flat.element_size() - skip
+            nbytes = min(nbytes, sd["scratch"].numel() * sd["scratch"].element_size()) // 16 * 16
+            L.check(L.load().s2t_comm_standin(src + skip, sd["scratch"].data_ptr(), nbytes, int(sd["workgroups"]),
+                                              int(sd["ranks"]), float(sd["bus_gbps"]), side.cuda_stream), "s2t_comm_standin")
+            self._standin_used = True
         if get_world_size() > 1:
             self.handles.append(dist.all_reduce(self.flat[start:end], group=self.group, async_op=True))
 
@@ -116,6 +132,9 @@ class BucketedGradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        if self.standin is not None and getattr(self, "_standin_used", False):
+            torch.cuda.current_stream().wait_stream(self.standin["stream"])      # clip / Adam need the reduced gradients
+            self._standin_used = False
 
 
 def project_exposed_allreduce(launches, finish_ms, n_ranks, bus_gbps, elem_bytes=4):
@@ -141,6 +160,13 @@ def all_reduce_stats(values, device=None):
     dist.all_reduce(buf)
     out = buf.tolist()
     return dict(zip(keys, out))
+
+
+def all_reduce_tensor(t, group=None):
+    """in-place sum of a device tensor over the ranks, stream-ordered, nothing read back (the update's sample size: trainer.train_step)"""
+    if get_world_size() > 1:
+        dist.all_reduce(t, group=group)
+    return t
 
 
 def check_grad_norms(grad_norm, device=None):

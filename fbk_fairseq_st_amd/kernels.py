@@ -598,7 +598,13 @@ def dropout(x, p, seed, out=None):
     return out
 
 
-def grad_norm_clip(g, scale, max_norm, ws, out2):
+def grad_norm_clip(g, scale, max_norm, ws, out2, divisor=None):
+    """divisor: f64 device scalar the gradients are also divided by (max(divisor, 1)): the all-reduced sample size, never read by the host"""
+    if divisor is not None:
+        assert divisor.dtype == torch.float64 and divisor.numel() == 1
+        L.check(_lib().s2t_grad_norm_clip_div(L.ptr(g), g.numel(), L.ptr(ws), float(scale), L.ptr(divisor), float(max_norm), L.ptr(out2),
+                                              L.stream()), "s2t_grad_norm_clip_div")
+        return out2
     L.check(_lib().s2t_grad_norm_clip(L.ptr(g), g.numel(), L.ptr(ws), float(scale), float(max_norm), L.ptr(out2), L.stream()),
             "s2t_grad_norm_clip")
     return out2

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("S2T_HIP_LIB") or os.path.join(_HERE, "libs2t_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8              # s2t_abi_version() of the library this binding was written against
+ABI_VERSION = 9              # s2t_abi_version() of the library this binding was written against
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_RELU_BWD, ACT_GELU_BWD, ACT_RELU_MASK, ACT_RELU_BWD_MASK = 0, 1, 2, 3, 4, 5, 6
 
 c_int, c_long, c_float, c_double, c_void_p, c_size_t = (ctypes.c_int, ctypes.c_long, ctypes.c_float,
@@ -67,10 +67,12 @@ SIGNATURES = {
     "s2t_add_inplace": [c_int, P, P, c_size_t, P],
     "s2t_dropout": [c_int, P, P, c_size_t, c_float, c_ull, P],
     "s2t_grad_norm_clip": [P, c_size_t, P, c_float, c_float, P, P],
+    "s2t_grad_norm_clip_div": [P, c_size_t, P, c_float, P, c_float, P, P],
     "s2t_adam_step": [P, P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, c_float, c_int, P],
     "s2t_cast": [c_int, c_int, P, P, c_size_t, P],
     "s2t_scale_by_device_scalar": [c_int, P, c_size_t, P, P],
     "s2t_set_option": [ctypes.c_char_p, c_int],
+    "s2t_comm_standin": [P, P, c_size_t, c_int, c_int, c_float, P],
     "s2t_prof_enable": [c_int],
     "s2t_prof_reset": [],
     "s2t_prof_read": [ctypes.c_char_p, P, P, P, P],
@@ -94,6 +96,13 @@ SIGNATURES = {
     "s2t_layer_bwd_tmp_bytes": [P],                             # returns size_t
     "s2t_layer_fwd": [P, P, P],
     "s2t_layer_bwd": [P, P, P],
+    "s2t_decode_prepare_enc": [c_int, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_decode_begin": [P, c_int, P],
+    "s2t_decode_step": [P, P],
+    "s2t_decode_lds_bytes": [P],                                # returns size_t
+    "s2t_decode_graph_create": [P, P],
+    "s2t_decode_graph_launch": [P, P],
+    "s2t_decode_graph_destroy": [P],
     "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],
     "s2t_host_ctc_uer": [P, P, c_int, c_int, P, P, c_int, c_int, P, P],
 }
@@ -125,6 +134,26 @@ class LayerCall(ctypes.Structure):
                 ("denc", c_void_p), ("denc_accumulate", c_int), ("tmp", c_void_p), ("items", c_void_p), ("max_items", c_int), ("n_items", c_int)]
 
 
+_DEC_LAYER = ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "lnx_g", "lnx_b", "w_xq", "b_xq", "w_xo", "b_xo", "ln2_g", "ln2_b",
+              "w_fc1", "b_fc1", "w_fc2", "b_fc2", "kv_enc", "vt_enc", "kv_cache")
+
+
+class DecodeLayer(ctypes.Structure):
+    """S2TDecodeLayer of include/s2t_hip.h"""
+    _fields_ = [(n, c_void_p) for n in _DEC_LAYER]
+
+
+class DecodeDesc(ctypes.Structure):
+    """S2TDecodeDesc of include/s2t_hip.h"""
+    _fields_ = ([(n, c_int) for n in ("dtype", "B", "beam", "D", "heads", "ffn", "layers", "V", "ldv", "Ts", "Tsp", "max_len", "min_len",
+                                      "ffn_slices", "gelu", "pad", "unk", "eos", "step0_all_slots")] +
+                [(n, c_float) for n in ("ln_eps", "embed_scale", "unk_penalty", "inv_temperature")] +
+                [(n, c_void_p) for n in ("layer", "lnf_g", "lnf_b", "w_out", "embed", "pos_table", "enc_klen", "init_scores",
+                                         "x0", "x1", "part0", "part1", "xn", "logits", "steps", "anc", "cand_val", "cand_idx",
+                                         "tok_hist", "par_hist", "cum_hist", "blacklist", "nfin", "finished", "fin_step", "fin_row",
+                                         "fin_score")])
+
+
 _lib = None
 
 
@@ -151,7 +180,7 @@ def build(verbose=False, twins=False):
 # never built here): both call the same libs2t_hip.so, neither computes anything.
 FAST_PATH = os.path.join(_HERE, "_s2t_fastcall.so")
 _HOST_SIDE = ("s2t_host_batch_by_size", "s2t_host_ctc_uer")          # CPU work: release the GIL around the call, as ctypes does
-_SIZE_T_RESULT = ("s2t_gemm_relu_mask_bytes", "s2t_layer_ws_bytes", "s2t_layer_bwd_tmp_bytes")
+_SIZE_T_RESULT = ("s2t_gemm_relu_mask_bytes", "s2t_layer_ws_bytes", "s2t_layer_bwd_tmp_bytes", "s2t_decode_lds_bytes")
 
 
 def signature_hash():

@@ -83,6 +83,9 @@ class SequenceGenerator:
         self.print_alignment = bool(print_alignment)
         self.retain_attention = bool(retain_attention) or self.print_alignment
         self.search = BeamSearch(tgt_dict) if search_strategy is None else search_strategy
+        self.device_graph = True                                          # replay one recorded step (hipGraph); False: launch every step's kernels
+        self.record_stats = False                                         # bench.py: two extra host syncs per call -> last_stats
+        self.last_stats = {}
 
     # ------------------------------------------------------------------ API of the reference
     @torch.no_grad()
@@ -102,9 +105,17 @@ class SequenceGenerator:
         B, src_len = src_tokens.shape[0], src_tokens.shape[1]
         max_len = min(int(self.max_len_a * src_len + self.max_len_b), min(m.max_decoder_positions() for m in self.models) - 1)
         assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
-        encs = [self._encode(m, net_input) for m in self.models]
+        if self.record_stats:
+            import time
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        encs = [m.encoder.forward_non_torchscript(net_input) for m in self.models]       # one column per SENTENCE (see _expand)
+        if self.record_stats:
+            torch.cuda.synchronize(); t1 = time.perf_counter()
         hyps = self._beam_search([m.decoder for m in self.models], encs, B, src_tokens.device, max_len, self.search, bos_token,
                                  self.pad, self.unk, self.eos, self.vocab_size, prefix_tokens=prefix_tokens)
+        if self.record_stats:
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            self.last_stats.update(encoder_s=t1 - t0, search_s=t2 - t1, src_frames=int(encs[0].encoder_out.shape[0]))
         for b, hs in enumerate(hyps):
             for h in hs:
                 h.pop("origin")
@@ -124,21 +135,49 @@ class SequenceGenerator:
         _, src_idx = attn.t()[valid.to(attn.device)].max(dim=1)
         return list(zip(src_idx.tolist(), valid.tolist()))
 
-    def _encode(self, model, net_input):
+    def _expand(self, decoder, enc, B):
         """encoder output with one copy per hypothesis slot (sequence_generator.py:176-196)"""
-        B = net_input["src_tokens"].shape[0]
-        enc = model.encoder.forward_non_torchscript(net_input)
-        order0 = torch.arange(B, device=net_input["src_tokens"].device).repeat_interleave(self.beam_size)
-        return model.encoder.reorder_encoder_out(enc, order0)
+        order0 = torch.arange(B, device=enc.encoder_out.device).repeat_interleave(self.beam_size)
+        return decoder.owner.encoder.reorder_encoder_out(enc, order0)
+
+    def _device_search(self, decoder, enc, B, max_len, search, bos_token, pad, unk, eos, V, prev_scores):
+        """The whole loop inside libs2t_hip.so (decode.py / csrc/decode.hip) when nothing but the plain or the hierarchical beam search
+        is asked for; None when this search needs the step-by-step path below."""
+        from . import decode as DEC
+        if not DEC.device_search_enabled() or type(search) not in (BeamSearch, HierarchicalBeamSearch):
+            return None
+        eng = decoder.engine
+        eo = enc.encoder_out.contiguous()
+        klen = enc.src_lengths.to(torch.int32) if enc.encoder_padding_mask is not None else None
+        ses = DEC.BeamDecodeSession(eng, decoder.pfx, eo, klen, self.beam_size, max_len, self.min_len, pad, unk, eos, V, self.unk_penalty,
+                                    self.temperature, init_scores=prev_scores, step0_all_slots=prev_scores is not None)
+        if not ses.ok:
+            return None
+        self.last_stats["steps"] = ses.run(eos if bos_token is None else bos_token, graph=self.device_graph)
+        self.last_stats["launches_per_step"] = ses.launches_per_step
+        hyps = ses.hypotheses(self.normalize_scores, self.len_penalty)
+        out = []
+        for hs in hyps:                                                    # sequence_generator.py:486-496: best first
+            idx = sorted(range(len(hs)), key=lambda i: hs[i]["_score"])
+            out.append([hs[i] for i in reversed(idx)])
+            for h in hs:
+                h.pop("_score")
+        return out
 
     def _beam_search(self, decoder, enc, B, dev, max_len, search, bos_token, pad, unk, eos, V, prev_scores=None, prefix_tokens=None):
         """The search loop of sequence_generator.py:198-500 over `decoder` (incremental HIP decoder; a LIST of decoders with a list
-        of encoder outputs = an ensemble).  prev_scores [B, beam, 1]: starting scores of the slots for a HierarchicalBeamSearch.
-        prefix_tokens int64 [B, P]: forced first tokens (pad = free).  Every hypothesis also records `origin`, the slot of step 0
-        it descends from.  Returns per sentence the finalized hypotheses, best first."""
+        of encoder outputs = an ensemble).  `enc`: the encoder output(s), one column per sentence.  prev_scores [B, beam, 1]: starting
+        scores of the slots for a HierarchicalBeamSearch.  prefix_tokens int64 [B, P]: forced first tokens (pad = free).  Every
+        hypothesis also records `origin`, the slot of step 0 it descends from.  Returns per sentence the finalized hypotheses, best first."""
         beam = self.beam_size
         decoders = list(decoder) if isinstance(decoder, (list, tuple)) else [decoder]
         encs = list(enc) if isinstance(decoder, (list, tuple)) else [enc]
+        if len(decoders) == 1 and prefix_tokens is None and self.no_repeat_ngram_size == 0 and not self.retain_attention \
+                and decoders[0].owner.training is False:
+            out = self._device_search(decoders[0], encs[0], B, max_len, search, bos_token, pad, unk, eos, V, prev_scores)
+            if out is not None:
+                return out
+        encs = [self._expand(d, e, B) for d, e in zip(decoders, encs)]
         states = [d.begin_incremental(e, max_len + 1) for d, e in zip(decoders, encs)]
         attn = None                                                        # [N, Ts, max_len + 2], column step + 1 = the attention of step `step` (:286-292)
         if self.retain_attention:
@@ -162,6 +201,7 @@ class SequenceGenerator:
 
         reorder = None
         for step in range(max_len + 1):                                   # one extra step for the EOS marker
+            self.last_stats["steps"] = step + 1
             member = []
             for d, st in zip(decoders, states):
                 if reorder is not None:
@@ -324,7 +364,7 @@ class TwoPhaseSequenceGenerator(SequenceGenerator):
         max_pos = model.max_decoder_positions() - 1
         max_len = min(int(self.max_len_a * src_len + self.max_len_b), max_pos)
         assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
-        enc = self._encode(model, net_input)
+        enc = model.encoder.forward_non_torchscript(net_input)
         aux = self._beam_search(model.auxiliary_decoder, enc, B, dev, max_len, self.src_search, bos_token,
                                 self.src_pad, self.src_unk, self.src_eos, self.src_vocab_size)
         assert all(len(hs) == beam for hs in aux)

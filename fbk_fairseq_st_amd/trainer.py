@@ -50,6 +50,14 @@ class Trainer:
         model.engine.on_grads_ready = self._grads_ready
         if self.world > 1 and getattr(model.engine, "defer_wgrad", False):
             model.engine.wgrad_flush_layers = max(1, model.hp.enc_layers // 2)     # see S2TEngine.wgrad_flush_layers
+        # --reserve-cus N (default 16 when gradients are all-reduced, 0 otherwise): the persistent one-workgroup-per-CU kernels
+        # (gemm256, wgrad_group: 128 KiB of LDS each) leave N CUs to RCCL's kernels, which run beside backward while a bucket
+        # travels -- a workgroup that finds its CU taken would otherwise wait for a whole round of the others.  Measured on one GPU
+        # against a stand-in for the collective: bench.py data_parallel.dry_run.comm_standin.
+        self.reserve_cus = int(getattr(args, "reserve_cus", 16 if self.world > 1 else 0) or 0)
+        if self.device.type == "cuda":
+            from . import kernels as K
+            K.set_option("reserve_cus", self.reserve_cus)
         self._ranges = {}
         self.dp_dry_run = False         # world 1 only: run the reducer's bookkeeping as a data-parallel rank would (set_dp_dry_run)
         self._sync_grads = True         # False while a non-final micro-batch accumulates locally (the reference's no_sync)
@@ -129,7 +137,7 @@ class Trainer:
             reference, a rank whose LAST micro-batch was a dummy reports sample_size 0 and no logging outputs."""
         if self._dummy_batch is None:
             self._dummy_batch = next((s for s in samples if s is not None and len(s) > 0), None)
-        self.model.set_seed(getattr(self.args, "seed", 1) + self.num_updates)        # trainer.py:655-661
+        self._set_seed()
         self.model.train(); self.criterion.train()
         self.optimizer.zero_grad()
         self.reducer.reset()
@@ -159,17 +167,36 @@ class Trainer:
         if flush is not None:
             flush()                                                                 # no queued weight gradient may outlive the backward passes
         self.reducer.finish()                                                       # R2
-        stats = {"sample_size": float(sample_size)}
-        if self.world > 1:
-            stats = D.all_reduce_stats(stats, self.device)                          # R3 (must land before scaling)
-        total_ss = max(stats["sample_size"], 1.0)
-        self.optimizer.multiply_grads(1.0 / total_ss)                               # trainer.py:426-430
+        if self.world > 1 and self.device.type == "cuda" and hasattr(self.optimizer, "set_device_divisor"):
+            # R3 without the host: the summed sample size stays on the device (a fill kernel, one 8-byte all-reduce) and the clip
+            # kernel divides by it -- the reference reads it back before scaling (trainer.py:416-430), which on this path would drain
+            # the GPU between backward and Adam on every update.  The host value is fetched with the logging statistics (reduce_stats).
+            total_ss = torch.full((1,), float(sample_size), dtype=torch.float64, device=self.device)
+            D.all_reduce_tensor(total_ss)
+            self.optimizer.set_device_divisor(total_ss)
+        else:
+            stats = {"sample_size": float(sample_size)}
+            if self.world > 1:
+                stats = D.all_reduce_stats(stats, self.device)                      # R3 (must land before scaling)
+            total_ss = max(stats["sample_size"], 1.0)
+            self.optimizer.multiply_grads(1.0 / total_ss)                           # trainer.py:426-430
         gnorm = self.optimizer.clip_grad_norm(getattr(self.args, "clip_norm", 25.0))
         self.optimizer.step()
         self.num_updates += 1
         self.lr_scheduler.step_update(self.num_updates)
         self._pending = (logs, gnorm, total_ss)
         return self._pending
+
+    def _set_seed(self):
+        """fairseq/trainer.py:655-661: every update starts from seed + num_updates, on every rank -- torch's generators (the LayerDrop
+        keep / drop draws of conv_transformer.py:238-243 come from the global CPU generator: ranks that consumed it differently before
+        this update, e.g. validation shards of unequal size, must still drop the SAME layers, or one rank's Adam steps a layer that
+        another skips) and the dropout streams of the kernels."""
+        seed = getattr(self.args, "seed", 1) + self.num_updates
+        torch.manual_seed(seed)
+        if self.device.type == "cuda":
+            torch.cuda.manual_seed(seed)
+        self.model.set_seed(seed)
 
     # ---- checkpoints (fairseq/trainer.py:173-266, fairseq/checkpoint_utils.py:245-285): the reference's file layout -- "args",
     # "model" (reference parameter names, f32 masters), "criterion", "optimizer_history", "extra_state", "last_optimizer_state".

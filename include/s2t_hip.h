@@ -76,7 +76,7 @@ int s2t_host_batch_by_size(const long long* indices, long long n, const long lon
 int s2t_abi_version(void);                       /* bumps when a signature OR a workspace contract changes.  8 (round 5): s2t_ctc_loss's la / lb
                                                   * workspaces are B*T*S2T_CTC_ROW(Lmax) floats holding log2 values with per-step offsets
                                                   * (a phase-1 workspace of a version-7 library is unusable by a version-8 phase 2);
-                                                  * the "gemm4w" option of s2t_set_option is gone */
+                                                  * the "gemm4w" option of s2t_set_option is gone.  9 (round 6): the s2t_decode_* entry points */
 const char* s2t_build_info(void);                /* "gfx950 <date> ..." */
 
 /* ---- GEMM with fused epilogue (MFMA) --------------------------------------------------------
@@ -373,11 +373,95 @@ int s2t_a2d_freq_bwd(int dtype, const void* qkv, const void* dcat, const float* 
 /* ---- optimizer (fairseq/trainer.py:416-443, fairseq/utils.py:253-277, fairseq/optim/adam.py:147-202) ----
  * out2[0] = gnorm = scale*||g||_2 ; out2[1] = scale * min(1, max_norm/(gnorm+1e-6)) (all on device) */
 int s2t_grad_norm_clip(const float* g, size_t n, double* acc_ws, float scale, float max_norm, float* out2, void* stream);
+/* the same with scale / max(*divisor_dev, 1) in place of scale: divisor_dev = the sample size summed over the data-parallel ranks, still
+ * on the device after its all-reduce (fairseq/trainer.py:416-430 reads it on the host; here no host synchronisation precedes Adam) */
+int s2t_grad_norm_clip_div(const float* g, size_t n, double* acc_ws, float scale, const double* divisor_dev, float max_norm,
+                           float* out2, void* stream);
 /* Adam over a flat arena; gradients are multiplied by mult2[1] (NULL = 1); optional bf16 shadow refresh */
 int s2t_adam_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, const float* mult2,
                   float lr, float beta1, float beta2, float eps, float wd, int step, void* stream);
 int s2t_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, void* stream);
 int s2t_scale_by_device_scalar(int dtype, void* x, size_t n, const float* scalar, void* stream);
+
+/* ---- incremental decoding + beam search as ONE stream-ordered sequence of launches per step ----------------------------------------
+ * Replaces, per decoding step, fairseq/sequence_generator.py:243-447 (the loop body of SequenceGenerator._generate: forward_decoder,
+ * log-softmax, the pad / unk / min-len / max-len rules, BeamSearch.step = fairseq/search.py:55-83, EOS finalisation bookkeeping :502-600,
+ * next-beam selection :417-446, reorder_incremental_state :430-447 / fairseq/modules/multihead_attention.py:246-283,407-420) and the
+ * incremental TransformerDecoder forward (fairseq/models/transformer.py:674-782, transformer_layer.py:243-377).
+ *
+ * N = B * beam hypothesis slots, slot n = s * beam + j of sentence s.  One step is 3 * layers + 4 launches:
+ *   per layer  S: LayerNorm -> q|k|v of one head (k, v written to the cache row of this step) -> attention over the cached rows of the
+ *                 hypothesis' ancestors -> this head's share of the output projection           grid (B, heads)
+ *              C: LayerNorm -> q of one head -> attention over the sentence's encoder rows -> share of the output projection
+ *              F: LayerNorm -> one slice of fc1 + activation -> that slice's share of fc2        grid (B, ffn_slices)
+ *   then       final LayerNorm; output projection over all N rows; per row: log-softmax, score rules, + cumulative score, 2*beam best;
+ *              per sentence: merge, finalise EOS candidates, choose the next beam, record it, embed its tokens for the next step.
+ * The shares (per head / per slice, f32) are summed in a fixed order by the launch that consumes them, together with the residual and the
+ * bias: no atomics, results do not depend on scheduling.  The K/V cache is never re-ordered: anc[n][p] names the slot whose row at
+ * position p belongs to hypothesis n's history (the index indirection that replaces reorder_incremental_state's index_select copies),
+ * the encoder-side K/V exist once per sentence.  The step index lives in device memory (steps[s]), so one recorded sequence (a hipGraph
+ * captured around s2t_decode_step) serves every step.  Nothing synchronises; the host polls `finished` when it chooses to.
+ * Limits (S2T_ENOTSUP otherwise): head size 64, D = 256, 512 or 1024, beam <= 16, B * beam <= 128, ffn / ffn_slices = 64, 128 or 256,
+ * max_len + 1 <= 1024 positions, Tsp a multiple of 128, and the LDS plan of every launch within 152 KiB (s2t_decode_lds_bytes). */
+typedef struct S2TDecodeLayer {
+    const void *ln1_g, *ln1_b;       /* f32 [D]: self_attn_layer_norm */
+    const void *w_qkv, *b_qkv;       /* T [3D][D], f32 [3D] */
+    const void *w_o, *b_o;           /* T [D][D], f32 [D] */
+    const void *lnx_g, *lnx_b;       /* encoder_attn_layer_norm */
+    const void *w_xq, *b_xq, *w_xo, *b_xo;
+    const void *ln2_g, *ln2_b;       /* final_layer_norm */
+    const void *w_fc1, *b_fc1;       /* T [ffn][D], f32 [ffn] */
+    const void *w_fc2, *b_fc2;       /* T [D][ffn], f32 [D] */
+    const void* kv_enc;              /* T [Ts][B][2D]: encoder-side K | V rows of this layer (static_kv), one copy per SENTENCE */
+    const void* vt_enc;              /* T [B][heads][64][Tsp]: the V half transposed (s2t_decode_prepare_enc), zero beyond Ts; Tsp % 128 == 0 */
+    void* kv_cache;                  /* T [max_len + 1][N][2D]: k | v rows written by step t at position t */
+} S2TDecodeLayer;
+
+typedef struct S2TDecodeDesc {
+    int dtype, B, beam, D, heads, ffn, layers, V, ldv, Ts, Tsp, max_len, min_len, ffn_slices, gelu;
+    int pad, unk, eos, step0_all_slots;      /* step0_all_slots: HierarchicalBeamSearch (twophase_sequence_generator.py:22-49) */
+    float ln_eps, embed_scale, unk_penalty, inv_temperature;
+    const S2TDecodeLayer* layer;             /* HOST array [layers] */
+    const void *lnf_g, *lnf_b;               /* decoder.layer_norm */
+    const void* w_out;                       /* T [V][D] output projection (= embed when shared) */
+    const void* embed;                       /* T [V][D] */
+    const float* pos_table;                  /* f32 [>= pad + 2 + max_len][D] sinusoidal table, row `pad` zero */
+    const int* enc_klen;                     /* i32 [B] valid encoder rows per sentence, or NULL (no padding) */
+    const float* init_scores;                /* f32 [N] starting score of every slot (step0_all_slots), or NULL */
+    /* state, all device memory owned by the caller */
+    float *x0, *x1;                          /* f32 [N][D] residual stream (ping-pong) */
+    float *part0, *part1;                    /* f32 [max(heads, ffn_slices)][N][D] shares (ping-pong) */
+    void* xn;                                /* T [N][D] final LayerNorm output */
+    float* logits;                           /* f32 [N][ldv] */
+    int* steps;                              /* i32 [B] */
+    int* anc;                                /* i32 [N][max_len + 1] */
+    float* cand_val; int* cand_idx;          /* [N][2 * beam] per-row candidates */
+    int* tok_hist; int* par_hist; float* cum_hist;   /* [max_len + 2][N]: arrangement i = the beam after i selections */
+    int* blacklist;                          /* i32 [N] */
+    int* nfin; int* finished;                /* i32 [B] */
+    int* fin_step; int* fin_row; float* fin_score;   /* [B][beam]: finalised hypotheses in the order the reference appends them */
+} S2TDecodeDesc;
+
+/* vt[b][h][d][t] = kv[t][b][D + h*64 + d] (t < Ts), 0 for Ts <= t < Tsp */
+int s2t_decode_prepare_enc(int dtype, const void* kv_enc, void* vt_enc, int Ts, int Tsp, int B, int D, int heads, void* stream);
+/* resets the state for a new search: steps, blacklist, nfin, finished = 0; arrangement 0 = `bos` in every slot; x0 = its embedding */
+int s2t_decode_begin(const S2TDecodeDesc* d, int bos, void* stream);
+/* the launches of one step (see above).  `d` and d->layer are HOST memory read during the call only. */
+int s2t_decode_step(const S2TDecodeDesc* d, void* stream);
+/* dynamic LDS bytes the S / C / F launches of `d` need (0 when `d` is outside the limits): the caller may compare with 160 KiB */
+size_t s2t_decode_lds_bytes(const S2TDecodeDesc* d);
+/* One step recorded as a hipGraph: `create` captures s2t_decode_step(d) on a private stream (nothing executes) and instantiates it,
+ * `launch` replays it on `stream` (the kernels read the step index from d->steps, so the same recording serves every step; `d`'s device
+ * buffers must stay where they are), `destroy` frees it after the caller has synchronised with the last replay.  *graph_exec is HOST. */
+int s2t_decode_graph_create(const S2TDecodeDesc* d, void** graph_exec);
+int s2t_decode_graph_launch(void* graph_exec, void* stream);
+int s2t_decode_graph_destroy(void* graph_exec);
+
+/* ---- measurement aid: what a collective costs the kernels beside it, on ONE GPU (bench.py data_parallel.dry_run) --------------------
+ * `workgroups` workgroups stay resident on `stream` for the time a ring all-reduce of `bytes` over `ranks` ranks takes at `bus_gbps`
+ * (2 (ranks - 1) / ranks * bytes / bus) and copy src -> dst twice meanwhile, evenly paced.  Stands in for RCCL's kernels of
+ * fairseq/legacy_distributed_data_parallel.py:96-170's all-reduce as a competitor for CUs and HBM; moves nothing between GPUs. */
+int s2t_comm_standin(const void* src, void* dst, size_t bytes, int workgroups, int ranks, float bus_gbps, void* stream);
 
 /* ---- in-library timing of kernel families with HIP events (bench.py roofline) ------------------------
  * While enabled, every launch of the named family on `stream` is bracketed by hipEvents; s2t_prof_read
@@ -393,7 +477,11 @@ int s2t_prof_enable(int on);
  *       "gemm256_sched": 1 selects gemm256's second K-loop schedule (diagnostic twins only: -95 in the product library);
  *       "gemm4w": 1 sends gemm256's NT products to the four-wave partition of the same tile (gemm4w.hip: an experiment,
  *                  bit-identical results, default 0);
- * returns the previous value, or S2T_EINVAL (-22) for an unknown key. */
+ *       "reserve_cus": 0..128 (default 0): the persistent one-workgroup-per-CU kernels (gemm256, wgrad_group) launch 256 - value
+ *                  workgroups and plan their rounds for that many CUs -- what a data-parallel run sets while RCCL's kernels share
+ *                  the chip with backward (trainer: --reserve-cus);
+ *       "decode_stop_after": diagnostic, ends s2t_decode_step after that many launches (0 = off);
+ * returns the previous value, or S2T_EINVAL (-22) for an unknown key or a value out of range. */
 int s2t_set_option(const char* key, int value);
 int s2t_prof_read(const char* family, double* ms, long long* launches, double* flops, double* bytes);
 int s2t_prof_reset(void);

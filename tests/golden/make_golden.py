@@ -431,14 +431,23 @@ def run_dual_case():
     print("dual loss", loss.item(), ss, {k: float(v) for k, v in log.items()})
 
 
-def run_generate_case():
-    """G9: beam search (fairseq/sequence_generator.py + search.py BeamSearch) on eval-mode models with deterministic weights."""
+def run_generate_case(wide=False):
+    """G9: beam search (fairseq/sequence_generator.py + search.py BeamSearch) on eval-mode models with deterministic weights.
+    wide=True -> generate_wide.npz: models with 64-wide heads and D a multiple of 256, the shapes the device-resident search of the
+    build takes (csrc/decode.hip); `c` ragged with CTC compression, `d` every score option set, `e` one sentence, beam 8, 3 decoder layers."""
     from fairseq.sequence_generator import SequenceGenerator
     out = {}
     cases = [("a", dict(D=64, H=2, Ff=128, EL=3, DL=2, ctc_layer=2, compress=True, seed=600, lens=[61, 50, 37]),
               dict(beam_size=5, max_len_a=0, max_len_b=12, min_len=1)),
              ("b", dict(D=64, H=2, Ff=128, EL=2, DL=2, ctc_layer=0, compress=False, seed=700, lens=[48, 48]),
               dict(beam_size=3, max_len_a=0.1, max_len_b=5, min_len=2, len_penalty=0.6, unk_penalty=0.5, temperature=1.5))]
+    if wide:
+        cases = [("c", dict(D=256, H=4, Ff=256, EL=2, DL=2, ctc_layer=1, compress=True, seed=610, lens=[61, 50, 37]),
+                  dict(beam_size=5, max_len_a=0, max_len_b=12, min_len=1)),
+                 ("d", dict(D=256, H=4, Ff=384, EL=2, DL=2, ctc_layer=0, compress=False, seed=710, lens=[48, 48]),
+                  dict(beam_size=3, max_len_a=0.1, max_len_b=5, min_len=2, len_penalty=0.6, unk_penalty=0.5, temperature=1.5)),
+                 ("e", dict(D=256, H=4, Ff=512, EL=1, DL=3, ctc_layer=0, compress=False, seed=810, lens=[77]),
+                  dict(beam_size=8, max_len_a=0, max_len_b=20, min_len=1))]
     for tag, m, g in cases:
         crit = ("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy") if m["compress"] else \
                ("label_smoothed_cross_entropy", "--label-smoothing", "0.1")
@@ -470,7 +479,7 @@ def run_generate_case():
                     tag + "_gen": np.array([g["beam_size"], g["max_len_a"], g["max_len_b"], g["min_len"], g.get("len_penalty", 1.0),
                                             g.get("unk_penalty", 0.0), g.get("temperature", 1.0)], np.float64)})
         print("gen", tag, [[(len(h["tokens"]), round(float(h["score"]), 4)) for h in hs] for hs in hyps])
-    np.savez_compressed(os.path.join(OUT, "generate.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "generate_wide.npz" if wide else "generate.npz"), **out)
 
 
 def run_generate_ext_case():
@@ -529,8 +538,8 @@ def run_generate_ext_case():
     np.savez_compressed(os.path.join(OUT, "generate_ext.npz"), **out)
 
 
-def run_twophase_case():
-    """G18: TwoPhaseSequenceGenerator (examples/speech_recognition/twophase_sequence_generator.py) on the dual-decoder
+def run_twophase_case(wide=False):
+    """wide=True -> twophase_wide.npz (64-wide heads, D 256: the device-resident search of the build).  G18: TwoPhaseSequenceGenerator (examples/speech_recognition/twophase_sequence_generator.py) on the dual-decoder
     model: beam search with the auxiliary (transcript) decoder, then HierarchicalBeamSearch with the target decoder seeded by the
     transcript hypotheses' scores; every target hypothesis carries the transcript it descends from (`aux_tokens`)."""
     from examples.speech_recognition.twophase_sequence_generator import TwoPhaseSequenceGenerator
@@ -538,6 +547,10 @@ def run_twophase_case():
     cases = [("a", dict(D=64, H=2, Ff=128, EL=2, DL=2, seed=1100, lens=[52, 41, 33]), dict(beam_size=4, max_len_a=0, max_len_b=10, min_len=1)),
              ("b", dict(D=64, H=2, Ff=128, EL=2, DL=1, seed=1200, lens=[44, 44]),
               dict(beam_size=3, max_len_a=0.1, max_len_b=4, min_len=2, len_penalty=0.7, unk_penalty=0.3, temperature=1.3))]
+    if wide:
+        cases = [("c", dict(D=256, H=4, Ff=256, EL=2, DL=2, seed=1110, lens=[52, 41, 33]), dict(beam_size=4, max_len_a=0, max_len_b=10, min_len=1)),
+                 ("d", dict(D=256, H=4, Ff=256, EL=1, DL=1, seed=1210, lens=[44, 44]),
+                  dict(beam_size=3, max_len_a=0.1, max_len_b=4, min_len=2, len_penalty=0.7, unk_penalty=0.3, temperature=1.3))]
     for tag, m, g in cases:
         args, task, model, crit, V_src, V_tgt = build("tp" + tag, m["D"], m["H"], m["Ff"], m["EL"], m["DL"], 0, False,
                                                       arch="conv_transformer_dualdecoder",
@@ -568,7 +581,7 @@ def run_twophase_case():
                     tag + "_gen": np.array([g["beam_size"], g["max_len_a"], g["max_len_b"], g["min_len"], g.get("len_penalty", 1.0),
                                             g.get("unk_penalty", 0.0), g.get("temperature", 1.0)], np.float64)})
         print("twophase", tag, [[(len(h["tokens"]), len(h["aux_tokens"]), round(float(h["score"]), 4)) for h in hs] for hs in hyps])
-    np.savez_compressed(os.path.join(OUT, "twophase.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "twophase_wide.npz" if wide else "twophase.npz"), **out)
 
 
 def run_data_case():
@@ -1089,6 +1102,8 @@ if __name__ == "__main__":
         run_data_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "generate":
         run_generate_case(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":
+        run_generate_case(wide=True); run_twophase_case(wide=True); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "extra":
         run_kd_case(); run_dual_case(); sys.exit(0)
     run_ctc_cases()

@@ -34,7 +34,7 @@ def model_case(name):
 
 def generate_case(tag):
     """cfg, weights, inputs, generator options and expected hypotheses of fixture generate.npz (case `a` or `b`)."""
-    g = load_golden("generate")
+    g = load_golden("generate" if tag in ("a", "b") else "generate_wide")      # c, d, e: 64-wide heads, D 256 (make_golden.py wide)
     D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed = [int(v) for v in g[tag + "_meta"]]
     cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer if compress else 0)
     W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=bool(compress)), seed)
@@ -56,7 +56,7 @@ def generate_case(tag):
 
 def twophase_case(tag):
     """fixture twophase.npz (dual-decoder model, TwoPhaseSequenceGenerator): as generate_case, hypotheses carry their transcript"""
-    g = load_golden("twophase")
+    g = load_golden("twophase" if tag in ("a", "b") else "twophase_wide")
     D, H, Ff, EL, DL, _, _, V_src, V_tgt, blank, seed = [int(v) for v in g[tag + "_meta"]]
     cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=0)
     W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, V_aux=V_src), seed)

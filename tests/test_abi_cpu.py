@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     # every declared function is also bound with argtypes in the ctypes layer
     bound = set(L.SIGNATURES) | {"s2t_build_info"}
     assert set(syms) <= bound, set(syms) - bound
-    assert lib.s2t_abi_version() == 8
+    assert lib.s2t_abi_version() == 9
     assert b"gfx950" in lib.s2t_build_info()
 
 

@@ -32,6 +32,13 @@ def test_gemm256_epilogue_keeps_wide_store_data_untouched(tmp_path):
     assert len(kernels) == 20, sorted(kernels)                      # 10 epilogue variants x 2 tile heights
     close = {k: v for k, v in kernels.items() if v[0] is not None and v[0] < MIN_STATES}
     assert not close, "VALU writes to wide-store data within %d states: %s" % (MIN_STATES, close)
+    # the transposed LDS reads behind inline asm (gemm_tile.hpp tr_read_asm): hipcc does not track them, the hand-placed
+    # `s_waitcnt lgkmcnt(0)` does -- no instruction may name their destination registers before that wait
+    tr = isa_store_hazards.scan_tr_reads(open(out).read())
+    nn = {k: v for k, v in tr.items() if "gemm256_kernel" in k and v[0] > 0}
+    assert nn, "no transposed reads found: the check is looking at the wrong instruction"
+    early = {k: v[1][:2] for k, v in nn.items() if v[1]}
+    assert not early, "a transposed LDS read's destination is used before s_waitcnt lgkmcnt(0): %s" % early
     # the checker itself: planted hazards of every kind it must see (VALU, both operands of a lane swap, LDS / vector-memory load
     # returns, a writer behind the loop's back edge) are found, an LDS-DMA load and a compare are not mistaken for writers
     assert isa_store_hazards.self_test()

@@ -197,7 +197,7 @@ def test_dual_decoder_loss():
     _check_gradnorms(g, Wg)
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e"])
 def test_beam_search_matches_reference_generator(tag):
     """G9: hypotheses (tokens exact, scores 1e-4) of the reference SequenceGenerator, fairseq/sequence_generator.py."""
     from helpers import generate_case
@@ -213,7 +213,7 @@ def test_beam_search_matches_reference_generator(tag):
             np.testing.assert_allclose(ps.numpy(), eps, atol=1e-4)
 
 
-@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_two_phase_beam_search_matches_reference_generator(tag):
     """G18: TwoPhaseSequenceGenerator on the dual-decoder model: target tokens and the transcript each hypothesis descends from
     exact, scores 1e-4 (examples/speech_recognition/twophase_sequence_generator.py)."""

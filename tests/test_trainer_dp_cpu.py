@@ -41,6 +41,7 @@ def _build(world_args):
             self.engine = Engine()
             self.arena = None
             self.backward_calls = 0
+            self.draws = []
 
         def materialize(self, device, dtype, extra=None):
             self.arena = ParamArena(OrderedDict((g + "weight", (n,)) for g, n in GROUPS.items()), device, dtype)
@@ -66,6 +67,7 @@ def _build(world_args):
 
     class Task:
         def train_step(self, sample, model, criterion, optimizer, update_num, ignore_grad=False):
+            model.draws.append(float(torch.empty(1).uniform_()))       # what a LayerDrop forward takes from the global generator
             model.fake_backward(float(sample["value"]), ignore_grad)
             return None, sample["ss"], {"loss": float(sample["value"]), "sample_size": sample["ss"]}
 
@@ -109,6 +111,8 @@ def _worker(rank, world, port, q):
     tr, model = _build({})
     n = tr.arena.numel
     out = {}
+    torch.manual_seed(100 + rank)                              # the ranks arrive with DIFFERENT generator states (unequal validation shards)
+    torch.rand(7 * rank + 1)
     # ---- update 1: update_freq 2, both micro-batches real.  value(rank, i) = 1 + 10 rank + 100 i
     tr.train_step([_sample(1 + 10 * rank + 0, 2), _sample(1 + 10 * rank + 100, 3)])
     launched = list(tr.reducer.launched)
@@ -127,6 +131,7 @@ def _worker(rank, world, port, q):
     out["u2_launched_same"] = tr.reducer.launched == launched
     out["u2_mult"] = tr.optimizer.mult                      # rank 1 reports sample_size 0 (its last micro-batch was the dummy)
     out["u2_stats"] = tr.reduce_stats()
+    out["draws"] = list(model.draws)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -144,6 +149,10 @@ def test_world2_update_freq_and_empty_shard():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0]["u1_launched"] == res[1]["u1_launched"], "ranks must issue identical collectives"
+    # every update reseeds torch's generators with seed + num_updates (fairseq/trainer.py:655-661), so ranks whose global
+    # generator had diverged still make the same LayerDrop draws -- and two updates do not repeat each other's
+    assert res[0]["draws"] == res[1]["draws"] and len(res[0]["draws"]) == 4
+    assert res[0]["draws"][:2] != res[0]["draws"][2:]
     for rank in range(world):
         o = res[rank]
         assert o["u1_grad_ok"], "update_freq 2: gradient != sum over ranks and micro-batches"

@@ -244,9 +244,16 @@ def test_overlapped_all_reduce_path_on_the_gpu(monkeypatch):
         orig = tr2.reducer.finish
         tr2.reducer.finish = lambda: (launched_during_backward.append(tr2.reducer.next), orig())[1]
         sample2 = tr2.prepare(task2.dummy_batch(seed=1, lengths=[200, 180, 150, 120]))
+        host_reads = []
+        real_stats = D.all_reduce_stats
+        monkeypatch.setattr(D, "all_reduce_stats", lambda v, device=None: (host_reads.append(sorted(v)), real_stats(v, device))[1])
         for _ in range(2):
             tr2.train_step([sample2])
+        # between backward and Adam nothing is read back -- the summed sample size stays on the device (one 8-byte
+        # all-reduce + s2t_grad_norm_clip_div); the statistics all-reduce (.tolist()) belongs to reduce_stats only
+        assert host_reads == [], host_reads
         got = tr2.reduce_stats()
+        assert len(host_reads) == 1
         torch.cuda.synchronize()
         assert launched_during_backward[-1] >= 1                  # at least one bucket went out before finish()
         close = lambda x, y: float(((x - y).abs() <= 1e-5 + 1e-3 * y.abs()).float().mean())

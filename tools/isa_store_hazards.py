@@ -90,8 +90,75 @@ def scan(text, horizon=8):
     return out
 
 
+def all_regs(ins):
+    """every VGPR an instruction names (operands of any position)"""
+    out = set()
+    for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", ins):
+        out |= regs(tok)
+    return out
+
+
+def scan_tr_reads(text):
+    """The transposed LDS reads issued as inline assembly (gemm_tile.hpp tr_read_asm: `ds_read_b64_tr_b16` behind an asm statement):
+    hipcc's wait-count pass does not know they are asynchronous, so the hand-placed `s_waitcnt lgkmcnt(0)` is what makes their
+    destination registers valid.  -> {kernel: (number of such reads, [violations])}: a violation is an instruction that names a
+    destination register of a transposed read before an `s_waitcnt` with lgkmcnt(0) has been passed (fall-through walk; a branch
+    ends the walk as a violation unless the wait came first)."""
+    out = {}
+    for fn in re.findall(r"^(\w+):\s*;? ?@?\1", text, re.M) or re.findall(r"^([A-Za-z_]\w*):", text, re.M):
+        i = text.index(fn + ":")
+        j = text.find(".Lfunc_end", i)
+        body, labels = [], {}
+        for l in (x.strip() for x in text[i:j].splitlines()):
+            m = re.match(r"^(\.L\w+):", l)
+            if m:
+                labels[m.group(1)] = len(body)
+                continue
+            if l and not l.startswith((";", ".")) and not re.match(r"^\w+:", l):
+                body.append(l)
+
+        def walk(pos, dst, hops):
+            """first offending instruction on the paths from `pos`, or None: conditional branches are taken AND fallen through,
+            unconditional ones followed (at most `hops` jumps per path)"""
+            while pos < len(body):
+                nx = body[pos]
+                if nx.startswith("s_waitcnt") and re.search(r"lgkmcnt\(0\)", nx):
+                    return None
+                if nx.startswith("ds_read_b64_tr_b16"):
+                    if regs(nx.split()[1].strip(",")) & dst:
+                        return nx
+                elif nx.startswith(("s_cbranch", "s_branch")):
+                    tgt = labels.get(nx.split()[1].strip(","))
+                    if tgt is None or hops == 0:
+                        return nx
+                    hit = walk(tgt, dst, hops - 1)
+                    if hit is not None or nx.startswith("s_branch"):
+                        return hit
+                elif nx.startswith(("s_endpgm", "s_setpc")) or all_regs(nx) & dst:
+                    return nx
+                pos += 1
+            return None
+        n, bad = 0, []
+        for k, l in enumerate(body):
+            if l.startswith("ds_read_b64_tr_b16"):
+                n += 1
+                hit = walk(k + 1, regs(l.split()[1].strip(",")), 3)
+                if hit is not None:
+                    bad.append((l[:40], hit[:60]))
+        out[fn] = (n, bad)
+    return out
+
+
 def self_test():
     """planted cases: every kind of writer the scan must see"""
+    t = lambda body: scan_tr_reads("k:\n\t" + "\n\t".join(body) + "\n.Lfunc_end0:\n")["k"]
+    assert t(["ds_read_b64_tr_b16 v[4:5], v1 offset:64", "v_mov_b32_e32 v9, v8", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v9, v4"]) == (1, [])
+    assert len(t(["ds_read_b64_tr_b16 v[4:5], v1", "v_mov_b32_e32 v9, v5", "s_waitcnt lgkmcnt(0)"])[1]) == 1          # read too early
+    assert len(t(["ds_read_b64_tr_b16 v[4:5], v1", "s_waitcnt vmcnt(0)", "v_mfma_f32_16x16x32_bf16 a[0:3], v[4:7], v[8:11], a[0:3]"])[1]) == 1
+    assert len(t(["ds_read_b64_tr_b16 v[4:5], v1", "s_waitcnt lgkmcnt(1)", "v_mov_b32_e32 v9, v4"])[1]) == 1          # a counted wait is not enough here
+    assert t([".LBB0_1:", "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v9, v4", "ds_read_b64_tr_b16 v[4:5], v1", "s_cbranch_scc1 .LBB0_1",
+              "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v9, v4"]) == (1, [])                                               # both ways out of a loop wait first
+    assert len(t([".LBB0_1:", "v_mov_b32_e32 v9, v4", "ds_read_b64_tr_b16 v[4:5], v1", "s_cbranch_scc1 .LBB0_1", "s_waitcnt lgkmcnt(0)"])[1]) == 1
     k = lambda body: scan("k:\n\t" + "\n\t".join(body) + "\n.Lfunc_end0:\n")["k"][0]
     assert k(["ds_write_b128 v1, v[4:7]", "v_mov_b32_e32 v5, 0"]) == 1
     assert k(["buffer_store_dwordx4 v[4:7], v1, s[0:3], 0 offen", "s_nop 3", "v_add_f32_e32 v7, v1, v2"]) == 5
