@@ -403,7 +403,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
     def _init_param(self, name, shape):
         """Reference initialisation."""
         hp = self.hp
-        if name.endswith("layer_norm.weight") or ((".bn." in name or ".bn_" in name) and name.endswith("weight")):
+        if name.endswith(("layer_norm.weight", "layernorm_embedding.weight")) or ((".bn." in name or ".bn_" in name) and name.endswith("weight")):
             return torch.ones(shape)
         if name.endswith("bias"):
             return torch.zeros(shape)
@@ -473,12 +473,16 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                 names += mha(lp + "self_attn.")
             names += wb(lp + "self_attn_layer_norm") + wb(lp + "fc1") + wb(lp + "fc2") + wb(lp + "final_layer_norm")
         names += wb("encoder.layer_norm")
+        if hp.layernorm_embedding:                 # registered after layer_norm in the encoder (conv_transformer.py:180-187) ...
+            names += wb("encoder.layernorm_embedding")
         if hp.ctc_layer:
             names += wb("encoder.ctc_fc")
         for dec, V in (("decoder.", hp.V_tgt), ("auxiliary_decoder.", hp.V_aux)):
             if V <= 0:
                 continue
             names.append(dec + "embed_tokens.weight")
+            if hp.layernorm_embedding:             # ... and right behind the embeddings in the decoder (transformer.py:578-581)
+                names += wb(dec + "layernorm_embedding")
             for l in range(hp.dec_layers):
                 lp = dec + "layers.%d." % l
                 names += mha(lp + "self_attn.") + wb(lp + "self_attn_layer_norm") + mha(lp + "encoder_attn.")
@@ -666,7 +670,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
     def _refuse_unbuilt_options(args):
         g = lambda k: getattr(args, k, None)
         bad = [k for k in ("encoder_embed_path", "decoder_embed_path", "encoder_learned_pos", "decoder_learned_pos", "share_all_embeddings",
-                           "no_token_positional_embeddings", "adaptive_softmax_cutoff", "layernorm_embedding", "no_cross_attention",
+                           "no_token_positional_embeddings", "adaptive_softmax_cutoff", "no_cross_attention",
                            "cross_self_attention", "encoder_layers_to_keep", "decoder_layers_to_keep", "quant_noise_pq",
                            "quant_noise_scalar") if g(k)]
         if g("decoder_output_dim") not in (None, g("decoder_embed_dim")):
@@ -715,6 +719,7 @@ class ConvolutionalTransformerModel(FairseqEncoderDecoderModel):
                      V_src=len(enc_dict), V_tgt=len(tgt_dict), distance_penalty=getattr(args, "distance_penalty", False) or False,
                      attn_2d=bool(getattr(args, "attn_2d", False)),
                      share_dec_embed=bool(getattr(args, "share_decoder_input_output_embed", False)),
+                     layernorm_embedding=bool(getattr(args, "layernorm_embedding", False)),
                      encoder_layerdrop=float(getattr(args, "encoder_layerdrop", 0) or 0),
                      decoder_layerdrop=float(getattr(args, "decoder_layerdrop", 0) or 0))
         assert args.decoder_ffn_embed_dim == args.encoder_ffn_embed_dim

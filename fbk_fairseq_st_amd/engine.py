@@ -37,6 +37,8 @@ class HParams:
         self.distance_penalty = False            # 'log': encoder self-attention scores -= max(0, ln|i-j|) (local_attention.py:131-133)
         self.attn_2d = False                     # two residual ConvAttention2D blocks after the convolutions (conv_transformer.py:155-157,216-222)
         self.V_aux = 0                           # > 0: second decoder `auxiliary_decoder.*` over this vocabulary (dual-decoder model)
+        self.layernorm_embedding = False         # LayerNorm on the embedded input of the encoder and of every decoder, before its dropout
+        #                                          (conv_transformer.py:184-187,230-231; fairseq/models/transformer.py:578-581,731-732)
         self.share_dec_embed = False             # --share-decoder-input-output-embed: output_projection.weight IS embed_tokens.weight (transformer.py:618-624)
         self.ln_eps = 1e-5; self.bn_eps = 1e-5; self.bn_momentum = 0.1
         self.encoder_layerdrop = 0.0; self.decoder_layerdrop = 0.0    # LayerDrop rates (decided on the host by the model)
@@ -67,6 +69,8 @@ class HParams:
                 s[p + "out_proj.weight"] = (C, 2 * H, 3, 3); s[p + "out_proj.bias"] = (C,)
                 s[p + "bn_out.weight"] = (C,); s[p + "bn_out.bias"] = (C,)
         s["encoder.fc3.weight"] = (D, C * self.F4); s["encoder.fc3.bias"] = (D,)
+        if self.layernorm_embedding:
+            s["encoder.layernorm_embedding.weight"] = (D,); s["encoder.layernorm_embedding.bias"] = (D,)
 
         def ln(p):
             s[p + ".weight"] = (D,); s[p + ".bias"] = (D,)
@@ -87,6 +91,8 @@ class HParams:
             if V <= 0:
                 continue
             s[dec + "embed_tokens.weight"] = (V, D)
+            if self.layernorm_embedding:
+                s[dec + "layernorm_embedding.weight"] = (D,); s[dec + "layernorm_embedding.bias"] = (D,)
             for l in range(self.dec_layers):
                 p = dec + "layers.%d." % l
                 ln(p + "self_attn_layer_norm"); lin(p + "self_attn.qkv", 3 * D, D); lin(p + "self_attn.out_proj", D, D)
@@ -374,14 +380,22 @@ class S2TEngine:
         pre3 = torch.empty((T4 * B, hp.D), dtype=self.dtype, device=self.dev) if gelu else None
         h3 = K.gemm(z2n.view(T4 * B, F4 * C), w3p, bias=self.P("encoder.fc3.bias"), act=act, aux_out=pre3)
         p = hp.dropout if training else 0.0
-        xe = K.add_pos(h3.view(T4, B, hp.D), self.table(T4 + 1, 0), len4_32, out=torch.empty((T4, B, hp.D), dtype=self.dtype, device=self.dev),
-                       p_drop=p, seed=seed + 3)
+        lne = None
+        if hp.layernorm_embedding:               # positions, LayerNorm, dropout (conv_transformer.py:228-232): the mask moves behind the LayerNorm
+            xp = K.add_pos(h3.view(T4, B, hp.D), self.table(T4 + 1, 0), len4_32, out=torch.empty((T4, B, hp.D), dtype=self.dtype, device=self.dev))
+            xn, m_, r_ = K.layernorm_fwd(xp.view(T4 * B, hp.D), self.P("encoder.layernorm_embedding.weight"),
+                                         self.P("encoder.layernorm_embedding.bias"), hp.ln_eps)
+            lne = dict(x=xp.view(T4 * B, hp.D), mean=m_, rstd=r_)
+            xe = (K.dropout(xn, p, seed + 3) if p > 0 else xn).view(T4, B, hp.D)
+        else:
+            xe = K.add_pos(h3.view(T4, B, hp.D), self.table(T4 + 1, 0), len4_32, out=torch.empty((T4, B, hp.D), dtype=self.dtype, device=self.dev),
+                           p_drop=p, seed=seed + 3)
         if self.relu_record is not None and not gelu:           # reference layouts: (B,C,T2,F2), (B,C,T4,F4), (T4,B,D)
             self.relu_record["encoder.conv0"] = (y1.view(B, T2, F2, C) > 0).permute(0, 3, 1, 2)
             self.relu_record["encoder.conv1"] = (z2.view(T4, B, F4, C) > 0).permute(1, 3, 0, 2)
             self.relu_record["encoder.fc3"] = (h3 > 0).view(T4, B, hp.D)
         c.update(y1=y1, y1n=y1n, z2=z2, z2n=z2n, h3=h3, w2p=w2p, w3p=w3p, mean1=mean1, rstd1=rstd1, mean2=mean2,
-                 rstd2=rstd2, cnt1=cnt1, P2=P2, p=p, pre1=pre1, pre2=pre2, pre3=pre3)
+                 rstd2=rstd2, cnt1=cnt1, P2=P2, p=p, pre1=pre1, pre2=pre2, pre3=pre3, lne=lne)
         return xe, c
 
     def subsample_bwd(self, c, dx):
@@ -390,7 +404,15 @@ class S2TEngine:
         B, T4, F4 = c["B"], c["T4"], c["F4"]
         mp = self.maps(B, c["T2"], c["F2"])
         dx = dx.contiguous()
-        dh3 = K.act_bwd(dx, c["h3"], 1, c["p"], c["seed"] + 3) if c["pre3"] is None else K.act_bwd(dx, c["pre3"], 2, c["p"], c["seed"] + 3)
+        p3 = c["p"]
+        if c.get("lne") is not None:             # back through dropout and the embedding LayerNorm first; the activation's gradient then has no mask
+            e = c["lne"]
+            if p3 > 0:
+                dx = K.dropout(dx, p3, c["seed"] + 3)
+            dx = K.layernorm_bwd(dx.view(-1, hp.D), e["x"], e["mean"], e["rstd"], self.P("encoder.layernorm_embedding.weight"),
+                                 self.G("encoder.layernorm_embedding.weight"), self.G("encoder.layernorm_embedding.bias"))
+            p3 = 0.0
+        dh3 = K.act_bwd(dx, c["h3"], 1, p3, c["seed"] + 3) if c["pre3"] is None else K.act_bwd(dx, c["pre3"], 2, p3, c["seed"] + 3)
         # fc3: weight gradient in the re-ordered layout, then scattered back (+=) to the master layout
         z2n2d = c["z2n"].view(T4 * B, F4 * C)
         if self.defer_wgrad and K.wgrad_group_ok(dh3, z2n2d):
@@ -687,11 +709,12 @@ class S2TEngine:
 
     def _layer_sizes(self, e, key, training):
         """(workspace bytes for this mode, backward scratch bytes) of the descriptor's CURRENT shape"""
-        sz = e["sizes"].get(key + (training,))
+        k = key + (training, K.OPTION_EPOCH)             # the ReLU record's size follows the GEMM route options (s2t_gemm_relu_mask_bytes)
+        sz = e["sizes"].get(k)
         if sz is None:
             if len(e["sizes"]) >= 64:
                 e["sizes"].clear()
-            sz = e["sizes"][key + (training,)] = (K.layer_ws_bytes(e["desc"], training), K.layer_tmp_bytes(e["desc"]))
+            sz = e["sizes"][k] = (K.layer_ws_bytes(e["desc"], training), K.layer_tmp_bytes(e["desc"]))
         return sz
 
     def layer_fwd(self, pfx, x, training, seeds, self_klen=None, causal=False, dist_penalty=False, enc2d=None, Ts=0, enc_klen=None):
@@ -892,12 +915,18 @@ class S2TEngine:
         tok = prev_tokens.contiguous()
         x = K.embed_fwd(tok, self.W(pfx + "embed_tokens.weight"), self.table(hp.pad + 1 + L, hp.pad), scale, hp.pad)
         p = hp.dropout if training else 0.0
+        lne = None
+        if hp.layernorm_embedding:               # transformer.py:731-732: LayerNorm between the embedding sum and its dropout
+            xn, m_, r_ = K.layernorm_fwd(x.view(L * B, D), self.P(pfx + "layernorm_embedding.weight"), self.P(pfx + "layernorm_embedding.bias"),
+                                         hp.ln_eps)
+            lne = dict(x=x.view(L * B, D), mean=m_, rstd=r_)
+            x = xn.view(L, B, D)
         if p > 0:
             K.dropout(x, p, seed * 1000 + 501, out=x)
         tlen = tok.ne(hp.pad).sum(dim=1).to(torch.int32)            # integer bookkeeping (suffix padding)
         Ts = enc_out.shape[0]
         enc2d = enc_out.reshape(Ts * B, D)
-        ctx = dict(tok=tok, layers=[], B=B, L=L, Ts=Ts, scale=scale, p=p, seed=seed, pfx=pfx)
+        ctx = dict(tok=tok, layers=[], B=B, L=L, Ts=Ts, scale=scale, p=p, seed=seed, pfx=pfx, lne=lne)
         for l in range(hp.dec_layers):
             if keep is not None and not keep[l]:
                 ctx["layers"].append(None)
@@ -975,6 +1004,8 @@ class S2TEngine:
         scale = 1.0 if hp.no_scale_embedding else math.sqrt(D)
         x = K.embed_fwd(last_tokens.view(N, 1).contiguous(), self.W(pfx + "embed_tokens.weight"),
                         self.table(hp.pad + 2 + st["max_steps"], hp.pad), scale, hp.pad, pos_offset=step).view(N, D)
+        if hp.layernorm_embedding:
+            x, _, _ = K.layernorm_fwd(x, self.P(pfx + "layernorm_embedding.weight"), self.P(pfx + "layernorm_embedding.bias"), hp.ln_eps)
         for l in range(hp.dec_layers):
             lp = pfx + "layers.%d." % l
             h, _, _ = K.layernorm_fwd(x, self.P(lp + "self_attn_layer_norm.weight"), self.P(lp + "self_attn_layer_norm.bias"), hp.ln_eps)
@@ -1047,6 +1078,10 @@ class S2TEngine:
             self._ready(lp)
         if ctx["p"] > 0:
             K.dropout(dx, ctx["p"], ctx["seed"] * 1000 + 501, out=dx)
+        if ctx.get("lne") is not None:
+            e = ctx["lne"]
+            dx = K.layernorm_bwd(dx.reshape(L * B, D).contiguous(), e["x"], e["mean"], e["rstd"], self.P(pfx + "layernorm_embedding.weight"),
+                                 self.G(pfx + "layernorm_embedding.weight"), self.G(pfx + "layernorm_embedding.bias"))
         K.embed_bwd(ctx["tok"], dx.view(L, B, D), self.G(pfx + "embed_tokens.weight"), ctx["scale"], hp.pad)
         self._ready(pfx + "embed_tokens.")
         if self.flush_decoder_wgrad:

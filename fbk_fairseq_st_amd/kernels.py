@@ -71,9 +71,11 @@ _MASK_BYTES = {}
 def relu_mask_bytes(M, N, K):
     """Bytes of the 1-bit ReLU record of an [M, N] bf16 product over K (ACT_RELU_MASK / ACT_RELU_BWD_MASK); 0 = products of this
     shape keep the activations as the backward operand (ACT_RELU / ACT_RELU_BWD)."""
-    key = (M, N, K)
+    key = (M, N, K, OPTION_EPOCH)           # the tile height, hence the record's size, follows the route options (reserve_cus, gemm256*)
     n = _MASK_BYTES.get(key)
     if n is None:
+        if len(_MASK_BYTES) > 4096:
+            _MASK_BYTES.clear()
         n = _MASK_BYTES[key] = int(_lib().s2t_gemm_relu_mask_bytes(M, N, K))
     return n
 
@@ -639,11 +641,16 @@ def host_ctc_uer(pred_cpu, in_len_cpu, targets_cpu, tgt_len_cpu, blank):
     return e.value, n.value
 
 
+OPTION_EPOCH = 0          # bumps with every set_option: sizes that depend on the kernel routes (the engine's cached workspace sizes) key on it
+
+
 def set_option(key, value):
     """kernel-route option of the library (include/s2t_hip.h, s2t_set_option); returns the previous value"""
+    global OPTION_EPOCH
     old = _lib().s2t_set_option(key.encode(), int(value))
     if old == -22:
-        raise ValueError("unknown libs2t_hip option %r" % key)
+        raise ValueError("unknown libs2t_hip option %r (or a value out of its range)" % key)
+    OPTION_EPOCH += 1
     return old
 
 

@@ -147,6 +147,8 @@ class SequenceGenerator:
         if not DEC.device_search_enabled() or type(search) not in (BeamSearch, HierarchicalBeamSearch):
             return None
         eng = decoder.engine
+        if eng.hp.layernorm_embedding:                                     # the step's first launch takes the embedding sum as it is
+            return None
         eo = enc.encoder_out.contiguous()
         klen = enc.src_lengths.to(torch.int32) if enc.encoder_padding_mask is not None else None
         ses = DEC.BeamDecodeSession(eng, decoder.pfx, eo, klen, self.beam_size, max_len, self.min_len, pad, unk, eos, V, self.unk_penalty,

@@ -50,11 +50,11 @@ class Trainer:
         model.engine.on_grads_ready = self._grads_ready
         if self.world > 1 and getattr(model.engine, "defer_wgrad", False):
             model.engine.wgrad_flush_layers = max(1, model.hp.enc_layers // 2)     # see S2TEngine.wgrad_flush_layers
-        # --reserve-cus N (default 16 when gradients are all-reduced, 0 otherwise): the persistent one-workgroup-per-CU kernels
+        # --reserve-cus N (default 0): the persistent one-workgroup-per-CU kernels
         # (gemm256, wgrad_group: 128 KiB of LDS each) leave N CUs to RCCL's kernels, which run beside backward while a bucket
         # travels -- a workgroup that finds its CU taken would otherwise wait for a whole round of the others.  Measured on one GPU
         # against a stand-in for the collective: bench.py data_parallel.dry_run.comm_standin.
-        self.reserve_cus = int(getattr(args, "reserve_cus", 16 if self.world > 1 else 0) or 0)
+        self.reserve_cus = int(getattr(args, "reserve_cus", 0) or 0)
         if self.device.type == "cuda":
             from . import kernels as K
             K.set_option("reserve_cus", self.reserve_cus)

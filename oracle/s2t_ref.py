@@ -23,7 +23,7 @@ EncOut = namedtuple("EncOut", "encoder_out encoder_padding_mask src_lengths ctc_
 def default_cfg(**kw):
     cfg = dict(D=256, heads=4, ffn=768, enc_layers=6, dec_layers=6, ctc_layer=0, act="relu",
                enc_pre_ln=True, dec_pre_ln=True, pad=1, strategy="avg", conv_ch=64, feat=80,
-               no_scale_embedding=False, ln_eps=1e-5, bn_eps=1e-5, bn_momentum=0.1)
+               no_scale_embedding=False, ln_eps=1e-5, bn_eps=1e-5, bn_momentum=0.1, layernorm_embedding=False)
     cfg.update(kw)
     return cfg
 
@@ -170,6 +170,8 @@ def subsample(W, cfg, src_tokens, src_lengths, training=False, trace=None):
     table = sinusoid_table(T4 + 1, cfg["D"], 0)
     pos = audio_positions(lengths, T4)
     x = x + table[pos].transpose(0, 1)                                         # :229
+    if cfg.get("layernorm_embedding"):                                         # :230-231 (before the dropout of :232)
+        x = layer_norm(W, "encoder.layernorm_embedding.", x, cfg["ln_eps"])
     if trace is not None:
         trace["embed"] = x
     return x, lengths, stats
@@ -294,6 +296,8 @@ def decoder_forward(W, cfg, prev_output_tokens, enc_out, enc_pad_mask, pfx="deco
     table = sinusoid_table(pad + 1 + L, D, pad)
     x = scale * W[pfx + "embed_tokens.weight"][prev_output_tokens]           # :720
     x = x + table[token_positions(prev_output_tokens, pad)]                   # :728-729
+    if cfg.get("layernorm_embedding"):                                         # :731-732
+        x = layer_norm(W, pfx + "layernorm_embedding.", x, cfg["ln_eps"])
     x = x.transpose(0, 1)
     self_pad = prev_output_tokens.eq(pad)
     self_pad = self_pad if bool(self_pad.any()) else None                     # :739-741
@@ -669,6 +673,8 @@ def param_shapes(cfg, V_src, V_tgt, criterion_fc=False, V_aux=0):
         s[p + "fc1.weight"] = (Ff, D); s[p + "fc1.bias"] = (Ff,)
         s[p + "fc2.weight"] = (D, Ff); s[p + "fc2.bias"] = (D,)
 
+    if cfg.get("layernorm_embedding"):
+        ln("encoder.layernorm_embedding.")
     for l in range(cfg["enc_layers"]):
         p = "encoder.layers.%d." % l
         attn(p + "self_attn."); ln(p + "self_attn_layer_norm."); ff(p); ln(p + "final_layer_norm.")
@@ -680,6 +686,8 @@ def param_shapes(cfg, V_src, V_tgt, criterion_fc=False, V_aux=0):
         if V <= 0:
             continue
         s[dec + "embed_tokens.weight"] = (V, D)
+        if cfg.get("layernorm_embedding"):
+            ln(dec + "layernorm_embedding.")
         for l in range(cfg["dec_layers"]):
             p = dec + "layers.%d." % l
             attn(p + "self_attn."); ln(p + "self_attn_layer_norm.")
@@ -707,7 +715,7 @@ def make_weights(shapes, seed):
             a = 0.5 + rs.rand(*shp)
         elif k.endswith("running_mean"):
             a = 0.1 * rs.randn(*shp)
-        elif "layer_norm" in k or ".bn." in k or ".bn_" in k:
+        elif "layer_norm" in k or "layernorm_embedding" in k or ".bn." in k or ".bn_" in k:
             a = (1.0 + 0.1 * rs.randn(*shp)) if k.endswith("weight") else 0.1 * rs.randn(*shp)
         elif k.endswith("bias"):
             a = 0.05 * rs.randn(*shp)

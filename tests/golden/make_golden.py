@@ -67,7 +67,7 @@ def mk_dict(n):
 
 
 def build(cfgname, D, H, Ff, EL, DL, ctc_layer, compress=True, strategy="avg", arch="conv_transformer",
-          criterion=("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy"), extra=(), attn_2d=False):
+          criterion=("ctc_multi_loss", "--underlying-criterion", "label_smoothed_cross_entropy"), extra=(), attn_2d=False, set_args=None):
     a = ["/nonexistent", "--user-dir", REF + "/examples/speech_recognition",
          "--task", "speech_translation_with_transcription", "-s", "en", "-t", "de",
          "--arch", arch] + ([] if attn_2d else ["--no-attn-2d"]) + ["--input-feat-per-channel", "80",
@@ -86,6 +86,8 @@ def build(cfgname, D, H, Ff, EL, DL, ctc_layer, compress=True, strategy="avg", a
     if compress:
         a.append("--ctc-compress-out")
     args = options.parse_args_and_arch(options.get_training_parser(), input_args=a)
+    for k, v in (set_args or {}).items():       # options the reference reads with getattr but registers no flag for (layernorm_embedding)
+        setattr(args, k, v)
     tgt, src = mk_dict(96), mk_dict(59)
     src.add_symbol("<ctc_blank>")           # speech_translation_ctc.py:42-46
     task = SpeechTranslationCTCTask(args, tgt)
@@ -429,6 +431,43 @@ def run_dual_case():
     out["gradnorm_keys"] = np.array(sorted(gn)); out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], np.float64)
     np.savez_compressed(os.path.join(OUT, "dual.npz"), **out)
     print("dual loss", loss.item(), ss, {k: float(v) for k, v in log.items()})
+
+
+def run_lne_case():
+    """`layernorm_embedding` (conv_transformer.py:184-187,230-231; fairseq/models/transformer.py:578-581,731-732): a LayerNorm on the
+    embedded input of the encoder and of the decoder, before the dropout.  The reference reads it with getattr (its arch functions
+    default it to False) and registers no flag for this model, so it is set on the parsed args.  Train-mode loss / gradient norms and the
+    eval-mode encoder output and logits."""
+    D, H, Ff, EL, DL, ctc_layer, seed = 64, 2, 128, 2, 2, 1, 1500
+    args, task, model, crit, V_src, V_tgt = build("lne", D, H, Ff, EL, DL, ctc_layer, True, set_args=dict(layernorm_embedding=True))
+    assert model.encoder.layernorm_embedding is not None and model.decoder.layernorm_embedding is not None
+    blank = task.source_dictionary.index("<ctc_blank>")
+    cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL, ctc_layer=ctc_layer, layernorm_embedding=True)
+    W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
+    load_weights(model, crit, W)
+    assert all(k in W for k in model.state_dict() if "layernorm_embedding" in k)
+    s = make_sample(seed + 1, [57, 44, 31], [6, 5, 4], [5, 4, 3], V_src, V_tgt, blank)
+    sample = to_ref_sample(s)
+    out = {("in_" + k): v for k, v in s.items() if isinstance(v, np.ndarray)}
+    out["in_ntokens"] = np.int64(s["ntokens"])
+    out["meta"] = np.array([D, H, Ff, EL, DL, ctc_layer, 1, V_src, V_tgt, blank, seed], np.int64)
+    model.train(); crit.train()
+    model.zero_grad(); crit.zero_grad()
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    out["train_loss"] = np.float64(loss.item()); out["train_sample_size"] = np.int64(sample_size)
+    gn = {k: float((p.grad if p.grad is not None else torch.zeros_like(p)).norm())
+          for k, p in list(model.named_parameters()) + [("criterion." + k, p) for k, p in crit.named_parameters()]}
+    out["gradnorm_keys"] = np.array(sorted(gn)); out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn)], np.float64)
+    args2, task2, model2, crit2, _, _ = build("lne", D, H, Ff, EL, DL, ctc_layer, True, set_args=dict(layernorm_embedding=True))
+    load_weights(model2, crit2, W)
+    model2.eval()
+    with torch.no_grad():
+        eo = model2.encoder(sample["net_input"]["src_tokens"], sample["net_input"]["src_lengths"])
+        logits, _ = model2.decoder(sample["net_input"]["prev_output_tokens"], encoder_out=eo)
+    out["eval_encoder_out"] = eo.encoder_out.numpy(); out["eval_logits"] = logits.numpy()
+    print("lne loss", loss.item(), "enc", tuple(eo.encoder_out.shape))
+    np.savez_compressed(os.path.join(OUT, "lne.npz"), **out)
 
 
 def run_generate_case(wide=False):
@@ -1102,6 +1141,8 @@ if __name__ == "__main__":
         run_data_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "generate":
         run_generate_case(); sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lne":
+        run_lne_case(); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wide":
         run_generate_case(wide=True); run_twophase_case(wide=True); sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "extra":

@@ -14,11 +14,11 @@ def load_golden(name):
 
 
 def model_case(name):
-    """Rebuild cfg, deterministic weights and the sample dict of a model_* fixture."""
+    """Rebuild cfg, deterministic weights and the sample dict of a model_* fixture (`lne`: the same with layernorm_embedding)."""
     g = load_golden(name)
     D, H, Ff, EL, DL, ctc_layer, compress, V_src, V_tgt, blank, seed = [int(v) for v in g["meta"]]
     cfg = s2t_ref.default_cfg(D=D, heads=H, ffn=Ff, enc_layers=EL, dec_layers=DL,
-                              ctc_layer=ctc_layer if compress else 0)
+                              ctc_layer=ctc_layer if compress else 0, layernorm_embedding=(name == "lne"))
     W = s2t_ref.make_weights(s2t_ref.param_shapes(cfg, V_src, V_tgt, criterion_fc=True), seed)
     t = lambda k: torch.from_numpy(g["in_" + k])
     sample = dict(

@@ -19,6 +19,7 @@ def build(name, dtype=torch.float32):
     from fbk_fairseq_st_amd.registry import namespace
     g, cfg, W, sample, meta = model_case(name)
     args = namespace(arch="conv_transformer", criterion="ctc_multi_loss", underlying_criterion="label_smoothed_cross_entropy",
+                     layernorm_embedding=bool(cfg.get("layernorm_embedding")),
                      label_smoothing=0.1, ctc_compress_out=meta["compress"], ctc_encoder_layer=meta["ctc_layer"], ctc_weight=1.0,
                      encoder_embed_dim=cfg["D"], encoder_ffn_embed_dim=cfg["ffn"], encoder_attention_heads=cfg["heads"],
                      encoder_layers=cfg["enc_layers"], decoder_layers=cfg["dec_layers"], no_attn_2d=True,
@@ -86,6 +87,38 @@ def test_forward_matches_reference_golden(name):
         logits, _ = model.decoder(ni["prev_output_tokens"], encoder_out=eo)
     close(eo.encoder_out, g["eval_encoder_out"], 1e-4, "eval encoder_out")
     close(logits, g["eval_logits"], 1e-4, "eval logits")
+
+
+def test_layernorm_embedding_matches_reference():
+    """`layernorm_embedding` on both sides (conv_transformer.py:184-187,230-231; transformer.py:578-581,731-732)
+    against the reference's own run (fixture lne.npz): eval outputs 1e-4, train loss 1e-4, every gradient norm 5e-4; the incremental
+    decoder applies it too (step logits = teacher-forced logits)."""
+    from fbk_fairseq_st_amd.conv_transformer import fused_to_reference
+    g, cfg, W, sample, meta, model, crit = build("lne")
+    assert "encoder.layernorm_embedding.weight" in model.arena.slices and "decoder.layernorm_embedding.bias" in model.arena.slices
+    s = to_dev(sample)
+    ni = s["net_input"]
+    model.eval()
+    with torch.no_grad():
+        eo = model.encoder(ni["src_tokens"], ni["src_lengths"])
+        logits, _ = model.decoder(ni["prev_output_tokens"], encoder_out=eo)
+        close(eo.encoder_out, g["eval_encoder_out"], 1e-4, "eval encoder_out")
+        close(logits, g["eval_logits"], 1e-4, "eval logits")
+        inc = {}
+        for t in range(ni["prev_output_tokens"].shape[1]):
+            step, _ = model.decoder(ni["prev_output_tokens"][:, :t + 1], encoder_out=eo, incremental_state=inc)
+            real = ni["prev_output_tokens"][:, t].ne(1).cpu().numpy()          # right-padded targets: padded steps are nobody's input
+            close(step[:, 0][torch.from_numpy(real).to(step.device)], g["eval_logits"][:, t][real], 1e-4, "step %d" % t)
+    model.load_state_dict({k: v for k, v in W.items() if not k.startswith("criterion.")})
+    model.train(); crit.train()
+    model.arena.zero_grad()
+    loss, ss, log = crit(model, s)
+    loss.backward()
+    close(loss, g["train_loss"], 1e-4, "loss")
+    grads = fused_to_reference({n: model.arena.g(n).detach().cpu().clone() for n in model.arena.slices})
+    for k, ref in zip([str(k) for k in g["gradnorm_keys"]], g["gradnorm_vals"]):
+        if k in grads:
+            assert abs(float(grads[k].norm()) - ref) <= 5e-4 * max(1.0, ref), (k, float(grads[k].norm()), ref)
 
 
 @pytest.mark.parametrize("name", ["model_a", "model_b", "model_c"])

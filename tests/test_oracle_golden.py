@@ -47,6 +47,26 @@ def test_encoder_decoder_train_mode(name):
         close(stats["encoder.bn.%d.running_var" % i], g["train_bn%d_running_var" % i], what="rv")
 
 
+def test_layernorm_embedding_case():
+    """`layernorm_embedding` (conv_transformer.py:184-187,230-231; transformer.py:731-732): eval outputs, train loss and every
+    gradient norm of the reference (fixture lne.npz)"""
+    g, cfg, W, sample, meta = model_case("lne")
+    ni = sample["net_input"]
+    with torch.no_grad():
+        enc, _ = s2t_ref.encoder_forward(W, cfg, ni["src_tokens"], ni["src_lengths"], training=False)
+        logits = s2t_ref.decoder_forward(W, cfg, ni["prev_output_tokens"], enc.encoder_out, enc.encoder_padding_mask)
+    close(enc.encoder_out, g["eval_encoder_out"], what="encoder_out")
+    close(logits, g["eval_logits"], what="logits")
+    Wg = {k: v.clone().requires_grad_("running" not in k) for k, v in W.items()}
+    loss, ss, _, _, _, _ = s2t_ref.ctc_multi_loss(Wg, cfg, sample, 0.1, 1.0, meta["blank"], training=True)
+    loss.backward()
+    assert abs(float(loss) - float(g["train_loss"])) <= 1e-4 * float(g["train_loss"]) and ss == int(g["train_sample_size"])
+    ref = dict(zip([str(k) for k in g["gradnorm_keys"]], g["gradnorm_vals"]))
+    for k in ("encoder.layernorm_embedding.weight", "encoder.layernorm_embedding.bias", "decoder.layernorm_embedding.weight",
+              "decoder.layernorm_embedding.bias", "encoder.fc3.weight", "decoder.embed_tokens.weight"):
+        assert abs(float(Wg[k].grad.norm()) - ref[k]) <= 5e-4 * max(1.0, ref[k]), k
+
+
 @pytest.mark.parametrize("name", ["model_a", "model_b", "model_c"])
 def test_eval_mode(name):
     g, cfg, W, sample, meta = model_case(name)
