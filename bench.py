@@ -45,7 +45,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 # kernel behind each profiled family (names as they appear in the rocprofv3 kernel trace, profiles/)
-KERNEL_OF = {"wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward pass in one launch: 256x256 tiles owned over all tokens, LDS-DMA, no split-K)",
+KERNEL_OF = {"wgrad_group_f32": "wgrad_f32_kernel (all dW = dY^T X of a backward pass in f32 mode: 128x128 tiles owned over all tokens, exact-f32 MFMA, no atomics)",
+             "wgrad_group": "wgrad_group_kernel (all dW = dY^T X of a backward pass in one launch: 256x256 tiles owned over all tokens, LDS-DMA, no split-K)",
              "gemm256_nt": "gemm256_kernel<bf16, TB=false> (Y = X W^T: 256/192 x 256 x 64, LDS-DMA, one persistent workgroup per CU)",
              "gemm256_nn": "gemm256_kernel<bf16, TB=true> (dX = dY W: 256/192 x 256 x 64, LDS-DMA, one persistent workgroup per CU)",
              "gemm_nt": "gemm_fast_kernel<.., 128, 128, 8 waves> (register-staged; products the LDS-DMA kernels do not take: decoder side, f32)",
@@ -278,7 +279,7 @@ def cpu_baseline(args, a, ref_sd, task):
                       % (Bc, args.frames, args.cpu_updates)}
 
 
-FAMILIES = ("wgrad_group", "gemm256_nt", "gemm256_nn", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small",
+FAMILIES = ("wgrad_group", "wgrad_group_f32", "gemm256_nt", "gemm256_nn", "gemm_tn", "gemm_nt", "gemm_nn", "gemm_tn_small", "gemm_nt_small", "gemm_nn_small",
             "gemm_gather", "conv2_fwd", "conv2_dgrad", "attn_fwd", "attn_bwd")
 
 

@@ -807,10 +807,15 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     // products with a k-strided operand (NN, TN) stage it through transposed LDS reads only in the 128-wide kernels (the 64-wide
     // form transposes in registers): they switch to 64x64 tiles much later (tools/small_gemm.py: NN 2560 x 512 x 8000 93 -> 67 us,
     // TN 512 x 512 18 -> 14.6 us with the 128-wide kernels; NT is better off with 64x64 below ~192 tiles)
-    const bool small = t128 < ((trans_a || trans_b) ? 40 : 192);
+    // f32 operands: the exact-f32 MFMA runs at 1/16 of the bf16 rate, so a product is bound by its tiles' MFMA time, not by staging, and
+    // what counts is that every CU has tiles: thresholds of their own (s2t_set_option "gemm_f32_small_nt" / "_kt": below that many 128 x 128
+    // tiles the 64 x 64 form; "gemm_f32_narrow": below that many the 128 x 64 form)
+    const bool f32in = in_dtype == S2T_F32 && !mapA && !mapB && !mapC;
+    const bool small = f32in ? t128 < ((trans_a || trans_b) ? g_s2t_opt_f32_small_kt : g_s2t_opt_f32_small_nt)
+                             : t128 < ((trans_a || trans_b) ? 40 : 192);
     // (128 x 64 tiles for products with 40-160 tiles of 128 x 128 -- twice the workgroups on the idle CUs -- measured 2-3 % SLOWER on
     // the decoder's M = 2,560 / 3,000 products, tools/dec_gemm_time.py: not used)
-    const bool narrow = !small && N <= 64;                 // conv2 implicit GEMM: 64 output channels
+    const bool narrow = !small && (N <= 64 || (f32in && t128 < g_s2t_opt_f32_narrow));    // N <= 64: conv2 implicit GEMM, 64 output channels
     // families for the roofline report (one kernel template each): dW-shaped (TN), forward (NT), dX-shaped (NN) products on
     // 128x128 tiles, their small-problem 64x64 forms, and the implicit-GEMM convolution
     // ONE KERNEL TEMPLATE per family: the 256 x 256 x 64 LDS-DMA kernel in its forward (NT) and data-gradient (NN) forms, and the

@@ -14,5 +14,5 @@ struct ProfScope {
 // Per-(device, stream) scratch of the entry points that hand workgroup partial sums to a finishing kernel: two calls of one entry
 // point on different streams (or devices) get different buffers; calls on ONE stream are ordered by the stream.  Grows, never
 // shrinks; lives until process exit.  Returns nullptr and sets *err when the allocation fails.
-enum { S2T_SCRATCH_LSCE = 0, S2T_SCRATCH_KD, S2T_SCRATCH_GNORM, S2T_SCRATCH_CONV1_BWD, S2T_SCRATCH_SLOTS };
+enum { S2T_SCRATCH_LSCE = 0, S2T_SCRATCH_KD, S2T_SCRATCH_GNORM, S2T_SCRATCH_CONV1_BWD, S2T_SCRATCH_WGRAD_F32, S2T_SCRATCH_SLOTS };
 void* s2t_scratch(int slot, hipStream_t st, size_t bytes, hipError_t* err);

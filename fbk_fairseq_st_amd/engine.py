@@ -196,7 +196,7 @@ class S2TEngine:
         # queue goes out as ONE grouped launch per decoder / encoder backward (K.wgrad_group: every 256 x 256 tile of every dW owned by
         # one workgroup over all tokens, no split-K atomics; csrc/wgrad_group.hip).  Parameter groups are reported final only after
         # the launch that holds their products (flush_wgrad).
-        self.defer_wgrad = arena.compute_dtype == torch.bfloat16
+        self.defer_wgrad = True                 # f32 mode too since round 6 (K.wgrad_group -> csrc/wgrad_f32.hip: no split-K atomics there either)
         self._wq, self._wq_ready, self._wq_post = [], [], []     # _wq_post: what must follow the grouped launch (re-ordering a dW)
         # One C call per Transformer layer and direction (csrc/layer.hip: the block schedules below restated in C++, launch for
         # launch): from Python a launch costs 6-12 us of host time, from C ~2.5 us, and with 8 utterances per GPU the host's launch
@@ -204,7 +204,7 @@ class S2TEngine:
         # reference the tests hold it to (bit for bit) and the path of f32 mode.
         # (shapes csrc/layer.hip refuses -- D or ffn not a multiple of 8, D not divisible by heads: its `bad()` -- stay on the per-kernel
         # schedule, whose products fall back to the linear_wgrad / 128-wide routes)
-        self.composite = self.defer_wgrad and hp.D % 8 == 0 and hp.ffn % 8 == 0 and hp.D % hp.heads == 0
+        self.composite = arena.compute_dtype == torch.bfloat16 and hp.D % 8 == 0 and hp.ffn % 8 == 0 and hp.D % hp.heads == 0
         self._descs = {}
         self._call = L.LayerCall()
         self._items = (L.WgradProblem * K.WGRAD_GROUP_MAX)()     # weight-gradient products appended by the layer calls

@@ -100,13 +100,13 @@ def wgrad_group(items):
     the decoder's backward, where the launch stream is what the GPU waits for)."""
     if not items:
         return
-    fn = _lib().s2t_wgrad_group
+    fn = _lib().s2t_wgrad_group if items[0][0].dtype == torch.bfloat16 else _lib().s2t_wgrad_group_f32
     for i in range(0, len(items), WGRAD_GROUP_MAX):
         chunk = items[i:i + WGRAD_GROUP_MAX]
         arr = (L.WgradProblem * len(chunk))()
         for k, (dy, x, dw, db) in enumerate(chunk):
             if not (dy.is_cuda and x.is_cuda and dw.is_cuda and dw.dtype == torch.float32 and dy.shape[0] == x.shape[0]
-                    and dw.shape[0] == dy.shape[1] and dw.shape[1] == x.shape[1]):
+                    and dw.shape[0] == dy.shape[1] and dw.shape[1] == x.shape[1] and dy.dtype == x.dtype == items[0][0].dtype):
                 raise L.S2THipError("wgrad_group: item %d is not a (dy [tokens, n_out], x [tokens, n_in], f32 dw [n_out, n_in]) device triple" % k)
             p = arr[k]
             p.dY = dy.data_ptr(); p.X = x.data_ptr(); p.dW = dw.data_ptr(); p.db = db.data_ptr() if db is not None else None
@@ -142,7 +142,11 @@ def layer_bwd(desc_addr, call_addr):
 
 
 def wgrad_group_ok(dy, x):
-    """shapes the grouped kernel takes (otherwise: linear_wgrad)"""
+    """shapes the grouped kernels take (otherwise: linear_wgrad): bf16 -> s2t_wgrad_group, f32 -> s2t_wgrad_group_f32"""
+    if dy.dtype == torch.float32 and x.dtype == torch.float32:
+        return (dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0
+                and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+                and (dy.shape[1] + 3) // 4 * 4 <= dy.stride(0) and (x.shape[1] + 3) // 4 * 4 <= x.stride(0))
     return (dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
             and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
             and dy.shape[1] >= 8 and x.shape[1] >= 8

@@ -33,6 +33,7 @@ SIGNATURES = {
     "s2t_gemm_relu_mask_bytes": [c_int, c_int, c_int],          # returns size_t
     "s2t_linear_wgrad": [c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, c_int, P, c_int, P],
     "s2t_wgrad_group": [c_int, P, P],
+    "s2t_wgrad_group_f32": [c_int, P, P],
     "s2t_colsum": [c_int, P, c_int, c_int, c_int, P, P],
     "s2t_attn_fwd": [c_int] * 6 + [P, c_long, c_long] * 4 + [P, P, c_int, c_int, c_float, c_float, c_ull, P],
     "s2t_attn_bwd": [c_int] * 6 + [P, c_long, c_long] * 5 + [P, P] + [P, c_long, c_long] * 3 +

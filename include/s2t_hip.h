@@ -125,6 +125,11 @@ typedef struct S2TWgradProblem {
     int n_out, n_in, tokens, ldy, ldx, ldw;
 } S2TWgradProblem;
 int s2t_wgrad_group(int n, const S2TWgradProblem* probs, void* stream);
+/* The same for f32 operands (the parity mode; csrc/wgrad_f32.hip): exact-f32 MFMA, every 128 x 128 tile of every dW owned by one workgroup
+ * over all its tokens (no atomics: results do not depend on scheduling), all tiles of all products dealt to two workgroups per CU,
+ * longest reductions first.  Requirements: ldy, ldx multiples of 4 elements and >= the column count rounded up to 4, 16-byte aligned
+ * operand bases; a dW must not appear twice in one call. */
+int s2t_wgrad_group_f32(int n, const S2TWgradProblem* probs, void* stream);
 
 /* out[n] += sum_m X[m][n]  (bias gradients of every nn.Linear above; f32 atomics) */
 /* Parameter gradients of a Linear in one pass over dY (autograd of F.linear: fairseq/modules/multihead_attention.py:190-208,
@@ -480,6 +485,10 @@ int s2t_prof_enable(int on);
  *       "reserve_cus": 0..128 (default 0): the persistent one-workgroup-per-CU kernels (gemm256, wgrad_group) launch 256 - value
  *                  workgroups and plan their rounds for that many CUs -- what a data-parallel run sets while RCCL's kernels share
  *                  the chip with backward (trainer: --reserve-cus);
+ *       "gemm_f32_small_nt" / "gemm_f32_small_kt" (defaults 1024 / 512): f32 products with fewer 128 x 128 tiles than this take the 64 x 64
+ *                  form (NT / NN and TN layouts): the exact-f32 MFMA is 1/16 of the bf16 rate, so what counts is that every CU has
+ *                  tiles (tools/f32_tile_sweep.py: 22.96 -> 20.03 ms per update of configs[1]); "gemm_f32_narrow" (default 0): below
+ *                  that many the 128 x 64 form;
  *       "decode_stop_after": diagnostic, ends s2t_decode_step after that many launches (0 = off);
  * returns the previous value, or S2T_EINVAL (-22) for an unknown key or a value out of range. */
 int s2t_set_option(const char* key, int value);

@@ -736,6 +736,54 @@ def test_wgrad_group_mixed_reduction_lengths(t_long, t_short, n_long):
             assert rel_err(db, rb) < 1e-4
 
 
+@pytest.mark.parametrize("tokens", [8000, 961, 30])
+def test_wgrad_group_f32_matches_per_linear_gradients(tokens):
+    """f32 mode's grouped weight gradients (csrc/wgrad_f32.hip): dW += dY^T X, db += colsum(dY) for a list of
+    Linears against f64 math on the same f32 operands -- token counts that are not a multiple of the 32-token stage, outputs that
+    are not multiples of the 128 x 128 tile (the CTC head's 5,001 rows, row-padded), accumulation into existing gradients -- and,
+    every tile having one owner, bit-identical reruns (a list whose longest tiles leave a round partly filled cuts that round's tiles
+    along the tokens and meets them in f32 atomics: test below)"""
+    shapes = [(256, 256, True), (768, 256, True), (2048, 256, True), (256, 2048, True), (5001, 256, True), (260, 1280, False)]
+    items, refs = [], []
+    for k, (n_out, n_in, has_b) in enumerate(shapes):
+        dy = rnd(tokens, n_out, seed=10 + k)
+        x = rnd(tokens, n_in, seed=20 + k, scale=0.5)
+        dyd = K.alloc_rows((tokens,), n_out, torch.float32, DEV); dyd.copy_(dy)             # row stride padded to 16 bytes
+        dw0 = rnd(n_out, n_in, seed=30 + k); db0 = rnd(n_out, seed=40 + k)
+        assert K.wgrad_group_ok(dyd, x.to(DEV))
+        items.append((dyd, x.to(DEV), dw0.to(DEV).clone(), db0.to(DEV).clone() if has_b else None))
+        refs.append((dw0.double() + dy.double().t() @ x.double(), db0.double() + dy.double().sum(0)))
+    K.wgrad_group(items)
+    for (dy, x, dw, db), (rw, rb) in zip(items, refs):
+        assert rel_err(dw, rw) < 2e-6 * max(1.0, tokens ** 0.5 / 8), (tuple(dw.shape), rel_err(dw, rw))
+        if db is not None:
+            assert rel_err(db, rb) < 1e-5
+    again = [(dy, x, torch.zeros_like(dw), None if db is None else torch.zeros_like(db)) for (dy, x, dw, db) in items]
+    K.wgrad_group(again); first = [(a[2].clone(), None if a[3] is None else a[3].clone()) for a in again]
+    for a in again:
+        a[2].zero_()
+        if a[3] is not None:
+            a[3].zero_()
+    K.wgrad_group(again)
+    for a, (fw, fb) in zip(again, first):
+        assert torch.equal(a[2], fw) and (fb is None or torch.equal(a[3], fb))
+
+
+def test_wgrad_group_f32_cut_round():
+    """1,060 equal long tiles on 512 workgroups: the 36 tiles of the third round are cut along the tokens (f32 atomics)"""
+    g = torch.Generator(device=DEV).manual_seed(7)
+    items = []
+    for _ in range(33):
+        dy = torch.randn(2048, 512, device=DEV, generator=g) * 0.5; x = torch.randn(2048, 1024, device=DEV, generator=g) * 0.5
+        items.append((dy, x, torch.randn(512, 1024, device=DEV, generator=g), torch.randn(512, device=DEV, generator=g)))
+    items.append((items[0][0][:, :256].contiguous(), items[0][1][:, :256].contiguous(), torch.zeros(256, 256, device=DEV), None))
+    refs = [(dw.double() + dy.double().t() @ x.double(), None if db is None else db.double() + dy.double().sum(0)) for dy, x, dw, db in items]
+    K.wgrad_group(items)
+    for (dy, x, dw, db), (rw, rb) in zip(items, refs):
+        assert rel_err(dw, rw) < 5e-6, rel_err(dw, rw)
+        assert db is None or rel_err(db, rb) < 1e-5
+
+
 TURN_SHAPES = [(24000, 384, 192), (24000, 512, 512), (24000, 1536, 512), (24000, 2048, 512), (24000, 512, 2048), (23000, 640, 1280),
                (6211, 1536, 512), (36800, 256, 512), (24000, 2048, 128), (12000, 1024, 1024)]
 
