@@ -123,8 +123,17 @@ __host__ __device__ inline FfnLds ffn_lds(int R, int D, int hs, int es) {
 // x, bias and eight shares of each of them together (the shares were written by other CUs: every one is an L2 miss), and the row
 // statistics go wave (DPP) -> LDS -> thread.  `red`: 32 floats of LDS.
 struct Pro {
-    const float *x_in, *part_in, *bias; float* x_out; const float *g, *b; int np; float eps;
+    const float *x_in; const void* part_in; const float* bias; float* x_out; const float *g, *b; int np; float eps;
 };
+// four consecutive shares (stored in the compute type: f32 in f32 mode, bf16 in bf16 mode, where they are half the bytes of the step's
+// second largest stream and rounded no more coarsely than that mode's activations)
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+    const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float (&v)[4]) {
@@ -159,7 +168,7 @@ __device__ __forceinline__ void dec_prologue(const Pro& p, bool writer, int N, i
             for (int u = 0; u < 8; ++u) {
                 const int q = min(q0 + u, p.np - 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[u][k] = *reinterpret_cast<const f32x4*>(p.part_in + ((size_t)q * N + n0 + row[k]) * D + col[k]);
+                for (int k = 0; k < 4; ++k) t[u][k] = load4<T>(reinterpret_cast<const T*>(p.part_in) + ((size_t)q * N + n0 + row[k]) * D + col[k]);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -240,7 +249,7 @@ __device__ __forceinline__ void mma_rows(const T* ap, const T* bp, size_t tile_s
 // A: LDS, T [R][lda] (rows >= R read row R-1: their results are never stored); W: global T, row stride ldw; all D output columns.
 // A wave owns the column tiles w, w+4, ... and requests the weight fragments of TG of them at a time (D/64 is a multiple of TG).
 template <typename T, int KST>
-__device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __restrict__ W, int ldw, int k_off, float* __restrict__ out, int D, int R) {
+__device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __restrict__ W, int ldw, int k_off, T* __restrict__ out, int D, int R) {
     constexpr int PER = FR<T>::PER, KS = FR<T>::KS, TG = KST >= 16 ? 1 : (KST == 8 ? 2 : 4);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const T* ap = a_s + (size_t)min(lane & 15, R - 1) * lda + PER * (lane >> 4);
@@ -264,7 +273,7 @@ __device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __re
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * (lane >> 4) + i;
-                if (r < R) out[(size_t)r * D + col] = acc[i];
+                if (r < R) out[(size_t)r * D + col] = from_f32<T>(acc[i]);
             }
         }
     }
@@ -282,7 +291,7 @@ __device__ __forceinline__ void load_share_w(u32x4 (&b)[NTILE][KST], const T* __
         for (int c = 0; c < KST; ++c) b[i][c] = ld16(wp + (size_t)(w + 4 * i) * 16 * ldw + c * KS);
 }
 template <typename T, int NTILE, int KST>
-__device__ __forceinline__ void share_regs(const T* a_s, int lda, const u32x4 (&b)[NTILE][KST], float* __restrict__ out, int D, int R) {
+__device__ __forceinline__ void share_regs(const T* a_s, int lda, const u32x4 (&b)[NTILE][KST], T* __restrict__ out, int D, int R) {
     constexpr int PER = FR<T>::PER, KS = FR<T>::KS;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const T* ap = a_s + (size_t)min(lane & 15, R - 1) * lda + PER * (lane >> 4);
@@ -298,7 +307,7 @@ __device__ __forceinline__ void share_regs(const T* a_s, int lda, const u32x4 (&
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 4 * (lane >> 4) + q;
-            if (r < R) out[(size_t)r * D + col] = acc[q];
+            if (r < R) out[(size_t)r * D + col] = from_f32<T>(acc[q]);
         }
     }
 }
@@ -322,7 +331,7 @@ __device__ __forceinline__ void mma_regs(const T* ap, const u32x4 (&b)[NT][KST],
     }
 }
 template <typename T>
-__device__ __forceinline__ void share_out(const T* a_s, int lda, int klen, const T* __restrict__ W, int ldw, int k_off, float* __restrict__ out,
+__device__ __forceinline__ void share_out(const T* a_s, int lda, int klen, const T* __restrict__ W, int ldw, int k_off, T* __restrict__ out,
                                           int D, int R) {
     switch (klen / FR<T>::KS) {
         case 2: share_out_t<T, 2>(a_s, lda, W, ldw, k_off, out, D, R); break;
@@ -336,7 +345,7 @@ __device__ __forceinline__ void share_out(const T* a_s, int lda, int klen, const
 // grid (heads, B): workgroups that stream the same head's weights have equal blockIdx.x, i.e. (round-robin dispatch) share an XCD's L2.
 struct SelfArgs {
     Pro pro; int B, beam, N, D, heads, maxpos, max_len; float scale;
-    const void *w_qkv; const float* b_qkv; const void* w_o; void* cache; const int* anc; const int* steps; float* part_out;
+    const void *w_qkv; const float* b_qkv; const void* w_o; void* cache; const int* anc; const int* steps; void* part_out;
 };
 // RT = rows held in registers by the attention loops: the beam itself for beam <= 8 (exact: no wasted lanes), 16 above (rows >= beam
 // repeat row beam-1 and are never stored)
@@ -500,15 +509,15 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
     }
     __syncthreads();
     DSTAMP(0, 6);
-    if constexpr (PRE_O) share_regs<T, NTO, DH / KS>(o_s, DH + PER, wo, a.part_out + ((size_t)h * N + n0) * D, D, R);
-    else share_out<T>(o_s, DH + PER, DH, reinterpret_cast<const T*>(a.w_o), D, h * DH, a.part_out + ((size_t)h * N + n0) * D, D, R);
+    if constexpr (PRE_O) share_regs<T, NTO, DH / KS>(o_s, DH + PER, wo, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
+    else share_out<T>(o_s, DH + PER, DH, reinterpret_cast<const T*>(a.w_o), D, h * DH, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
     DSTAMP(0, 7);
 }
 
 // ------------------------------------------------------------------------------------------------ C: encoder-attention block of one head
 struct CrossArgs {
     Pro pro; int B, beam, N, D, heads, Ts, Tsp, max_len; float scale;
-    const void* w_q; const float* b_q; const void* w_o; const void* kv_enc; const void* vt_enc; const int* klen; const int* steps; float* part_out;
+    const void* w_q; const float* b_q; const void* w_o; const void* kv_enc; const void* vt_enc; const int* klen; const int* steps; void* part_out;
 };
 template <typename T, int DD>          // DD as in dec_self_kernel
 __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
@@ -614,15 +623,15 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     }
     __syncthreads();
     DSTAMP(1, 5);
-    if constexpr (PRE) share_regs<T, NTO, DH / KS>(o_s, ldq, wo, a.part_out + ((size_t)h * N + n0) * D, D, R);
-    else share_out<T>(o_s, ldq, DH, reinterpret_cast<const T*>(a.w_o), D, h * DH, a.part_out + ((size_t)h * N + n0) * D, D, R);
+    if constexpr (PRE) share_regs<T, NTO, DH / KS>(o_s, ldq, wo, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
+    else share_out<T>(o_s, ldq, DH, reinterpret_cast<const T*>(a.w_o), D, h * DH, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
     DSTAMP(1, 6);
 }
 
 // ------------------------------------------------------------------------------------------------ F: one slice of the feed-forward block
 struct FfnArgs {
     Pro pro; int B, beam, N, D, ffn, hs, gelu, max_len;
-    const void* w_fc1; const float* b_fc1; const void* w_fc2; const int* steps; float* part_out;
+    const void* w_fc1; const float* b_fc1; const void* w_fc2; const int* steps; void* part_out;
 };
 template <typename T, int TPW, int DD>          // TPW = hs / 64 column tiles of fc1 per wave; DD as in dec_self_kernel
 __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
@@ -670,8 +679,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
     }
     __syncthreads();
     DSTAMP(2, 2);
-    if constexpr (PRE2) share_regs<T, NTO, KST2>(h_s, ldh, w2, a.part_out + ((size_t)j * N + n0) * D, D, R);
-    else share_out<T>(h_s, ldh, hs, reinterpret_cast<const T*>(a.w_fc2), a.ffn, j * hs, a.part_out + ((size_t)j * N + n0) * D, D, R);
+    if constexpr (PRE2) share_regs<T, NTO, KST2>(h_s, ldh, w2, reinterpret_cast<T*>(a.part_out) + ((size_t)j * N + n0) * D, D, R);
+    else share_out<T>(h_s, ldh, hs, reinterpret_cast<const T*>(a.w_fc2), a.ffn, j * hs, reinterpret_cast<T*>(a.part_out) + ((size_t)j * N + n0) * D, D, R);
     DSTAMP(2, 3);
 }
 
@@ -1093,7 +1102,7 @@ int step_impl(const S2TDecodeDesc* d, hipStream_t st) {
     const int B = d->B, R = d->beam, N = B * R, D = d->D, H = d->heads, FS = d->ffn_slices, hs = d->ffn / FS, maxpos = d->max_len + 1;
     const LdsNeed need = lds_need(d);
     float* X[2] = {d->x0, d->x1};
-    float* P[2] = {d->part0, d->part1};
+    void* P[2] = {d->part0, d->part1};
     const float scale = 1.0f / sqrtf((float)DH);
     const int dd = pre_dd<T>(D);                           // weight fragments held in registers for the whole launch (bf16, D <= 512)
     int k = 0;                                             // launch k reads X[k & 1], the shares in P[(k + 1) & 1]; writes X[(k + 1) & 1], P[k & 1]

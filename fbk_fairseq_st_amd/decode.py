@@ -93,7 +93,7 @@ class BeamDecodeSession:
         self.read_f = self.foff["cand_val"][0]
         d.x0, d.x1 = dev_t((N, D), torch.float32, "x0").data_ptr(), dev_t((N, D), torch.float32, "x1").data_ptr()
         np_max = max(H, FS)
-        d.part0, d.part1 = dev_t((np_max, N, D), torch.float32, "part0").data_ptr(), dev_t((np_max, N, D), torch.float32, "part1").data_ptr()
+        d.part0, d.part1 = dev_t((np_max, N, D), dtype, "part0").data_ptr(), dev_t((np_max, N, D), dtype, "part1").data_ptr()
         d.xn = dev_t((N, D), dtype, "xn").data_ptr()
         d.logits = dev_t((N, V), torch.float32, "logits").data_ptr()
         if enc_klen is not None:

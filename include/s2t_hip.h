@@ -401,7 +401,7 @@ int s2t_scale_by_device_scalar(int dtype, void* x, size_t n, const float* scalar
  *              F: LayerNorm -> one slice of fc1 + activation -> that slice's share of fc2        grid (B, ffn_slices)
  *   then       final LayerNorm; output projection over all N rows; per row: log-softmax, score rules, + cumulative score, 2*beam best;
  *              per sentence: merge, finalise EOS candidates, choose the next beam, record it, embed its tokens for the next step.
- * The shares (per head / per slice, f32) are summed in a fixed order by the launch that consumes them, together with the residual and the
+ * The shares (per head / per slice, in the compute type T) are summed in f32, in a fixed order, by the launch that consumes them, together with the residual and the
  * bias: no atomics, results do not depend on scheduling.  The K/V cache is never re-ordered: anc[n][p] names the slot whose row at
  * position p belongs to hypothesis n's history (the index indirection that replaces reorder_incremental_state's index_select copies),
  * the encoder-side K/V exist once per sentence.  The step index lives in device memory (steps[s]), so one recorded sequence (a hipGraph
@@ -435,7 +435,7 @@ typedef struct S2TDecodeDesc {
     const float* init_scores;                /* f32 [N] starting score of every slot (step0_all_slots), or NULL */
     /* state, all device memory owned by the caller */
     float *x0, *x1;                          /* f32 [N][D] residual stream (ping-pong) */
-    float *part0, *part1;                    /* f32 [max(heads, ffn_slices)][N][D] shares (ping-pong) */
+    void *part0, *part1;                     /* T [max(heads, ffn_slices)][N][D] shares (ping-pong) */
     void* xn;                                /* T [N][D] final LayerNorm output */
     float* logits;                           /* f32 [N][ldv] */
     int* steps;                              /* i32 [B] */
