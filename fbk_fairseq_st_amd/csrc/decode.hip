@@ -224,18 +224,27 @@ __device__ __forceinline__ void dec_prologue(const Pro& p, bool writer, int N, i
     }
 }
 
-// acc[i] += A (LDS fragment stream at ap, 16 rows) x W_i^T for NT column tiles whose weight rows start at bp + i * tile_stride, K deep
-// (K a multiple of CH * KS).  Every global fragment of a chunk of CH k-steps is requested before the first MFMA of the chunk (NT * CH
+// ---- weights in FRAGMENT-MAJOR order (s2t_decode_pack_weight): W [N][K] -> [N / 16 column tiles][K / KS k-steps][64 lanes][16 bytes], the
+// 16 bytes of lane l of (tile, step) being W[16 tile + (l & 15)][KS step + PER (l >> 4) ..]: exactly the B operand of one MFMA, so a wave's
+// load of a fragment is ONE contiguous KiB (eight whole cache lines) instead of 16 rows x 64 bytes (sixteen half lines).  A CU keeps a
+// limited number of line requests in flight: measured on the feed-forward launch, the wait for 256 KB of weights went from 24,500 to
+// 13,400 cycles (profiles/r06_decode_experiments.txt).
+template <typename T> __device__ __forceinline__ const T* wfrag(const T* Wp, int ksteps, int tile, int step) {
+    return Wp + ((size_t)((size_t)tile * ksteps + step) * 64 + (threadIdx.x & 63)) * FR<T>::PER;
+}
+
+// acc[i] += A (LDS fragment stream at ap, 16 rows) x W_i^T for NT column tiles of a fragment-major weight, K deep
+// (K a multiple of CH * KS; the tiles' fragments at wfrag(Wp, ksteps, tile0 + i tile_step, step)).  Every global fragment of a chunk of CH k-steps is requested before the first MFMA of the chunk (NT * CH
 // 16-byte loads in flight per lane); nothing in the chunk is conditional, so the compiler keeps one straight-line block per chunk.
 template <typename T, int NT, int CH>
-__device__ __forceinline__ void mma_rows(const T* ap, const T* bp, size_t tile_stride, int K, f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void mma_rows(const T* ap, const T* Wp, int ksteps, int tile0, int tile_step, int K, f32x4 (&acc)[NT]) {
     constexpr int KS = FR<T>::KS;
     for (int k0 = 0; k0 < K; k0 += CH * KS) {
         u32x4 b[NT][CH];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int c = 0; c < CH; ++c) b[i][c] = ld16(bp + (size_t)i * tile_stride + k0 + c * KS);
+            for (int c = 0; c < CH; ++c) b[i][c] = ld16(wfrag<T>(Wp, ksteps, tile0 + i * tile_step, k0 / KS + c));
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const u32x4 af = ld16(ap + k0 + c * KS);
@@ -245,11 +254,12 @@ __device__ __forceinline__ void mma_rows(const T* ap, const T* bp, size_t tile_s
     }
 }
 
-// one head's (or slice's) share of an output projection: out[row][col] = sum_k A[row][k] * W[col][k_off + k], k < KST * KS
-// A: LDS, T [R][lda] (rows >= R read row R-1: their results are never stored); W: global T, row stride ldw; all D output columns.
+// one head's (or slice's) share of an output projection: out[row][col] = sum_k A[row][k] * W[col][KS step_off + k], k < KST * KS
+// A: LDS, T [R][lda] (rows >= R read row R-1: their results are never stored); Wp: the fragment-major weight (`ksteps` k-steps per row
+// of tiles); all D output columns.
 // A wave owns the column tiles w, w+4, ... and requests the weight fragments of TG of them at a time (D/64 is a multiple of TG).
 template <typename T, int KST>
-__device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __restrict__ W, int ldw, int k_off, T* __restrict__ out, int D, int R) {
+__device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __restrict__ Wp, int ksteps, int step_off, T* __restrict__ out, int D, int R) {
     constexpr int PER = FR<T>::PER, KS = FR<T>::KS, TG = KST >= 16 ? 1 : (KST == 8 ? 2 : 4);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const T* ap = a_s + (size_t)min(lane & 15, R - 1) * lda + PER * (lane >> 4);
@@ -257,13 +267,12 @@ __device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __re
 #pragma unroll
     for (int c = 0; c < KST; ++c) af[c] = ld16(ap + c * KS);
     const int per_wave = D / 64;
-    const T* wp = W + (size_t)(lane & 15) * ldw + k_off + PER * (lane >> 4);
     for (int i0 = 0; i0 < per_wave; i0 += TG) {
         u32x4 b[TG][KST];
 #pragma unroll
         for (int g = 0; g < TG; ++g)
 #pragma unroll
-            for (int c = 0; c < KST; ++c) b[g][c] = ld16(wp + (size_t)(w + 4 * (i0 + g)) * 16 * ldw + c * KS);
+            for (int c = 0; c < KST; ++c) b[g][c] = ld16(wfrag<T>(Wp, ksteps, w + 4 * (i0 + g), step_off + c));
 #pragma unroll
         for (int g = 0; g < TG; ++g) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -281,14 +290,12 @@ __device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __re
 // the same product with the weight fragments already in registers (requested at the top of the kernel): b[i][c] = fragment c of the
 // wave's i-th column tile (tile w + 4 i)
 template <typename T, int NTILE, int KST>
-__device__ __forceinline__ void load_share_w(u32x4 (&b)[NTILE][KST], const T* __restrict__ W, int ldw, int k_off) {
-    constexpr int PER = FR<T>::PER, KS = FR<T>::KS;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const T* wp = W + (size_t)(lane & 15) * ldw + k_off + PER * (lane >> 4);
+__device__ __forceinline__ void load_share_w(u32x4 (&b)[NTILE][KST], const T* __restrict__ Wp, int ksteps, int step_off) {
+    const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NTILE; ++i)
 #pragma unroll
-        for (int c = 0; c < KST; ++c) b[i][c] = ld16(wp + (size_t)(w + 4 * i) * 16 * ldw + c * KS);
+        for (int c = 0; c < KST; ++c) b[i][c] = ld16(wfrag<T>(Wp, ksteps, w + 4 * i, step_off + c));
 }
 template <typename T, int NTILE, int KST>
 __device__ __forceinline__ void share_regs(const T* a_s, int lda, const u32x4 (&b)[NTILE][KST], T* __restrict__ out, int D, int R) {
@@ -311,14 +318,13 @@ __device__ __forceinline__ void share_regs(const T* a_s, int lda, const u32x4 (&
         }
     }
 }
-// the fragments of NT column tiles (rows bp + i * tile_stride) over a K of KST k-steps, and the product from them
+// the fragments of NT column tiles (tile0 + i tile_step) over a K of KST k-steps, and the product from them
 template <typename T, int NT, int KST>
-__device__ __forceinline__ void load_rows_w(u32x4 (&b)[NT][KST], const T* bp, size_t tile_stride) {
-    constexpr int KS = FR<T>::KS;
+__device__ __forceinline__ void load_rows_w(u32x4 (&b)[NT][KST], const T* Wp, int tile0, int tile_step) {
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int c = 0; c < KST; ++c) b[i][c] = ld16(bp + (size_t)i * tile_stride + c * KS);
+        for (int c = 0; c < KST; ++c) b[i][c] = ld16(wfrag<T>(Wp, KST, tile0 + i * tile_step, c));
 }
 template <typename T, int NT, int KST>
 __device__ __forceinline__ void mma_regs(const T* ap, const u32x4 (&b)[NT][KST], f32x4 (&acc)[NT]) {
@@ -331,13 +337,13 @@ __device__ __forceinline__ void mma_regs(const T* ap, const u32x4 (&b)[NT][KST],
     }
 }
 template <typename T>
-__device__ __forceinline__ void share_out(const T* a_s, int lda, int klen, const T* __restrict__ W, int ldw, int k_off, T* __restrict__ out,
+__device__ __forceinline__ void share_out(const T* a_s, int lda, int klen, const T* __restrict__ Wp, int ksteps, int step_off, T* __restrict__ out,
                                           int D, int R) {
     switch (klen / FR<T>::KS) {
-        case 2: share_out_t<T, 2>(a_s, lda, W, ldw, k_off, out, D, R); break;
-        case 4: share_out_t<T, 4>(a_s, lda, W, ldw, k_off, out, D, R); break;
-        case 8: share_out_t<T, 8>(a_s, lda, W, ldw, k_off, out, D, R); break;
-        default: share_out_t<T, 16>(a_s, lda, W, ldw, k_off, out, D, R); break;       // 16: f32 with 256 hidden units per slice
+        case 2: share_out_t<T, 2>(a_s, lda, Wp, ksteps, step_off, out, D, R); break;
+        case 4: share_out_t<T, 4>(a_s, lda, Wp, ksteps, step_off, out, D, R); break;
+        case 8: share_out_t<T, 8>(a_s, lda, Wp, ksteps, step_off, out, D, R); break;
+        default: share_out_t<T, 16>(a_s, lda, Wp, ksteps, step_off, out, D, R); break;       // 16: f32 with 256 hidden units per slice
     }
 }
 
@@ -366,8 +372,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
     DSTAMP(0, 0);
     u32x4 wqkv[3][KSTD], wo[NTO][DH / KS];
     if constexpr (PRE)
-        load_rows_w<T, 3, KSTD>(wqkv, reinterpret_cast<const T*>(a.w_qkv) + (size_t)(h * DH + 16 * w + (lane & 15)) * D + PER * (lane >> 4), (size_t)D * D);
-    if constexpr (PRE_O) load_share_w<T, NTO, DH / KS>(wo, reinterpret_cast<const T*>(a.w_o), D, h * DH);
+        load_rows_w<T, 3, KSTD>(wqkv, reinterpret_cast<const T*>(a.w_qkv), h * 4 + w, D / 16);
+    if constexpr (PRE_O) load_share_w<T, NTO, DH / KS>(wo, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS));
     const SelfLds L = self_lds(RT, D, maxpos, (int)sizeof(T));
     float* red0 = reinterpret_cast<float*>(smem);
     T* a_ln = reinterpret_cast<T*>(smem + L.a_ln);
@@ -388,12 +394,11 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
 
     {   // q | k | v columns of this head: wave w owns column tile w of each of the three (3 x 16 columns), K = D
         const T* ap = a_ln + (size_t)min(lane & 15, R - 1) * lda + PER * (lane >> 4);
-        const T* bp = reinterpret_cast<const T*>(a.w_qkv) + (size_t)(h * DH + 16 * w + (lane & 15)) * D + PER * (lane >> 4);
         f32x4 acc[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (PRE) mma_regs<T, 3, KSTD>(ap, wqkv, acc);
-        else mma_rows<T, 3, 8>(ap, bp, (size_t)D * D, D, acc);
+        else mma_rows<T, 3, 8>(ap, reinterpret_cast<const T*>(a.w_qkv), D / KS, h * 4 + w, D / 16, D, acc);
         const int col = 16 * w + (lane & 15);
         const float bq = a.b_qkv[h * DH + col], bk = a.b_qkv[D + h * DH + col], bv = a.b_qkv[2 * D + h * DH + col];
 #pragma unroll
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
     __syncthreads();
     DSTAMP(0, 6);
     if constexpr (PRE_O) share_regs<T, NTO, DH / KS>(o_s, DH + PER, wo, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
-    else share_out<T>(o_s, DH + PER, DH, reinterpret_cast<const T*>(a.w_o), D, h * DH, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
+    else share_out<T>(o_s, DH + PER, DH, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS), reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
     DSTAMP(0, 7);
 }
 
@@ -531,8 +536,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     DSTAMP(1, 0);
     u32x4 wq[1][KSTD], wo[NTO][DH / KS];
     if constexpr (PRE) {
-        load_rows_w<T, 1, KSTD>(wq, reinterpret_cast<const T*>(a.w_q) + (size_t)(h * DH + 16 * w + (lane & 15)) * D + PER * (lane >> 4), 0);
-        load_share_w<T, NTO, DH / KS>(wo, reinterpret_cast<const T*>(a.w_o), D, h * DH);
+        load_rows_w<T, 1, KSTD>(wq, reinterpret_cast<const T*>(a.w_q), h * 4 + w, 0);
+        load_share_w<T, NTO, DH / KS>(wo, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS));
     }
     const CrossLds L = cross_lds(R, D, Tsp, (int)sizeof(T));
     float* red0 = reinterpret_cast<float*>(smem);
@@ -548,10 +553,9 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     DSTAMP(1, 1);
     {   // q of this head: wave w owns 16 of its 64 columns
         const T* ap = a_ln + (size_t)arow * lda + PER * (lane >> 4);
-        const T* bp = reinterpret_cast<const T*>(a.w_q) + (size_t)(h * DH + 16 * w + (lane & 15)) * D + PER * (lane >> 4);
         f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
         if constexpr (PRE) mma_regs<T, 1, KSTD>(ap, wq, acc);
-        else mma_rows<T, 1, 8>(ap, bp, 0, D, acc);
+        else mma_rows<T, 1, 8>(ap, reinterpret_cast<const T*>(a.w_q), D / KS, h * 4 + w, 0, D, acc);
         const int col = 16 * w + (lane & 15);
         const float bq = a.b_q[h * DH + col];
 #pragma unroll
@@ -564,9 +568,10 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     DSTAMP(1, 2);
     {   // scores over the sentence's encoder rows: 16 positions per MFMA tile, K = 64; padding rows -> -inf (multihead_attention.py:318-327)
         const int klen = a.klen ? min(a.klen[s], Ts) : Ts;
-        const T* Ke = reinterpret_cast<const T*>(a.kv_enc);
-        const T* ap = q_s + (size_t)arow * ldq + PER * (lane >> 4);
         constexpr int KST = DH / KS, TG = 8 / KST;                 // position tiles requested together (8 fragments in flight)
+        // this sentence's keys of this head, fragment-major (s2t_decode_prepare_enc): [Tsp / 16 position tiles][KST steps][64 lanes][16 B]
+        const T* Kp = reinterpret_cast<const T*>(a.kv_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;
+        const T* ap = q_s + (size_t)arow * ldq + PER * (lane >> 4);
         u32x4 af[KST];
 #pragma unroll
         for (int c = 0; c < KST; ++c) af[c] = ld16(ap + c * KS);
@@ -577,10 +582,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
 #pragma unroll
             for (int g = 0; g < TG; ++g) {
                 ptg[g] = min(pt0 + 4 * g, last);                   // past the end: the last tile again (same values stored twice)
-                const int krow = min(ptg[g] * 16 + (lane & 15), Ts - 1);
-                const T* bp = Ke + ((size_t)krow * a.B + s) * 2 * D + h * DH + PER * (lane >> 4);
 #pragma unroll
-                for (int c = 0; c < KST; ++c) b[g][c] = ld16(bp + c * KS);
+                for (int c = 0; c < KST; ++c) b[g][c] = ld16(wfrag<T>(Kp, KST, ptg[g], c));
             }
 #pragma unroll
             for (int g = 0; g < TG; ++g) {
@@ -609,11 +612,11 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     }
     __syncthreads();
     DSTAMP(1, 4);
-    {   // o = P V: wave w owns 16 of the 64 value columns; V is read through its transposed copy (rows = value columns, contiguous positions)
+    {   // o = P V: wave w owns 16 of the 64 value columns; V is read through its transposed, fragment-major copy
         const T* ap = p_s + (size_t)arow * ldp + PER * (lane >> 4);
-        const T* bp = reinterpret_cast<const T*>(a.vt_enc) + (((size_t)s * a.heads + h) * DH + 16 * w + (lane & 15)) * Tsp + PER * (lane >> 4);
+        const T* Vp = reinterpret_cast<const T*>(a.vt_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;      // [4 column tiles][Tsp / KS steps][64][16 B]
         f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        mma_rows<T, 1, 128 / KS>(ap, bp, 0, Tsp, acc);
+        mma_rows<T, 1, 128 / KS>(ap, Vp, Tsp / KS, w, 0, Tsp, acc);
         const int col = 16 * w + (lane & 15);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     __syncthreads();
     DSTAMP(1, 5);
     if constexpr (PRE) share_regs<T, NTO, DH / KS>(o_s, ldq, wo, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
-    else share_out<T>(o_s, ldq, DH, reinterpret_cast<const T*>(a.w_o), D, h * DH, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
+    else share_out<T>(o_s, ldq, DH, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS), reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
     DSTAMP(1, 6);
 }
 
@@ -645,8 +648,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
     DSTAMP(2, 0);
     u32x4 w1[TPW][KSTD], w2[NTO][KST2];
     if constexpr (PRE)
-        load_rows_w<T, TPW, KSTD>(w1, reinterpret_cast<const T*>(a.w_fc1) + (size_t)(j * HS + w * TPW * 16 + (lane & 15)) * D + PER * (lane >> 4), (size_t)16 * D);
-    if constexpr (PRE2) load_share_w<T, NTO, KST2>(w2, reinterpret_cast<const T*>(a.w_fc2), a.ffn, j * HS);
+        load_rows_w<T, TPW, KSTD>(w1, reinterpret_cast<const T*>(a.w_fc1), j * (HS / 16) + w * TPW, 1);
+    if constexpr (PRE2) load_share_w<T, NTO, KST2>(w2, reinterpret_cast<const T*>(a.w_fc2), a.ffn / KS, j * (HS / KS));
     const FfnLds L = ffn_lds(R, D, hs, (int)sizeof(T));
     float* red0 = reinterpret_cast<float*>(smem);
     T* a_ln = reinterpret_cast<T*>(smem + L.a_ln);
@@ -658,12 +661,11 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
     DSTAMP(2, 1);
     {   // hidden units j*hs .. +hs: wave w owns TPW column tiles (transformer_layer.py:367-368: fc1, activation)
         const T* ap = a_ln + (size_t)arow * lda + PER * (lane >> 4);
-        const T* bp = reinterpret_cast<const T*>(a.w_fc1) + (size_t)(j * hs + w * TPW * 16 + (lane & 15)) * D + PER * (lane >> 4);
         f32x4 acc[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (PRE) mma_regs<T, TPW, KSTD>(ap, w1, acc);
-        else mma_rows<T, TPW, (TPW == 4 ? 4 : 8)>(ap, bp, (size_t)16 * D, D, acc);
+        else mma_rows<T, TPW, (TPW == 4 ? 4 : 8)>(ap, reinterpret_cast<const T*>(a.w_fc1), D / KS, j * (HS / 16) + w * TPW, 1, D, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const int col = (w * TPW + i) * 16 + (lane & 15);
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
     __syncthreads();
     DSTAMP(2, 2);
     if constexpr (PRE2) share_regs<T, NTO, KST2>(h_s, ldh, w2, reinterpret_cast<T*>(a.part_out) + ((size_t)j * N + n0) * D, D, R);
-    else share_out<T>(h_s, ldh, hs, reinterpret_cast<const T*>(a.w_fc2), a.ffn, j * hs, reinterpret_cast<T*>(a.part_out) + ((size_t)j * N + n0) * D, D, R);
+    else share_out<T>(h_s, ldh, hs, reinterpret_cast<const T*>(a.w_fc2), a.ffn / KS, j * (HS / KS), reinterpret_cast<T*>(a.part_out) + ((size_t)j * N + n0) * D, D, R);
     DSTAMP(2, 3);
 }
 
@@ -709,7 +711,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_logits_kernel(LogitArgs a) {
     const int ct = blockIdx.x * 4 + w;
     T* x_s = reinterpret_cast<T*>(smem);                      // [N][LDX]
     const T* X = reinterpret_cast<const T*>(a.xn);
-    const T* bp = reinterpret_cast<const T*>(a.w) + (size_t)min(ct * 16 + (lane & 15), a.V - 1) * D + PER * (lane >> 4);
+    const T* Wp = reinterpret_cast<const T*>(a.w);               // fragment-major, ceil(V / 16) tiles (rows past V are zero)
+    const int ctc = min(ct, (a.V + 15) / 16 - 1);
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_logits_kernel(LogitArgs a) {
     for (int kc0 = 0; kc0 < D; kc0 += KC) {
         u32x4 b[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) b[c] = ld16(bp + kc0 + c * KS);
+        for (int c = 0; c < 8; ++c) b[c] = ld16(wfrag<T>(Wp, D / KS, ctc, kc0 / KS + c));
         __syncthreads();
         for (int i0 = 0; i0 < N * PPR; i0 += 8 * NTHREADS) {        // eight 16-byte pieces per thread in flight
             u32x4 piece[8];
@@ -1013,14 +1016,53 @@ __global__ __launch_bounds__(NTHREADS) void dec_begin_kernel(BeginArgs a) {
         for (int d = tid; d < a.D; d += NTHREADS) a.x0[(size_t)(n0 + j) * a.D + d] = a.embed_scale * to_f32(e[d]) + pe[d];
 }
 
+// fragment-major copies of a layer's encoder-side K and V^T (from kv [Ts][B][2D]), zero beyond Ts:
+//   kp [B][heads][Tsp / 16 position tiles][64 / KS steps][64 lanes][16 B]: lane l of (pt, step) = K[16 pt + (l & 15)][KS step + PER (l >> 4) ..]
+//   vp [B][heads][4 column tiles][Tsp / KS steps][64 lanes][16 B]:        lane l of (ct, step) = V[KS step + PER (l >> 4) ..][16 ct + (l & 15)]
 template <typename T>
-__global__ __launch_bounds__(NTHREADS) void dec_vt_kernel(const T* __restrict__ kv, T* __restrict__ vt, int Ts, int Tsp, int B, int D, int heads) {
-    const size_t total = (size_t)B * heads * DH * Tsp;
-    for (size_t i = (size_t)blockIdx.x * NTHREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * NTHREADS) {
-        const int t = (int)(i % Tsp);
-        const size_t r = i / Tsp;
-        const int d = (int)(r % DH), h = (int)((r / DH) % heads), b = (int)(r / ((size_t)DH * heads));
-        vt[i] = t < Ts ? kv[((size_t)t * B + b) * 2 * D + D + h * DH + d] : from_f32<T>(0.f);
+__global__ __launch_bounds__(NTHREADS) void dec_enc_pack_kernel(const T* __restrict__ kv, T* __restrict__ kp, T* __restrict__ vp, int Ts, int Tsp, int B,
+                                                                int D, int heads) {
+    constexpr int PER = FR<T>::PER, KS = FR<T>::KS;
+    const size_t pieces = (size_t)B * heads * Tsp * DH / PER;        // 16-byte pieces of each output
+    for (size_t p = (size_t)blockIdx.x * NTHREADS + threadIdx.x; p < 2 * pieces; p += (size_t)gridDim.x * NTHREADS) {
+        const bool isv = p >= pieces;
+        const size_t q = isv ? p - pieces : p;
+        const int lane = (int)(q & 63);
+        size_t r = q >> 6;
+        T out[PER];
+        if (!isv) {
+            const int step = (int)(r % (DH / KS)); r /= (DH / KS);
+            const int pt = (int)(r % (Tsp / 16)); r /= (Tsp / 16);
+            const int h = (int)(r % heads), b = (int)(r / heads);
+            const int pos = pt * 16 + (lane & 15), d0 = step * KS + PER * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) out[j] = pos < Ts ? kv[((size_t)pos * B + b) * 2 * D + h * DH + d0 + j] : from_f32<T>(0.f);
+            *reinterpret_cast<u32x4*>(kp + q * PER) = *reinterpret_cast<const u32x4*>(out);
+        } else {
+            const int step = (int)(r % (Tsp / KS)); r /= (Tsp / KS);
+            const int ct = (int)(r % 4); r /= 4;
+            const int h = (int)(r % heads), b = (int)(r / heads);
+            const int d = ct * 16 + (lane & 15), pos0 = step * KS + PER * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) out[j] = pos0 + j < Ts ? kv[((size_t)(pos0 + j) * B + b) * 2 * D + D + h * DH + d] : from_f32<T>(0.f);
+            *reinterpret_cast<u32x4*>(vp + q * PER) = *reinterpret_cast<const u32x4*>(out);
+        }
+    }
+}
+// W [N][K] (row stride ldw) -> fragment-major [ceil(N / 16)][K / KS][64][16 B] (wfrag), rows past N zero
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void dec_pack_kernel(const T* __restrict__ W, int ldw, int N, int K, T* __restrict__ Wp) {
+    constexpr int PER = FR<T>::PER, KS = FR<T>::KS;
+    const int ksteps = K / KS;
+    const size_t pieces = (size_t)((N + 15) / 16) * ksteps * 64;
+    for (size_t p = (size_t)blockIdx.x * NTHREADS + threadIdx.x; p < pieces; p += (size_t)gridDim.x * NTHREADS) {
+        const int lane = (int)(p & 63);
+        const size_t r = p >> 6;
+        const int step = (int)(r % ksteps), tile = (int)(r / ksteps);
+        const int n = tile * 16 + (lane & 15), k = step * KS + PER * (lane >> 4);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (n < N) v = ld16(W + (size_t)n * ldw + k);
+        *reinterpret_cast<u32x4*>(Wp + p * PER) = v;
     }
 }
 
@@ -1237,14 +1279,27 @@ extern "C" int s2t_decode_step(const S2TDecodeDesc* d, void* stream) {
     return d->dtype == S2T_BF16 ? step_impl<bf16>(d, (hipStream_t)stream) : step_impl<float>(d, (hipStream_t)stream);
 }
 
-extern "C" int s2t_decode_prepare_enc(int dtype, const void* kv_enc, void* vt_enc, int Ts, int Tsp, int B, int D, int heads, void* stream) {
-    if (!kv_enc || !vt_enc || Ts < 1 || Tsp < Ts || B < 1 || heads < 1 || D != heads * DH) return S2T_EINVAL;
-    const size_t total = (size_t)B * heads * DH * Tsp;
+extern "C" int s2t_decode_prepare_enc(int dtype, const void* kv_enc, void* kp_enc, void* vp_enc, int Ts, int Tsp, int B, int D, int heads, void* stream) {
+    if (!kv_enc || !kp_enc || !vp_enc || Ts < 1 || Tsp < Ts || Tsp % 128 || B < 1 || heads < 1 || D != heads * DH) return S2T_EINVAL;
+    const size_t total = (size_t)2 * B * heads * Tsp * DH / (dtype == S2T_BF16 ? 8 : 4);
     const unsigned grid = (unsigned)((total + NTHREADS - 1) / NTHREADS < 4096 ? (total + NTHREADS - 1) / NTHREADS : 4096);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == S2T_BF16) hipLaunchKernelGGL(dec_vt_kernel<bf16>, dim3(grid), dim3(NTHREADS), 0, st, (const bf16*)kv_enc, (bf16*)vt_enc, Ts, Tsp, B, D, heads);
-    else if (dtype == S2T_F32) hipLaunchKernelGGL(dec_vt_kernel<float>, dim3(grid), dim3(NTHREADS), 0, st, (const float*)kv_enc, (float*)vt_enc, Ts, Tsp, B, D, heads);
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(dec_enc_pack_kernel<bf16>, dim3(grid), dim3(NTHREADS), 0, st, (const bf16*)kv_enc, (bf16*)kp_enc, (bf16*)vp_enc, Ts, Tsp, B, D, heads);
+    else if (dtype == S2T_F32) hipLaunchKernelGGL(dec_enc_pack_kernel<float>, dim3(grid), dim3(NTHREADS), 0, st, (const float*)kv_enc, (float*)kp_enc, (float*)vp_enc, Ts, Tsp, B, D, heads);
     else return S2T_ENOTSUP;
+    S2T_LAUNCH_CHECK();
+    return S2T_OK;
+}
+
+extern "C" int s2t_decode_pack_weight(int dtype, const void* W, int ldw, int N, int K, void* Wp, void* stream) {
+    if (!W || !Wp || N < 1 || K < 1 || ldw < K) return S2T_EINVAL;
+    const int ks = dtype == S2T_BF16 ? 32 : 16;
+    if ((dtype != S2T_BF16 && dtype != S2T_F32) || K % ks || ((uintptr_t)W & 15) || (ldw * (dtype == S2T_BF16 ? 2 : 4)) % 16) return S2T_ENOTSUP;
+    const size_t pieces = (size_t)((N + 15) / 16) * (K / ks) * 64;
+    const unsigned grid = (unsigned)((pieces + NTHREADS - 1) / NTHREADS < 8192 ? (pieces + NTHREADS - 1) / NTHREADS : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S2T_BF16) hipLaunchKernelGGL(dec_pack_kernel<bf16>, dim3(grid), dim3(NTHREADS), 0, st, (const bf16*)W, ldw, N, K, (bf16*)Wp);
+    else hipLaunchKernelGGL(dec_pack_kernel<float>, dim3(grid), dim3(NTHREADS), 0, st, (const float*)W, ldw, N, K, (float*)Wp);
     S2T_LAUNCH_CHECK();
     return S2T_OK;
 }

@@ -106,8 +106,17 @@ class BeamDecodeSession:
             d.init_scores = init_scores.data_ptr()
         W, P = engine.W, engine.P
         ptr = lambda t: (keep.append(t), t.data_ptr())[1]
+
+        def packed(name):
+            """the weight in fragment-major order (s2t_decode_pack_weight): re-made per search -- the weights may have moved since the last
+            one, and 52 MB of copies are tens of microseconds against a search of tens of milliseconds"""
+            w = W(name)
+            n, k = w.shape
+            wp = dev_t(((n + 15) // 16 * 16, k), dtype)
+            L.check(lib.s2t_decode_pack_weight(d.dtype, w.data_ptr(), w.stride(0), n, k, wp.data_ptr(), st), "s2t_decode_pack_weight")
+            return wp.data_ptr()
         d.lnf_g, d.lnf_b = ptr(P(pfx + "layer_norm.weight")), ptr(P(pfx + "layer_norm.bias"))
-        d.w_out = ptr(W(engine.out_proj(pfx) + ".weight"))
+        d.w_out = packed(engine.out_proj(pfx) + ".weight")
         d.embed = ptr(W(pfx + "embed_tokens.weight"))
         d.pos_table = ptr(engine.table(pad + 3 + max_len, pad))
         enc2d = enc_out.reshape(Ts * B, D)
@@ -118,11 +127,12 @@ class BeamDecodeSession:
                 setattr(y, ln + "_g", ptr(P(lp + stem + ".weight"))); setattr(y, ln + "_b", ptr(P(lp + stem + ".bias")))
             for f, stem in (("qkv", "self_attn.qkv"), ("o", "self_attn.out_proj"), ("xq", "encoder_attn.q_proj"),
                             ("xo", "encoder_attn.out_proj"), ("fc1", "fc1"), ("fc2", "fc2")):
-                setattr(y, "w_" + f, ptr(W(lp + stem + ".weight"))); setattr(y, "b_" + f, ptr(P(lp + stem + ".bias")))
+                setattr(y, "w_" + f, packed(lp + stem + ".weight")); setattr(y, "b_" + f, ptr(P(lp + stem + ".bias")))
             kv = engine.linear(enc2d, lp + "encoder_attn.kv")               # [Ts * B, 2D]: the reference's static_kv, once per sentence
-            vt = dev_t((B, H, 64, Tsp), dtype)
-            L.check(lib.s2t_decode_prepare_enc(d.dtype, kv.data_ptr(), vt.data_ptr(), Ts, Tsp, B, D, H, st), "s2t_decode_prepare_enc")
-            y.kv_enc, y.vt_enc = ptr(kv), vt.data_ptr()
+            kp, vp = dev_t((B, H, Tsp, 64), dtype), dev_t((B, H, 64, Tsp), dtype)      # fragment-major inside (include/s2t_hip.h)
+            L.check(lib.s2t_decode_prepare_enc(d.dtype, kv.data_ptr(), kp.data_ptr(), vp.data_ptr(), Ts, Tsp, B, D, H, st), "s2t_decode_prepare_enc")
+            keep.append(kv)
+            y.kv_enc, y.vt_enc = kp.data_ptr(), vp.data_ptr()
             y.kv_cache = dev_t((max_len + 1, N, 2 * D), dtype, "cache%d" % l).data_ptr()
         self.launches_per_step = 3 * Ld + 4
         self.steps_run = 0

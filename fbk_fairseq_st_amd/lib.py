@@ -97,7 +97,8 @@ SIGNATURES = {
     "s2t_layer_bwd_tmp_bytes": [P],                             # returns size_t
     "s2t_layer_fwd": [P, P, P],
     "s2t_layer_bwd": [P, P, P],
-    "s2t_decode_prepare_enc": [c_int, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_decode_prepare_enc": [c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P],
+    "s2t_decode_pack_weight": [c_int, P, c_int, c_int, c_int, P, P],
     "s2t_decode_begin": [P, c_int, P],
     "s2t_decode_step": [P, P],
     "s2t_decode_lds_bytes": [P],                                # returns size_t

@@ -410,15 +410,17 @@ int s2t_scale_by_device_scalar(int dtype, void* x, size_t n, const float* scalar
  * max_len + 1 <= 1024 positions, Tsp a multiple of 128, and the LDS plan of every launch within 152 KiB (s2t_decode_lds_bytes). */
 typedef struct S2TDecodeLayer {
     const void *ln1_g, *ln1_b;       /* f32 [D]: self_attn_layer_norm */
-    const void *w_qkv, *b_qkv;       /* T [3D][D], f32 [3D] */
-    const void *w_o, *b_o;           /* T [D][D], f32 [D] */
+    /* every w_* below is the nn.Linear weight in FRAGMENT-MAJOR order (s2t_decode_pack_weight): [rows / 16][K / ks][64 lanes][16 bytes] */
+    const void *w_qkv, *b_qkv;       /* T [3D][D] packed, f32 [3D] */
+    const void *w_o, *b_o;           /* T [D][D] packed, f32 [D] */
     const void *lnx_g, *lnx_b;       /* encoder_attn_layer_norm */
     const void *w_xq, *b_xq, *w_xo, *b_xo;
     const void *ln2_g, *ln2_b;       /* final_layer_norm */
-    const void *w_fc1, *b_fc1;       /* T [ffn][D], f32 [ffn] */
-    const void *w_fc2, *b_fc2;       /* T [D][ffn], f32 [D] */
-    const void* kv_enc;              /* T [Ts][B][2D]: encoder-side K | V rows of this layer (static_kv), one copy per SENTENCE */
-    const void* vt_enc;              /* T [B][heads][64][Tsp]: the V half transposed (s2t_decode_prepare_enc), zero beyond Ts; Tsp % 128 == 0 */
+    const void *w_fc1, *b_fc1;       /* T [ffn][D] packed, f32 [ffn] */
+    const void *w_fc2, *b_fc2;       /* T [D][ffn] packed, f32 [D] */
+    const void* kv_enc;              /* T [B][heads][Tsp / 16][64 / ks][64][16 B]: this layer's encoder-side keys (static_kv), fragment-major, one
+                                      * copy per SENTENCE, zero beyond Ts (s2t_decode_prepare_enc); Tsp % 128 == 0 */
+    const void* vt_enc;              /* T [B][heads][4][Tsp / ks][64][16 B]: the values, transposed and fragment-major (same call) */
     void* kv_cache;                  /* T [max_len + 1][N][2D]: k | v rows written by step t at position t */
 } S2TDecodeLayer;
 
@@ -428,7 +430,7 @@ typedef struct S2TDecodeDesc {
     float ln_eps, embed_scale, unk_penalty, inv_temperature;
     const S2TDecodeLayer* layer;             /* HOST array [layers] */
     const void *lnf_g, *lnf_b;               /* decoder.layer_norm */
-    const void* w_out;                       /* T [V][D] output projection (= embed when shared) */
+    const void* w_out;                       /* T [V][D] output projection (the embedding when shared), packed like the layers' weights */
     const void* embed;                       /* T [V][D] */
     const float* pos_table;                  /* f32 [>= pad + 2 + max_len][D] sinusoidal table, row `pad` zero */
     const int* enc_klen;                     /* i32 [B] valid encoder rows per sentence, or NULL (no padding) */
@@ -447,8 +449,13 @@ typedef struct S2TDecodeDesc {
     int* fin_step; int* fin_row; float* fin_score;   /* [B][beam]: finalised hypotheses in the order the reference appends them */
 } S2TDecodeDesc;
 
-/* vt[b][h][d][t] = kv[t][b][D + h*64 + d] (t < Ts), 0 for Ts <= t < Tsp */
-int s2t_decode_prepare_enc(int dtype, const void* kv_enc, void* vt_enc, int Ts, int Tsp, int B, int D, int heads, void* stream);
+/* Fragment-major copies for the MFMA B operand: lane l of fragment (tile, step) holds rows 16 tile + (l & 15), columns ks step + per (l >> 4) ..
+ * (ks = 32, per = 8 for bf16; 16, 4 for f32), so a wave loads a fragment as one contiguous KiB.
+ * s2t_decode_pack_weight: W [N][K] (row stride ldw elements, K % ks == 0) -> Wp [ceil(N / 16)][K / ks][64][per], rows past N zero.
+ * s2t_decode_prepare_enc: kv [Ts][B][2D] (K | V rows of the encoder output under one layer's encoder_attn.kv) -> the layer's kv_enc and
+ * vt_enc as S2TDecodeLayer describes them. */
+int s2t_decode_pack_weight(int dtype, const void* W, int ldw, int N, int K, void* Wp, void* stream);
+int s2t_decode_prepare_enc(int dtype, const void* kv, void* kv_enc, void* vt_enc, int Ts, int Tsp, int B, int D, int heads, void* stream);
 /* resets the state for a new search: steps, blacklist, nfin, finished = 0; arrangement 0 = `bos` in every slot; x0 = its embedding */
 int s2t_decode_begin(const S2TDecodeDesc* d, int bos, void* stream);
 /* the launches of one step (see above).  `d` and d->layer are HOST memory read during the call only. */
