@@ -1304,8 +1304,8 @@ extern "C" int s2t_decode_pack_weight(int dtype, const void* W, int ldw, int N, 
     return S2T_OK;
 }
 
-extern "C" int s2t_decode_graph_create(const S2TDecodeDesc* d, void** graph_exec) {
-    if (!graph_exec) return S2T_EINVAL;
+extern "C" int s2t_decode_graph_create(const S2TDecodeDesc* d, int n_steps, void** graph_exec) {
+    if (!graph_exec || n_steps < 1 || n_steps > 64) return S2T_EINVAL;
     *graph_exec = nullptr;
     const int rc = decode_check(d);
     if (rc != S2T_OK) return rc;
@@ -1317,7 +1317,7 @@ extern "C" int s2t_decode_graph_create(const S2TDecodeDesc* d, void** graph_exec
     int out = S2T_OK;
     e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
     if (e == hipSuccess) {
-        out = d->dtype == S2T_BF16 ? step_impl<bf16>(d, cs) : step_impl<float>(d, cs);
+        for (int i = 0; i < n_steps && out == S2T_OK; ++i) out = d->dtype == S2T_BF16 ? step_impl<bf16>(d, cs) : step_impl<float>(d, cs);
         e = hipStreamEndCapture(cs, &g);
     }
     if (e == hipSuccess && out == S2T_OK) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);

@@ -151,24 +151,26 @@ class BeamDecodeSession:
         st = L.stream()
         L.check(lib.s2t_decode_begin(self.addr, int(bos), st), "s2t_decode_begin")
         exec_ = ctypes.c_void_p(0)
+        per = POLL_STEPS if graph else 1                    # steps per launch: one recorded graph holds POLL_STEPS of them
         if graph:
-            L.check(lib.s2t_decode_graph_create(self.addr, ctypes.addressof(exec_)), "s2t_decode_graph_create")
+            L.check(lib.s2t_decode_graph_create(self.addr, per, ctypes.addressof(exec_)), "s2t_decode_graph_create")
         fo, fn = self.ioff["finished"]
         finished = self.ibuf[fo:fo + fn]
         steps = 0
         try:
-            for step in range(self.max_len + 1):
+            while steps < self.max_len + 1:
                 if graph:
                     L.check(lib.s2t_decode_graph_launch(exec_.value, st), "s2t_decode_graph_launch")
                 else:
                     L.check(lib.s2t_decode_step(self.addr, st), "s2t_decode_step")
-                steps += 1
-                if (step + 1) % POLL_STEPS == 0 and step < self.max_len and bool(finished.all()):
+                steps += per                                # (the last graph may run past max_len: its kernels return at once there)
+                if steps % POLL_STEPS == 0 and steps < self.max_len + 1 and bool(finished.all()):
                     break
         finally:
             if graph and exec_.value:
                 torch.cuda.current_stream().synchronize()
                 lib.s2t_decode_graph_destroy(exec_.value)
+        steps = min(steps, self.max_len + 1)
         self.steps_run = steps
         return steps
 

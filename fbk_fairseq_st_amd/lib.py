@@ -102,7 +102,7 @@ SIGNATURES = {
     "s2t_decode_begin": [P, c_int, P],
     "s2t_decode_step": [P, P],
     "s2t_decode_lds_bytes": [P],                                # returns size_t
-    "s2t_decode_graph_create": [P, P],
+    "s2t_decode_graph_create": [P, c_int, P],
     "s2t_decode_graph_launch": [P, P],
     "s2t_decode_graph_destroy": [P],
     "s2t_host_batch_by_size": [P, c_longlong, P, c_longlong, c_longlong, c_int, P, P, P],

@@ -462,10 +462,12 @@ int s2t_decode_begin(const S2TDecodeDesc* d, int bos, void* stream);
 int s2t_decode_step(const S2TDecodeDesc* d, void* stream);
 /* dynamic LDS bytes the S / C / F launches of `d` need (0 when `d` is outside the limits): the caller may compare with 160 KiB */
 size_t s2t_decode_lds_bytes(const S2TDecodeDesc* d);
-/* One step recorded as a hipGraph: `create` captures s2t_decode_step(d) on a private stream (nothing executes) and instantiates it,
- * `launch` replays it on `stream` (the kernels read the step index from d->steps, so the same recording serves every step; `d`'s device
- * buffers must stay where they are), `destroy` frees it after the caller has synchronised with the last replay.  *graph_exec is HOST. */
-int s2t_decode_graph_create(const S2TDecodeDesc* d, void** graph_exec);
+/* n_steps (1..64) consecutive steps recorded as ONE hipGraph: `create` captures n_steps x s2t_decode_step(d) on a private stream (nothing
+ * executes) and instantiates it, `launch` replays it on `stream` (the kernels read the step index from d->steps, so the same recording
+ * serves every step, and every kernel returns at once for a sentence whose step index has passed max_len: replaying past the end is
+ * harmless; `d`'s device buffers must stay where they are), `destroy` frees it after the caller has synchronised with the last replay.
+ * *graph_exec is HOST. */
+int s2t_decode_graph_create(const S2TDecodeDesc* d, int n_steps, void** graph_exec);
 int s2t_decode_graph_launch(void* graph_exec, void* stream);
 int s2t_decode_graph_destroy(void* graph_exec);
 
