@@ -43,6 +43,14 @@
 // Persistent: gridDim.x workgroups (one per CU) walk the output tiles; the operand stream never stops at a tile boundary (the
 // half-tiles staged in the last two K-tiles of a tile are the first ones of the next tile), and the stores of a tile drain under
 // the next tile's K-loop.
+#ifdef S2T_G256_STAGGER
+// "CUs out of phase" experiment (profiles/r06_gemm_stagger.txt): workgroups with an odd CU index inside their XCD
+// wait this many ticks of the 100 MHz real-time counter before their first tile, so that their store bursts fall into the other half's K-loops
+__device__ long long g_g256_stagger = 0;
+extern "C" int s2t_g256_set_stagger(long long ticks) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_g256_stagger), &ticks, sizeof(ticks)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <typename TO, bool TB, int MT, int ACT, int EXT, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,6 +61,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs p) {
     const int G = gridDim.x;
     int tile = xcd_remap(blockIdx.x, G);             // then tile += G: every round is a contiguous run of tiles, an XCD's share contiguous inside it
     if (tile >= tiles) return;
+#ifdef S2T_G256_STAGGER                                 /* experiment twin (tools/gemm_stagger.py): every other CU of an XCD starts late */
+    if (g_g256_stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        const long long t0 = wall_clock64();
+        while ((long long)wall_clock64() - t0 < g_g256_stagger) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const int nk = p.K / BK;
 
     const int lane = threadIdx.x & 63;
