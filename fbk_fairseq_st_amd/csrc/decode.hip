@@ -27,9 +27,16 @@ __device__ unsigned long long s2t_dec_stamps[8 * 16];
 #define DSTAMP(kid, i) do { } while (0)
 #endif
 
+#ifndef S2T_DEC_NB_FFN
+#define S2T_DEC_NB_FFN 8
+#endif
+#ifndef S2T_DEC_NB_CROSS
+#define S2T_DEC_NB_CROSS 8
+#endif
 namespace {
 constexpr int DH = 64;                 // head size (256/4, 512/8, 1024/16: every preset of the reference and of SURVEY 8-P)
 constexpr int NTHREADS = 256;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct FR { static constexpr int PER = 16 / (int)sizeof(T), KS = 4 * PER; };   // elements per 16 B, k per mma16
 
 __host__ __device__ inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -86,11 +93,13 @@ __device__ __forceinline__ void wave_argmax(float v, int i, float& mv, int& mi) 
 }
 
 // ------------------------------------------------------------------------------------------------ LDS plans (host and device agree)
-struct SelfLds { size_t a_ln, q, sc, anc, o, red, total; };
+struct SelfLds { size_t a_ln, q, kt, vt, sc, anc, o, red, total; };
 __host__ __device__ inline SelfLds self_lds(int RT, int D, int maxpos, int es) {
     SelfLds l; size_t o = 128; const int per = 16 / es;           // the first 128 bytes: the prologue's reduction scratch
     l.a_ln = o; o += up16((size_t)RT * (D + per) * es);
     l.q = o;    o += up16((size_t)RT * DH * 4);
+    l.kt = o;   o += up16((size_t)RT * DH * es);                  // this step's key / value rows (position t), as stored in the cache
+    l.vt = o;   o += up16((size_t)RT * DH * es);
     l.sc = o;   o += up16((size_t)RT * maxpos * 4);
     l.anc = o;  o += up16((size_t)RT * maxpos * 4);
     l.o = o;    o += up16((size_t)RT * (DH + per) * es);
@@ -116,71 +125,99 @@ __host__ __device__ inline FfnLds ffn_lds(int R, int D, int hs, int es) {
 }
 
 // ------------------------------------------------------------------------------------------------ shared prologue
+// Every launch of a step is a chain of dependent phases on one wave per SIMD, so its length is (bytes streamed) / (what one CU keeps in
+// flight) + (number of DEPENDENT memory round trips) x (1-2 us each for lines another CU wrote).  The rules the kernels below follow:
+// everything whose address is known at the top of the launch is requested there, in the order in which it is needed (loads return in
+// order); workgroup barriers between the phases order LDS only (lds_barrier), so that requests stay in flight across them -- a
+// __syncthreads() waits for every outstanding load of the wave.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 // rows n0 .. n0+R-1:  v = x_in + bias + sum_p part_in[p]   (fixed order: the result does not depend on scheduling)
 // the writer workgroup stores v (the residual stream after the previous block) to x_out; every workgroup normalises its copy:
 // dst[r * ld + d] = T(LayerNorm(v)[d])  (fairseq/modules/layer_norm.py: eps inside the square root, biased variance, f32 statistics).
-// All 256 threads work on all rows at once: a thread owns up to four float4 of the [R][D] block (item = row * D/4 + column/4), requests
-// x, bias and eight shares of each of them together (the shares were written by other CUs: every one is an L2 miss), and the row
-// statistics go wave (DPP) -> LDS -> thread.  `red`: 32 floats of LDS.
+// All 256 threads work on all rows at once: a thread owns up to four float4 of the [R][D] block (item = row * D/4 + column/4) and requests
+// x, bias, gamma, beta and the first NB shares of each of them together (the shares were written by other CUs: every one is an L2 miss);
+// the row statistics go wave (DPP) -> LDS -> thread.  `red`: 32 floats of LDS.
+// mid(): called once, after those requests and before the first barrier: the caller requests what else it streams (weights) behind them
+// and returns false when the workgroup has nothing to do (the sentence is past its last step): the prologue then returns false at once.
 struct Pro {
     const float *x_in; const void* part_in; const float* bias; float* x_out; const float *g, *b; int np; float eps;
 };
-// four consecutive shares (stored in the compute type: f32 in f32 mode, bf16 in bf16 mode, where they are half the bytes of the step's
-// second largest stream and rounded no more coarsely than that mode's activations)
-template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
-template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
-    const u32x2 w = *reinterpret_cast<const u32x2*>(p);
-    return f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
-                 __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
-}
+// four consecutive elements of a share (stored in the compute type: f32 in f32 mode, bf16 in bf16 mode, where they are half the bytes of
+// the step's second largest stream and rounded no more coarsely than that mode's activations), as loaded and as f32
+template <typename T> struct Raw4;
+template <> struct Raw4<float> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ type ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ f32x4 cvt(type r) { return r; }
+};
+template <> struct Raw4<bf16> {
+    typedef u32x2 type;
+    static __device__ __forceinline__ type ld(const bf16* p) { return *reinterpret_cast<const u32x2*>(p); }
+    static __device__ __forceinline__ f32x4 cvt(type w) {
+        return f32x4{__builtin_bit_cast(float, w[0] << 16), __builtin_bit_cast(float, w[0] & 0xffff0000u),
+                     __builtin_bit_cast(float, w[1] << 16), __builtin_bit_cast(float, w[1] & 0xffff0000u)};
+    }
+};
 template <typename T> __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
 template <> __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float (&v)[4]) {
     typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
     *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
-template <typename T>
-__device__ __forceinline__ void dec_prologue(const Pro& p, bool writer, int N, int D, int n0, int R, T* dst, int ld, float* red) {
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+// one pass: the 1024 items from `base` (whole rows: 1024 is a multiple of the items per row)
+template <typename T, int NB, typename Mid>
+__device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D, int n0, int R, T* dst, int ld, float* red, int base, Mid&& mid) {
+    typedef typename Raw4<T>::type raw_t;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int sh = D == 256 ? 6 : (D == 512 ? 7 : 8);           // log2(float4 items per row)
     const int IPR = 1 << sh, WPR = IPR >> 6, total = R << sh;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < total; base += 1024) {             // whole rows per pass (1024 is a multiple of IPR)
-        int row[4], col[4]; bool ok[4];
+    {
+        int row[4]; unsigned off[4]; bool ok[4];
         f32x4 v[4];
+        raw_t t[NB][4];
+        const int col = (tid & (IPR - 1)) * 4;                   // IPR divides 256: a thread's four items are in one column
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int it = base + k * 256 + tid;
             ok[k] = it < total;
-            const int itc = ok[k] ? it : total - 1;
-            row[k] = itc >> sh; col[k] = (itc & (IPR - 1)) * 4;
+            row[k] = min(it, total - 1) >> sh;                   // past the end: the last row again (same column), never stored
+            off[k] = (unsigned)((n0 + row[k]) * D + col);        // element offset inside an [N][D] slab
         }
+        auto request = [&](int q0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(p.x_in + (size_t)(n0 + row[k]) * D + col[k]);
-        if (p.bias) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += *reinterpret_cast<const f32x4*>(p.bias + col[k]);
-        }
-        for (int q0 = 0; q0 < p.np; q0 += 8) {
-            f32x4 t[8][4];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 const int q = min(q0 + u, p.np - 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[u][k] = load4<T>(reinterpret_cast<const T*>(p.part_in) + ((size_t)q * N + n0 + row[k]) * D + col[k]);
+                for (int k = 0; k < 4; ++k) t[u][k] = Raw4<T>::ld(reinterpret_cast<const T*>(p.part_in) + (size_t)q * N * D + off[k]);
             }
+        };
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(p.x_in + off[k]);
+        const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : zero;
+        if (p.np > 0) request(0);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(p.g + col), bb = *reinterpret_cast<const f32x4*>(p.b + col);
+        if (!mid()) return false;
+        if (p.bias) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += bs;
+        }
+        for (int q0 = 0; q0 < p.np; q0 += NB) {
+            if (q0 > 0) request(q0);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
                 const bool use = q0 + u < p.np;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += use ? t[u][k] : zero;
+                for (int k = 0; k < 4; ++k) v[k] += use ? Raw4<T>::cvt(t[u][k]) : zero;
             }
         }
         if (writer) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (ok[k]) *reinterpret_cast<f32x4*>(p.x_out + (size_t)(n0 + row[k]) * D + col[k]) = v[k];
+                if (ok[k]) *reinterpret_cast<f32x4*>(p.x_out + off[k]) = v[k];
         }
         float st[4];
 #pragma unroll
@@ -189,7 +226,7 @@ __device__ __forceinline__ void dec_prologue(const Pro& p, bool writer, int N, i
 #pragma unroll
             for (int k = 0; k < 4; ++k) red[k * 4 + w] = st[k];
         }
-        __syncthreads();
+        lds_barrier();
         float mean[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -207,21 +244,70 @@ __device__ __forceinline__ void dec_prologue(const Pro& p, bool writer, int N, i
 #pragma unroll
             for (int k = 0; k < 4; ++k) red[16 + k * 4 + w] = st[k];
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int first = ((row[k] << sh) - base) >> 6;
             float q2 = 0.f;
             for (int j = 0; j < WPR; ++j) q2 += red[16 + first + j];
             const float rstd = rsqrtf(q2 / (float)D + p.eps);
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(p.g + col[k]), bb = *reinterpret_cast<const f32x4*>(p.b + col[k]);
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mean[k]) * rstd * gg[j] + bb[j];
-            if (ok[k]) store4<T>(dst + (size_t)row[k] * ld + col[k], o);
+            if (ok[k]) store4<T>(dst + (size_t)row[k] * ld + col, o);
         }
-        __syncthreads();
+        lds_barrier();
     }
+    return true;
+}
+// the first pass is straight-line code around mid() (values it defines -- weight fragments -- are not carried around a loop)
+template <typename T, int NB, typename Mid>
+__device__ __forceinline__ bool dec_prologue(const Pro& p, bool writer, int N, int D, int n0, int R, T* dst, int ld, float* red, Mid&& mid) {
+    if (!pro_pass<T, NB>(p, writer, N, D, n0, R, dst, ld, red, 0, mid)) return false;
+    const int total = R * (D / 4);
+    for (int base = 1024; base < total; base += 1024) pro_pass<T, NB>(p, writer, N, D, n0, R, dst, ld, red, base, []() { return true; });
+    return true;
+}
+
+// ---- softmax over the positions of R rows of scores in LDS.  GRP lanes per row: a wave for up to four rows, half a wave for up to
+// eight, a 16-lane row above -- so that the rows of the beam run side by side instead of one after the other on the same wave.
+// fin(row, position, probability) stores the result.  f32 throughout (multihead_attention.py:338-339).
+template <int GRP> __device__ __forceinline__ float grp_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    if (GRP == 16) return v;
+    const float lo = fmaxf(rl_f(v, 0), rl_f(v, 16)), hi = fmaxf(rl_f(v, 32), rl_f(v, 48));
+    if (GRP == 32) return (threadIdx.x & 32) ? hi : lo;
+    return fmaxf(lo, hi);
+}
+template <int GRP> __device__ __forceinline__ float grp_sum(float v) {
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+    if (GRP == 16) return v;
+    const float lo = rl_f(v, 0) + rl_f(v, 16), hi = rl_f(v, 32) + rl_f(v, 48);
+    if (GRP == 32) return (threadIdx.x & 32) ? hi : lo;
+    return lo + hi;
+}
+template <int GRP, typename Fin>
+__device__ __forceinline__ void softmax_rows_g(float* sc, int ldsc, int R, int n, Fin&& fin) {
+    constexpr int NG = NTHREADS / GRP;
+    const int g = threadIdx.x / GRP, gl = threadIdx.x % GRP;
+    for (int r0 = 0; r0 < R; r0 += NG) {                       // the same trip count in every lane: the DPP reductions need all 64 active
+        const bool act = r0 + g < R;
+        float* row = sc + (size_t)min(r0 + g, R - 1) * ldsc;      // an idle group reads the last row and stores nothing
+        float m = -INFINITY;
+        for (int p = gl; p < n; p += GRP) m = fmaxf(m, row[p]);
+        m = grp_max<GRP>(m);
+        float z = 0.f;
+        for (int p = gl; p < n; p += GRP) { const float e = expf(row[p] - m); if (act) row[p] = e; z += e; }
+        z = grp_sum<GRP>(z);
+        if (act)
+            for (int p = gl; p < n; p += GRP) fin(r0 + g, p, row[p] / z);
+    }
+}
+template <typename Fin>
+__device__ __forceinline__ void softmax_rows(float* sc, int ldsc, int R, int n, Fin&& fin) {
+    if (R <= 4) softmax_rows_g<64>(sc, ldsc, R, n, fin);
+    else if (R <= 8) softmax_rows_g<32>(sc, ldsc, R, n, fin);
+    else softmax_rows_g<16>(sc, ldsc, R, n, fin);
 }
 
 // ---- weights in FRAGMENT-MAJOR order (s2t_decode_pack_weight): W [N][K] -> [N / 16 column tiles][K / KS k-steps][64 lanes][16 bytes], the
@@ -229,8 +315,11 @@ __device__ __forceinline__ void dec_prologue(const Pro& p, bool writer, int N, i
 // load of a fragment is ONE contiguous KiB (eight whole cache lines) instead of 16 rows x 64 bytes (sixteen half lines).  A CU keeps a
 // limited number of line requests in flight: measured on the feed-forward launch, the wait for 256 KB of weights went from 24,500 to
 // 13,400 cycles (profiles/r06_decode_experiments.txt).
+// (a wave-uniform base -- the callers' tile indices come from readfirstlane -- plus a 32-bit lane offset: one scalar base and immediate
+// offsets for a run of fragments instead of a 64-bit address pair in VGPRs per load)
 template <typename T> __device__ __forceinline__ const T* wfrag(const T* Wp, int ksteps, int tile, int step) {
-    return Wp + ((size_t)((size_t)tile * ksteps + step) * 64 + (threadIdx.x & 63)) * FR<T>::PER;
+    const T* ub = Wp + ((size_t)tile * ksteps + step) * (64 * FR<T>::PER);
+    return ub + (unsigned)((threadIdx.x & 63) * FR<T>::PER);
 }
 
 // acc[i] += A (LDS fragment stream at ap, 16 rows) x W_i^T for NT column tiles of a fragment-major weight, K deep
@@ -261,7 +350,7 @@ __device__ __forceinline__ void mma_rows(const T* ap, const T* Wp, int ksteps, i
 template <typename T, int KST>
 __device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __restrict__ Wp, int ksteps, int step_off, T* __restrict__ out, int D, int R) {
     constexpr int PER = FR<T>::PER, KS = FR<T>::KS, TG = KST >= 16 ? 1 : (KST == 8 ? 2 : 4);
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const T* ap = a_s + (size_t)min(lane & 15, R - 1) * lda + PER * (lane >> 4);
     u32x4 af[KST];
 #pragma unroll
@@ -291,7 +380,7 @@ __device__ __forceinline__ void share_out_t(const T* a_s, int lda, const T* __re
 // wave's i-th column tile (tile w + 4 i)
 template <typename T, int NTILE, int KST>
 __device__ __forceinline__ void load_share_w(u32x4 (&b)[NTILE][KST], const T* __restrict__ Wp, int ksteps, int step_off) {
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int i = 0; i < NTILE; ++i)
 #pragma unroll
@@ -300,7 +389,7 @@ __device__ __forceinline__ void load_share_w(u32x4 (&b)[NTILE][KST], const T* __
 template <typename T, int NTILE, int KST>
 __device__ __forceinline__ void share_regs(const T* a_s, int lda, const u32x4 (&b)[NTILE][KST], T* __restrict__ out, int D, int R) {
     constexpr int PER = FR<T>::PER, KS = FR<T>::KS;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const T* ap = a_s + (size_t)min(lane & 15, R - 1) * lda + PER * (lane >> 4);
     u32x4 af[KST];
 #pragma unroll
@@ -355,43 +444,77 @@ struct SelfArgs {
 };
 // RT = rows held in registers by the attention loops: the beam itself for beam <= 8 (exact: no wasted lanes), 16 above (rows >= beam
 // repeat row beam-1 and are never stored)
-// DD = D when the weight fragments of the whole launch fit in registers (bf16, D <= 512: q|k|v 3 * D/32 and the output projection's D/32
-// 16-byte fragments per lane, 256 VGPRs at D = 512): they are requested FIRST, so the weight stream runs under the prologue's share
-// traffic and the LayerNorm instead of behind them (every __syncthreads waits for outstanding loads: what matters is when they were
-// issued).  DD = 0: D at run time, fragments requested chunk by chunk where they are used (f32, D = 1024).
+// DD = D when the weight fragments of the whole launch fit in registers (bf16, D <= 512: q|k|v 3 * D/32 fragments per lane, the output
+// projection's D/32 after them in the same registers).  DD = 0: D at run time, fragments requested chunk by chunk where they are used
+// (f32, D = 1024).
+// Order of requests (they return in order): x / bias / shares / gamma / beta of the prologue; the ancestor rows; q|k|v weights; then,
+// once the ancestors are in LDS, the cached keys AND values of the first PU * NSLOT positions (all of them while t < 128 at beam 5) --
+// they depend on nothing this launch computes, so they travel under the LayerNorm and the q|k|v product; the output projection's
+// fragments go out when the q|k|v fragments are dead.  Position t's own key / value rows are used from LDS, not read back.
 template <typename T, int RT, int DD>
 __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PER = FR<T>::PER, KS = FR<T>::KS, DC = DH / PER, NSLOT = NTHREADS / DC, PU = RT <= 4 ? 4 : (RT <= 8 ? 2 : 1);
+    constexpr int PER = FR<T>::PER, KS = FR<T>::KS, DC = DH / PER, NSLOT = NTHREADS / DC, PU = RT <= 5 ? 4 : (RT <= 8 ? 2 : 1);
     constexpr bool PRE = DD > 0, PRE_O = PRE && RT <= 8;
-    constexpr int KSTD = PRE ? DD / KS : 1, NTO = PRE_O ? DD / 64 : 1;
+    constexpr int KSTD = PRE ? DD / KS : 1, NTO = PRE_O ? DD / 64 : 1, CH0 = PU * NSLOT;
     const int h = blockIdx.x, s = blockIdx.y, R = a.beam, n0 = s * R, D = PRE ? DD : a.D, N = a.N, maxpos = a.maxpos;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int t = a.steps[s];
-    if (t > a.max_len) return;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int t_raw = a.steps[s];
     DSTAMP(0, 0);
     u32x4 wqkv[3][KSTD], wo[NTO][DH / KS];
-    if constexpr (PRE)
-        load_rows_w<T, 3, KSTD>(wqkv, reinterpret_cast<const T*>(a.w_qkv), h * 4 + w, D / 16);
-    if constexpr (PRE_O) load_share_w<T, NTO, DH / KS>(wo, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS));
     const SelfLds L = self_lds(RT, D, maxpos, (int)sizeof(T));
     float* red0 = reinterpret_cast<float*>(smem);
     T* a_ln = reinterpret_cast<T*>(smem + L.a_ln);
     float* q_s = reinterpret_cast<float*>(smem + L.q);
+    T* k_s = reinterpret_cast<T*>(smem + L.kt);
+    T* v_s = reinterpret_cast<T*>(smem + L.vt);
     float* sc = reinterpret_cast<float*>(smem + L.sc);
     int* anc_s = reinterpret_cast<int*>(smem + L.anc);
     T* o_s = reinterpret_cast<T*>(smem + L.o);
     float* red = reinterpret_cast<float*>(smem + L.red);
     const int lda = D + PER;
     T* cache = reinterpret_cast<T*>(a.cache);
-
-    for (int r = 0; r < R; ++r) {
-        for (int p = tid; p < t; p += NTHREADS) anc_s[r * maxpos + p] = a.anc[(size_t)(n0 + r) * maxpos + p];
-        if (tid == 0) anc_s[r * maxpos + t] = n0 + r;
-    }
-    dec_prologue<T>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0);
+    int t = 0;
+    const bool go = dec_prologue<T, 16>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0, [&]() {
+        t = t_raw;
+        if (t > a.max_len) return false;
+        // ancestors of the sentence's rows at positions < t, RT rows x 256 positions requested together; the weights go out behind the
+        // first batch and before its LDS stores (which wait for those RT loads only)
+        for (int p0 = 0; p0 < t || p0 == 0; p0 += NTHREADS) {
+            int av[RT];
+            const int pc = min(p0 + tid, max(t - 1, 0));
+#pragma unroll
+            for (int r = 0; r < RT; ++r) av[r] = a.anc[(size_t)(n0 + (r < R ? r : R - 1)) * maxpos + pc];
+            if constexpr (PRE) { if (p0 == 0) load_rows_w<T, 3, KSTD>(wqkv, reinterpret_cast<const T*>(a.w_qkv), h * 4 + w, D / 16); }
+            if (p0 + tid < t) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) if (r < R) anc_s[r * maxpos + p0 + tid] = av[r];
+            }
+        }
+        if (tid < R) anc_s[tid * maxpos + t] = n0 + tid;          // position t: the row itself
+        return true;
+    });
+    if (!go) return;
     DSTAMP(0, 1);
 
+    const int slot = tid / DC, dc = tid % DC;
+    // cached keys and values of positions [0, CH0): DC lanes share one 64-wide row (16 bytes each), NSLOT rows per pass, PU passes, all RT
+    // hypotheses.  Positions >= t are served from LDS below; their requests here repeat position t-1 (never used).
+    u32x4 kv[PU][RT], vv[PU][RT];
+    {
+        const int tm1 = max(t - 1, 0);
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int pc = min(u * NSLOT + slot, tm1);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int rr = r < R ? r : R - 1;
+                const T* src = cache + ((size_t)pc * N + anc_s[rr * maxpos + pc]) * 2 * D + h * DH + dc * PER;
+                kv[u][r] = ld16(src);
+                vv[u][r] = ld16(src + D);
+            }
+        }
+    }
     {   // q | k | v columns of this head: wave w owns column tile w of each of the three (3 x 16 columns), K = D
         const T* ap = a_ln + (size_t)min(lane & 15, R - 1) * lda + PER * (lane >> 4);
         f32x4 acc[3];
@@ -406,57 +529,61 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
             const int r = 4 * (lane >> 4) + i;
             if (r < R) {
                 q_s[r * DH + col] = (acc[0][i] + bq) * a.scale;               // multihead_attention.py:155-160: q = (Wq x + b) * d^-1/2
+                const T kt = from_f32<T>(acc[1][i] + bk), vt = from_f32<T>(acc[2][i] + bv);
                 T* row = cache + ((size_t)t * N + n0 + r) * 2 * D + h * DH + col;
-                row[0] = from_f32<T>(acc[1][i] + bk);
-                row[D] = from_f32<T>(acc[2][i] + bv);
+                row[0] = kt; row[D] = vt;                                       // the cache row of position t: later steps read it
+                k_s[r * DH + col] = kt; v_s[r * DH + col] = vt;                 // this step reads it from here
             }
         }
     }
-    __threadfence_block();
-    __syncthreads();                                     // the rows of position t are read back below by other waves of this workgroup
+    if constexpr (PRE_O) load_share_w<T, NTO, DH / KS>(wo, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS));
+    lds_barrier();
     DSTAMP(0, 2);
 
-    const int slot = tid / DC, dc = tid % DC;
-    // scores[r][pos] = q_r . k_{anc(r, pos)}: DC lanes share one 64-wide key row (16 bytes each), NSLOT rows per pass, all RT hypotheses,
-    // PU passes requested together.  Positions past t are clamped to t (same value written twice), rows past the beam to the last row.
-    for (int pos0 = 0; pos0 <= t; pos0 += PU * NSLOT) {
-        u32x4 kv[PU][RT];
-        int posu[PU];
+    // scores[r][pos] = q_r . k_{anc(r, pos)}.  Positions past t repeat position t (same value written twice), rows past the beam the last row.
+    float qr[RT][PER];                                   // this lane's PER columns of every row's query, and of the step's own keys
+    u32x4 kown[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int rr = r < R ? r : R - 1;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) qr[r][j] = q_s[rr * DH + dc * PER + j];
+        kown[r] = ld16(k_s + rr * DH + dc * PER);
+    }
+    auto score_chunk = [&](int pos0, const u32x4 (&kk)[PU][RT]) {
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
-            posu[u] = min(pos0 + u * NSLOT + slot, t);
+            const int pos = pos0 + u * NSLOT + slot;
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const int rr = r < R ? r : R - 1;
-                kv[u][r] = ld16(cache + ((size_t)posu[u] * N + anc_s[rr * maxpos + posu[u]]) * 2 * D + h * DH + dc * PER);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PU; ++u) {
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                const int rr = r < R ? r : R - 1;
+                const Unp<T> kf(pos >= t ? kown[r] : kk[u][r]);
                 float d = 0.f;
-                const Unp<T> kf(kv[u][r]);
 #pragma unroll
-                for (int j = 0; j < PER; ++j) d += q_s[rr * DH + dc * PER + j] * kf.f[j];
+                for (int j = 0; j < PER; ++j) d += qr[r][j] * kf.f[j];
                 d = group_sum<DC>(d);
-                if (dc == 0) sc[rr * maxpos + posu[u]] = d;
+                if (dc == 0) sc[rr * maxpos + min(pos, t)] = d;
             }
         }
+    };
+    score_chunk(0, kv);
+    for (int pos0 = CH0; pos0 <= t; pos0 += CH0) {
+        u32x4 kk[PU][RT];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int pc = min(pos0 + u * NSLOT + slot, t - 1);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const int rr = r < R ? r : R - 1;
+                kk[u][r] = ld16(cache + ((size_t)pc * N + anc_s[rr * maxpos + pc]) * 2 * D + h * DH + dc * PER);
+            }
+        }
+        score_chunk(pos0, kk);
     }
-    __syncthreads();
+    lds_barrier();
     DSTAMP(0, 3);
-    for (int r = w; r < R; r += 4) {                     // softmax over positions 0..t (f32, multihead_attention.py:338-339)
-        float m = -INFINITY;
-        for (int p = lane; p <= t; p += 64) m = fmaxf(m, sc[r * maxpos + p]);
-        m = wave_max64(m);
-        float z = 0.f;
-        for (int p = lane; p <= t; p += 64) { const float e = expf(sc[r * maxpos + p] - m); sc[r * maxpos + p] = e; z += e; }
-        z = group_sum<64>(z);
-        for (int p = lane; p <= t; p += 64) sc[r * maxpos + p] /= z;
-    }
-    __syncthreads();
+    softmax_rows(sc, maxpos, R, t + 1, [&](int r, int p, float v) { sc[r * maxpos + p] = v; });
+    lds_barrier();
     DSTAMP(0, 4);
     {   // o[r][:] = sum_pos p[r][pos] * v_{anc(r, pos)}
         float acc[RT][PER];
@@ -464,32 +591,38 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
         for (int r = 0; r < RT; ++r)
 #pragma unroll
             for (int j = 0; j < PER; ++j) acc[r][j] = 0.f;
-        for (int pos0 = 0; pos0 <= t; pos0 += PU * NSLOT) {
-            u32x4 vv[PU][RT];
-            int posu[PU];
+        u32x4 vown[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) vown[r] = ld16(v_s + (r < R ? r : R - 1) * DH + dc * PER);
+        auto pv_chunk = [&](int pos0, const u32x4 (&vk)[PU][RT]) {
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
-                posu[u] = pos0 + u * NSLOT + slot;
-                const int pc = min(posu[u], t);
-#pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    const int rr = r < R ? r : R - 1;
-                    vv[u][r] = ld16(cache + ((size_t)pc * N + anc_s[rr * maxpos + pc]) * 2 * D + D + h * DH + dc * PER);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                const int pc = min(posu[u], t);
-                const bool live = posu[u] <= t;
+                const int pos = pos0 + u * NSLOT + slot;
+                const int pc = min(pos, t);
+                const bool live = pos <= t;
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
                     const int rr = r < R ? r : R - 1;
                     const float p = live ? sc[rr * maxpos + pc] : 0.f;
-                    const Unp<T> vf(vv[u][r]);
+                    const Unp<T> vf(pos >= t ? vown[r] : vk[u][r]);
 #pragma unroll
                     for (int j = 0; j < PER; ++j) acc[r][j] += p * vf.f[j];
                 }
             }
+        };
+        pv_chunk(0, vv);
+        for (int pos0 = CH0; pos0 <= t; pos0 += CH0) {
+            u32x4 vk[PU][RT];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int pc = min(pos0 + u * NSLOT + slot, t - 1);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const int rr = r < R ? r : R - 1;
+                    vk[u][r] = ld16(cache + ((size_t)pc * N + anc_s[rr * maxpos + pc]) * 2 * D + D + h * DH + dc * PER);
+                }
+            }
+            pv_chunk(pos0, vk);
         }
         // sum over the NSLOT position slots: inside a 16-lane row by DPP (two slots per row when DC = 8), the 16 rows of the workgroup
         // through LDS
@@ -503,7 +636,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     DSTAMP(0, 5);
     for (int i = tid; i < R * DH; i += NTHREADS) {
         const int r = i / DH, d = i % DH;
@@ -512,7 +645,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
         for (int g = 0; g < 16; ++g) v += red[((size_t)g * RT + r) * DH + d];
         o_s[(size_t)r * (DH + PER) + d] = from_f32<T>(v);
     }
-    __syncthreads();
+    lds_barrier();
     DSTAMP(0, 6);
     if constexpr (PRE_O) share_regs<T, NTO, DH / KS>(o_s, DH + PER, wo, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
     else share_out<T>(o_s, DH + PER, DH, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS), reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
@@ -524,21 +657,20 @@ struct CrossArgs {
     Pro pro; int B, beam, N, D, heads, Ts, Tsp, max_len; float scale;
     const void* w_q; const float* b_q; const void* w_o; const void* kv_enc; const void* vt_enc; const int* klen; const int* steps; void* part_out;
 };
-template <typename T, int DD>          // DD as in dec_self_kernel
+// DD as in dec_self_kernel.  TP = Tsp / 128 when the sentence's encoder keys and values of this head fit in registers beside the weights
+// (Tsp <= 256: 2 TP position tiles of keys and Tsp / KS k-steps of one value column tile per wave): they are requested at the top of the
+// launch with the weights, so nothing is waited for after the LayerNorm.  TP = 0: requested where they are used.
+template <typename T, int DD, int TP>
 __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PER = FR<T>::PER, KS = FR<T>::KS;
-    constexpr bool PRE = DD > 0;
-    constexpr int KSTD = PRE ? DD / KS : 1, NTO = PRE ? DD / 64 : 1;
-    const int h = blockIdx.x, s = blockIdx.y, R = a.beam, n0 = s * R, D = PRE ? DD : a.D, N = a.N, Ts = a.Ts, Tsp = a.Tsp;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (a.steps[s] > a.max_len) return;
+    constexpr int PER = FR<T>::PER, KS = FR<T>::KS, KST = DH / KS;
+    constexpr bool PRE = DD > 0, PKV = TP > 0;
+    constexpr int KSTD = PRE ? DD / KS : 1, NTO = PRE ? DD / 64 : 1, TPT = PKV ? 2 * TP : 1, NV = PKV ? 128 * TP / KS : 1;
+    const int h = blockIdx.x, s = blockIdx.y, R = a.beam, n0 = s * R, D = PRE ? DD : a.D, N = a.N, Ts = a.Ts, Tsp = PKV ? 128 * TP : a.Tsp;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int t_raw = a.steps[s];
     DSTAMP(1, 0);
-    u32x4 wq[1][KSTD], wo[NTO][DH / KS];
-    if constexpr (PRE) {
-        load_rows_w<T, 1, KSTD>(wq, reinterpret_cast<const T*>(a.w_q), h * 4 + w, 0);
-        load_share_w<T, NTO, DH / KS>(wo, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS));
-    }
+    u32x4 wq[1][KSTD], wo[NTO][KST], kf[TPT][KST], vf[1][NV];
     const CrossLds L = cross_lds(R, D, Tsp, (int)sizeof(T));
     float* red0 = reinterpret_cast<float*>(smem);
     T* a_ln = reinterpret_cast<T*>(smem + L.a_ln);
@@ -548,8 +680,22 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     T* o_s = reinterpret_cast<T*>(smem + L.o);
     const int lda = D + PER, ldq = DH + PER, ldp = Tsp + PER;
     const int arow = min(lane & 15, R - 1);
+    // this sentence's keys and values of this head, fragment-major (s2t_decode_prepare_enc):
+    //   keys [Tsp / 16 position tiles][KST steps][64 lanes][16 B], values (transposed) [4 column tiles][Tsp / KS steps][64][16 B]
+    const T* Kp = reinterpret_cast<const T*>(a.kv_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;
+    const T* Vp = reinterpret_cast<const T*>(a.vt_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;
 
-    dec_prologue<T>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0);
+    const bool go = dec_prologue<T, S2T_DEC_NB_CROSS>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0, [&]() {
+        if (t_raw > a.max_len) return false;
+        if constexpr (PRE) load_rows_w<T, 1, KSTD>(wq, reinterpret_cast<const T*>(a.w_q), h * 4 + w, 0);
+        if constexpr (PKV) {
+            load_rows_w<T, TPT, KST>(kf, Kp, w, 4);                 // position tiles w, w + 4, ...
+            load_rows_w<T, 1, NV>(vf, Vp, w, 0);                    // value column tile w
+        }
+        if constexpr (PRE) load_share_w<T, NTO, KST>(wo, reinterpret_cast<const T*>(a.w_o), D / KS, h * KST);
+        return true;
+    });
+    if (!go) return;
     DSTAMP(1, 1);
     {   // q of this head: wave w owns 16 of its 64 columns
         const T* ap = a_ln + (size_t)arow * lda + PER * (lane >> 4);
@@ -564,59 +710,62 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
             if (r < R) q_s[(size_t)r * ldq + col] = from_f32<T>((acc[0][i] + bq) * a.scale);
         }
     }
-    __syncthreads();
+    lds_barrier();
     DSTAMP(1, 2);
     {   // scores over the sentence's encoder rows: 16 positions per MFMA tile, K = 64; padding rows -> -inf (multihead_attention.py:318-327)
         const int klen = a.klen ? min(a.klen[s], Ts) : Ts;
-        constexpr int KST = DH / KS, TG = 8 / KST;                 // position tiles requested together (8 fragments in flight)
-        // this sentence's keys of this head, fragment-major (s2t_decode_prepare_enc): [Tsp / 16 position tiles][KST steps][64 lanes][16 B]
-        const T* Kp = reinterpret_cast<const T*>(a.kv_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;
         const T* ap = q_s + (size_t)arow * ldq + PER * (lane >> 4);
         u32x4 af[KST];
 #pragma unroll
         for (int c = 0; c < KST; ++c) af[c] = ld16(ap + c * KS);
-        const int last = Tsp / 16 - 4 + w;                         // this wave's last tile (Tsp is a multiple of 128)
-        for (int pt0 = w; pt0 <= last; pt0 += 4 * TG) {
-            u32x4 b[TG][KST];
-            int ptg[TG];
+        auto put = [&](int pt, const f32x4& acc) {
+            const int pos = pt * 16 + (lane & 15);
 #pragma unroll
-            for (int g = 0; g < TG; ++g) {
-                ptg[g] = min(pt0 + 4 * g, last);                   // past the end: the last tile again (same values stored twice)
-#pragma unroll
-                for (int c = 0; c < KST; ++c) b[g][c] = ld16(wfrag<T>(Kp, KST, ptg[g], c));
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * (lane >> 4) + i;
+                if (r < R) sc[(size_t)r * Tsp + pos] = pos < klen ? acc[i] : -INFINITY;
             }
+        };
+        if constexpr (PKV) {
 #pragma unroll
-            for (int g = 0; g < TG; ++g) {
+            for (int i = 0; i < TPT; ++i) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < KST; ++c) acc = mma16<T>(af[c], b[g][c], acc);
-                const int pos = ptg[g] * 16 + (lane & 15);
+                for (int c = 0; c < KST; ++c) acc = mma16<T>(af[c], kf[i][c], acc);
+                put(w + 4 * i, acc);
+            }
+        } else {
+            constexpr int TG = 8 / KST;                                // position tiles requested together (8 fragments in flight)
+            const int last = Tsp / 16 - 4 + w;                         // this wave's last tile (Tsp is a multiple of 128)
+            for (int pt0 = w; pt0 <= last; pt0 += 4 * TG) {
+                u32x4 b[TG][KST];
+                int ptg[TG];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * (lane >> 4) + i;
-                    if (r < R) sc[(size_t)r * Tsp + pos] = pos < klen ? acc[i] : -INFINITY;
+                for (int g = 0; g < TG; ++g) {
+                    ptg[g] = min(pt0 + 4 * g, last);                   // past the end: the last tile again (same values stored twice)
+#pragma unroll
+                    for (int c = 0; c < KST; ++c) b[g][c] = ld16(wfrag<T>(Kp, KST, ptg[g], c));
+                }
+#pragma unroll
+                for (int g = 0; g < TG; ++g) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < KST; ++c) acc = mma16<T>(af[c], b[g][c], acc);
+                    put(ptg[g], acc);
                 }
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     DSTAMP(1, 3);
-    for (int r = w; r < R; r += 4) {
-        float m = -INFINITY;
-        for (int p = lane; p < Tsp; p += 64) m = fmaxf(m, sc[(size_t)r * Tsp + p]);
-        m = wave_max64(m);
-        float z = 0.f;
-        for (int p = lane; p < Tsp; p += 64) { const float e = expf(sc[(size_t)r * Tsp + p] - m); sc[(size_t)r * Tsp + p] = e; z += e; }
-        z = group_sum<64>(z);
-        for (int p = lane; p < Tsp; p += 64) p_s[(size_t)r * ldp + p] = from_f32<T>(sc[(size_t)r * Tsp + p] / z);
-    }
-    __syncthreads();
+    softmax_rows(sc, Tsp, R, Tsp, [&](int r, int p, float v) { p_s[(size_t)r * ldp + p] = from_f32<T>(v); });
+    lds_barrier();
     DSTAMP(1, 4);
     {   // o = P V: wave w owns 16 of the 64 value columns; V is read through its transposed, fragment-major copy
         const T* ap = p_s + (size_t)arow * ldp + PER * (lane >> 4);
-        const T* Vp = reinterpret_cast<const T*>(a.vt_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;      // [4 column tiles][Tsp / KS steps][64][16 B]
         f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        mma_rows<T, 1, 128 / KS>(ap, Vp, Tsp / KS, w, 0, Tsp, acc);
+        if constexpr (PKV) mma_regs<T, 1, NV>(ap, vf, acc);
+        else mma_rows<T, 1, 128 / KS>(ap, Vp, Tsp / KS, w, 0, Tsp, acc);
         const int col = 16 * w + (lane & 15);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -624,10 +773,10 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
             if (r < R) o_s[(size_t)r * ldq + col] = from_f32<T>(acc[0][i]);
         }
     }
-    __syncthreads();
+    lds_barrier();
     DSTAMP(1, 5);
-    if constexpr (PRE) share_regs<T, NTO, DH / KS>(o_s, ldq, wo, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
-    else share_out<T>(o_s, ldq, DH, reinterpret_cast<const T*>(a.w_o), D / KS, h * (DH / KS), reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
+    if constexpr (PRE) share_regs<T, NTO, KST>(o_s, ldq, wo, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
+    else share_out<T>(o_s, ldq, DH, reinterpret_cast<const T*>(a.w_o), D / KS, h * KST, reinterpret_cast<T*>(a.part_out) + ((size_t)h * N + n0) * D, D, R);
     DSTAMP(1, 6);
 }
 
@@ -643,13 +792,10 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
     constexpr bool PRE = DD > 0, PRE2 = PRE && TPW <= 2;         // fc2's fragments too while they fit (TPW 4: 512 VGPRs with fc1's)
     constexpr int KSTD = PRE ? DD / KS : 1, NTO = PRE2 ? DD / 64 : 1, KST2 = PRE2 ? HS / KS : 1;
     const int j = blockIdx.x, s = blockIdx.y, R = a.beam, n0 = s * R, D = PRE ? DD : a.D, N = a.N, hs = HS;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    if (a.steps[s] > a.max_len) return;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int t_raw = a.steps[s];
     DSTAMP(2, 0);
     u32x4 w1[TPW][KSTD], w2[NTO][KST2];
-    if constexpr (PRE)
-        load_rows_w<T, TPW, KSTD>(w1, reinterpret_cast<const T*>(a.w_fc1), j * (HS / 16) + w * TPW, 1);
-    if constexpr (PRE2) load_share_w<T, NTO, KST2>(w2, reinterpret_cast<const T*>(a.w_fc2), a.ffn / KS, j * (HS / KS));
     const FfnLds L = ffn_lds(R, D, hs, (int)sizeof(T));
     float* red0 = reinterpret_cast<float*>(smem);
     T* a_ln = reinterpret_cast<T*>(smem + L.a_ln);
@@ -657,7 +803,13 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
     const int lda = D + PER, ldh = hs + PER;
     const int arow = min(lane & 15, R - 1);
 
-    dec_prologue<T>(a.pro, j == 0, N, D, n0, R, a_ln, lda, red0);
+    const bool go = dec_prologue<T, S2T_DEC_NB_FFN>(a.pro, j == 0, N, D, n0, R, a_ln, lda, red0, [&]() {
+        if (t_raw > a.max_len) return false;
+        if constexpr (PRE) load_rows_w<T, TPW, KSTD>(w1, reinterpret_cast<const T*>(a.w_fc1), j * (HS / 16) + w * TPW, 1);
+        if constexpr (PRE2) load_share_w<T, NTO, KST2>(w2, reinterpret_cast<const T*>(a.w_fc2), a.ffn / KS, j * (HS / KS));
+        return true;
+    });
+    if (!go) return;
     DSTAMP(2, 1);
     {   // hidden units j*hs .. +hs: wave w owns TPW column tiles (transformer_layer.py:367-368: fc1, activation)
         const T* ap = a_ln + (size_t)arow * lda + PER * (lane >> 4);
@@ -679,7 +831,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     DSTAMP(2, 2);
     if constexpr (PRE2) share_regs<T, NTO, KST2>(h_s, ldh, w2, reinterpret_cast<T*>(a.part_out) + ((size_t)j * N + n0) * D, D, R);
     else share_out<T>(h_s, ldh, hs, reinterpret_cast<const T*>(a.w_fc2), a.ffn / KS, j * (HS / KS), reinterpret_cast<T*>(a.part_out) + ((size_t)j * N + n0) * D, D, R);
@@ -692,22 +844,25 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void dec_final_kernel(FinalArgs a) {
     __shared__ float red0[32];
     const int s = blockIdx.x, n0 = s * a.beam;
-    if (a.steps[s] > a.max_len) return;
+    const int t_raw = a.steps[s];
     DSTAMP(6, 0);
-    dec_prologue<T>(a.pro, true, a.N, a.D, n0, a.beam, reinterpret_cast<T*>(a.xn) + (size_t)n0 * a.D, a.D, red0);
+    dec_prologue<T, 16>(a.pro, true, a.N, a.D, n0, a.beam, reinterpret_cast<T*>(a.xn) + (size_t)n0 * a.D, a.D, red0,
+                        [&]() { return t_raw <= a.max_len; });
     DSTAMP(6, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ output projection, all N rows
 // logits[n][v] = xn[n] . W[v]: a workgroup owns 64 vocabulary columns (one 16-column tile per wave) and every row tile (MT of them), so
-// the weight matrix is read exactly once per step.  K goes in chunks of 8 k-steps: the wave's eight weight fragments of the chunk are
-// requested first, then the chunk's columns of all N rows are staged in LDS, then 8 x MT MFMAs.
+// the weight matrix is read exactly once per step.  K goes in chunks of KCH = 16 k-steps (all of D = 512 in bf16): the wave's weight
+// fragments of the chunk are requested first, then the chunk's columns of all N rows are staged in LDS (up to 24 sixteen-byte pieces per
+// thread in flight: one round trip for 80 rows), then KCH x MT MFMAs.
 struct LogitArgs { int N, D, V, ldv; const void* xn; const void* w; float* logits; };
+constexpr int LOGIT_KCH = 16;
 template <typename T, int MT>
 __global__ __launch_bounds__(NTHREADS) void dec_logits_kernel(LogitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PER = FR<T>::PER, KS = FR<T>::KS, KC = 8 * KS, LDX = KC + PER, PPR = KC / PER;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, D = a.D, N = a.N;
+    constexpr int PER = FR<T>::PER, KS = FR<T>::KS, KCH = LOGIT_KCH, KC = KCH * KS, LDX = KC + PER, PPR = KC / PER, UB = 24;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, D = a.D, N = a.N;
     const int ct = blockIdx.x * 4 + w;
     T* x_s = reinterpret_cast<T*>(smem);                      // [N][LDX]
     const T* X = reinterpret_cast<const T*>(a.xn);
@@ -720,29 +875,33 @@ __global__ __launch_bounds__(NTHREADS) void dec_logits_kernel(LogitArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) arow[mt] = min(mt * 16 + (lane & 15), N - 1) * LDX + PER * (lane >> 4);
     DSTAMP(5, 0);
+    const int kc_w = min(KC, D), ppr = kc_w / PER;              // D = 256 in bf16: one chunk of 8 k-steps
+    const int psh = 31 - __builtin_clz(ppr);                    // pieces per row: a power of two (32 or 64)
     for (int kc0 = 0; kc0 < D; kc0 += KC) {
-        u32x4 b[8];
+        u32x4 b[KCH];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) b[c] = ld16(wfrag<T>(Wp, D / KS, ctc, kc0 / KS + c));
-        __syncthreads();
-        for (int i0 = 0; i0 < N * PPR; i0 += 8 * NTHREADS) {        // eight 16-byte pieces per thread in flight
-            u32x4 piece[8];
+        for (int c = 0; c < KCH; ++c) b[c] = ld16(wfrag<T>(Wp, D / KS, ctc, min(kc0 / KS + c, D / KS - 1)));
+        if (kc0 > 0) lds_barrier();                              // the previous chunk's fragment reads are done
+        for (int i0 = 0; i0 < N * ppr; i0 += UB * NTHREADS) {
+            u32x4 piece[UB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = min(i0 + u * NTHREADS + tid, N * PPR - 1);
-                piece[u] = ld16(X + (size_t)(i / PPR) * D + kc0 + (i % PPR) * PER);
+            for (int u = 0; u < UB; ++u) {
+                const int i = min(i0 + u * NTHREADS + tid, N * ppr - 1);
+                piece[u] = ld16(X + (size_t)(i >> psh) * D + kc0 + (i & (ppr - 1)) * PER);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UB; ++u) {
                 const int i = i0 + u * NTHREADS + tid;
-                if (i < N * PPR) *reinterpret_cast<u32x4*>(x_s + (size_t)(i / PPR) * LDX + (i % PPR) * PER) = piece[u];
+                if (i < N * ppr) *reinterpret_cast<u32x4*>(x_s + (size_t)(i >> psh) * LDX + (i & (ppr - 1)) * PER) = piece[u];
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < KCH; ++c) {
+            if (c * KS < kc_w) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(ld16(x_s + arow[mt] + c * KS), b[c], acc[mt]);
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mma16<T>(ld16(x_s + arow[mt] + c * KS), b[c], acc[mt]);
+            }
         }
     }
     DSTAMP(5, 1);
@@ -822,19 +981,25 @@ __global__ __launch_bounds__(NTHREADS) void dec_row_kernel(RowArgs a) {
         float lm = -INFINITY;
 #pragma unroll
         for (int i = 0; i < VPT; ++i) lm = fmaxf(lm, val[i]);
-        float kth = -INFINITY;
-        for (int k = 0; k < K2; ++k) {
-            float mv; int mi;
-            wave_argmax(lm, lane, mv, mi);
-            if (lane == mi) lm = -INFINITY;
-            kth = mv;
+        // the K2-th largest of the wave's 64 lane maxima: every lane counts the lanes that come before it in the order (value descending,
+        // lane ascending) -- 64 broadcasts from scalar registers, no cross-lane dependency chain (K2 rounds of arg-max took 11,000 cycles
+        // here on a wave that runs alone on its SIMD; this takes ~2,500) -- and the lane with K2 - 1 before it holds the value
+        int before = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const float o = rl_f(lm, j);
+            before += (o > lm || (o == lm && j < lane)) ? 1 : 0;
         }
+        const unsigned long long hit = __ballot(before == K2 - 1);
+        const float kth = rl_f(lm, (int)__builtin_ctzll(hit | (1ull << 63)));
         if (lane == 0) wv[w] = kth;
         if (tid == 0) wi[127] = 0;                                 // list length
     }
+    DSTAMP(3, 3);
     __syncthreads();
     const float thr = fmaxf(fmaxf(wv[0], wv[1]), fmaxf(wv[2], wv[3]));
     __syncthreads();
+    DSTAMP(3, 4);
     constexpr int CAP = 120;                                       // list entries (wv / wi [4 .. 123])
     if (thr > -INFINITY) {
 #pragma unroll
@@ -848,7 +1013,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_row_kernel(RowArgs a) {
     }
     __syncthreads();
     const int cnt = wi[127];
-    DSTAMP(3, 3);
+    DSTAMP(3, 5);
     if (thr > -INFINITY && cnt <= CAP) {
         if (w == 0) {
             float c0v = -INFINITY, c1v = -INFINITY; int c0i = 0x7fffffff, c1i = 0x7fffffff;
@@ -903,7 +1068,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_row_kernel(RowArgs a) {
             }
         }
     }
-    DSTAMP(3, 4);
+    DSTAMP(3, 6);
 }
 
 // ------------------------------------------------------------------------------------------------ search, part 2: one sentence
@@ -921,8 +1086,9 @@ struct SentArgs {
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void dec_sent_kernel(SentArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float l_val[16 * 32];
-    __shared__ int l_idx[16 * 32], pick_par[16], pick_tok[16];
+    __shared__ __attribute__((aligned(16))) float l_val[16 * 32];
+    __shared__ __attribute__((aligned(16))) int l_idx[16 * 32];
+    __shared__ int pick_par[16], pick_tok[16];
     int* anc_l = reinterpret_cast<int*>(smem);                     // [beam][maxpos]
     const int s = blockIdx.x, tid = threadIdx.x, beam = a.beam, n0 = s * beam, K2 = a.K2, N = a.N;
     const int t = a.steps[s];
@@ -932,24 +1098,45 @@ __global__ __launch_bounds__(NTHREADS) void dec_sent_kernel(SentArgs a) {
     const long ncols = first ? a.V : (long)beam * a.V;
     const int k = (int)min((long)K2, ncols - 1);                   // search.py:71-75: pad is never selected
     const int rows = first ? 1 : beam;
-    for (int i = tid; i < rows * K2; i += NTHREADS) { l_val[i] = a.cand_val[(size_t)n0 * K2 + i]; l_idx[i] = a.cand_idx[(size_t)n0 * K2 + i]; }
+    // everything this launch reads is requested at once: the rows' candidate lists, the sentence's flags, its ancestor rows
+    const int ne = rows * K2;                                      // <= 512 entries: two per thread
+    float ev[2]; int ei[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = min(tid + u * NTHREADS, ne - 1);
+        ev[u] = a.cand_val[(size_t)n0 * K2 + i]; ei[u] = a.cand_idx[(size_t)n0 * K2 + i];
+    }
     int bl = 0, done = 0, nf = 0;
     if (tid < 64) {                                                // wave 0 keeps the sentence's flags in registers
         bl = tid < beam ? a.blacklist[n0 + tid] : 0;
         done = a.finished[s]; nf = a.nfin[s];
     }
-    for (int r = 0; r < beam; ++r)                                 // old ancestor rows of the sentence (read before anything is rewritten)
-        for (int p = tid; p < t; p += NTHREADS) anc_l[r * a.maxpos + p] = a.anc[(size_t)(n0 + r) * a.maxpos + p];
+    for (int p0 = 0; p0 < t; p0 += NTHREADS) {                     // old ancestor rows of the sentence (read before anything is rewritten)
+        int av[16];
+        const int pc = min(p0 + tid, t - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) av[r] = a.anc[(size_t)(n0 + min(r, beam - 1)) * a.maxpos + pc];
+        if (p0 + tid < t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (r < beam) anc_l[r * a.maxpos + p0 + tid] = av[r];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * NTHREADS;
+        if (i < ne) { l_val[i] = ev[u]; l_idx[i] = (i / K2) * a.V + ei[u]; }      // flat index: row * V + column
+    }
     __syncthreads();
     DSTAMP(4, 1);
     if (tid < 64) {
         // k-way merge of the `rows` sorted lists: lane j < rows offers the head of list j; the winner of round r becomes candidate r,
-        // kept by lane r
+        // kept by lane r.  (Counting, for every entry, the entries before it -- one pass over the lists in LDS -- was measured at 10,700
+        // cycles for 50 entries against 5,500 for these k = 10 rounds.)
         int head = 0;
         float my_val = -INFINITY; int my_tok = 0, my_row = n0;
         for (int r = 0; r < k; ++r) {
-            float v = -INFINITY; int flat = 0x7fffffff, idx = 0;
-            if (tid < rows && head < K2) { v = l_val[tid * K2 + head]; idx = l_idx[tid * K2 + head]; flat = tid * a.V + idx; }
+            float v = -INFINITY; int flat = 0x7fffffff;
+            if (tid < rows && head < K2) { v = l_val[tid * K2 + head]; flat = l_idx[tid * K2 + head]; }
             float mv; int mf;
             wave_argmax(v, flat, mv, mf);
             if (flat == mf && tid < rows) ++head;
@@ -987,14 +1174,33 @@ __global__ __launch_bounds__(NTHREADS) void dec_sent_kernel(SentArgs a) {
     __syncthreads();
     DSTAMP(4, 3);
     if (t < a.max_len) {
+        // the next step's decoder input: embedding of the chosen token * scale + position row (transformer.py:720-737), four columns per
+        // item, four items per thread requested together (all of beam 5 x D 512 in one round trip)
+        const int dq = a.D / 4, items = beam * dq;
+        for (int i0 = 0; i0 < items; i0 += 4 * NTHREADS) {
+            f32x4 ev4[4], pv4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * NTHREADS + tid, items - 1), j = i / dq, d = (i - j * dq) * 4;
+                const int tok = pick_tok[j];
+                ev4[u] = Raw4<T>::cvt(Raw4<T>::ld(reinterpret_cast<const T*>(a.embed) + (size_t)tok * a.D + d));
+                pv4[u] = *reinterpret_cast<const f32x4*>(a.pos_table + (size_t)(tok == a.pad ? a.pad : a.pad + 2 + t) * a.D + d);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NTHREADS + tid, j = i / dq, d = (i - j * dq) * 4;
+                if (i < items) {
+                    f32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = a.embed_scale * ev4[u][q] + pv4[u][q];
+                    *reinterpret_cast<f32x4*>(a.x0 + (size_t)(n0 + j) * a.D + d) = o;
+                }
+            }
+        }
         for (int j = 0; j < beam; ++j) {
             const int par = pick_par[j];
             for (int p = tid; p < t; p += NTHREADS) a.anc[(size_t)(n0 + j) * a.maxpos + p] = anc_l[(par - n0) * a.maxpos + p];
             if (tid == 0) a.anc[(size_t)(n0 + j) * a.maxpos + t] = par;
-            const int tok = pick_tok[j];
-            const T* e = reinterpret_cast<const T*>(a.embed) + (size_t)tok * a.D;
-            const float* pe = a.pos_table + (size_t)(tok == a.pad ? a.pad : a.pad + 2 + t) * a.D;
-            for (int d = tid; d < a.D; d += NTHREADS) a.x0[(size_t)(n0 + j) * a.D + d] = a.embed_scale * to_f32(e[d]) + pe[d];
         }
     }
     DSTAMP(4, 4);
@@ -1087,7 +1293,7 @@ LdsNeed lds_need(const S2TDecodeDesc* d) {
     n.cross = cross_lds(d->beam, d->D, d->Tsp, es).total;
     n.ffn = ffn_lds(d->beam, d->D, d->ffn / d->ffn_slices, es).total;
     n.sent = up16((size_t)d->beam * (d->max_len + 1) * 4);
-    n.logits = (size_t)d->B * d->beam * (8 * (64 / es) + 16 / es) * es;
+    n.logits = (size_t)d->B * d->beam * (LOGIT_KCH * (64 / es) + 16 / es) * es;
     return n;
 }
 constexpr size_t LDS_CAP = 152 * 1024;                // leaves 8 KiB for the static arrays (dec_sent_kernel: 4.3 KiB)
@@ -1101,7 +1307,7 @@ template <typename T, int DD> hipError_t configure_dd() {
     DEC_ALLOW((dec_self_kernel<T, 1, DD>)); DEC_ALLOW((dec_self_kernel<T, 2, DD>)); DEC_ALLOW((dec_self_kernel<T, 3, DD>));
     DEC_ALLOW((dec_self_kernel<T, 4, DD>)); DEC_ALLOW((dec_self_kernel<T, 5, DD>)); DEC_ALLOW((dec_self_kernel<T, 6, DD>));
     DEC_ALLOW((dec_self_kernel<T, 7, DD>)); DEC_ALLOW((dec_self_kernel<T, 8, DD>)); DEC_ALLOW((dec_self_kernel<T, 16, DD>));
-    DEC_ALLOW((dec_cross_kernel<T, DD>));
+    DEC_ALLOW((dec_cross_kernel<T, DD, 0>)); DEC_ALLOW((dec_cross_kernel<T, DD, 1>)); DEC_ALLOW((dec_cross_kernel<T, DD, 2>));
     DEC_ALLOW((dec_ffn_kernel<T, 1, DD>)); DEC_ALLOW((dec_ffn_kernel<T, 2, DD>)); DEC_ALLOW((dec_ffn_kernel<T, 4, DD>));
     return hipSuccess;
 }
@@ -1127,6 +1333,12 @@ void launch_self(int rt, dim3 grid, size_t lds, hipStream_t st, const SelfArgs& 
         default: DEC_SELF(16); break;
     }
 #undef DEC_SELF
+}
+template <typename T, int DD>
+void launch_cross(int tp, dim3 grid, size_t lds, hipStream_t st, const CrossArgs& a) {
+    if (tp == 1) hipLaunchKernelGGL((dec_cross_kernel<T, DD, 1>), grid, dim3(NTHREADS), lds, st, a);
+    else if (tp == 2) hipLaunchKernelGGL((dec_cross_kernel<T, DD, 2>), grid, dim3(NTHREADS), lds, st, a);
+    else hipLaunchKernelGGL((dec_cross_kernel<T, DD, 0>), grid, dim3(NTHREADS), lds, st, a);
 }
 template <typename T, int DD>
 void launch_ffn(int hs, dim3 grid, size_t lds, hipStream_t st, const FfnArgs& a) {
@@ -1170,9 +1382,10 @@ int step_impl(const S2TDecodeDesc* d, hipStream_t st) {
             CrossArgs a; a.pro = pro(y.lnx_g, y.lnx_b); a.B = B; a.beam = R; a.N = N; a.D = D; a.heads = H; a.Ts = d->Ts; a.Tsp = d->Tsp;
             a.max_len = d->max_len; a.scale = scale; a.w_q = y.w_xq; a.b_q = (const float*)y.b_xq; a.w_o = y.w_xo; a.kv_enc = y.kv_enc;
             a.vt_enc = y.vt_enc; a.klen = d->enc_klen; a.steps = d->steps; a.part_out = P[k & 1];
-            if (dd == 256) hipLaunchKernelGGL((dec_cross_kernel<T, (sizeof(T) == 2 ? 256 : 0)>), dim3(H, B), dim3(NTHREADS), need.cross, st, a);
-            else if (dd == 512) hipLaunchKernelGGL((dec_cross_kernel<T, (sizeof(T) == 2 ? 512 : 0)>), dim3(H, B), dim3(NTHREADS), need.cross, st, a);
-            else hipLaunchKernelGGL((dec_cross_kernel<T, 0>), dim3(H, B), dim3(NTHREADS), need.cross, st, a);
+            const int tp = d->Tsp == 128 ? 1 : (d->Tsp == 256 ? 2 : 0);     // encoder keys / values in registers for the launch
+            if (dd == 256) launch_cross<T, (sizeof(T) == 2 ? 256 : 0)>(tp, dim3(H, B), need.cross, st, a);
+            else if (dd == 512) launch_cross<T, (sizeof(T) == 2 ? 512 : 0)>(tp, dim3(H, B), need.cross, st, a);
+            else launch_cross<T, 0>(tp, dim3(H, B), need.cross, st, a);
             ++k; np = H; bias = (const float*)y.b_xo;
             DEC_STOP_CHECK();
         }
@@ -1207,9 +1420,14 @@ int step_impl(const S2TDecodeDesc* d, hipStream_t st) {
         a.max_len = d->max_len; a.min_len = d->min_len; a.step0_all = d->step0_all_slots; a.it = d->inv_temperature; a.unk_penalty = d->unk_penalty;
         a.logits = d->logits; a.steps = d->steps; a.cum_hist = d->cum_hist; a.init_scores = d->init_scores; a.cand_val = d->cand_val;
         a.cand_idx = d->cand_idx;
-        if (d->V <= 32 * NTHREADS) hipLaunchKernelGGL(dec_row_kernel<32>, dim3(N), dim3(NTHREADS), 0, st, a);
-        else if (d->V <= 64 * NTHREADS) hipLaunchKernelGGL(dec_row_kernel<64>, dim3(N), dim3(NTHREADS), 0, st, a);
-        else hipLaunchKernelGGL(dec_row_kernel<128>, dim3(N), dim3(NTHREADS), 0, st, a);
+        // columns per thread: the kernel is bound by its per-column VALU work on a wave that runs alone on its SIMD, so the unrolled loops
+        // are sized to the vocabulary (V = 5,000: 20, not 32)
+#define DEC_ROW(VPT_) hipLaunchKernelGGL(dec_row_kernel<VPT_>, dim3(N), dim3(NTHREADS), 0, st, a)
+        const int vpt = (d->V + NTHREADS - 1) / NTHREADS;
+        if (vpt <= 8) DEC_ROW(8); else if (vpt <= 12) DEC_ROW(12); else if (vpt <= 16) DEC_ROW(16); else if (vpt <= 20) DEC_ROW(20);
+        else if (vpt <= 24) DEC_ROW(24); else if (vpt <= 32) DEC_ROW(32); else if (vpt <= 40) DEC_ROW(40); else if (vpt <= 48) DEC_ROW(48);
+        else if (vpt <= 64) DEC_ROW(64); else if (vpt <= 96) DEC_ROW(96); else DEC_ROW(128);
+#undef DEC_ROW
     }
     {
         SentArgs a; a.beam = R; a.N = N; a.D = D; a.V = d->V; a.K2 = 2 * R; a.pad = d->pad; a.eos = d->eos; a.max_len = d->max_len; a.maxpos = maxpos;

@@ -1,6 +1,6 @@
 """Where a decode step's kernels spend their cycles: runs the Cfg5 beam-5 search on the stamps twin of the library
 (make -C fbk_fairseq_st_amd/csrc dec_stamps; S2T_HIP_LIB=.../libs2t_hip_decstamps.so) and prints, for workgroup (0, 0) of every kernel of the
-LAST step, the shader cycles between phase boundaries and the clock (shader cycles per 100 MHz real-time tick)."""
+chosen step (third argument; default the last), the shader cycles between phase boundaries and the clock (shader cycles per 100 MHz real-time tick)."""
 import ctypes
 import os
 import sys
@@ -24,11 +24,31 @@ gen = SequenceGenerator([model], task.target_dictionary, beam_size=5, max_len_a=
 gen.device_graph = False
 sample = trainer.prepare(task.dummy_batch(seed=100))
 net = {"net_input": {k: v for k, v in sample["net_input"].items() if k in ("src_tokens", "src_lengths")}}
+# stamps of step number `at` (third argument; default: the last step, which is the forced-EOS one): the step function is wrapped, the
+# search synchronised and the stamps read right after that call
+at = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+buf = (ctypes.c_ulonglong * 128)()
+lib = L.load()
+inner = lib.s2t_decode_step
+calls = [0]
+
+
+def step(addr, st):
+    rc = inner(addr, st)
+    if calls[0] == at:
+        torch.cuda.synchronize()
+        assert L.load_ctypes().s2t_decode_read_stamps(buf) == 0
+    calls[0] += 1
+    return rc
+
+
+lib.s2t_decode_step = step
 gen.generate([model], net)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 128)()
-rc = L.load_ctypes().s2t_decode_read_stamps(buf)
-assert rc == 0, rc
+if at < 0 or at >= calls[0]:
+    rc = L.load_ctypes().s2t_decode_read_stamps(buf)
+    assert rc == 0, rc
+print("stamps of step %d of %d" % (at if 0 <= at < calls[0] else calls[0] - 1, calls[0]))
 names = ["self", "cross", "ffn", "row", "sent", "logits", "final"]
 for k, n in enumerate(names):
     v = list(buf[k * 16:(k + 1) * 16])
