@@ -572,6 +572,8 @@ def main():
     ap.add_argument("--no-dry-run", dest="dry_run", action="store_false",
                     help="skip data_parallel.dry_run (9 updates on the data-parallel schedule after the timed region; the profiling passes of "
                          "tools/refresh_profiles.sh pass it so that profiles/ describe the single-GPU schedule alone)")
+    ap.add_argument("--set", dest="opts", action="append", default=[], metavar="KEY=INT",
+                    help="s2t_set_option before anything runs (experiments: tile thresholds, reserve_cus ...); repeatable")
     ap.add_argument("--only", default=None, help="run ONE secondary workload by name (profiling runs: tools/refresh_profiles.sh) and print its entry")
     ap.add_argument("--loader", action="store_true", help="feed the headline workload from the batch iterator (collate, pinned prefetch, H2D in the timed loop)")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -589,6 +591,11 @@ def main():
     if args.attn_2d:
         args.cpu_baseline = False
 
+    if args.opts:
+        from fbk_fairseq_st_amd import kernels as K_
+        for kv in args.opts:
+            k_, v_ = kv.split("=")
+            K_.set_option(k_, int(v_))
     if args.only:
         torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
         torch.cuda.set_device(0)

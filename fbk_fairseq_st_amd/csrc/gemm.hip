@@ -812,7 +812,7 @@ static int gemm_run(int in_dtype, int out_dtype, int trans_a, int trans_b, int M
     // tiles the 64 x 64 form; "gemm_f32_narrow": below that many the 128 x 64 form)
     const bool f32in = in_dtype == S2T_F32 && !mapA && !mapB && !mapC;
     const bool small = f32in ? t128 < ((trans_a || trans_b) ? g_s2t_opt_f32_small_kt : g_s2t_opt_f32_small_nt)
-                             : t128 < ((trans_a || trans_b) ? 40 : 192);
+                             : t128 < ((trans_a || trans_b) ? g_s2t_opt_small_kt : g_s2t_opt_small_nt);
     // (128 x 64 tiles for products with 40-160 tiles of 128 x 128 -- twice the workgroups on the idle CUs -- measured 2-3 % SLOWER on
     // the decoder's M = 2,560 / 3,000 products, tools/dec_gemm_time.py: not used)
     const bool narrow = !small && (N <= 64 || (f32in && t128 < g_s2t_opt_f32_narrow));    // N <= 64: conv2 implicit GEMM, 64 output channels
