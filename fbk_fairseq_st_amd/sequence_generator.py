@@ -150,6 +150,8 @@ class SequenceGenerator:
         if eng.hp.layernorm_embedding:                                     # the step's first launch takes the embedding sum as it is
             return None
         eo = enc.encoder_out.contiguous()
+        if not eo.is_cuda:       # host tensors only reach this class under the CPU tests' stand-in engine (tests/cpu_stubs.py: host logic)
+            return None
         klen = enc.src_lengths.to(torch.int32) if enc.encoder_padding_mask is not None else None
         ses = DEC.BeamDecodeSession(eng, decoder.pfx, eo, klen, self.beam_size, max_len, self.min_len, pad, unk, eos, V, self.unk_penalty,
                                     self.temperature, init_scores=prev_scores, step0_all_slots=prev_scores is not None)

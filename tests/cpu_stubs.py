@@ -26,8 +26,11 @@ def _scale_by_device_scalar(x, scalar):
     return x
 
 
-def _grad_norm_clip(g, scale, max_norm, ws, out2):
-    """out2[0] = |scale * g|, out2[1] = scale * min(1, max_norm / (norm + 1e-6)) (0 disables clipping) -- csrc/norm_optim.hip"""
+def _grad_norm_clip(g, scale, max_norm, ws, out2, divisor=None):
+    """out2[0] = |scale * g|, out2[1] = scale * min(1, max_norm / (norm + 1e-6)) (0 disables clipping) -- csrc/norm_optim.hip;
+    divisor (f64 scalar tensor): the gradients are also divided by max(divisor, 1), folded into `scale` (s2t_grad_norm_clip_div)"""
+    if divisor is not None:
+        scale = scale / max(float(divisor), 1.0)
     norm = (g.double() * scale).norm()
     coef = 1.0 if max_norm <= 0 else min(1.0, float(max_norm) / (float(norm) + 1e-6))
     out2[0] = float(norm)
