@@ -498,6 +498,8 @@ int s2t_prof_enable(int on);
  *                  form (NT / NN and TN layouts): the exact-f32 MFMA is 1/16 of the bf16 rate, so what counts is that every CU has
  *                  tiles (tools/f32_tile_sweep.py: 22.96 -> 20.03 ms per update of configs[1]); "gemm_f32_narrow" (default 0): below
  *                  that many the 128 x 64 form;
+ *       "gemm_small_nt" / "gemm_small_kt" (defaults 192 / 40): the same thresholds for bf16 products (tools/small_m_sweep.py: at M = 3,000 the
+ *                  64 x 64 form loses on every NN product and the whole update moves within its noise: the defaults stay);
  *       "decode_stop_after": diagnostic, ends s2t_decode_step after that many launches (0 = off);
  * returns the previous value, or S2T_EINVAL (-22) for an unknown key or a value out of range. */
 int s2t_set_option(const char* key, int value);

@@ -454,6 +454,47 @@ def test_cfg5_m_beam5_generation():
             np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), ops, atol=1e-4)
 
 
+@pytest.mark.parametrize("arch,dtype,beam,lengths,max_len_b", [
+    ("s2t_transformer_m", torch.float32, 12, [1000, 600], 10),        # beam > 8: 16-row attention loops, output projection not in registers
+    ("s2t_transformer_l", torch.float32, 5, [1300, 700], 8),          # D 1024, 16 heads (two prologue passes, two share batches); 325 encoder
+                                                                     # frames: keys / values requested where they are used
+    ("s2t_transformer_s", torch.float32, 8, [400, 250, 90], 12),      # D 256, 100 encoder frames: one 128-position block in registers
+    ("s2t_transformer_m", torch.bfloat16, 12, [1000, 600], 10),
+    ("s2t_transformer_s", torch.bfloat16, 8, [400, 250, 90], 12)])
+def test_device_search_equals_step_search(arch, dtype, beam, lengths, max_len_b, monkeypatch):
+    """The device-resident search (csrc/decode.hip) at the shapes the reference fixtures do not reach -- beams above 8, D = 1024,
+    encoder lengths on either side of the 256 frames that fit in registers -- against the step-by-step search of the same library
+    (pinned to the reference by tests/test_model_gpu.py): fp32 tokens exact and scores 1e-4; bf16 (the two routes round differently:
+    shares and LayerNorm inputs are bf16 in one, f32 in the other) well-formed hypotheses whose best scores agree to BF16_GEN_ATOL."""
+    from fbk_fairseq_st_amd.sequence_generator import SequenceGenerator
+    a, task, model, crit, cfg, W = build(arch, dtype, criterion="label_smoothed_cross_entropy")
+    sample = batch(task, len(lengths), max(lengths), 8, 8, 9, lengths=lengths)
+    net = dict(net_input=dict(src_tokens=sample["net_input"]["src_tokens"].to(DEV), src_lengths=sample["net_input"]["src_lengths"].to(DEV)))
+    opts = dict(beam_size=beam, max_len_a=0.0, max_len_b=max_len_b, min_len=1, len_penalty=1.0, unk_penalty=0.0, temperature=1.0)
+    model.eval()
+    gen = SequenceGenerator([model], task.target_dictionary, **opts)
+    dev_h = gen.generate([model], net)
+    assert "launches_per_step" in gen.last_stats, "the device route was not taken"
+    monkeypatch.setenv("S2T_DEVICE_SEARCH", "0")
+    gen2 = SequenceGenerator([model], task.target_dictionary, **opts)
+    step_h = gen2.generate([model], net)
+    assert "launches_per_step" not in gen2.last_stats
+    assert len(dev_h) == len(step_h) == len(lengths)
+    for hs, ss in zip(dev_h, step_h):
+        assert len(hs) == len(ss) == beam
+        if dtype == torch.float32:
+            for h, s_ in zip(hs, ss):
+                assert h["tokens"].tolist() == s_["tokens"].tolist()
+                assert abs(float(h["score"]) - float(s_["score"])) < 1e-4
+                np.testing.assert_allclose(h["positional_scores"].cpu().numpy(), s_["positional_scores"].cpu().numpy(), atol=1e-4)
+        else:
+            sc = [float(h["score"]) for h in hs]
+            assert sc == sorted(sc, reverse=True)
+            for h in hs:
+                assert int(h["tokens"][-1]) == 2 and not bool((h["tokens"][:-1] == 2).any())
+            assert abs(sc[0] - float(ss[0]["score"])) < BF16_GEN_ATOL
+
+
 def test_cfg5_m_beam5_generation_bf16():
     """beam-5 on the m preset in bf16 mode.  A bf16 forward can legitimately order two near-tied candidates differently from the f32
     oracle, so the statement that holds is about scores: (1) every hypothesis the engine returns, re-scored by the f32 oracle with

@@ -26,7 +26,7 @@ for cfg in cfg5_beam5 cfg2_s_fp32 cfg5_kd_train; do
   cp $(find /tmp/p_$cfg -name "*kernel_stats.csv" | head -1) $R/gpurun_out/ref/kernel_stats_$cfg.csv
 done
 cd $R
-python tools/decode_stamps.py bf16 100 > $R/gpurun_out/ref/decode_stamps.txt 2>&1
+python tools/decode_stamps.py bf16 200 100 > $R/gpurun_out/ref/decode_stamps.txt 2>&1
 python tools/gemm_soak.py 2000 > $R/gpurun_out/ref/gemm_soak.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $R/gpurun_out/ref/smoke.txt 2>&1
 tail -2 $R/gpurun_out/ref/smoke.txt
