@@ -1166,6 +1166,208 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnArgs p) {
     ASTAMP(7, 3)
 }
 
+// ------------------------------------------------------------------------------------ backward, one kernel (short key sequences)
+// The two second-generation kernels each rebuild S, dP, the softmax and the dropout mask of every (query, key) pair -- and that
+// element-wise work, not the MFMAs, is what they are bound by (PMC, round 3: VALU : MFMA = 498 : 32 per wave-tile).  When ALL keys of a
+// head fit in one workgroup's LDS (Tk <= 384: the encoder's 1,500 frames / 4 = 375) one workgroup can own the head: eight waves x 48
+// keys, K and V parked in LDS for the whole launch (96 KiB), 32-query tiles of Q and dO streamed by LDS-DMA.  Per tile every wave
+// makes P and dS for its 48 keys ONCE (the dK/dV kernel's arithmetic, instruction for instruction, so the dropout mask is the
+// forward's), feeds dV^T += dO^T P and dK^T += Q^T dS from the accumulators as before, and also writes dS (bf16) to a
+// [32 queries][384 keys] LDS tile; after a barrier the eight waves split that tile's dQ^T = K^T dS^T by (query block, d block) and run
+// the contraction over all 384 keys from LDS (K^T through the transposed reads that also serve dK/dV): complete per tile, so no
+// atomics and no cross-workgroup sums.  Delta comes from attn_delta_kernel.  Plain softmax only (no causal mask, no distance penalty).
+constexpr int FB_KEYS = 384, FB_DS_ROWB = 800;          // dS tile row: 768 B of keys + 32 B (a query's 8-byte reads fall on distinct banks)
+constexpr int FB_STAGE = 8192, FB_STAT = 2 * FB_STAGE, FB_K = FB_STAT + 1024, FB_V = FB_K + FB_KEYS * 128, FB_DS = FB_V + FB_KEYS * 128,
+              FB_LDS = FB_DS + 32 * FB_DS_ROWB;
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnArgs p) {
+    constexpr int DH = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
+    const int head = blockIdx.x, b = head / p.H, h = head % p.H, kw = wave * 48;
+    const int klen = p.klen ? min(p.klen[b], p.Tk) : p.Tk;
+    const bf16* Qg = reinterpret_cast<const bf16*>(p.Q) + (long)b * p.q_sb + (long)h * DH;
+    const bf16* Kg = reinterpret_cast<const bf16*>(p.K) + (long)b * p.k_sb + (long)h * DH;
+    const bf16* Vg = reinterpret_cast<const bf16*>(p.V) + (long)b * p.v_sb + (long)h * DH;
+    const bf16* dOg = reinterpret_cast<const bf16*>(p.dO) + (long)b * p.do_sb + (long)h * DH;
+    const float* lse = p.LSE + ((long)b * p.H + h) * p.Tq;
+    const float* dlt = p.Delta + ((long)b * p.H + h) * p.Tq;
+    char* sKown = smem + FB_K;                                        // [384 keys][64 d], chunk swizzle row & 7
+    char* sVown = smem + FB_V;
+    char* sDS = smem + FB_DS;                                         // [32 queries][FB_DS_ROWB]: dS of the tile, keys contiguous
+    float* sStat = reinterpret_cast<float*>(smem + FB_STAT);          // [2 stages][2][32]: LSE, Delta of the tile's queries
+
+    f32x4 dkT[3][4], dvT[3][4];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { dkT[kb][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dvT[kb][n] = dkT[kb][n]; }
+    const uint32_t drop_th16 = (uint32_t)fminf(p.p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float drop_inv = 1.f / (1.f - p.p_drop);
+    const uint32_t drop_ks = drop_seed_key(p.seed), drop_hwm = drop_high_mix(p.seed, 0);
+    const uint32_t tkq = (uint32_t)((p.Tk + 3) >> 2);
+    const uint32_t drop_thm1x2 = (drop_th16 - 1u) * 0x00010001u;
+    const uint32_t own_bit = ((r16 & 1) ? 0x00010000u : 1u) << ((r16 >> 1) & 1);
+
+    const int ntile = (p.Tq + 31) / 32;
+    // one tile = 32 rows of Q (waves 0-3, 8 rows each) and of dO (waves 4-7) by LDS-DMA, LSE / Delta by waves 0 / 1 (lanes < 32)
+    auto stage = [&](int qt, int stg) {
+        const int r8 = 8 * (wave & 3), row = r8 + (lane >> 3), pos = lane & 7;
+        const uint32_t r = (uint32_t)min(qt + row, p.Tq - 1);
+        const uint32_t ch = (uint32_t)((pos ^ (row & 7)) << 4);
+        char* dst = smem + stg * FB_STAGE + __builtin_amdgcn_readfirstlane((wave < 4 ? 0 : 4096) + r8 * 128);
+        const char* src = wave < 4 ? reinterpret_cast<const char*>(Qg) + (__umul24(r, (uint32_t)p.q_st * 2u) + ch)
+                                   : reinterpret_cast<const char*>(dOg) + (__umul24(r, (uint32_t)p.do_st * 2u) + ch);
+        __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        if (wave < 2 && lane < 32) {
+            // rows past Tq: LSE = +inf, so their probabilities -- and with them dS -- are exact zeros without a mask per element
+            float* sd = sStat + stg * 64 + wave * 32;
+            if (wave == 1 || qt + lane < p.Tq) {
+                const char* sb = reinterpret_cast<const char*>(wave == 0 ? lse : dlt);
+                const char* ss = sb + (uint32_t)(min(qt + lane, p.Tq - 1) * 4);
+                __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)ss, (__attribute__((address_space(3))) void*)sd, 4, 0, 0);
+            } else sd[lane] = INFINITY;
+        }
+    };
+    if (ntile > 0) stage(0, 0);
+    {   // the head's keys and values: twelve 16-byte loads per thread, all out together; rows past klen are zeros (their dK / dV are
+        // never stored and they add nothing to dQ)
+        u32x4 kk[6], vv[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int cid = threadIdx.x + 512 * i, row = cid >> 3, c = cid & 7;
+            const long key = min(row, p.Tk - 1);
+            kk[i] = *reinterpret_cast<const u32x4*>(Kg + key * p.k_st + c * 8);
+            vv[i] = *reinterpret_cast<const u32x4*>(Vg + key * p.v_st + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int cid = threadIdx.x + 512 * i, row = cid >> 3, c = cid & 7;
+            const bool in = row < klen;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { kk[i][w] = in ? kk[i][w] : 0u; vv[i][w] = in ? vv[i][w] : 0u; }
+            *reinterpret_cast<u32x4*>(sKown + row * 128 + ((c ^ (row & 7)) << 4)) = kk[i];
+            *reinterpret_cast<u32x4*>(sVown + row * 128 + ((c ^ (row & 7)) << 4)) = vv[i];
+        }
+    }
+    S2T_WAIT_VM0();
+    __syncthreads();
+    const float sc2 = p.scale * 1.44269504088896f;
+    const int nblk = (min(klen, FB_KEYS) + 31) / 32;                  // 32-key blocks that hold a valid key
+    const int dq_j = wave & 1, dq_n = wave >> 1;                      // this wave's share of a tile's dQ^T: queries 16 j .., d 16 n ..
+    bf16* dQg = reinterpret_cast<bf16*>(p.dQ) + (long)b * p.dq_sb + (long)h * DH;
+    for (int t = 0; t < ntile; ++t) {
+        const int qt = t * 32;
+        const char* sQ = smem + (t & 1) * FB_STAGE;
+        const char* sDO = sQ + 4096;
+        const float* sL = sStat + (t & 1) * 64;
+        if (t + 1 < ntile) stage(qt + 32, (t + 1) & 1);
+        auto tile = [&](auto drop_tag) {
+            constexpr bool DROP = decltype(drop_tag)::value;
+            u32x4 pf[3], sf[3];                             // [key block]: D*P and dS as B operands (k = the tile's 32 queries)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                u32x4 qa[2], da[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) { qa[g] = row_frag128(sQ, 16 * ii + r16, 4 * g + q); da[g] = row_frag128(sDO, 16 * ii + r16, 4 * g + q); }
+                const f32x4 L = *reinterpret_cast<const f32x4*>(sL + 16 * ii + 4 * q) * 1.44269504088896f;
+                const f32x4 Dl = *reinterpret_cast<const f32x4*>(sL + 32 + 16 * ii + 4 * q);
+                const uint32_t qrow_quads = DROP ? (uint32_t)(((b * p.H + h) * p.Tq + qt + 16 * ii + 4 * q + (r16 & 3))) * tkq : 0u;
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb) {
+                    f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+                    const int krow = kw + 16 * kb + r16;
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        st = mma16<bf16>(qa[g], row_frag128(sKown, krow, 4 * g + q), st);
+                        dp = mma16<bf16>(da[g], row_frag128(sVown, krow, 4 * g + q), dp);
+                    }
+                    uint32_t nib = 0u;
+                    if constexpr (DROP) {                     // as in attn_bwd_dkv2_kernel: keep bits of the own quad, one hash per lane
+                        const u32x2 hq = drop_hash4_lo(drop_ks, drop_hwm, qrow_quads + ((uint32_t)krow >> 2));
+                        uint32_t dy, dx, ky, kx;
+                        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dy) : "v"(hq[1]), "v"(drop_thm1x2));
+                        asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(dx) : "v"(hq[0]), "v"(drop_thm1x2));
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(ky) : "v"(dy), "v"(0x00010001u));
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(kx) : "v"(dx), "v"(0x00010001u));
+                        nib = drop_th16 > 0 ? (ky | (kx << 1)) : 0x00030003u;
+                    }
+                    float pv[4], ds[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], sc2, -L[r]));
+                        if constexpr (DROP) {
+                            const bool keep = (quad_bcast(nib, r) & own_bit) != 0u;
+                            pv[r] = keep ? e : 0.f;
+                            ds[r] = e * __builtin_fmaf(keep ? dp[r] : 0.f, drop_inv, -Dl[r]);
+                        } else {
+                            pv[r] = e;
+                            ds[r] = e * (dp[r] - Dl[r]);
+                        }
+                    }
+                    pf[kb][2 * ii] = pack_bf16(pv[0], pv[1]); pf[kb][2 * ii + 1] = pack_bf16(pv[2], pv[3]);
+                    sf[kb][2 * ii] = pack_bf16(ds[0], ds[1]); sf[kb][2 * ii + 1] = pack_bf16(ds[2], ds[3]);
+                    // the same dS, keys contiguous, for the dQ product: element (query 16 ii + 4 q + r, key krow)
+                    const uint32_t w01 = sf[kb][2 * ii], w23 = sf[kb][2 * ii + 1];
+                    char* drow = sDS + (16 * ii + 4 * q) * FB_DS_ROWB + krow * 2;
+                    *reinterpret_cast<uint16_t*>(drow) = (uint16_t)w01;
+                    *reinterpret_cast<uint16_t*>(drow + FB_DS_ROWB) = (uint16_t)(w01 >> 16);
+                    *reinterpret_cast<uint16_t*>(drow + 2 * FB_DS_ROWB) = (uint16_t)w23;
+                    *reinterpret_cast<uint16_t*>(drow + 3 * FB_DS_ROWB) = (uint16_t)(w23 >> 16);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const u32x4 dot = tr_frag128(sDO, 0, n, r16, q), qtf = tr_frag128(sQ, 0, n, r16, q);
+#pragma unroll
+                for (int kb = 0; kb < 3; ++kb) {
+                    dvT[kb][n] = mma16<bf16>(dot, pf[kb], dvT[kb][n]);
+                    dkT[kb][n] = mma16<bf16>(qtf, sf[kb], dkT[kb][n]);
+                }
+            }
+        };
+        if (p.p_drop > 0.f) tile(std::true_type{}); else tile(std::false_type{});
+        __syncthreads();                                  // every wave's dS of this tile is in LDS
+        {   // dQ^T[d 16 n + 4 q + r][query 16 j + r16] = sum over all keys K^T dS^T: A = K^T by transposed reads, B = the query's keys
+            // (two accumulators over alternating key blocks, or the fragments of four blocks requested together, spill: the
+            // element-wise phase above sits at the 256-register edge of two waves per SIMD)
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+            const char* brow = sDS + (16 * dq_j + r16) * FB_DS_ROWB + 8 * q;
+            for (int blk = 0; blk < nblk; ++blk) {
+                const u32x4 kt = tr_frag128(sKown, blk, dq_n, r16, q);
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(brow + 64 * blk), hi = *reinterpret_cast<const u32x2*>(brow + 64 * blk + 32);
+                a4 = mma16<bf16>(kt, (u32x4){lo[0], lo[1], hi[0], hi[1]}, a4);
+            }
+            const int qrow = qt + 16 * dq_j + r16;
+            if (qrow < p.Tq) {
+                u32x2 w;
+                w[0] = pack_bf16(a4[0] * p.scale, a4[1] * p.scale); w[1] = pack_bf16(a4[2] * p.scale, a4[3] * p.scale);
+                *reinterpret_cast<u32x2*>(dQg + (long)qrow * p.dq_st + 16 * dq_n + 4 * q) = w;
+            }
+        }
+        S2T_WAIT_VM0();                                   // tile t + 1 has landed (this wave's share; the barrier covers the rest)
+        __syncthreads();                                  // and nobody still reads this tile's dS
+    }
+    const float dv_scale = p.p_drop > 0.f ? drop_inv : 1.f;
+    bf16* dKg = reinterpret_cast<bf16*>(p.dK) + (long)b * p.dk_sb + (long)h * DH;
+    bf16* dVg = reinterpret_cast<bf16*>(p.dV) + (long)b * p.dv_sb + (long)h * DH;
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+        const int key = kw + 16 * kb + r16;
+        if (key >= p.Tk) continue;
+        const float kz = key < klen ? 1.f : 0.f;          // padded keys get exact zeros
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { dkT[kb][n] *= kz * p.scale; dvT[kb][n] *= kz * dv_scale; }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            u32x2 w;
+            w[0] = pack_bf16(dkT[kb][n][0], dkT[kb][n][1]); w[1] = pack_bf16(dkT[kb][n][2], dkT[kb][n][3]);
+            *reinterpret_cast<u32x2*>(dKg + (long)key * p.dk_st + 16 * n + 4 * q) = w;
+            w[0] = pack_bf16(dvT[kb][n][0], dvT[kb][n][1]); w[1] = pack_bf16(dvT[kb][n][2], dvT[kb][n][3]);
+            *reinterpret_cast<u32x2*>(dVg + (long)key * p.dv_st + 16 * n + 4 * q) = w;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ C ABI
 // the second-generation kernels address the rows of a staged tensor by 32-bit byte offsets built with a 24-bit multiply
 static bool span32(long stride, int rows) {
@@ -1195,6 +1397,17 @@ template <typename T, int DH> static int bwd_launch(const AttnArgs& a, hipStream
                         !((uintptr_t)a.dK & 7) && !((uintptr_t)a.dV & 7) && !((uintptr_t)a.dQ & 7);
         // the second-generation kernels keep the dropout quad index in one 32-bit word
         const bool idx32 = (unsigned long long)a.B * a.H * a.Tq * (unsigned long long)((a.Tk + 3) & ~3) < (1ull << 34);
+        // one kernel for the whole backward when a head's keys fit in one workgroup (plain softmax, Tk <= 384: the encoder's self-attention)
+        if (!v1 && g_s2t_opt_attn_bwd_fused && al && idx32 && !a.causal && !a.dist_pen && a.Tk >= 128 && a.Tk <= FB_KEYS && a.Tq >= 128 &&
+            span32(a.q_st, a.Tq) && span32(a.do_st, a.Tq)) {
+            hipLaunchKernelGGL((attn_delta_kernel<T, DH>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, st, a);
+            S2T_LAUNCH_CHECK();
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FB_LDS); attr = true; }
+            hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(a.B * a.H), dim3(512), FB_LDS, st, a);
+            S2T_LAUNCH_CHECK();
+            return S2T_OK;
+        }
         dkv2 = !v1 && al && idx32 && a.Tk >= 128 && span32(a.q_st, a.Tq) && span32(a.do_st, a.Tq);
         dq2 = !v1 && al && idx32 && span32(a.k_st, a.Tk) && span32(a.v_st, a.Tk) && (a.Tq >= 128 || (a.Tq >= S2T_ATTN_V2_MIN_TQ && a.Tk >= 128)) && !(a.o_st % 8) && !(a.o_sb % 8) && !((uintptr_t)a.O & 15);
         if (dq2) {                                       // first: it also writes Delta for the dK/dV kernel

@@ -1268,3 +1268,31 @@ def test_dropout_fused_into_bn_apply_and_scattered_gemm_epilogue(dtype):
         assert torch.equal(o1, ref)
     else:                                                       # ... the epilogue scales the f32 accumulator (one rounding instead of two)
         assert rel_err(o1, ref) < 1e-2
+
+def test_attn_bwd_fused_matches_two_kernel_path():
+    """s2t_set_option "attn_bwd_fused" (default off: measured no faster, profiles/r06_attn_bwd_fused.txt): the one-kernel attention backward
+    for Tk <= 384 against the two-kernel path on the encoder's shape with dropout and ragged key lengths -- dV identical (the same
+    arithmetic in the same order), dK / dQ within 4e-3 of the largest element (bf16 operands, another order over the keys)."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, H, T = 3, 8, 375
+    D = 64 * H
+    qkv = (torch.randn(T, B, 3 * D, device=DEV, generator=g) * 0.7).to(torch.bfloat16)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    do = torch.randn(T, B, D, device=DEV, generator=g).to(torch.bfloat16)
+    kl = torch.tensor([375, 250, 131], dtype=torch.int32, device=DEV)
+    o, lse = K.attn_fwd(q, k, v, H, klen=kl, p_drop=0.1, seed=9)
+    res = []
+    try:
+        for fused in (0, 1):
+            K.set_option("attn_bwd_fused", fused)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            K.attn_bwd(q, k, v, o, do, lse, H, dq, dk, dv, klen=kl, p_drop=0.1, seed=9)
+            torch.cuda.synchronize()
+            res.append((dq.float(), dk.float(), dv.float()))
+    finally:
+        K.set_option("attn_bwd_fused", 0)
+    (q0, k0, v0), (q1, k1, v1) = res
+    assert torch.equal(v0, v1)
+    for a, b_ in ((q0, q1), (k0, k1)):
+        assert torch.isfinite(b_).all()
+        assert float((a - b_).abs().max()) <= 4e-3 * float(a.abs().max())
