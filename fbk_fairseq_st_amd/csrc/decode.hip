@@ -61,6 +61,17 @@ template <> struct Unp<bf16> {
     }
 };
 
+// bf16 dot products of the self-attention launch: the lane's query slice is rounded to bf16 once (as the training attention kernels hold
+// q) and a 16-byte key fragment costs four v_dot2_f32_bf16 -- unpacking eight bf16 and eight FMAs were 16 of the ~25 VALU instructions
+// per (position, hypothesis) of the score loop, on a wave that issues one every ~8 cycles.  f32 keeps the plain multiply-adds.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t));
+}
 // ------------------------------------------------------------------------------------------------ cross-lane reductions on DPP
 // The kernels below run one wave per SIMD on dependent chains, so a reduction's LATENCY is what counts: a ds_bpermute butterfly
 // (__shfl_xor) costs ~100+ cycles per step, a DPP operand ~8.  quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror leave
@@ -541,13 +552,20 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
     DSTAMP(0, 2);
 
     // scores[r][pos] = q_r . k_{anc(r, pos)}.  Positions past t repeat position t (same value written twice), rows past the beam the last row.
-    float qr[RT][PER];                                   // this lane's PER columns of every row's query, and of the step's own keys
+    constexpr bool DOT2 = sizeof(T) == 2;                // bf16: packed query slices and v_dot2_f32_bf16
+    float qr[RT][DOT2 ? 1 : PER];                        // this lane's PER columns of every row's query, and of the step's own keys
+    uint32_t qp[RT][DOT2 ? 4 : 1];
     u32x4 kown[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int rr = r < R ? r : R - 1;
+        if constexpr (DOT2) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) qr[r][j] = q_s[rr * DH + dc * PER + j];
+            for (int j = 0; j < 4; ++j) qp[r][j] = pack2_bf16(q_s[rr * DH + dc * PER + 2 * j], q_s[rr * DH + dc * PER + 2 * j + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) qr[r][j] = q_s[rr * DH + dc * PER + j];
+        }
         kown[r] = ld16(k_s + rr * DH + dc * PER);
     }
     auto score_chunk = [&](int pos0, const u32x4 (&kk)[PU][RT]) {
@@ -557,10 +575,16 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const int rr = r < R ? r : R - 1;
-                const Unp<T> kf(pos >= t ? kown[r] : kk[u][r]);
                 float d = 0.f;
+                if constexpr (DOT2) {
+                    const u32x4 kf = pos >= t ? kown[r] : kk[u][r];
 #pragma unroll
-                for (int j = 0; j < PER; ++j) d += qr[r][j] * kf.f[j];
+                    for (int j = 0; j < 4; ++j) d = dot2_bf16(qp[r][j], kf[j], d);
+                } else {
+                    const Unp<T> kf(pos >= t ? kown[r] : kk[u][r]);
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) d += qr[r][j] * kf.f[j];
+                }
                 d = group_sum<DC>(d);
                 if (dc == 0) sc[rr * maxpos + min(pos, t)] = d;
             }
@@ -595,18 +619,42 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) vown[r] = ld16(v_s + (r < R ? r : R - 1) * DH + dc * PER);
         auto pv_chunk = [&](int pos0, const u32x4 (&vk)[PU][RT]) {
+            if constexpr (sizeof(T) == 2 && PU % 2 == 0) {
+                // bf16: two positions at a time.  The two probabilities are packed as bf16 (as the training attention kernels hold P), the
+                // two value fragments are interleaved element by element (v_perm_b32) and every output column takes one
+                // v_dot2_f32_bf16: 17 instructions per 16 multiply-adds where unpack + FMA took 32.
 #pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                const int pos = pos0 + u * NSLOT + slot;
-                const int pc = min(pos, t);
-                const bool live = pos <= t;
+                for (int u = 0; u < PU; u += 2) {
+                    const int pa = pos0 + u * NSLOT + slot, pb = pa + NSLOT;
 #pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    const int rr = r < R ? r : R - 1;
-                    const float p = live ? sc[rr * maxpos + pc] : 0.f;
-                    const Unp<T> vf(pos >= t ? vown[r] : vk[u][r]);
+                    for (int r = 0; r < RT; ++r) {
+                        const int rr = r < R ? r : R - 1;
+                        const float wa = pa <= t ? sc[rr * maxpos + min(pa, t)] : 0.f, wb = pb <= t ? sc[rr * maxpos + min(pb, t)] : 0.f;
+                        const uint32_t pp = pack2_bf16(wa, wb);
+                        const u32x4 va = pa >= t ? vown[r] : vk[u][r], vb = pb >= t ? vown[r] : vk[u + 1][r];
 #pragma unroll
-                    for (int j = 0; j < PER; ++j) acc[r][j] += p * vf.f[j];
+                        for (int w = 0; w < 4; ++w) {
+                            const uint32_t lo = __builtin_amdgcn_perm(vb[w], va[w], 0x05040100u);      // (va element 2w, vb element 2w)
+                            const uint32_t hi = __builtin_amdgcn_perm(vb[w], va[w], 0x07060302u);      // (va element 2w+1, vb element 2w+1)
+                            acc[r][2 * w] = dot2_bf16(pp, lo, acc[r][2 * w]);
+                            acc[r][2 * w + 1] = dot2_bf16(pp, hi, acc[r][2 * w + 1]);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    const int pos = pos0 + u * NSLOT + slot;
+                    const int pc = min(pos, t);
+                    const bool live = pos <= t;
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        const int rr = r < R ? r : R - 1;
+                        const float p = live ? sc[rr * maxpos + pc] : 0.f;
+                        const Unp<T> vf(pos >= t ? vown[r] : vk[u][r]);
+#pragma unroll
+                        for (int j = 0; j < PER; ++j) acc[r][j] += p * vf.f[j];
+                    }
                 }
             }
         };
