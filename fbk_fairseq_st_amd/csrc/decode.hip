@@ -179,7 +179,7 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float (&
     *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
 // one pass: the 1024 items from `base` (whole rows: 1024 is a multiple of the items per row)
-template <typename T, int NB, typename Mid>
+template <typename T, int NB, int NK, typename Mid>
 __device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D, int n0, int R, T* dst, int ld, float* red, int base, Mid&& mid) {
     typedef typename Raw4<T>::type raw_t;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -187,12 +187,12 @@ __device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D
     const int IPR = 1 << sh, WPR = IPR >> 6, total = R << sh;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     {
-        int row[4]; unsigned off[4]; bool ok[4];
-        f32x4 v[4];
-        raw_t t[NB][4];
+        int row[NK]; unsigned off[NK]; bool ok[NK];
+        f32x4 v[NK];
+        raw_t t[NB][NK];
         const int col = (tid & (IPR - 1)) * 4;                   // IPR divides 256: a thread's four items are in one column
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int it = base + k * 256 + tid;
             ok[k] = it < total;
             row[k] = min(it, total - 1) >> sh;                   // past the end: the last row again (same column), never stored
@@ -203,18 +203,18 @@ __device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D
             for (int u = 0; u < NB; ++u) {
                 const int q = min(q0 + u, p.np - 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[u][k] = Raw4<T>::ld(reinterpret_cast<const T*>(p.part_in) + (size_t)q * N * D + off[k]);
+                for (int k = 0; k < NK; ++k) t[u][k] = Raw4<T>::ld(reinterpret_cast<const T*>(p.part_in) + (size_t)q * N * D + off[k]);
             }
         };
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(p.x_in + off[k]);
+        for (int k = 0; k < NK; ++k) v[k] = *reinterpret_cast<const f32x4*>(p.x_in + off[k]);
         const f32x4 bs = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + col) : zero;
         if (p.np > 0) request(0);
         const f32x4 gg = *reinterpret_cast<const f32x4*>(p.g + col), bb = *reinterpret_cast<const f32x4*>(p.b + col);
         if (!mid()) return false;
         if (p.bias) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += bs;
+            for (int k = 0; k < NK; ++k) v[k] += bs;
         }
         for (int q0 = 0; q0 < p.np; q0 += NB) {
             if (q0 > 0) request(q0);
@@ -222,42 +222,42 @@ __device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D
             for (int u = 0; u < NB; ++u) {
                 const bool use = q0 + u < p.np;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += use ? Raw4<T>::cvt(t[u][k]) : zero;
+                for (int k = 0; k < NK; ++k) v[k] += use ? Raw4<T>::cvt(t[u][k]) : zero;
             }
         }
         if (writer) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < NK; ++k)
                 if (ok[k]) *reinterpret_cast<f32x4*>(p.x_out + off[k]) = v[k];
         }
-        float st[4];
+        float st[NK];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) st[k] = group_sum<64>(ok[k] ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]) : 0.f);
+        for (int k = 0; k < NK; ++k) st[k] = group_sum<64>(ok[k] ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]) : 0.f);
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) red[k * 4 + w] = st[k];
+            for (int k = 0; k < NK; ++k) red[k * 4 + w] = st[k];
         }
         lds_barrier();
-        float mean[4];
+        float mean[NK];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int first = ((row[k] << sh) - base) >> 6;
             float m = 0.f;
             for (int j = 0; j < WPR; ++j) m += red[first + j];
             mean[k] = m / (float)D;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const f32x4 c = v[k] - mean[k];
             st[k] = group_sum<64>(ok[k] ? (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]) : 0.f);
         }
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) red[16 + k * 4 + w] = st[k];
+            for (int k = 0; k < NK; ++k) red[16 + k * 4 + w] = st[k];
         }
         lds_barrier();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int first = ((row[k] << sh) - base) >> 6;
             float q2 = 0.f;
             for (int j = 0; j < WPR; ++j) q2 += red[16 + first + j];
@@ -274,9 +274,12 @@ __device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D
 // the first pass is straight-line code around mid() (values it defines -- weight fragments -- are not carried around a loop)
 template <typename T, int NB, typename Mid>
 __device__ __forceinline__ bool dec_prologue(const Pro& p, bool writer, int N, int D, int n0, int R, T* dst, int ld, float* red, Mid&& mid) {
-    if (!pro_pass<T, NB>(p, writer, N, D, n0, R, dst, ld, red, 0, mid)) return false;
+    // NK = 256-item slots of a pass (a thread's items): three when the rows fit (beam 5 x D 512 = 640 items), so that the fourth slot's
+    // clamped duplicates cost neither requests nor arithmetic; chosen once, outside the straight-line pass
     const int total = R * (D / 4);
-    for (int base = 1024; base < total; base += 1024) pro_pass<T, NB>(p, writer, N, D, n0, R, dst, ld, red, base, []() { return true; });
+    if (total <= 768) return pro_pass<T, NB, 3>(p, writer, N, D, n0, R, dst, ld, red, 0, mid);
+    if (!pro_pass<T, NB, 4>(p, writer, N, D, n0, R, dst, ld, red, 0, mid)) return false;
+    for (int base = 1024; base < total; base += 1024) pro_pass<T, NB, 4>(p, writer, N, D, n0, R, dst, ld, red, base, []() { return true; });
     return true;
 }
 
