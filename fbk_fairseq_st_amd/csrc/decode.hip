@@ -179,7 +179,7 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float (&
     *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 }
 // one pass: the 1024 items from `base` (whole rows: 1024 is a multiple of the items per row)
-template <typename T, int NB, int NK, typename Mid>
+template <typename T, int NB, int NK, bool FULL, typename Mid>
 __device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D, int n0, int R, T* dst, int ld, float* red, int base, Mid&& mid) {
     typedef typename Raw4<T>::type raw_t;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -220,7 +220,7 @@ __device__ __forceinline__ bool pro_pass(const Pro& p, bool writer, int N, int D
             if (q0 > 0) request(q0);
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const bool use = q0 + u < p.np;
+                const bool use = FULL || q0 + u < p.np;        // FULL: np is a multiple of NB -- no select per addend
 #pragma unroll
                 for (int k = 0; k < NK; ++k) v[k] += use ? Raw4<T>::cvt(t[u][k]) : zero;
             }
@@ -277,9 +277,12 @@ __device__ __forceinline__ bool dec_prologue(const Pro& p, bool writer, int N, i
     // NK = 256-item slots of a pass (a thread's items): three when the rows fit (beam 5 x D 512 = 640 items), so that the fourth slot's
     // clamped duplicates cost neither requests nor arithmetic; chosen once, outside the straight-line pass
     const int total = R * (D / 4);
-    if (total <= 768) return pro_pass<T, NB, 3>(p, writer, N, D, n0, R, dst, ld, red, 0, mid);
-    if (!pro_pass<T, NB, 4>(p, writer, N, D, n0, R, dst, ld, red, 0, mid)) return false;
-    for (int base = 1024; base < total; base += 1024) pro_pass<T, NB, 4>(p, writer, N, D, n0, R, dst, ld, red, base, []() { return true; });
+    if (total <= 768) {
+        if (p.np == NB) return pro_pass<T, NB, 3, true>(p, writer, N, D, n0, R, dst, ld, red, 0, mid);
+        return pro_pass<T, NB, 3, false>(p, writer, N, D, n0, R, dst, ld, red, 0, mid);
+    }
+    if (!pro_pass<T, NB, 4, false>(p, writer, N, D, n0, R, dst, ld, red, 0, mid)) return false;
+    for (int base = 1024; base < total; base += 1024) pro_pass<T, NB, 4, false>(p, writer, N, D, n0, R, dst, ld, red, base, []() { return true; });
     return true;
 }
 
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
     const int lda = D + PER;
     T* cache = reinterpret_cast<T*>(a.cache);
     int t = 0;
-    const bool go = dec_prologue<T, 16>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0, [&]() {
+    const bool go = dec_prologue<T, 16>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0, [&]() __attribute__((always_inline)) {
         t = t_raw;
         if (t > a.max_len) return false;
         // ancestors of the sentence's rows at positions < t, RT rows x 256 positions requested together; the weights go out behind the
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     const T* Kp = reinterpret_cast<const T*>(a.kv_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;
     const T* Vp = reinterpret_cast<const T*>(a.vt_enc) + ((size_t)s * a.heads + h) * (size_t)Tsp * DH;
 
-    const bool go = dec_prologue<T, S2T_DEC_NB_CROSS>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0, [&]() {
+    const bool go = dec_prologue<T, S2T_DEC_NB_CROSS>(a.pro, h == 0, N, D, n0, R, a_ln, lda, red0, [&]() __attribute__((always_inline)) {
         if (t_raw > a.max_len) return false;
         if constexpr (PRE) load_rows_w<T, 1, KSTD>(wq, reinterpret_cast<const T*>(a.w_q), h * 4 + w, 0);
         if constexpr (PKV) {
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_ffn_kernel(FfnArgs a) {
     const int lda = D + PER, ldh = hs + PER;
     const int arow = min(lane & 15, R - 1);
 
-    const bool go = dec_prologue<T, S2T_DEC_NB_FFN>(a.pro, j == 0, N, D, n0, R, a_ln, lda, red0, [&]() {
+    const bool go = dec_prologue<T, S2T_DEC_NB_FFN>(a.pro, j == 0, N, D, n0, R, a_ln, lda, red0, [&]() __attribute__((always_inline)) {
         if (t_raw > a.max_len) return false;
         if constexpr (PRE) load_rows_w<T, TPW, KSTD>(w1, reinterpret_cast<const T*>(a.w_fc1), j * (HS / 16) + w * TPW, 1);
         if constexpr (PRE2) load_share_w<T, NTO, KST2>(w2, reinterpret_cast<const T*>(a.w_fc2), a.ffn / KS, j * (HS / KS));
