@@ -303,7 +303,9 @@ template <int GRP> __device__ __forceinline__ float grp_sum(float v) {
     if (GRP == 32) return (threadIdx.x & 32) ? hi : lo;
     return lo + hi;
 }
-template <int GRP, typename Fin>
+// FAST (bf16 mode: the probabilities are rounded to bf16 or multiplied into bf16 values next): v_exp_f32 on (x - m) log2 e and one reciprocal
+// per row instead of expf and a division per element -- a third of the loop's instructions on a wave that issues one every ~8 cycles
+template <int GRP, bool FAST, typename Fin>
 __device__ __forceinline__ void softmax_rows_g(float* sc, int ldsc, int R, int n, Fin&& fin) {
     constexpr int NG = NTHREADS / GRP;
     const int g = threadIdx.x / GRP, gl = threadIdx.x % GRP;
@@ -314,17 +316,22 @@ __device__ __forceinline__ void softmax_rows_g(float* sc, int ldsc, int R, int n
         for (int p = gl; p < n; p += GRP) m = fmaxf(m, row[p]);
         m = grp_max<GRP>(m);
         float z = 0.f;
-        for (int p = gl; p < n; p += GRP) { const float e = expf(row[p] - m); if (act) row[p] = e; z += e; }
+        for (int p = gl; p < n; p += GRP) {
+            const float e = FAST ? __builtin_amdgcn_exp2f((row[p] - m) * 1.44269504088896f) : expf(row[p] - m);
+            if (act) row[p] = e;
+            z += e;
+        }
         z = grp_sum<GRP>(z);
+        const float iz = FAST ? __builtin_amdgcn_rcpf(z) : 0.f;
         if (act)
-            for (int p = gl; p < n; p += GRP) fin(r0 + g, p, row[p] / z);
+            for (int p = gl; p < n; p += GRP) fin(r0 + g, p, FAST ? row[p] * iz : row[p] / z);
     }
 }
-template <typename Fin>
+template <bool FAST, typename Fin>
 __device__ __forceinline__ void softmax_rows(float* sc, int ldsc, int R, int n, Fin&& fin) {
-    if (R <= 4) softmax_rows_g<64>(sc, ldsc, R, n, fin);
-    else if (R <= 8) softmax_rows_g<32>(sc, ldsc, R, n, fin);
-    else softmax_rows_g<16>(sc, ldsc, R, n, fin);
+    if (R <= 4) softmax_rows_g<64, FAST>(sc, ldsc, R, n, fin);
+    else if (R <= 8) softmax_rows_g<32, FAST>(sc, ldsc, R, n, fin);
+    else softmax_rows_g<16, FAST>(sc, ldsc, R, n, fin);
 }
 
 // ---- weights in FRAGMENT-MAJOR order (s2t_decode_pack_weight): W [N][K] -> [N / 16 column tiles][K / KS k-steps][64 lanes][16 bytes], the
@@ -612,7 +619,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_self_kernel(SelfArgs a) {
     }
     lds_barrier();
     DSTAMP(0, 3);
-    softmax_rows(sc, maxpos, R, t + 1, [&](int r, int p, float v) { sc[r * maxpos + p] = v; });
+    softmax_rows<sizeof(T) == 2>(sc, maxpos, R, t + 1, [&](int r, int p, float v) { sc[r * maxpos + p] = v; });
     lds_barrier();
     DSTAMP(0, 4);
     {   // o[r][:] = sum_pos p[r][pos] * v_{anc(r, pos)}
@@ -812,7 +819,7 @@ __global__ __launch_bounds__(NTHREADS) void dec_cross_kernel(CrossArgs a) {
     }
     lds_barrier();
     DSTAMP(1, 3);
-    softmax_rows(sc, Tsp, R, Tsp, [&](int r, int p, float v) { p_s[(size_t)r * ldp + p] = from_f32<T>(v); });
+    softmax_rows<sizeof(T) == 2>(sc, Tsp, R, Tsp, [&](int r, int p, float v) { p_s[(size_t)r * ldp + p] = from_f32<T>(v); });
     lds_barrier();
     DSTAMP(1, 4);
     {   // o = P V: wave w owns 16 of the 64 value columns; V is read through its transposed, fragment-major copy
