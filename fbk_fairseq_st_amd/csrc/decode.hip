@@ -1076,7 +1076,18 @@ __global__ __launch_bounds__(NTHREADS) void dec_row_kernel(RowArgs a) {
     const int cnt = wi[127];
     DSTAMP(3, 5);
     if (thr > -INFINITY && cnt <= CAP) {
-        if (w == 0) {
+        if (w == 0 && cnt <= 64) {
+            // one candidate per lane: its place in the order (value descending, column ascending) = how many of the others come before
+            // it, counted through `cnt` scalar broadcasts (the list is about K2 + a few long; K2 rounds of arg-max over it took 5,400 cycles)
+            float v = -INFINITY; int ix = 0x7fffffff;
+            if (lane < cnt) { v = wv[4 + lane]; ix = wi[4 + lane]; }
+            int before = 0;
+            for (int j = 0; j < cnt; ++j) {
+                const float ov = rl_f(v, j); const int oi = __builtin_amdgcn_readlane(ix, j);
+                before += (ov > v || (ov == v && oi < ix)) ? 1 : 0;
+            }
+            if (lane < cnt && before < K2) { a.cand_val[(size_t)n * K2 + before] = v; a.cand_idx[(size_t)n * K2 + before] = ix; }
+        } else if (w == 0) {
             float c0v = -INFINITY, c1v = -INFINITY; int c0i = 0x7fffffff, c1i = 0x7fffffff;
             if (lane < cnt) { c0v = wv[4 + lane]; c0i = wi[4 + lane]; }
             if (lane + 64 < cnt) { c1v = wv[4 + lane + 64]; c1i = wi[4 + lane + 64]; }
@@ -1191,8 +1202,8 @@ __global__ __launch_bounds__(NTHREADS) void dec_sent_kernel(SentArgs a) {
     DSTAMP(4, 1);
     if (tid < 64) {
         // k-way merge of the `rows` sorted lists: lane j < rows offers the head of list j; the winner of round r becomes candidate r,
-        // kept by lane r.  (Counting, for every entry, the entries before it -- one pass over the lists in LDS -- was measured at 10,700
-        // cycles for 50 entries against 5,500 for these k = 10 rounds.)
+        // kept by lane r.  (Measured alternatives for 50 entries against the 5,900 cycles of these k = 10 rounds: every entry counting
+        // the entries before it over the lists in LDS 10,700; the same count through scalar broadcasts of one entry per lane 11,300.)
         int head = 0;
         float my_val = -INFINITY; int my_tok = 0, my_row = n0;
         for (int r = 0; r < k; ++r) {
