@@ -443,7 +443,7 @@ __device__ __forceinline__ void mma_tile(const char* la, const char* lb, int aro
 // NW = 4: waves 2 x 2, each (BM/2) x (BN/2).  NW = 8: waves 2 x 4, each (BM/2) x (BN/4): twice the wavefronts per CU to
 // cover the global-load latency of the k-loop, at 1.5x the LDS fragment traffic per MFMA.
 template <typename TI, typename TO, bool TA, bool TB, int BM, int BN, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(GemmArgs p) {   // 2nd argument = min waves per SIMD
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(GemmArgs p, const bool g_deep_ok) {   // 2nd argument = min waves per SIMD
     constexpr int BK = 128 / (int)sizeof(TI);
     constexpr int NTH = NW * 64, WN = NW / 2;
     constexpr int MT = BM / 32, NT = BN / (16 * WN);
@@ -494,8 +494,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
 
     int left = nk;                                  // tiles not yet requested from global memory
     auto step = [&]() { left -= 1; return left > 0 ? 128 : 0; };
-    { const int st = step(); sa.load(a0, st); sb.load(b0, st); }      // tile 0
-    { const int st = step(); sa.load(a1, st); sb.load(b1, st); }      // tile 1 (or tile 0 again)
+    // DEEP: the 64 x 64 four-wave form (the small products: decoder-side rows, M of a few thousand) is a chain of memory round trips --
+    // two k-tiles in flight make ~1.3 us per k-tile whatever the tile costs to multiply.  A thread stages only 2 + 2 (transposed
+    // operand: 2 + 4) 16-byte chunks per k-tile there, so DEPTH register sets fit (8 x 16 = 128 VGPRs, or 4 x 24): all of K = 512 is
+    // requested before the first MFMA.  Same k order, same MFMAs: bit-identical results.  Taken when the k-tile count is a multiple of
+    // DEPTH (every K of the model is), so that the unrolled rotation needs no guard around its loads.
+    constexpr int DEPTH = (NW == 4 && BM == 64 && BN == 64 && sizeof(TI) == 2) ? ((TA || TB) ? 4 : 8) : 0;
+    bool deep = false;
+    if constexpr (DEPTH > 0) deep = g_deep_ok && nk % DEPTH == 0 && !(TA && p.rowsum != nullptr);
+    if (!deep) {
+        { const int st = step(); sa.load(a0, st); sb.load(b0, st); }  // tile 0
+        { const int st = step(); sa.load(a1, st); sb.load(b1, st); }  // tile 1 (or tile 0 again)
+    }
     // bias gradient: the first column tile's wc == 0 waves also sum their A rows (wave-uniform choice)
     const bool do_rs = TA && p.rowsum != nullptr && tn == 0 && wc == 0;
     f32x4 rs[MT];
@@ -538,6 +548,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
         if (rem > 3) { S2T_STEP(a0, b0, a1, b1, l1, l0)
         if (rem > 4) { S2T_STEP(a1, b1, a2, b2, l0, l1) } } } } }
 #undef S2T_STEP
+    } else if (deep) {
+        if constexpr (DEPTH > 0) {
+            typename SA::Regs ra[DEPTH];
+            typename SB::Regs rb[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) { const int st = step(); sa.load(ra[d], st); sb.load(rb[d], st); }
+            for (int t0 = 0; t0 < nk; t0 += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {                     // tile t0 + d: set d, stage d & 1 (DEPTH is even)
+                    char* l = (d & 1) ? l1 : l0;
+                    sa.store(l, ra[d]); sb.store(l + BM * 128, rb[d]);
+                    __syncthreads();
+                    { const int st = step(); sa.load(ra[d], st); sb.load(rb[d], st); }   // tile t0 + d + DEPTH (past the end: the last tile again)
+                    mma(l);
+                }
+            }
+        }
     } else {
     sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
     __syncthreads();
@@ -736,7 +763,7 @@ static int launch(const GemmArgs& a_in, hipStream_t st) {
             // are gathered by transposed LDS reads (fragment traffic dominates)
             static bool attr3 = false;
             if (!attr3) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr3 = true; }
-            hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), grid, dim3(512), lds, st, a);
+            hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN, 8>), grid, dim3(512), lds, st, a, g_s2t_opt_gemm_deep != 0);
             S2T_LAUNCH_CHECK();
             return S2T_OK;
         }
@@ -744,7 +771,7 @@ static int launch(const GemmArgs& a_in, hipStream_t st) {
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         }
-        hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((gemm_fast_kernel<TI, TO, TA, TB, BM, BN>), grid, dim3(256), lds, st, a, g_s2t_opt_gemm_deep != 0);
         S2T_LAUNCH_CHECK();
         return S2T_OK;
     }
