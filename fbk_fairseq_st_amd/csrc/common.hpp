@@ -27,7 +27,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // kernel-route options (runtime.hip, s2t_set_option)
 extern int g_s2t_opt_gemm256, g_s2t_opt_attn_v1, g_s2t_opt_attn_v2_min_tq, g_s2t_opt_gemm256_min_tiles, g_s2t_opt_gemm256_sched;
-extern int g_s2t_opt_reserve_cus, g_s2t_opt_f32_small_nt, g_s2t_opt_f32_small_kt, g_s2t_opt_f32_narrow, g_s2t_opt_small_nt, g_s2t_opt_small_kt, g_s2t_opt_attn_bwd_fused, g_s2t_opt_gemm_deep;
+extern int g_s2t_opt_reserve_cus, g_s2t_opt_f32_small_nt, g_s2t_opt_f32_small_kt, g_s2t_opt_f32_narrow, g_s2t_opt_small_nt, g_s2t_opt_small_kt, g_s2t_opt_attn_bwd_fused, g_s2t_opt_gemm_deep, g_s2t_opt_ln_small;
 // workgroups of a persistent one-per-CU launch: the chip's 256 CUs minus the ones left to a collective that runs beside it
 // (s2t_set_option "reserve_cus": RCCL's kernels hold CUs while a bucket travels; a 128 KiB-LDS workgroup that finds its CU taken
 // waits for a whole round of the others)

@@ -208,6 +208,95 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const T* __restrict__ d
     }
 }
 
+// Small M (decoder-sized activations, small batches): at most 64 workgroups x 16 waves, i.e. 3-4 rows per wave, and inside an update every
+// row is a round trip to lines the previous launch wrote: with one row of lookahead the launch was a chain of them (11-13 us for 3,000-4,000
+// rows against 4.5 us for the forward).  Here a wave requests ALL its rows of a pass (four) before it reduces the first; the rows stay
+// raw (16 bytes per operand and lane) until they are used, so the twelve vectors fit the 128-register budget of a 1,024-thread workgroup.
+// Same arithmetic per row, same row order per wave: bit-identical to ln_bwd_kernel.  bf16, D = 512 (8 elements per lane).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_small_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const bf16* __restrict__ dres,
+                                                           bf16* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int M, int D,
+                                                           bf16* __restrict__ dx_drop, float p_drop, unsigned long long seed) {
+    constexpr int EPL = 8, RPW = 3;
+    typedef RowIO<bf16, EPL> IO;
+    typedef RowIO<bf16, EPL, (S2T_LN_NT & 2) != 0> IOS;
+    extern __shared__ float sh_ln[];                       // [2][NW][D]
+    const uint32_t th16 = (uint32_t)fminf(p_drop * 4294967296.f, 4294967295.f) >> 16;
+    const float inv_keep = 1.f / (1.f - p_drop);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float ag[EPL], ab[EPL], gm[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; gm[i] = gamma[lane * EPL + i]; }
+    const int stride = gridDim.x * NW;
+    const bf16* rsrc = dres ? dres : dy;                   // no residual: a second read of dy that is never used (no branch around a load)
+    for (int row0 = blockIdx.x * NW + w; row0 < M; row0 += RPW * stride) {
+        u32x4 xr[RPW], dr[RPW], rr[RPW];
+        float mu[RPW], rs[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const size_t r = (size_t)min(row0 + k * stride, M - 1);          // past the end: the last row again, never used
+            xr[k] = *reinterpret_cast<const u32x4*>(x + r * D + lane * EPL);
+            dr[k] = *reinterpret_cast<const u32x4*>(dy + r * D + lane * EPL);
+            rr[k] = *reinterpret_cast<const u32x4*>(rsrc + r * D + lane * EPL);
+            mu[k] = mean[r]; rs[k] = rstd[r];
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int row = row0 + k * stride;
+            if (row < M) {                                                   // wave-uniform; nothing inside requests memory
+                float xv[16], dv[16];
+                const bf16* xe = reinterpret_cast<const bf16*>(&xr[k]);
+                const bf16* de = reinterpret_cast<const bf16*>(&dr[k]);
+                const bf16* re = reinterpret_cast<const bf16*>(&rr[k]);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) {
+                    xv[i] = (to_f32(xe[i]) - mu[k]) * rs[k];              // xhat
+                    const float d = to_f32(de[i]);
+                    ag[i] += d * xv[i];
+                    ab[i] += d;
+                    dv[i] = d * gm[i];                                     // g
+                    s1 += dv[i];
+                    s2 += dv[i] * xv[i];
+                }
+                const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) {
+                    float r = rs[k] * (dv[i] - c1 - xv[i] * c2);
+                    if (dres) r += to_f32(re[i]);
+                    dv[i] = r;
+                }
+                IOS::store(dx + (size_t)row * D, lane, D, dv);
+                if (dx_drop) {
+#pragma unroll
+                    for (int kk = 0; kk < EPL / 4; ++kk) {
+                        const u32x2 h = drop_hash4(seed, (((uint64_t)row * D) >> 2) + (uint64_t)(lane * (EPL / 4) + kk));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            dv[4 * kk + e] = drop_field(h, e) >= th16 ? to_f32(from_f32<bf16>(dv[4 * kk + e])) * inv_keep : 0.f;
+                    }
+                    IOS::store(dx_drop + (size_t)row * D, lane, D, dv);
+                }
+            }
+        }
+    }
+    float* sg = sh_ln;
+    float* sb = sh_ln + NW * D;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) { sg[w * D + lane * EPL + i] = ag[i]; sb[w * D + lane * EPL + i] = ab[i]; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * D; j += NW * 64) {
+        const float* src = j < D ? sg + j : sb + (j - D);
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) t += src[k * D];
+        atomicAdd((j < D ? dgamma + j : dbeta + (j - D)), t);
+    }
+}
+
 static int ln_epl(int D, const void* a, const void* b, const void* c, const void* d, const void* e = nullptr, const void* f = nullptr) {
     const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f;
     if ((al & 15) != 0) return 0;
@@ -274,7 +363,13 @@ extern "C" int s2t_layernorm_bwd(int dtype, const void* dy, const void* x, const
         if (epl == 4) LN_BWD_LAUNCH(T, 4, 16); else if (epl == 8) LN_BWD_LAUNCH(T, 8, 16);                                  \
         else if (epl == 16) LN_BWD_LAUNCH(T, 16, 8); else LN_BWD_LAUNCH(T, 0, 8);                                           \
     } while (0)
-    if (dtype == S2T_BF16) LN_BWD_EPL(bf16);
+    if (dtype == S2T_BF16 && epl == 8 && !big && g_s2t_opt_ln_small) {
+        static bool attr = false;
+        if (!attr && lds > 65536) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_bwd_small_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 1024 * 4); attr = true; }
+        hipLaunchKernelGGL(ln_bwd_small_kernel<16>, grid, dim3(16 * 64), lds, st, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma,
+                           (const bf16*)dres, (bf16*)dx, dgamma, dbeta, M, D, (bf16*)dx_drop, p_drop, seed);
+    }
+    else if (dtype == S2T_BF16) LN_BWD_EPL(bf16);
     else if (dtype == S2T_F32) LN_BWD_EPL(float);
     else return S2T_ENOTSUP;
 #undef LN_BWD_EPL

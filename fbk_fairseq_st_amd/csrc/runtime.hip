@@ -10,6 +10,7 @@
 
 int g_s2t_prof_on = 0;
 int g_s2t_opt_gemm256 = 1, g_s2t_opt_attn_v1 = 0, g_s2t_opt_attn_v2_min_tq = 16, g_s2t_opt_gemm256_min_tiles = 0, g_s2t_opt_gemm256_sched = 0;
+int g_s2t_opt_ln_small = 1;                                 // 1: the LayerNorm backward of small activations requests a wave's rows four at a time (norm_optim.hip)
 int g_s2t_opt_gemm_deep = 1;                                // 1: the 64 x 64 bf16 products request DEPTH k-tiles before the first MFMA (gemm.hip)
 int g_s2t_opt_attn_bwd_fused = 0;                          // 1: the one-kernel attention backward for Tk <= 384 (attention.hip)
 int g_s2t_opt_small_nt = 192, g_s2t_opt_small_kt = 40;      // bf16 products: below that many 128 x 128 tiles the 64 x 64 form (NT / NN and TN)
@@ -109,7 +110,8 @@ extern "C" int s2t_set_option(const char* key, int value) {
               : !strcmp(key, "reserve_cus") ? &g_s2t_opt_reserve_cus : !strcmp(key, "gemm_f32_small_nt") ? &g_s2t_opt_f32_small_nt
               : !strcmp(key, "gemm_f32_small_kt") ? &g_s2t_opt_f32_small_kt : !strcmp(key, "gemm_f32_narrow") ? &g_s2t_opt_f32_narrow
               : !strcmp(key, "gemm_small_nt") ? &g_s2t_opt_small_nt : !strcmp(key, "gemm_small_kt") ? &g_s2t_opt_small_kt
-              : !strcmp(key, "attn_bwd_fused") ? &g_s2t_opt_attn_bwd_fused : !strcmp(key, "gemm_deep") ? &g_s2t_opt_gemm_deep : nullptr;
+              : !strcmp(key, "attn_bwd_fused") ? &g_s2t_opt_attn_bwd_fused : !strcmp(key, "gemm_deep") ? &g_s2t_opt_gemm_deep
+              : !strcmp(key, "ln_small") ? &g_s2t_opt_ln_small : nullptr;
     if (slot == &g_s2t_opt_reserve_cus && (value < 0 || value > 128)) return S2T_EINVAL;
     if (!slot) return S2T_EINVAL;
     const int old = *slot;

@@ -502,6 +502,8 @@ int s2t_prof_enable(int on);
  *                  64 x 64 form loses on every NN product and the whole update moves within its noise: the defaults stay);
  *       "gemm_deep" (default 1): the 64 x 64 four-wave bf16 GEMM form requests 8 (NT) / 4 (NN, TN) k-tiles before its first MFMA instead
  *                  of keeping two in flight; bit-identical results (tools/gemm_deep_check.py); 0 restores the two-set loop;
+ *       "ln_small" (default 1): the bf16, D = 512 LayerNorm backward of activations below 8,192 rows requests a wave's rows three at a
+ *                  time instead of one ahead (same formulas; results agree with the other kernel to bf16 rounding); 0 restores it;
  *       "attn_bwd_fused" (default 0): 1 sends the bf16, d = 64, plain-softmax attention backward with 128 <= Tk <= 384 and Tq >= 128 to
  *                  the one-kernel form (attention.hip: attn_bwd_fused_kernel; same results within bf16 rounding, measured no faster:
  *                  profiles/r06_attn_bwd_fused.txt);
