@@ -564,6 +564,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void gemm_fast_kernel(Gem
                     mma(l);
                 }
             }
+            // the epilogue stores the accumulators into the same LDS at once: every wave's fragment reads of the last k-tile must be done
+            // (the other loops end their last iteration on a barrier; without this one an eight-wave variant of this loop produced NaNs)
+            __syncthreads();
         }
     } else {
     sa.store(l0, a0); sb.store(l0 + BM * 128, b0);
